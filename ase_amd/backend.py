@@ -1,0 +1,172 @@
+"""Tensor-level wrapper over the C ABI: extracts pointers / leading dimensions from torch tensors
+that live in HBM and enqueues the HIP kernels on torch's current stream.
+
+PyTorch is used here only for device memory and streams.  All arithmetic of the update path
+happens inside ``libase_hip.so``.  There is no CPU implementation in the product; the engine's
+host logic is exercised on CPU by ``tests/emu_backend.py`` (test infrastructure with the same
+method names).
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _ld(t):
+    return 0 if t is None else int(t.stride(0))
+
+
+def _code(dtype):
+    if dtype == torch.bfloat16:
+        return L.BF16
+    if dtype == torch.float32:
+        return L.F32
+    raise L.AseHipError(f"unsupported storage dtype {dtype}")
+
+
+class HipBackend:
+    name = "hip"
+
+    def __init__(self, device=None):
+        if not torch.cuda.is_available():
+            raise L.AseHipError("HipBackend needs a ROCm GPU (torch.cuda.is_available() is False); "
+                                "the update path has no CPU fallback")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.lib = L.get()
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def zero_(self, t):
+        t.zero_()
+
+    # ------------------------------------------------------------------ GEMMs
+    def gemm_nt(self, A, B, Cm, M, N, K, bias=None, aux=None, aux_mode=L.AUX_NONE, colsum=None, colsum_n=0,
+                act=L.ACT_NONE, alpha=1.0):
+        dt = _code(A.dtype)
+        assert B.dtype == A.dtype and (aux is None or aux.dtype == A.dtype)
+        out_f32 = int(Cm.dtype == torch.float32 and A.dtype != torch.float32)
+        L.check(self.lib.ase_hip_gemm_nt(_ptr(A), _ld(A), _ptr(B), _ld(B), _ptr(Cm), _ld(Cm), _ptr(bias), _ptr(aux),
+                                         _ld(aux), _ptr(colsum), int(colsum_n), M, N, K, act, aux_mode, out_f32,
+                                         float(alpha), dt, self._stream()), "gemm_nt")
+
+    def gemm_tn(self, A, B, G, M, N, K, n_real, k_real, split_src, split_dst, alpha=1.0):
+        L.check(self.lib.ase_hip_gemm_tn(_ptr(A), _ld(A), _ptr(B), _ld(B), _ptr(G), M, N, K, n_real, k_real,
+                                         split_src, split_dst, float(alpha), _code(A.dtype), self._stream()), "gemm_tn")
+
+    def refresh_shadow(self, W, Ws, Wts, split_src, split_dst):
+        n, k = W.shape
+        ref = Ws if Ws is not None else Wts
+        L.check(self.lib.ase_hip_refresh_shadow(_ptr(W), n, k, _ptr(Ws), _ld(Ws), _ptr(Wts), _ld(Wts), split_src,
+                                                split_dst, _code(ref.dtype), self._stream()), "refresh_shadow")
+
+    # ------------------------------------------------------------------ normaliser / gather
+    def rms_moments(self, src, D, idx, remap, M, state, sums):
+        L.check(self.lib.ase_hip_rms_moments(_ptr(src), _ld(src), D, _ptr(idx), remap[0], remap[1], M, _ptr(state),
+                                             _ptr(sums), self._stream()), "rms_moments")
+
+    def rms_finalize(self, state, D, sums, count, n_streams, mean_out, std_out):
+        counts = (C.c_int32 * max(n_streams, 1))(*([int(count)] * max(n_streams, 1)))
+        L.check(self.lib.ase_hip_rms_finalize(_ptr(state), D, _ptr(sums), counts, n_streams, _ptr(mean_out),
+                                              _ptr(std_out), self._stream()), "rms_finalize")
+
+    def rms_normalize(self, src, D, idx, remap, M, mean, std, outs):
+        outs = list(outs) + [None] * (3 - len(outs))
+        dt = _code(outs[0].dtype)
+        L.check(self.lib.ase_hip_rms_normalize(_ptr(src), _ld(src), D, _ptr(idx), remap[0], remap[1], M, _ptr(mean),
+                                               _ptr(std), _ptr(outs[0]), _ld(outs[0]), _ptr(outs[1]), _ld(outs[1]),
+                                               _ptr(outs[2]), _ld(outs[2]), dt, self._stream()), "rms_normalize")
+
+    def rms_unnormalize(self, state, x, y):
+        L.check(self.lib.ase_hip_rms_unnormalize(_ptr(state), _ptr(x), _ptr(y), x.numel(), self._stream()),
+                "rms_unnormalize")
+
+    def gather_rows(self, src, D, idx, remap, M, dst):
+        L.check(self.lib.ase_hip_gather_rows(_ptr(src), _ld(src), D, _ptr(idx), remap[0], remap[1], M, _ptr(dst),
+                                             _ld(dst), _code(dst.dtype), self._stream()), "gather_rows")
+
+    # ------------------------------------------------------------------ heads
+    def reduce_sum(self, x, n, square, acc, slot):
+        L.check(self.lib.ase_hip_reduce_sum(_ptr(x), n, int(square), _ptr(acc), slot, self._stream()), "reduce_sum")
+
+    def ppo_head(self, mu, value, mb, new_z, logstd, d_mu, d_value, db_mu, db_value, acc, M, m_global, act_dim,
+                 z_dim, masked, div_on, mu_tanh, clip_value, e_clip, critic_coef, bounds_coef, div_coef, div_tar,
+                 mu_out=None):
+        L.check(self.lib.ase_hip_ppo_head(
+            _ptr(mu), _ld(mu), _ptr(value), _ld(value), _ptr(mb['actions']), _ptr(mb['mu']), _ptr(mb['sigma']),
+            _ptr(mb['old_logp_actions']), _ptr(mb['advantages']), _ptr(mb.get('old_values')), _ptr(mb['returns']),
+            _ptr(mb.get('rand_action_mask')), _ptr(mb.get('ase_latents')), _ptr(new_z), _ptr(logstd),
+            _ptr(d_mu), _ld(d_mu), _ptr(d_value), _ld(d_value), _ptr(db_mu), _ptr(db_value), _ptr(mu_out), _ptr(acc),
+            M, m_global, act_dim, z_dim, int(masked), int(div_on), int(mu_tanh), int(clip_value),
+            float(e_clip), float(critic_coef), float(bounds_coef), float(div_coef), float(div_tar),
+            _code(d_mu.dtype), self._stream()), "ppo_head")
+
+    def disc_head(self, logit, d_logit, db_logit, acc, amb, amb_global, disc_coef):
+        L.check(self.lib.ase_hip_disc_head(_ptr(logit), _ld(logit), _ptr(d_logit), _ld(d_logit), _ptr(db_logit),
+                                           _ptr(acc), amb, amb_global, float(disc_coef), _code(d_logit.dtype),
+                                           self._stream()), "disc_head")
+
+    def enc_head(self, e, z, d_e, db_enc, enc_out, acc, amb, amb_global, z_dim, enc_coef):
+        L.check(self.lib.ase_hip_enc_head(_ptr(e), _ld(e), _ptr(z), _ld(z), _ptr(d_e), _ld(d_e), _ptr(db_enc),
+                                          _ptr(enc_out), _ptr(acc), amb, amb_global, z_dim, float(enc_coef),
+                                          _code(d_e.dtype), self._stream()), "enc_head")
+
+    def gp_seed(self, h, w, g, rows, width):
+        L.check(self.lib.ase_hip_gp_seed(_ptr(h), _ld(h), _ptr(w), _ptr(g), _ld(g), rows, width, _code(h.dtype),
+                                         self._stream()), "gp_seed")
+
+    def sqnorm(self, x, rows, cols, acc, slot):
+        L.check(self.lib.ase_hip_sqnorm(_ptr(x), _ld(x), rows, cols, _ptr(acc), slot, _code(x.dtype), self._stream()),
+                "sqnorm")
+
+    def finalize_scalars(self, acc, out, m_global, amb_global, masked, has_disc, has_enc, has_div, c):
+        L.check(self.lib.ase_hip_finalize_scalars(
+            _ptr(acc), _ptr(out), m_global, amb_global, int(masked), int(has_disc), int(has_enc), int(has_div),
+            float(c['critic_coef']), float(c['entropy_coef']), float(c['bounds_loss_coef']), float(c.get('disc_coef', 0)),
+            float(c.get('disc_logit_reg', 0)), float(c.get('disc_grad_penalty', 0)), float(c.get('disc_weight_decay', 0)),
+            float(c.get('enc_coef', 0)), float(c.get('enc_weight_decay', 0)), float(c.get('amp_diversity_bonus', 0)),
+            self._stream()), "finalize_scalars")
+
+    # ------------------------------------------------------------------ optimizer
+    def begin_step(self, opt_state, acc):
+        L.check(self.lib.ase_hip_begin_step(_ptr(opt_state), _ptr(acc), 0 if acc is None else acc.numel(),
+                                            self._stream()), "begin_step")
+
+    def adam(self, w, g, m, v, opt_state):
+        L.check(self.lib.ase_hip_adam(_ptr(w), _ptr(g), _ptr(m), _ptr(v), w.numel(), _ptr(opt_state), self._stream()),
+                "adam")
+
+    def axpy(self, g, w, c):
+        L.check(self.lib.ase_hip_axpy(_ptr(g), _ptr(w), g.numel(), float(c), self._stream()), "axpy")
+
+    # ------------------------------------------------------------------ rollout tail
+    def disc_reward(self, logit, r, n, scale):
+        L.check(self.lib.ase_hip_disc_reward(_ptr(logit), _ld(logit), _ptr(r), n, float(scale), self._stream()),
+                "disc_reward")
+
+    def enc_reward(self, e, z, r, n, z_dim, scale):
+        L.check(self.lib.ase_hip_enc_reward(_ptr(e), _ld(e), _ptr(z), _ld(z), _ptr(r), n, z_dim, float(scale),
+                                            self._stream()), "enc_reward")
+
+    def gae(self, dones, values, next_values, r_task, r_disc, r_enc, w_task, w_disc, w_enc, gamma, tau, advs, returns,
+            H, N):
+        L.check(self.lib.ase_hip_gae(_ptr(dones), _ptr(values), _ptr(next_values), _ptr(r_task), _ptr(r_disc),
+                                     _ptr(r_enc), float(w_task), float(w_disc), float(w_enc), float(gamma), float(tau),
+                                     _ptr(advs), _ptr(returns), H, N, self._stream()), "gae")
+
+    def adv_norm(self, returns, values, mask, adv, acc3, n, normalize, phase):
+        L.check(self.lib.ase_hip_adv_norm(_ptr(returns), _ptr(values), _ptr(mask), _ptr(adv), _ptr(acc3), n,
+                                          int(normalize), phase, self._stream()), "adv_norm")
+
+    def ring_store(self, src, D, idx, remap, n, dst, size, head):
+        L.check(self.lib.ase_hip_ring_store(_ptr(src), _ld(src), D, _ptr(idx), remap[0], remap[1], n, _ptr(dst), size,
+                                            head, self._stream()), "ring_store")
+
+    def sample_latents(self, z, rows, dim, rng_state):
+        L.check(self.lib.ase_hip_sample_latents(_ptr(z), rows, dim, _ptr(rng_state), self._stream()), "sample_latents")

@@ -1,0 +1,93 @@
+// Shared device/host helpers for libase_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/ase_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+void ase_set_error(const char* fmt, ...);
+
+#define ASE_CHECK_ARG(cond, ...)                 \
+    do {                                         \
+        if (!(cond)) {                           \
+            ase_set_error(__VA_ARGS__);          \
+            return ASE_EINVAL;                   \
+        }                                        \
+    } while (0)
+
+#define ASE_CHECK_LAUNCH(name)                                              \
+    do {                                                                    \
+        hipError_t e__ = hipGetLastError();                                 \
+        if (e__ != hipSuccess) {                                            \
+            ase_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return ASE_ELAUNCH;                                             \
+        }                                                                   \
+    } while (0)
+
+// ---- storage type conversion --------------------------------------------------------------
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }
+
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }  // RNE
+
+// ---- dataset row map (see ase_hip.h) -------------------------------------------------------
+__device__ __forceinline__ int64_t map_row(int r, const int32_t* __restrict__ idx, int remap_h, int remap_n) {
+    int64_t p = idx ? (int64_t)idx[r] : (int64_t)r;
+    if (remap_h > 0) {
+        int64_t env = p / remap_h;
+        int64_t t = p - env * remap_h;
+        p = t * remap_n + env;
+    }
+    return p;
+}
+
+// ---- reductions ------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// sum within aligned groups of W lanes (W power of two <= 64)
+template <int W> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// block-wide sum of NV doubles; result valid in thread 0. blockDim.x <= 1024.
+template <int NV> __device__ __forceinline__ void block_sum(double (&v)[NV], double* smem /* [NV*16] */) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) smem[i * 16 + wid] = v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            double s = 0;
+            for (int w = 0; w < nw; ++w) s += smem[i * 16 + w];
+            v[i] = s;
+        }
+    }
+}
+
+__device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }

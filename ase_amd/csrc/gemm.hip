@@ -1,0 +1,502 @@
+// Matrix-core kernels for the dense layers of the ASE/AMP update (gfx950 / CDNA4).
+//
+//   gemm_nt : C = mask(act(alpha * A·Bᵀ + bias))      forward, data-gradient, gradient-penalty chain
+//   gemm_tn : G += alpha * Aᵀ·B                        weight gradient (split over M, f32 atomics)
+//
+// Both come in two storage types: bf16 (v_mfma_f32_32x32x16_bf16, f32 accumulate) and exact f32
+// (v_mfma_f32_32x32x2_f32).  Wave64, 256-thread workgroups (4 waves), LDS-staged tiles whose rows
+// are 128 bytes (+16 B pad => conflict-free ds_read_b128), register-staged double buffering with
+// one barrier per K-tile, XCD-aware tile order (8 XCDs, private L2s).
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kRowBytes = 128;               // one staged tile row (64 bf16 / 32 f32)
+constexpr int kLdsStride = kRowBytes + 16;   // bytes
+
+// Bijective XCD-aware remap: workgroup b runs on XCD b % 8; give each XCD a contiguous tile range.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + loc;
+}
+
+template <typename T> struct Mma;
+
+template <> struct Mma<bf16_t> {
+    // one staged row = 64 k-values = 4 steps of 16
+    template <int FM, int FN>
+    static __device__ __forceinline__ void tile(const char* sA, const char* sB, int lane, f32x16 (&acc)[FM][FN]) {
+        const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 a[FM], b[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+                a[i] = *reinterpret_cast<const bf16x8*>(sA + (i * 32 + r) * kLdsStride + (ks * 2 + h) * 16);
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                b[j] = *reinterpret_cast<const bf16x8*>(sB + (j * 32 + r) * kLdsStride + (ks * 2 + h) * 16);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+};
+
+template <> struct Mma<float> {
+    // one staged row = 32 k-values = 4 blocks of 8; within a block lane-half h holds k = 4h..4h+3
+    // and MFMA j multiplies element j of both operands (any k order is fine if A and B agree).
+    template <int FM, int FN>
+    static __device__ __forceinline__ void tile(const char* sA, const char* sB, int lane, f32x16 (&acc)[FM][FN]) {
+        const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            f32x4 a[FM], b[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+                a[i] = *reinterpret_cast<const f32x4*>(sA + (i * 32 + r) * kLdsStride + (kb * 2 + h) * 16);
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                b[j] = *reinterpret_cast<const f32x4*>(sB + (j * 32 + r) * kLdsStride + (kb * 2 + h) * 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+        }
+    }
+};
+
+// 32 rows x 8 chunks per pass: thread (lrow, lchunk) stages rows lrow + 32*i.
+template <int LOADS>
+__device__ __forceinline__ void nt_gload(uint4 (&r)[LOADS], const char* g, int64_t ld, int row0, int rows, int64_t koff) {
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+        r[i] = make_uint4(0, 0, 0, 0);
+        if (row0 + 32 * i < rows) r[i] = *reinterpret_cast<const uint4*>(g + (int64_t)(32 * i) * ld + koff);
+    }
+}
+template <int LOADS>
+__device__ __forceinline__ void nt_sstore(const uint4 (&r)[LOADS], char* s) {
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) *reinterpret_cast<uint4*>(s + (32 * i) * kLdsStride) = r[i];
+}
+
+struct NTParams {
+    const char* A; int64_t lda;     // leading dims in BYTES
+    const char* B; int64_t ldb;
+    char* C; int64_t ldc;           // bytes
+    const float* bias;
+    const char* aux; int64_t ldaux; // bytes
+    float* colsum; int colsum_n;
+    int M, N, K;                    // K in elements (multiple of 128/sizeof(T))
+    int act, aux_mode, out_f32;
+    float alpha;
+    int tiles_m, tiles_n;
+};
+
+template <typename T, int WGM, int WGN, int FM, int FN>
+__global__ __launch_bounds__(kThreads) void gemm_nt_kernel(NTParams p) {
+    constexpr int BM = WGM * FM * 32, BN = WGN * FN * 32;
+    constexpr int BK = kRowBytes / (int)sizeof(T);
+    constexpr int A_LOADS = BM / 32, B_LOADS = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int kBuf = (BM + BN) * kLdsStride;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WGN, wn = wid % WGN;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int tile = xcd_remap(blockIdx.x, nwg);
+    const int bm0 = (tile / p.tiles_n) * BM, bn0 = (tile % p.tiles_n) * BN;
+
+    const int lrow = tid >> 3, lchunk = tid & 7;
+    uint4 ra[A_LOADS], rb[B_LOADS];
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = p.K / BK;
+    const char* gA = p.A + (int64_t)(bm0 + lrow) * p.lda + lchunk * 16;
+    const char* gB = p.B + (int64_t)(bn0 + lrow) * p.ldb + lchunk * 16;
+    char* const lds_st = smem + lrow * kLdsStride + lchunk * 16;
+    nt_gload<A_LOADS>(ra, gA, p.lda, bm0 + lrow, p.M, 0);
+    nt_gload<B_LOADS>(rb, gB, p.ldb, bn0 + lrow, p.N, 0);
+    nt_sstore<A_LOADS>(ra, lds_st);
+    nt_sstore<B_LOADS>(rb, lds_st + BM * kLdsStride);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) {
+            nt_gload<A_LOADS>(ra, gA, p.lda, bm0 + lrow, p.M, (int64_t)(kt + 1) * kRowBytes);
+            nt_gload<B_LOADS>(rb, gB, p.ldb, bn0 + lrow, p.N, (int64_t)(kt + 1) * kRowBytes);
+        }
+        const char* sA = smem + buf * kBuf + (wm * FM * 32) * kLdsStride;
+        const char* sB = smem + buf * kBuf + BM * kLdsStride + (wn * FN * 32) * kLdsStride;
+        Mma<T>::template tile<FM, FN>(sA, sB, lane, acc);
+        if (kt + 1 < nk) {
+            nt_sstore<A_LOADS>(ra, lds_st + (buf ^ 1) * kBuf);
+            nt_sstore<B_LOADS>(rb, lds_st + (buf ^ 1) * kBuf + BM * kLdsStride);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    const int col_in = lane & 31, row_hi = (lane >> 5) * 4;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int n = bn0 + (wn * FN + j) * 32 + col_in;
+        const bool n_ok = n < p.N;
+        const float bias = (p.bias && n_ok) ? p.bias[n] : 0.f;
+        float csum = 0.f;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int mbase = bm0 + (wm * FM + i) * 32 + row_hi;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = mbase + (e & 3) + 8 * (e >> 2);
+                if (m < p.M && n_ok) {
+                    float v = p.alpha * acc[i][j][e] + bias;
+                    if (p.act == ASE_ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (p.act == ASE_ACT_TANH) v = tanhf(v);
+                    if (p.aux_mode != ASE_AUX_NONE) {
+                        const float a = to_f32(*reinterpret_cast<const T*>(p.aux + (int64_t)m * p.ldaux + (int64_t)n * sizeof(T)));
+                        v = (p.aux_mode == ASE_AUX_RELU_MASK) ? (a > 0.f ? v : 0.f) : v * (1.f - a * a);
+                    }
+                    if (p.out_f32) {
+                        *reinterpret_cast<float*>(p.C + (int64_t)m * p.ldc + (int64_t)n * 4) = v;
+                    } else {
+                        const T o = from_f32<T>(v);
+                        *reinterpret_cast<T*>(p.C + (int64_t)m * p.ldc + (int64_t)n * sizeof(T)) = o;
+                        v = to_f32(o);
+                    }
+                    csum += v;
+                }
+            }
+        }
+        if (p.colsum) {
+            csum += __shfl_xor(csum, 32, 64);
+            if (lane < 32 && n < p.colsum_n) atomic_add_f32(p.colsum + n, csum);
+        }
+    }
+}
+
+template <typename T, int WGM, int WGN, int FM, int FN>
+int launch_nt(const NTParams& p0, hipStream_t stream) {
+    constexpr int BM = WGM * FM * 32, BN = WGN * FN * 32;
+    constexpr int lds = 2 * (BM + BN) * kLdsStride;
+    static bool attr_done = false;
+    auto kern = gemm_nt_kernel<T, WGM, WGN, FM, FN>;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            ase_set_error("gemm_nt: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return ASE_ELAUNCH;
+        }
+        attr_done = true;
+    }
+    NTParams p = p0;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(kThreads), lds, stream, p);
+    ASE_CHECK_LAUNCH("gemm_nt");
+    return ASE_OK;
+}
+
+template <typename T> int dispatch_nt(const NTParams& p, hipStream_t s) {
+    if (p.N > 64) return launch_nt<T, 2, 2, 2, 2>(p, s);   // 128 x 128
+    if (p.N > 32) return launch_nt<T, 4, 1, 1, 2>(p, s);   // 128 x 64
+    return launch_nt<T, 4, 1, 1, 1>(p, s);                 // 128 x 32
+}
+
+// ------------------------------------------------------------------------------------------------
+// TN: G[n, k] += alpha * sum_m A[m, n] * B[m, k].  The contraction runs over ROWS of both operands,
+// so fragments need the transpose of what a row-major tile holds:
+//   bf16: ds_read_b64_tr_b16 (gfx950 LDS transpose read) delivers 4 consecutive m for one column;
+//   f32 : the 32x32x2 MFMA takes one scalar per lane, so a plain ds_read_b32 walks a tile row.
+// ------------------------------------------------------------------------------------------------
+struct TNParams {
+    const char* A; int64_t lda;   // bytes
+    const char* B; int64_t ldb;   // bytes
+    float* G;
+    int M, N, K;                  // padded widths N (of A), K (of B), in elements
+    int n_real, k_real, split_src, split_dst;
+    float alpha;
+    int tiles_n, tiles_k, m_chunk;
+};
+
+template <typename T> struct TNGeom;
+template <> struct TNGeom<bf16_t> { static constexpr int BKM = 64, ROWB = 256, STRIDE = 256 + 16, CPR = 16; };
+template <> struct TNGeom<float>  { static constexpr int BKM = 16, ROWB = 512, STRIDE = 512 + 16, CPR = 32; };
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+__device__ __forceinline__ bf16x4 lds_tr_read(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+        (lds_bf16x4*)(__attribute__((address_space(3))) void*)(p));
+}
+
+template <typename T, int LOADS>
+__device__ __forceinline__ void tn_gload(uint4 (&ra)[LOADS], uint4 (&rb)[LOADS], const TNParams& p, int tid, int m0,
+                                         int m_end, int bn0, int bk0) {
+    constexpr int CPR = TNGeom<T>::CPR, EPC = 16 / (int)sizeof(T);
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+        const int c = tid + kThreads * i;
+        const int row = c / CPR, ch = c % CPR;
+        const int m = m0 + row;
+        const int ca = bn0 + ch * EPC, cb = bk0 + ch * EPC;
+        ra[i] = make_uint4(0, 0, 0, 0);
+        rb[i] = make_uint4(0, 0, 0, 0);
+        if (m < m_end && ca < p.N) ra[i] = *reinterpret_cast<const uint4*>(p.A + (int64_t)m * p.lda + (int64_t)ca * sizeof(T));
+        if (m < m_end && cb < p.K) rb[i] = *reinterpret_cast<const uint4*>(p.B + (int64_t)m * p.ldb + (int64_t)cb * sizeof(T));
+    }
+}
+template <typename T, int LOADS>
+__device__ __forceinline__ void tn_sstore(const uint4 (&ra)[LOADS], const uint4 (&rb)[LOADS], char* sbuf, int tid) {
+    constexpr int CPR = TNGeom<T>::CPR, STRIDE = TNGeom<T>::STRIDE, kOp = TNGeom<T>::BKM * TNGeom<T>::STRIDE;
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+        const int c = tid + kThreads * i;
+        const int row = c / CPR, ch = c % CPR;
+        *reinterpret_cast<uint4*>(sbuf + row * STRIDE + ch * 16) = ra[i];
+        *reinterpret_cast<uint4*>(sbuf + kOp + row * STRIDE + ch * 16) = rb[i];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void gemm_tn_kernel(TNParams p) {
+    using Gm = TNGeom<T>;
+    constexpr int BKM = Gm::BKM, STRIDE = Gm::STRIDE, CPR = Gm::CPR;
+    constexpr int LOADS = BKM * CPR / kThreads;          // 16-B chunks per thread per operand
+    constexpr int kOp = BKM * STRIDE;                    // bytes per operand tile
+    constexpr int EPC = 16 / (int)sizeof(T);             // elements per chunk
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wi = wid >> 1, wj = wid & 1;               // wave position in the 128x128 output tile
+    const int nwg = p.tiles_n * p.tiles_k;
+    const int tile = xcd_remap(blockIdx.x, nwg);
+    const int bn0 = (tile / p.tiles_k) * 128, bk0 = (tile % p.tiles_k) * 128;
+    const int m_begin = blockIdx.z * p.m_chunk;
+    const int m_end = min(p.M, m_begin + p.m_chunk);
+    if (m_begin >= m_end) return;
+
+    uint4 ra[LOADS], rb[LOADS];
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nt = (m_end - m_begin + BKM - 1) / BKM;
+    tn_gload<T, LOADS>(ra, rb, p, tid, m_begin, m_end, bn0, bk0);
+    tn_sstore<T, LOADS>(ra, rb, smem, tid);
+    __syncthreads();
+    for (int mt = 0; mt < nt; ++mt) {
+        const int buf = mt & 1;
+        if (mt + 1 < nt) tn_gload<T, LOADS>(ra, rb, p, tid, m_begin + (mt + 1) * BKM, m_end, bn0, bk0);
+        const char* sA = smem + buf * 2 * kOp;
+        const char* sB = sA + kOp;
+        if constexpr (sizeof(T) == 2) {
+            // lane l: 16-lane group g = l>>4 -> half h = g>>1 (k-group of the MFMA), column group cg = g&1;
+            // within the group lane t supplies the address of row (t>>2), columns (t&3)*4..+3 and receives
+            // column t of the 4x16 block (4 consecutive m).
+            const int t = lane & 15, g = lane >> 4, h = g >> 1, cg = g & 1;
+            const int arow = h * 8 + (t >> 2);
+            const int acol = cg * 16 + (t & 3) * 4;
+#pragma unroll
+            for (int ks = 0; ks < BKM / 16; ++ks) {
+                bf16x8 a[2], b[2];
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    const char* pa = sA + (ks * 16 + arow) * STRIDE + ((wi * 2 + f) * 32 + acol) * 2;
+                    const char* pb = sB + (ks * 16 + arow) * STRIDE + ((wj * 2 + f) * 32 + acol) * 2;
+                    const bf16x4 a0 = lds_tr_read(pa), a1 = lds_tr_read(pa + 4 * STRIDE);
+                    const bf16x4 b0 = lds_tr_read(pb), b1 = lds_tr_read(pb + 4 * STRIDE);
+                    a[f] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    b[f] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+            for (int ks = 0; ks < BKM / 2; ++ks) {
+                float a[2], b[2];
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    a[f] = *reinterpret_cast<const float*>(sA + (ks * 2 + h) * STRIDE + ((wi * 2 + f) * 32 + r) * 4);
+                    b[f] = *reinterpret_cast<const float*>(sB + (ks * 2 + h) * STRIDE + ((wj * 2 + f) * 32 + r) * 4);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (mt + 1 < nt) tn_sstore<T, LOADS>(ra, rb, smem + (buf ^ 1) * 2 * kOp, tid);
+        __syncthreads();
+    }
+
+    const int col_in = lane & 31, row_hi = (lane >> 5) * 4;
+    const int gap = p.split_dst - p.split_src;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int k = bk0 + (wj * 2 + j) * 32 + col_in;
+        int kk = -1;
+        if (k < p.split_src) kk = k;
+        else if (k >= p.split_dst && k - gap < p.k_real) kk = k - gap;
+        if (kk < 0) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int nbase = bn0 + (wi * 2 + i) * 32 + row_hi;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = nbase + (e & 3) + 8 * (e >> 2);
+                if (n < p.n_real) atomic_add_f32(p.G + (int64_t)n * p.k_real + kk, p.alpha * acc[i][j][e]);
+            }
+        }
+    }
+}
+
+template <typename T> int launch_tn(TNParams p, hipStream_t stream) {
+    using Gm = TNGeom<T>;
+    constexpr int lds = 4 * Gm::BKM * Gm::STRIDE;
+    static bool attr_done = false;
+    auto kern = gemm_tn_kernel<T>;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            ase_set_error("gemm_tn: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return ASE_ELAUNCH;
+        }
+        attr_done = true;
+    }
+    p.tiles_n = (p.n_real + 127) / 128;
+    p.tiles_k = (p.K + 127) / 128;
+    const int tiles = p.tiles_n * p.tiles_k;
+    int splits = (1024 + tiles - 1) / tiles;                       // aim at >= 1024 workgroups (256 CUs)
+    const int max_splits = (p.M + 4 * Gm::BKM - 1) / (4 * Gm::BKM); // >= 4 staged tiles per split
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    int chunk = (p.M + splits - 1) / splits;
+    chunk = (chunk + Gm::BKM - 1) / Gm::BKM * Gm::BKM;
+    splits = (p.M + chunk - 1) / chunk;
+    p.m_chunk = chunk;
+    hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(kThreads), lds, stream, p);
+    ASE_CHECK_LAUNCH("gemm_tn");
+    return ASE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// refresh_shadow: f32 master [n_real, k_real] -> dtype W_s [*, ldws] and transposed Wt_s [*, ldwts]
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void refresh_shadow_kernel(const float* __restrict__ W, int n_real, int k_real, T* __restrict__ Ws,
+                                      int64_t ldws, T* __restrict__ Wts, int64_t ldwts, int split_src, int gap) {
+    __shared__ float tile[32][33];
+    const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + ty + 8 * i, k = k0 + tx;
+        float v = 0.f;
+        if (n < n_real && k < k_real) v = W[(int64_t)n * k_real + k];
+        tile[ty + 8 * i][tx] = v;
+        if (Ws && n < n_real && k < k_real) {
+            const int kd = (k < split_src) ? k : k + gap;
+            Ws[(int64_t)n * ldws + kd] = from_f32<T>(v);
+        }
+    }
+    __syncthreads();
+    if (Wts) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + ty + 8 * i, n = n0 + tx;
+            if (k < k_real && n < n_real) {
+                const int kd = (k < split_src) ? k : k + gap;
+                Wts[(int64_t)kd * ldwts + n] = from_f32<T>(tile[tx][ty + 8 * i]);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int ase_hip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                               const float* bias, const void* aux, int64_t ldaux, float* colsum, int colsum_n,
+                               int M, int N, int K, int act, int aux_mode, int out_f32, float alpha, int dtype, void* stream) {
+    const int es = (dtype == ASE_BF16) ? 2 : 4;
+    ASE_CHECK_ARG(dtype == ASE_F32 || dtype == ASE_BF16, "gemm_nt: bad dtype %d", dtype);
+    ASE_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0, "gemm_nt: null/empty operand (M=%d N=%d K=%d)", M, N, K);
+    ASE_CHECK_ARG((K * es) % kRowBytes == 0, "gemm_nt: K=%d is not a multiple of %d elements", K, kRowBytes / es);
+    ASE_CHECK_ARG(lda >= K && ldb >= K && ldc >= N, "gemm_nt: leading dimension too small");
+    ASE_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && (lda * es) % 16 == 0 && (ldb * es) % 16 == 0,
+                  "gemm_nt: A/B must be 16-byte aligned with 16-byte row pitch");
+    ASE_CHECK_ARG(aux_mode == ASE_AUX_NONE || aux != nullptr, "gemm_nt: aux_mode %d without aux", aux_mode);
+    NTParams p;
+    p.A = (const char*)A; p.lda = lda * es;
+    p.B = (const char*)B; p.ldb = ldb * es;
+    p.C = (char*)C; p.ldc = ldc * (out_f32 ? 4 : es);
+    p.bias = bias; p.aux = (const char*)aux; p.ldaux = ldaux * es; p.colsum = colsum; p.colsum_n = colsum ? colsum_n : 0;
+    p.M = M; p.N = N; p.K = K; p.act = act; p.aux_mode = aux_mode; p.out_f32 = out_f32; p.alpha = alpha;
+    p.tiles_m = p.tiles_n = 0;
+    return dtype == ASE_BF16 ? dispatch_nt<bf16_t>(p, (hipStream_t)stream) : dispatch_nt<float>(p, (hipStream_t)stream);
+}
+
+extern "C" int ase_hip_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* G, int M, int N, int K,
+                               int n_real, int k_real, int split_src, int split_dst, float alpha, int dtype,
+                               void* stream) {
+    const int es = (dtype == ASE_BF16) ? 2 : 4;
+    ASE_CHECK_ARG(dtype == ASE_F32 || dtype == ASE_BF16, "gemm_tn: bad dtype %d", dtype);
+    ASE_CHECK_ARG(A && B && G && M > 0 && N > 0 && K > 0, "gemm_tn: null/empty operand");
+    ASE_CHECK_ARG((N * es) % 16 == 0 && (K * es) % 16 == 0, "gemm_tn: N=%d / K=%d must cover whole 16-byte chunks", N, K);
+    ASE_CHECK_ARG(lda >= N && ldb >= K, "gemm_tn: leading dimension too small");
+    ASE_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && (lda * es) % 16 == 0 && (ldb * es) % 16 == 0,
+                  "gemm_tn: A/B must be 16-byte aligned with 16-byte row pitch");
+    ASE_CHECK_ARG(n_real > 0 && n_real <= N && k_real > 0 && split_src <= split_dst && split_src <= k_real,
+                  "gemm_tn: bad real dims / split");
+    TNParams p;
+    p.A = (const char*)A; p.lda = lda * es; p.B = (const char*)B; p.ldb = ldb * es; p.G = G;
+    p.M = M; p.N = N; p.K = K; p.n_real = n_real; p.k_real = k_real; p.split_src = split_src; p.split_dst = split_dst;
+    p.alpha = alpha; p.tiles_n = p.tiles_k = p.m_chunk = 0;
+    return dtype == ASE_BF16 ? launch_tn<bf16_t>(p, (hipStream_t)stream) : launch_tn<float>(p, (hipStream_t)stream);
+}
+
+extern "C" int ase_hip_refresh_shadow(const float* W, int n_real, int k_real, void* Ws, int64_t ldws, void* Wts,
+                                      int64_t ldwts, int split_src, int split_dst, int dtype, void* stream) {
+    ASE_CHECK_ARG(W && n_real > 0 && k_real > 0 && (Ws || Wts), "refresh_shadow: null/empty operand");
+    ASE_CHECK_ARG(split_src <= split_dst && split_src <= k_real, "refresh_shadow: bad split");
+    const dim3 grid((k_real + 31) / 32, (n_real + 31) / 32), block(256);
+    const int gap = split_dst - split_src;
+    if (dtype == ASE_BF16)
+        hipLaunchKernelGGL(refresh_shadow_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, W, n_real, k_real,
+                           (bf16_t*)Ws, ldws, (bf16_t*)Wts, ldwts, split_src, gap);
+    else if (dtype == ASE_F32)
+        hipLaunchKernelGGL(refresh_shadow_kernel<float>, grid, block, 0, (hipStream_t)stream, W, n_real, k_real,
+                           (float*)Ws, ldws, (float*)Wts, ldwts, split_src, gap);
+    else
+        ASE_CHECK_ARG(false, "refresh_shadow: bad dtype %d", dtype);
+    ASE_CHECK_LAUNCH("refresh_shadow");
+    return ASE_OK;
+}

@@ -1,0 +1,469 @@
+// Loss heads of the ASE/AMP/PPO update: forward value and analytic input-gradient in one pass,
+// f32 math (as the reference), f64 accumulators for the reported scalars.
+#include "common.h"
+
+namespace {
+
+constexpr float kHalfLog2Pi = 0.91893853320467274178f;  // 0.5 * ln(2*pi)
+
+__global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict__ x, int64_t n, int square,
+                                                         double* __restrict__ acc) {
+    __shared__ double sm[16];
+    double v[1] = {0.0};
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double t = (double)x[i];
+        v[0] += square ? t * t : t;
+    }
+    block_sum<1>(v, sm);
+    if (threadIdx.x == 0) atomic_add_f64(acc, v[0]);
+}
+
+struct PpoArgs {
+    const float* mu; int64_t ld_mu;
+    const float* value; int64_t ld_v;
+    const float *actions, *old_mu, *old_sigma, *old_logp, *adv, *old_value, *ret, *mask, *z, *new_z, *logstd;
+    void* d_mu; int64_t ld_dmu;
+    void* d_value; int64_t ld_dv;
+    float *db_mu, *db_value, *mu_out;
+    double* acc;
+    int M, m_global, act_dim, z_dim, masked, div_on, mu_tanh, clip_value;
+    float e_clip, critic_coef, bounds_coef, div_coef, div_tar;
+};
+
+// 32 lanes per row (act_dim <= 32), 8 rows per 256-thread block.
+template <typename T>
+__global__ __launch_bounds__(256) void ppo_head_kernel(PpoArgs p) {
+    __shared__ double sm[7 * 16];
+    __shared__ float sdb[8][33];
+    const int lane = threadIdx.x & 31;
+    float gm_out = 0.f, gm2_out = 0.f, dv_out = 0.f;
+    const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const bool row_ok = i < p.M;
+    const bool act_ok = row_ok && lane < p.act_dim;
+    const int D = p.act_dim;
+    double part[7] = {0, 0, 0, 0, 0, 0, 0};  // a_loss, b_loss, entropy, clipped, c_loss, kl, div
+
+    if (row_ok) {
+        const float S = p.masked ? (float)p.acc[ASE_ACC_MASK_SUM] : (float)p.m_global;
+        const float mk = p.masked ? p.mask[i] : 1.f;
+        const float w = mk / S;
+
+        float m = 0.f, a = 0.f, ls = 0.f, sg = 1.f, d = 0.f, omu = 0.f, osg = 1.f;
+        if (act_ok) {
+            const float raw = p.mu[(int64_t)i * p.ld_mu + lane];
+            m = p.mu_tanh ? tanhf(raw) : raw;
+            a = p.actions[(int64_t)i * D + lane];
+            ls = p.logstd[lane];
+            sg = expf(ls);
+            d = (a - m) / sg;
+            omu = p.old_mu[(int64_t)i * D + lane];
+            osg = p.old_sigma[(int64_t)i * D + lane];
+            if (p.mu_out) p.mu_out[(int64_t)i * D + lane] = m;
+        }
+        const float sum_d2 = group_sum<32>(act_ok ? d * d : 0.f);
+        const float sum_ls = group_sum<32>(act_ok ? ls : 0.f);
+        const float nlp = 0.5f * sum_d2 + kHalfLog2Pi * (float)D + sum_ls;
+        const float ratio = expf(p.old_logp[i] - nlp);
+        const float adv = p.adv[i];
+        const float rc = fminf(fmaxf(ratio, 1.f - p.e_clip), 1.f + p.e_clip);
+        const float s1 = -adv * ratio, s2 = -adv * rc;
+        const float a_loss = fmaxf(s1, s2);
+        float g;  // d a_loss / d ratio  (torch.max splits ties evenly; clamp passes gradient inside [lo, hi])
+        if (ratio == rc) g = -adv;
+        else g = (s1 > s2) ? -adv : ((s1 == s2) ? -0.5f * adv : 0.f);
+
+        // bound loss, entropy, KL (rl_games policy_kl(p0 = new, p1 = old))
+        const float bh = fmaxf(m - 1.f, 0.f), bl = fminf(m + 1.f, 0.f);
+        const float b_row = group_sum<32>(act_ok ? bh * bh + bl * bl : 0.f);
+        const float ent_row = group_sum<32>(act_ok ? 0.5f + kHalfLog2Pi + ls : 0.f);
+        float klj = 0.f;
+        if (act_ok) {
+            const float c1 = logf(osg / sg + 1e-5f);
+            const float c2 = (sg * sg + (omu - m) * (omu - m)) / (2.f * (osg * osg + 1e-5f));
+            klj = c1 + c2 - 0.5f;
+        }
+        const float kl_row = group_sum<32>(klj);
+
+        float gm = w * g * ratio * d / sg + p.bounds_coef * w * 2.f * (bh + bl);
+
+        // diversity (learning/ase_agent.py:445-467)
+        float div_row = 0.f, gm2 = 0.f, m2 = 0.f;
+        if (p.div_on) {
+            float cm = 0.f, cm2 = 0.f;
+            if (act_ok) {
+                const float raw2 = p.mu[(int64_t)(p.M + i) * p.ld_mu + lane];
+                m2 = p.mu_tanh ? tanhf(raw2) : raw2;
+                cm = fminf(fmaxf(m, -1.f), 1.f);
+                cm2 = fminf(fmaxf(m2, -1.f), 1.f);
+            }
+            const float diff = cm - cm2;
+            const float a_diff = group_sum<32>(act_ok ? diff * diff : 0.f) / (float)D;
+            float zz = 0.f;
+            for (int k = lane; k < p.z_dim; k += 32) zz += p.new_z[(int64_t)i * p.z_dim + k] * p.z[(int64_t)i * p.z_dim + k];
+            zz = group_sum<32>(zz);
+            const float z_diff = 0.5f - 0.5f * zz;
+            const float inv = 1.f / (z_diff + 1e-5f);
+            const float bonus = a_diff * inv;
+            const float t = p.div_tar - bonus;
+            div_row = t * t;
+            const float dl_dbonus = p.div_coef * w * 2.f * (bonus - p.div_tar);
+            const float db = dl_dbonus * 2.f * diff / (float)D * inv;
+            if (act_ok) {
+                if (m >= -1.f && m <= 1.f) gm += db;
+                if (m2 >= -1.f && m2 <= 1.f) gm2 = -db;
+            }
+        }
+        if (act_ok) {
+            if (p.mu_tanh) {
+                gm *= (1.f - m * m);
+                gm2 *= (1.f - m2 * m2);
+            }
+            const T o1 = from_f32<T>(gm), o2 = from_f32<T>(gm2);
+            reinterpret_cast<T*>(p.d_mu)[(int64_t)i * p.ld_dmu + lane] = o1;
+            if (p.div_on) reinterpret_cast<T*>(p.d_mu)[(int64_t)(p.M + i) * p.ld_dmu + lane] = o2;
+            gm_out = to_f32(o1);
+            gm2_out = p.div_on ? to_f32(o2) : 0.f;
+        }
+
+        if (lane == 0) {
+            // critic (learning/common_agent.py:521-534)
+            const float v = p.value[(int64_t)i * p.ld_v];
+            const float R = p.ret[i];
+            float c, dv;
+            if (p.clip_value) {
+                const float ov = p.old_value[i];
+                const float dlt = v - ov;
+                const float vpc = ov + fminf(fmaxf(dlt, -p.e_clip), p.e_clip);
+                const float l1 = (v - R) * (v - R), l2 = (vpc - R) * (vpc - R);
+                const float inside = (dlt >= -p.e_clip && dlt <= p.e_clip) ? 1.f : 0.f;
+                c = fmaxf(l1, l2);
+                const float g1 = 2.f * (v - R), g2 = 2.f * (vpc - R) * inside;
+                dv = (l1 > l2) ? g1 : ((l1 < l2) ? g2 : 0.5f * (g1 + g2));
+            } else {
+                c = (R - v) * (R - v);
+                dv = 2.f * (v - R);
+            }
+            const T ov = from_f32<T>(p.critic_coef * dv / (float)p.m_global);
+            reinterpret_cast<T*>(p.d_value)[(int64_t)i * p.ld_dv] = ov;
+            dv_out = to_f32(ov);
+            part[0] = (double)(mk * a_loss);
+            part[1] = (double)(mk * b_row);
+            part[2] = (double)(mk * ent_row);
+            part[3] = (double)(mk * ((fabsf(ratio - 1.f) > p.e_clip) ? 1.f : 0.f));
+            part[4] = (double)c;
+            part[5] = (double)kl_row;
+            part[6] = (double)(mk * div_row);
+        }
+    }
+    if (p.db_mu) {  // head bias gradients: column sums over this block's 8 rows, one atomic per column
+        sdb[threadIdx.x >> 5][lane] = gm_out + gm2_out;
+        if (lane == 0) sdb[threadIdx.x >> 5][32] = dv_out;
+        __syncthreads();
+        if (threadIdx.x < 33) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t += sdb[q][threadIdx.x];
+            if (threadIdx.x < p.act_dim) atomic_add_f32(p.db_mu + threadIdx.x, t);
+            else if (threadIdx.x == 32 && p.db_value) atomic_add_f32(p.db_value, t);
+        }
+    }
+    block_sum<7>(part, sm);
+    if (threadIdx.x == 0) {
+        atomic_add_f64(p.acc + ASE_ACC_A_LOSS, part[0]);
+        atomic_add_f64(p.acc + ASE_ACC_B_LOSS, part[1]);
+        atomic_add_f64(p.acc + ASE_ACC_ENTROPY, part[2]);
+        atomic_add_f64(p.acc + ASE_ACC_CLIPPED, part[3]);
+        atomic_add_f64(p.acc + ASE_ACC_C_LOSS, part[4]);
+        atomic_add_f64(p.acc + ASE_ACC_KL, part[5]);
+        if (p.div_on) atomic_add_f64(p.acc + ASE_ACC_DIV, part[6]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void disc_head_kernel(const float* __restrict__ logit, int64_t ld_l, T* __restrict__ d_logit,
+                                                        int64_t ld_d, float* __restrict__ db_logit, double* __restrict__ acc,
+                                                        int amb, int amb_global, float disc_coef) {
+    __shared__ double sm[5 * 16];
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    double part[5] = {0, 0, 0, 0, 0};  // bce agent, bce demo, agent acc, demo acc, sum of d_logit
+    if (r < 3 * amb) {
+        const float l = logit[(int64_t)r * ld_l];
+        const float sp_abs = log1pf(expf(-fabsf(l)));
+        float g;
+        if (r < 2 * amb) {  // BCE(l, 0) = softplus(l)
+            part[0] = (double)(fmaxf(l, 0.f) + sp_abs);
+            part[2] = (l < 0.f) ? 1.0 : 0.0;
+            const float sig = 1.f / (1.f + expf(-l));
+            g = disc_coef * 0.5f * sig / (2.f * (float)amb_global);
+        } else {            // BCE(l, 1) = softplus(-l)
+            part[1] = (double)(fmaxf(-l, 0.f) + sp_abs);
+            part[3] = (l > 0.f) ? 1.0 : 0.0;
+            const float sig_neg = 1.f / (1.f + expf(l));
+            g = -disc_coef * 0.5f * sig_neg / (float)amb_global;
+        }
+        const T o = from_f32<T>(g);
+        d_logit[(int64_t)r * ld_d] = o;
+        part[4] = (double)to_f32(o);
+    }
+    block_sum<5>(part, sm);
+    if (threadIdx.x == 0) {
+        if (db_logit) atomic_add_f32(db_logit, (float)part[4]);
+        atomic_add_f64(acc + ASE_ACC_BCE_AGENT, part[0]);
+        atomic_add_f64(acc + ASE_ACC_BCE_DEMO, part[1]);
+        atomic_add_f64(acc + ASE_ACC_AGENT_ACC, part[2]);
+        atomic_add_f64(acc + ASE_ACC_DEMO_ACC, part[3]);
+    }
+}
+
+// one wave per row; z_dim <= 128
+template <typename T>
+__global__ __launch_bounds__(256) void enc_head_kernel(const float* __restrict__ e, int64_t ld_e, const float* __restrict__ z,
+                                                       int64_t ld_z, T* __restrict__ d_e, int64_t ld_de,
+                                                       float* __restrict__ db_enc, float* __restrict__ enc_out,
+                                                       double* __restrict__ acc, int amb, int amb_global, int z_dim,
+                                                       float enc_coef) {
+    __shared__ double sm[16];
+    __shared__ float sdb[4][128];
+    float dbv[2] = {0.f, 0.f};
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    double part[1] = {0.0};
+    if (r < amb) {
+        float ev[2] = {0.f, 0.f}, zv[2] = {0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int j = lane + 64 * q;
+            if (j < z_dim) {
+                ev[q] = e[(int64_t)r * ld_e + j];
+                zv[q] = z[(int64_t)r * ld_z + j];
+            }
+        }
+        const float ss = wave_sum(ev[0] * ev[0] + ev[1] * ev[1]);
+        const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+        const float h0 = ev[0] / nrm, h1 = ev[1] / nrm;
+        const float dot = wave_sum(h0 * zv[0] + h1 * zv[1]);
+        const float sc = enc_coef / (float)amb_global;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int j = lane + 64 * q;
+            if (j < z_dim) {
+                const float h = q ? h1 : h0;
+                const T o = from_f32<T>(-sc * (zv[q] - h * dot) / nrm);
+                d_e[(int64_t)r * ld_de + j] = o;
+                dbv[q] = to_f32(o);
+                if (enc_out) enc_out[(int64_t)r * z_dim + j] = h;
+            }
+        }
+        if (lane == 0) part[0] = (double)(-dot);
+    }
+    if (db_enc) {
+        sdb[threadIdx.x >> 6][lane] = dbv[0];
+        sdb[threadIdx.x >> 6][lane + 64] = dbv[1];
+        __syncthreads();
+        if (threadIdx.x < z_dim) {
+            const float t = sdb[0][threadIdx.x] + sdb[1][threadIdx.x] + sdb[2][threadIdx.x] + sdb[3][threadIdx.x];
+            atomic_add_f32(db_enc + threadIdx.x, t);
+        }
+    }
+    block_sum<1>(part, sm);
+    if (threadIdx.x == 0) atomic_add_f64(acc + ASE_ACC_ENC, part[0]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gp_seed_kernel(const T* __restrict__ h, int64_t ld_h, const float* __restrict__ w,
+                                                      T* __restrict__ g, int64_t ld_g, int rows, int width) {
+    const int64_t n = (int64_t)rows * width;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / width), j = (int)(i - (int64_t)r * width);
+        const float hv = to_f32(h[(int64_t)r * ld_h + j]);
+        g[(int64_t)r * ld_g + j] = from_f32<T>(hv > 0.f ? w[j] : 0.f);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sqnorm_kernel(const T* __restrict__ x, int64_t ld, int rows, int cols,
+                                                     double* __restrict__ acc) {
+    __shared__ double sm[16];
+    const int64_t n = (int64_t)rows * cols;
+    double v[1] = {0.0};
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / cols), j = (int)(i - (int64_t)r * cols);
+        const double t = (double)to_f32(x[(int64_t)r * ld + j]);
+        v[0] += t * t;
+    }
+    block_sum<1>(v, sm);
+    if (threadIdx.x == 0) atomic_add_f64(acc, v[0]);
+}
+
+struct FinArgs {
+    int m_global, amb_global, masked, has_disc, has_enc, has_div;
+    float critic_coef, entropy_coef, bounds_coef, disc_coef, disc_logit_reg, disc_grad_penalty, disc_weight_decay,
+        enc_coef, enc_weight_decay, div_coef;
+};
+
+__global__ void finalize_scalars_kernel(const double* __restrict__ acc, float* __restrict__ out, FinArgs a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double S = acc[ASE_ACC_MASK_SUM];
+    const double den = a.masked ? S : (double)a.m_global;
+    const double al = acc[ASE_ACC_A_LOSS] / den, bl = acc[ASE_ACC_B_LOSS] / den, ent = acc[ASE_ACC_ENTROPY] / den;
+    const double cf = acc[ASE_ACC_CLIPPED] / den;
+    const double cl = acc[ASE_ACC_C_LOSS] / (double)a.m_global, kl = acc[ASE_ACC_KL] / (double)a.m_global;
+    double loss = al + a.critic_coef * cl - a.entropy_coef * ent + a.bounds_coef * bl;
+    for (int i = 0; i < ASE_RES_COUNT; ++i) out[i] = 0.f;
+    out[ASE_RES_A_LOSS] = (float)al;
+    out[ASE_RES_C_LOSS] = (float)cl;
+    out[ASE_RES_B_LOSS] = (float)bl;
+    out[ASE_RES_ENTROPY] = (float)ent;
+    out[ASE_RES_CLIP_FRAC] = (float)cf;
+    out[ASE_RES_KL] = (float)kl;
+    out[ASE_RES_MASK_SUM] = (float)S;
+    if (a.has_disc) {
+        const double amb = (double)a.amb_global;
+        const double bce = 0.5 * (acc[ASE_ACC_BCE_AGENT] / (2.0 * amb) + acc[ASE_ACC_BCE_DEMO] / amb);
+        const double gp = acc[ASE_ACC_GP] / amb;
+        const double dl = bce + a.disc_logit_reg * acc[ASE_ACC_LOGIT_W2] + a.disc_grad_penalty * gp +
+                          a.disc_weight_decay * acc[ASE_ACC_DISC_W2];
+        loss += a.disc_coef * dl;
+        out[ASE_RES_DISC_LOSS] = (float)dl;
+        out[ASE_RES_DISC_GP] = (float)gp;
+        out[ASE_RES_DISC_LOGIT_LOSS] = (float)acc[ASE_ACC_LOGIT_W2];
+        out[ASE_RES_DISC_AGENT_ACC] = (float)(acc[ASE_ACC_AGENT_ACC] / (2.0 * amb));
+        out[ASE_RES_DISC_DEMO_ACC] = (float)(acc[ASE_ACC_DEMO_ACC] / amb);
+    }
+    if (a.has_enc) {
+        const double el = acc[ASE_ACC_ENC] / (double)a.amb_global + a.enc_weight_decay * acc[ASE_ACC_ENC_W2];
+        loss += a.enc_coef * el;
+        out[ASE_RES_ENC_LOSS] = (float)el;
+    }
+    if (a.has_div) {
+        const double dv = acc[ASE_ACC_DIV] / S;
+        loss += a.div_coef * dv;
+        out[ASE_RES_DIV_LOSS] = (float)dv;
+    }
+    out[ASE_RES_LOSS] = (float)loss;
+}
+
+inline int grid_for(int64_t n, int block = 256, int cap = 2048) {
+    int64_t g = (n + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" int ase_hip_reduce_sum(const float* x, int64_t n, int square, double* acc, int slot, void* stream) {
+    ASE_CHECK_ARG(x && acc && n > 0 && slot >= 0, "reduce_sum: null/empty operand");
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, x, n, square,
+                       acc + slot);
+    ASE_CHECK_LAUNCH("reduce_sum");
+    return ASE_OK;
+}
+
+extern "C" int ase_hip_ppo_head(const float* mu, int64_t ld_mu, const float* value, int64_t ld_v,
+                                const float* mb_actions, const float* mb_old_mu, const float* mb_old_sigma,
+                                const float* mb_old_logp, const float* mb_adv, const float* mb_old_value,
+                                const float* mb_return, const float* mb_mask, const float* mb_z, const float* new_z,
+                                const float* logstd, void* d_mu, int64_t ld_dmu, void* d_value, int64_t ld_dv,
+                                float* db_mu, float* db_value, float* mu_out, double* acc, int M, int m_global, int act_dim, int z_dim, int masked,
+                                int div_on, int mu_tanh, int clip_value, float e_clip, float critic_coef,
+                                float bounds_coef, float div_coef, float div_tar, int dtype, void* stream) {
+    ASE_CHECK_ARG(mu && value && mb_actions && mb_old_mu && mb_old_sigma && mb_old_logp && mb_adv && mb_return &&
+                      logstd && d_mu && d_value && acc && M > 0 && m_global >= M,
+                  "ppo_head: null/empty operand");
+    ASE_CHECK_ARG(act_dim >= 1 && act_dim <= 32, "ppo_head: act_dim %d not in [1,32]", act_dim);
+    ASE_CHECK_ARG(!masked || mb_mask, "ppo_head: masked reduction without a mask");
+    ASE_CHECK_ARG(!div_on || (mb_z && new_z && z_dim > 0), "ppo_head: diversity loss without latents");
+    ASE_CHECK_ARG(!clip_value || mb_old_value, "ppo_head: clip_value without old values");
+    PpoArgs p;
+    p.mu = mu; p.ld_mu = ld_mu; p.value = value; p.ld_v = ld_v;
+    p.actions = mb_actions; p.old_mu = mb_old_mu; p.old_sigma = mb_old_sigma; p.old_logp = mb_old_logp;
+    p.adv = mb_adv; p.old_value = mb_old_value; p.ret = mb_return; p.mask = mb_mask; p.z = mb_z; p.new_z = new_z;
+    p.logstd = logstd; p.d_mu = d_mu; p.ld_dmu = ld_dmu; p.d_value = d_value; p.ld_dv = ld_dv; p.db_mu = db_mu; p.db_value = db_value; p.mu_out = mu_out;
+    p.acc = acc; p.M = M; p.m_global = m_global; p.act_dim = act_dim; p.z_dim = z_dim; p.masked = masked;
+    p.div_on = div_on; p.mu_tanh = mu_tanh; p.clip_value = clip_value; p.e_clip = e_clip; p.critic_coef = critic_coef;
+    p.bounds_coef = bounds_coef; p.div_coef = div_coef; p.div_tar = div_tar;
+    const dim3 grid((M + 7) / 8);
+    if (dtype == ASE_BF16) hipLaunchKernelGGL(ppo_head_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else if (dtype == ASE_F32) hipLaunchKernelGGL(ppo_head_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else ASE_CHECK_ARG(false, "ppo_head: bad dtype %d", dtype);
+    ASE_CHECK_LAUNCH("ppo_head");
+    return ASE_OK;
+}
+
+extern "C" int ase_hip_disc_head(const float* logit, int64_t ld_l, void* d_logit, int64_t ld_d, float* db_logit,
+                                 double* acc, int amb, int amb_global, float disc_coef, int dtype, void* stream) {
+    ASE_CHECK_ARG(logit && d_logit && acc && amb > 0 && amb_global >= amb, "disc_head: null/empty operand");
+    const dim3 grid((3 * amb + 255) / 256);
+    if (dtype == ASE_BF16)
+        hipLaunchKernelGGL(disc_head_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, logit, ld_l,
+                           (bf16_t*)d_logit, ld_d, db_logit, acc, amb, amb_global, disc_coef);
+    else if (dtype == ASE_F32)
+        hipLaunchKernelGGL(disc_head_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, logit, ld_l,
+                           (float*)d_logit, ld_d, db_logit, acc, amb, amb_global, disc_coef);
+    else ASE_CHECK_ARG(false, "disc_head: bad dtype %d", dtype);
+    ASE_CHECK_LAUNCH("disc_head");
+    return ASE_OK;
+}
+
+extern "C" int ase_hip_enc_head(const float* e, int64_t ld_e, const float* z, int64_t ld_z, void* d_e, int64_t ld_de,
+                                float* db_enc, float* enc_out, double* acc, int amb, int amb_global, int z_dim, float enc_coef,
+                                int dtype, void* stream) {
+    ASE_CHECK_ARG(e && z && d_e && acc && amb > 0 && amb_global >= amb, "enc_head: null/empty operand");
+    ASE_CHECK_ARG(z_dim >= 1 && z_dim <= 128, "enc_head: z_dim %d not in [1,128]", z_dim);
+    const dim3 grid((amb + 3) / 4);
+    if (dtype == ASE_BF16)
+        hipLaunchKernelGGL(enc_head_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, e, ld_e, z, ld_z,
+                           (bf16_t*)d_e, ld_de, db_enc, enc_out, acc, amb, amb_global, z_dim, enc_coef);
+    else if (dtype == ASE_F32)
+        hipLaunchKernelGGL(enc_head_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, e, ld_e, z, ld_z,
+                           (float*)d_e, ld_de, db_enc, enc_out, acc, amb, amb_global, z_dim, enc_coef);
+    else ASE_CHECK_ARG(false, "enc_head: bad dtype %d", dtype);
+    ASE_CHECK_LAUNCH("enc_head");
+    return ASE_OK;
+}
+
+extern "C" int ase_hip_gp_seed(const void* h, int64_t ld_h, const float* w, void* g, int64_t ld_g, int rows, int width,
+                               int dtype, void* stream) {
+    ASE_CHECK_ARG(h && w && g && rows > 0 && width > 0, "gp_seed: null/empty operand");
+    const dim3 grid(grid_for((int64_t)rows * width));
+    if (dtype == ASE_BF16)
+        hipLaunchKernelGGL(gp_seed_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h, ld_h, w,
+                           (bf16_t*)g, ld_g, rows, width);
+    else if (dtype == ASE_F32)
+        hipLaunchKernelGGL(gp_seed_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)h, ld_h, w,
+                           (float*)g, ld_g, rows, width);
+    else ASE_CHECK_ARG(false, "gp_seed: bad dtype %d", dtype);
+    ASE_CHECK_LAUNCH("gp_seed");
+    return ASE_OK;
+}
+
+extern "C" int ase_hip_sqnorm(const void* x, int64_t ld, int rows, int cols, double* acc, int slot, int dtype,
+                              void* stream) {
+    ASE_CHECK_ARG(x && acc && rows > 0 && cols > 0 && slot >= 0, "sqnorm: null/empty operand");
+    const dim3 grid(grid_for((int64_t)rows * cols, 256, 1024));
+    if (dtype == ASE_BF16)
+        hipLaunchKernelGGL(sqnorm_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, rows,
+                           cols, acc + slot);
+    else if (dtype == ASE_F32)
+        hipLaunchKernelGGL(sqnorm_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ld, rows,
+                           cols, acc + slot);
+    else ASE_CHECK_ARG(false, "sqnorm: bad dtype %d", dtype);
+    ASE_CHECK_LAUNCH("sqnorm");
+    return ASE_OK;
+}
+
+extern "C" int ase_hip_finalize_scalars(const double* acc, float* out, int m_global, int amb_global, int masked,
+                                        int has_disc, int has_enc, int has_div, float critic_coef, float entropy_coef,
+                                        float bounds_coef, float disc_coef, float disc_logit_reg,
+                                        float disc_grad_penalty, float disc_weight_decay, float enc_coef,
+                                        float enc_weight_decay, float div_coef, void* stream) {
+    ASE_CHECK_ARG(acc && out && m_global > 0, "finalize_scalars: null/empty operand");
+    FinArgs a;
+    a.m_global = m_global; a.amb_global = amb_global; a.masked = masked; a.has_disc = has_disc; a.has_enc = has_enc;
+    a.has_div = has_div; a.critic_coef = critic_coef; a.entropy_coef = entropy_coef; a.bounds_coef = bounds_coef;
+    a.disc_coef = disc_coef; a.disc_logit_reg = disc_logit_reg; a.disc_grad_penalty = disc_grad_penalty;
+    a.disc_weight_decay = disc_weight_decay; a.enc_coef = enc_coef; a.enc_weight_decay = enc_weight_decay;
+    a.div_coef = div_coef;
+    hipLaunchKernelGGL(finalize_scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, acc, out, a);
+    ASE_CHECK_LAUNCH("finalize_scalars");
+    return ASE_OK;
+}

@@ -1,0 +1,196 @@
+// Running mean/std input normaliser (rl_games RunningMeanStd semantics) fused with the minibatch
+// row gather, plus the generic row gather/cast.  HBM-bound: every element is read once for the
+// moments and once for the normalised write; nothing is materialised in between.
+#include "common.h"
+
+namespace {
+
+// ---- batch moments: grid (col tiles of 64, row chunks); block 64 x 4 ---------------------------
+constexpr int kRowsPerBlock = 256;
+
+__global__ __launch_bounds__(256) void rms_moments_kernel(const float* __restrict__ src, int64_t ld_src, int D,
+                                                          const int32_t* __restrict__ idx, int remap_h, int remap_n,
+                                                          int M, const double* __restrict__ state,
+                                                          double* __restrict__ sums) {
+    __shared__ double red[2][4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + tx;
+    const int r0 = blockIdx.y * kRowsPerBlock;
+    const int r1 = min(M, r0 + kRowsPerBlock);
+    double s1 = 0.0, s2 = 0.0;
+    if (j < D) {
+        const float shift = (float)state[j];
+        for (int r = r0 + ty; r < r1; r += 4) {
+            const int64_t p = map_row(r, idx, remap_h, remap_n);
+            const double d = (double)(src[p * ld_src + j] - shift);
+            s1 += d;
+            s2 += d * d;
+        }
+    }
+    red[0][ty][tx] = s1;
+    red[1][ty][tx] = s2;
+    __syncthreads();
+    if (ty == 0 && j < D) {
+        s1 = red[0][0][tx] + red[0][1][tx] + red[0][2][tx] + red[0][3][tx];
+        s2 = red[1][0][tx] + red[1][1][tx] + red[1][2][tx] + red[1][3][tx];
+        atomic_add_f64(sums + j, s1);
+        atomic_add_f64(sums + D + j, s2);
+    }
+}
+
+// ---- merge into the running state; single block so `count` is read before it is rewritten ------
+__global__ __launch_bounds__(256) void rms_finalize_kernel(double* __restrict__ state, int D,
+                                                           const double* __restrict__ sums, int count,
+                                                           int n_streams, float* __restrict__ mean_out,
+                                                           float* __restrict__ std_out) {
+    const double count0 = state[2 * D];
+    __syncthreads();
+    for (int j = threadIdx.x; j < D; j += blockDim.x) {
+        double mean = state[j], var = state[D + j], cnt = count0;
+        const float shift = (float)mean;  // the shift rms_moments used (state is untouched in between)
+        if (n_streams == 0) {
+            mean_out[j] = (float)mean;
+            std_out[j] = sqrtf((float)var + 1e-5f);
+        }
+        for (int s = 0; s < n_streams; ++s) {
+            const double n = (double)count;
+            const double s1 = sums[(int64_t)s * 2 * D + j], s2 = sums[(int64_t)s * 2 * D + D + j];
+            // batch mean / unbiased variance, rounded to f32 like torch's x.mean(0) / x.var(0) on f32 data
+            const double bm = (double)(float)((double)shift + s1 / n);
+            const double bv = (double)(float)((s2 - s1 * s1 / n) / (n - 1.0));
+            const double delta = bm - mean;
+            const double tot = cnt + n;
+            const double new_mean = mean + delta * n / tot;
+            const double m2 = var * cnt + bv * n + delta * delta * cnt * n / tot;
+            mean = new_mean;
+            var = m2 / tot;
+            cnt = tot;
+            mean_out[(int64_t)s * D + j] = (float)mean;
+            std_out[(int64_t)s * D + j] = sqrtf((float)var + 1e-5f);
+        }
+        state[j] = mean;
+        state[D + j] = var;
+    }
+    if (threadIdx.x == 0 && n_streams > 0) state[2 * D] = count0 + (double)n_streams * (double)count;
+}
+
+template <typename T> __device__ __forceinline__ void store_opt(void* base, int64_t ld, int r, int j, float v) {
+    if (base) reinterpret_cast<T*>(base)[(int64_t)r * ld + j] = from_f32<T>(v);
+}
+
+// grid (col tiles of 256, rows/4); block 256 = 64 cols x 4 rows  -> coalesced 256-B row segments
+template <typename T>
+__global__ __launch_bounds__(256) void rms_normalize_kernel(const float* __restrict__ src, int64_t ld_src, int D,
+                                                            const int32_t* __restrict__ idx, int remap_h, int remap_n,
+                                                            int M, const float* __restrict__ mean,
+                                                            const float* __restrict__ stdv, void* out0, int64_t ld0,
+                                                            void* out1, int64_t ld1, void* out2, int64_t ld2) {
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int r = blockIdx.y * 4 + ty;
+    if (r >= M) return;
+    const int64_t p = map_row(r, idx, remap_h, remap_n);
+    const float* row = src + p * ld_src;
+    for (int j = blockIdx.x * 256 + tx; j < min(D, (int)(blockIdx.x + 1) * 256); j += 64) {
+        float y = (row[j] - mean[j]) / stdv[j];
+        y = fminf(fmaxf(y, -5.f), 5.f);
+        store_opt<T>(out0, ld0, r, j, y);
+        store_opt<T>(out1, ld1, r, j, y);
+        store_opt<T>(out2, ld2, r, j, y);
+    }
+}
+
+__global__ void rms_unnormalize_kernel(const double* __restrict__ state, const float* __restrict__ x,
+                                       float* __restrict__ y, int64_t n) {
+    const float mean = (float)state[0], sd = sqrtf((float)state[1] + 1e-5f);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float c = fminf(fmaxf(x[i], -5.f), 5.f);
+        y[i] = sd * c + mean;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, int64_t ld_src, int D,
+                                                          const int32_t* __restrict__ idx, int remap_h, int remap_n,
+                                                          int M, T* __restrict__ dst, int64_t ld_dst) {
+    // a group of W lanes walks one row; W = 64 for wide rows, fewer for narrow ones (set by blockDim.x)
+    const int W = blockDim.x, rpb = blockDim.y;
+    const int r = blockIdx.x * rpb + threadIdx.y;
+    if (r >= M) return;
+    const int64_t p = map_row(r, idx, remap_h, remap_n);
+    for (int j = threadIdx.x; j < D; j += W) dst[(int64_t)r * ld_dst + j] = from_f32<T>(src[p * ld_src + j]);
+}
+
+}  // namespace
+
+extern "C" int ase_hip_rms_moments(const float* src, int64_t ld_src, int D, const int32_t* idx, int remap_h,
+                                   int remap_n, int M, const double* state, double* sums, void* stream) {
+    ASE_CHECK_ARG(src && state && sums && D > 0 && M > 0, "rms_moments: null/empty operand");
+    const dim3 grid((D + 63) / 64, (M + kRowsPerBlock - 1) / kRowsPerBlock);
+    hipLaunchKernelGGL(rms_moments_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, D, idx, remap_h,
+                       remap_n, M, state, sums);
+    ASE_CHECK_LAUNCH("rms_moments");
+    return ASE_OK;
+}
+
+extern "C" int ase_hip_rms_finalize(double* state, int D, const double* sums, const int32_t* counts, int n_streams,
+                                    float* mean_out, float* std_out, void* stream) {
+    // `counts` is a HOST array of n_streams global row counts; all streams of one call share one count.
+    ASE_CHECK_ARG(state && mean_out && std_out && D > 0 && n_streams >= 0, "rms_finalize: null/empty operand");
+    int count = 0;
+    if (n_streams > 0) {
+        ASE_CHECK_ARG(sums && counts, "rms_finalize: sums/counts missing");
+        count = counts[0];
+        for (int s = 1; s < n_streams; ++s)
+            ASE_CHECK_ARG(counts[s] == count, "rms_finalize: all streams of one call must have the same row count");
+        ASE_CHECK_ARG(count > 1, "rms_finalize: need at least 2 rows for an unbiased variance");
+    }
+    hipLaunchKernelGGL(rms_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, state, D, sums, count,
+                       n_streams, mean_out, std_out);
+    ASE_CHECK_LAUNCH("rms_finalize");
+    return ASE_OK;
+}
+
+extern "C" int ase_hip_rms_normalize(const float* src, int64_t ld_src, int D, const int32_t* idx, int remap_h,
+                                     int remap_n, int M, const float* mean, const float* stdv, void* out0,
+                                     int64_t ld0, void* out1, int64_t ld1, void* out2, int64_t ld2, int dtype,
+                                     void* stream) {
+    ASE_CHECK_ARG(src && mean && stdv && out0 && D > 0 && M > 0, "rms_normalize: null/empty operand");
+    const dim3 grid((D + 255) / 256, (M + 3) / 4);
+    if (dtype == ASE_BF16)
+        hipLaunchKernelGGL(rms_normalize_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, D, idx,
+                           remap_h, remap_n, M, mean, stdv, out0, ld0, out1, ld1, out2, ld2);
+    else if (dtype == ASE_F32)
+        hipLaunchKernelGGL(rms_normalize_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, D, idx,
+                           remap_h, remap_n, M, mean, stdv, out0, ld0, out1, ld1, out2, ld2);
+    else
+        ASE_CHECK_ARG(false, "rms_normalize: bad dtype %d", dtype);
+    ASE_CHECK_LAUNCH("rms_normalize");
+    return ASE_OK;
+}
+
+extern "C" int ase_hip_rms_unnormalize(const double* state, const float* x, float* y, int64_t n, void* stream) {
+    ASE_CHECK_ARG(state && x && y && n > 0, "rms_unnormalize: null/empty operand");
+    const int blocks = (int)min((int64_t)2048, (n + 255) / 256);
+    hipLaunchKernelGGL(rms_unnormalize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, state, x, y, n);
+    ASE_CHECK_LAUNCH("rms_unnormalize");
+    return ASE_OK;
+}
+
+extern "C" int ase_hip_gather_rows(const float* src, int64_t ld_src, int D, const int32_t* idx, int remap_h,
+                                   int remap_n, int M, void* dst, int64_t ld_dst, int dst_dtype, void* stream) {
+    ASE_CHECK_ARG(src && dst && D > 0 && M > 0, "gather_rows: null/empty operand");
+    int W = 64;
+    while (W > 1 && W / 2 >= D) W /= 2;
+    const dim3 block(W, 256 / W);
+    const dim3 grid((M + block.y - 1) / block.y);
+    if (dst_dtype == ASE_BF16)
+        hipLaunchKernelGGL(gather_rows_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, src, ld_src, D, idx,
+                           remap_h, remap_n, M, (bf16_t*)dst, ld_dst);
+    else if (dst_dtype == ASE_F32)
+        hipLaunchKernelGGL(gather_rows_kernel<float>, grid, block, 0, (hipStream_t)stream, src, ld_src, D, idx,
+                           remap_h, remap_n, M, (float*)dst, ld_dst);
+    else
+        ASE_CHECK_ARG(false, "gather_rows: bad dtype %d", dst_dtype);
+    ASE_CHECK_LAUNCH("gather_rows");
+    return ASE_OK;
+}

@@ -1,0 +1,501 @@
+"""MI355X update engine: one ASE / AMP / PPO optimisation step as an explicit sequence of HIP
+kernel launches (no autograd, no allocation, no host sync) — capturable in a hipGraph.
+
+It replaces, for the hot path, what the reference expresses as
+``self.model(batch_dict)`` + the loss arithmetic + ``loss.backward()`` + ``optimizer.step()``
+in ``ASEAgent.calc_gradients`` (learning/ase_agent.py:159-308 under /root/reference/ase),
+``AMPAgent.calc_gradients`` (learning/amp_agent.py:266-390) and
+``CommonAgent.calc_gradients`` (learning/common_agent.py:353-435), plus the rollout tail
+(rewards / GAE / advantage + value normalisation).
+
+Data layout in HBM
+  * master parameters, gradients, Adam moments: four flat f32 buffers in checkpoint layout
+    (one Adam launch, one RCCL all-reduce over the flat gradient buffer);
+  * per layer "shadow" copies in the compute dtype (bf16 or f32): W_s [P(N), Kpad] and its
+    transpose Wt_s [Kpad, P(N)], zero padded (P(x) = x rounded up to 64), refreshed after the
+    optimizer step; the concat inputs [obs | z] of the first actor/critic layer are laid out as
+    [obs, pad to P(obs) | z], so the latent block starts on a 128-byte boundary;
+  * activations [rows, P(features)] in the compute dtype; head outputs and all loss math in f32;
+  * the experience buffer stays time-major [H, N, ...]; minibatch rows are addressed through
+    the epoch permutation (env-major flat index -> physical row) inside the gather/normalise
+    kernels, so neither swap_and_flatten01 nor the dataset gather materialise anything.
+"""
+import math
+
+import torch
+
+from . import lib as L
+
+
+def P(x, m=64):
+    return (int(x) + m - 1) // m * m
+
+
+_ACT = {'relu': L.ACT_RELU, 'tanh': L.ACT_TANH, 'None': L.ACT_NONE, 'none': L.ACT_NONE, None: L.ACT_NONE}
+_AUX = {L.ACT_RELU: L.AUX_RELU_MASK, L.ACT_TANH: L.AUX_TANH_GRAD, L.ACT_NONE: L.AUX_NONE}
+
+
+class Dense:
+    """One linear layer (or a group of heads sharing an input, stacked along N at 64-aligned offsets)."""
+
+    def __init__(self, parts, k_in, act, split=None):
+        # parts: list of (param prefix, n_real, row offset in the padded N dimension)
+        self.parts = parts
+        self.K = k_in
+        self.act = _ACT[act] if not isinstance(act, int) else act
+        if split is None:
+            self.split_src = self.split_dst = k_in
+            self.k_pad = P(k_in)
+        else:
+            self.split_src, self.split_dst, self.k_pad = split
+        self.n_pad = max(off + P(n) for _, n, off in parts)
+        self.N = parts[0][1]
+
+    @property
+    def name(self):
+        return self.parts[0][0]
+
+
+class UpdateEngine:
+    """kind: 'ase' | 'amp' | 'ppo'.  sizes: rows handled by THIS rank (M, AMB) and global counts."""
+
+    def __init__(self, kind, net, cfg, backend, *, minibatch, amp_minibatch=0, dtype=torch.bfloat16,
+                 world_size=1, rank=0, infer_rows=0):
+        self.kind, self.net, self.cfg, self.be = kind, net, cfg, backend
+        self.dtype = dtype
+        self.dev = net.flat_params.device
+        self.R, self.rank = world_size, rank
+        assert minibatch % world_size == 0 and amp_minibatch % world_size == 0
+        self.Mg, self.AMBg = minibatch, amp_minibatch
+        self.M, self.AMB = minibatch // world_size, amp_minibatch // world_size
+        self.obs, self.act = net.obs_size, net.actions_num
+        self.z = net.latent_dim if kind == 'ase' else 0
+        self.amp = net.amp_obs_size if kind in ('amp', 'ase') else 0
+        self.masked = kind in ('amp', 'ase')
+        self.has_disc = kind in ('amp', 'ase')
+        self.has_enc = kind == 'ase'
+        self.div_on = kind == 'ase' and cfg.get('amp_diversity_bonus', 0) != 0
+        self.enc_sep = bool(getattr(net, 'enc_separate', False))
+        assert cfg.get('enc_grad_penalty', 0) == 0, "enc_grad_penalty: not on the default path (SURVEY §8f N4)"
+        self.mu_tanh = kind == 'ppo' and getattr(net, 'mu_tanh', False)
+        self._build_layers()
+        self._bind_params()
+        self._alloc(infer_rows)
+        self.refresh_shadows()
+
+    # ------------------------------------------------------------------ structure
+    def _build_layers(self):
+        net, z = self.net, self.z
+        act = net.activation
+        split = (self.obs, P(self.obs), P(self.obs) + P(z)) if z else None
+        self.style = []
+        if self.kind == 'ase':
+            k = z
+            for i, u in enumerate(net.style_units):
+                self.style.append(Dense([(f'actor_mlp._style_mlp.{2 * i}', u, 0)], k, act))
+                k = u
+            self.style.append(Dense([('actor_mlp._style_dense', z, 0)], k, 'tanh'))
+            names_a = [f'actor_mlp._dense_layers.{i}' for i in range(len(net.units))]
+            names_c = [f'critic_mlp._mlp.{2 * i}' for i in range(len(net.units))]
+        else:
+            names_a = [f'actor_mlp.{2 * i}' for i in range(len(net.units))]
+            names_c = [f'critic_mlp.{2 * i}' for i in range(len(net.units))]
+        self.actor, self.critic = [], []
+        k = self.obs + z
+        for i, u in enumerate(net.units):
+            sp = split if (i == 0 and z) else None
+            self.actor.append(Dense([(names_a[i], u, 0)], k, act, sp))
+            self.critic.append(Dense([(names_c[i], u, 0)], k, act, sp))
+            k = u
+        self.mu_head = Dense([('mu', self.act, 0)], k, 'None')
+        self.value_head = Dense([('value', 1, 0)], k, 'None')
+        self.disc, self.enc_chain = [], []
+        self.disc_head = self.enc_head = None
+        if self.has_disc:
+            k = self.amp
+            for i, u in enumerate(net.disc_units):
+                self.disc.append(Dense([(f'_disc_mlp.{2 * i}', u, 0)], k, net.disc_activation))
+                k = u
+            parts = [('_disc_logits', 1, 0)]
+            if self.has_enc and not self.enc_sep:
+                parts.append(('_enc', z, P(1)))
+            self.disc_head = Dense(parts, k, 'None')
+            if self.has_enc and self.enc_sep:
+                k = self.amp
+                for i, u in enumerate(net.enc_units):
+                    self.enc_chain.append(Dense([(f'_enc_mlp.{2 * i}', u, 0)], k, net.enc_activation))
+                    k = u
+                self.enc_head = Dense([('_enc', z, 0)], k, 'None')
+        self.layers = (self.style + self.actor + [self.mu_head] + self.critic + [self.value_head] + self.disc +
+                       ([self.disc_head] if self.disc_head else []) + self.enc_chain +
+                       ([self.enc_head] if self.enc_head else []))
+
+    def _bind_params(self):
+        net, dev, T = self.net, self.dev, self.dtype
+        self.params = net.flat_params
+        n = self.params.numel()
+        self.grads = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.adam_m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.adam_v = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.n_train = net.trainable_numel           # trainable tensors come first in the flat buffer
+        lr = float(self.cfg['learning_rate'])
+        self.opt_state = torch.tensor([0.0, lr, 0.9, 0.999, 1e-8, 1.0, 1.0, 0.0], dtype=torch.float64, device=dev)
+        for d in self.layers:
+            d.Ws = torch.zeros(d.n_pad, d.k_pad, dtype=T, device=dev)
+            d.Wts = torch.zeros(d.k_pad, d.n_pad, dtype=T, device=dev)
+            d.bs = torch.zeros(d.n_pad, dtype=torch.float32, device=dev)
+            d.W, d.b, d.gW, d.gb = [], [], [], []
+            for name, nr, off in d.parts:
+                o, shp = net.param_slices[name + '.weight']
+                assert tuple(shp) == (nr, d.K), (name, shp, nr, d.K)
+                d.W.append(self.params[o:o + nr * d.K].view(nr, d.K))
+                d.gW.append(self.grads[o:o + nr * d.K].view(nr, d.K))
+                ob, _ = net.param_slices[name + '.bias']
+                d.b.append(self.params[ob:ob + nr])
+                d.gb.append(self.grads[ob:ob + nr])
+        o, shp = net.param_slices['sigma']
+        self.logstd = self.params[o:o + shp[0]]
+        # weight-only loss terms (learning/amp_agent.py:449-466, learning/ase_agent.py:420-425): ranges of the flat buffer
+        self.l2_terms = []
+        c = self.cfg
+        if self.has_disc:
+            dc, wd, lr_ = c['disc_coef'], c['disc_weight_decay'], c['disc_logit_reg']
+            for d in self.disc:
+                self.l2_terms.append((d.W[0], d.gW[0], dc * 2.0 * wd, L.ACC_DISC_W2 if wd != 0 else None))
+            self.l2_terms.append((self.disc_head.W[0], self.disc_head.gW[0], dc * 2.0 * (wd + lr_), None))
+        if self.has_enc and c.get('enc_weight_decay', 0) != 0:
+            ew = c['enc_coef'] * 2.0 * c['enc_weight_decay']
+            chain = self.enc_chain if self.enc_sep else self.disc
+            for d in chain:
+                self.l2_terms.append((d.W[0], d.gW[0], ew, L.ACC_ENC_W2))
+            eh = self.enc_head if self.enc_sep else self.disc_head
+            ei = 0 if self.enc_sep else 1
+            self.l2_terms.append((eh.W[ei], eh.gW[ei], ew, L.ACC_ENC_W2))
+
+    def _alloc(self, infer_rows):
+        dev, T = self.dev, self.dtype
+        M, AMB = self.M, self.AMB
+        Ra = 2 * M if self.div_on else M
+        self.Ra = Ra
+
+        def zt(r, c, dt=T):
+            return torch.zeros(r, c, dtype=dt, device=dev)
+
+        def chain_bufs(chain, rows):
+            return [zt(rows, d.n_pad) for d in chain], [zt(rows, d.n_pad) for d in chain]
+
+        f32 = torch.float32
+        self.Xa = zt(Ra, self.actor[0].k_pad)
+        self.Xc = zt(M, self.critic[0].k_pad)
+        self.Ha, self.dZa = chain_bufs(self.actor, Ra)
+        self.Hc, self.dZc = chain_bufs(self.critic, M)
+        self.MU = zt(Ra, self.mu_head.n_pad, f32)
+        self.dMU = zt(Ra, self.mu_head.n_pad)
+        self.V = zt(M, self.value_head.n_pad, f32)
+        self.dV = zt(M, self.value_head.n_pad)
+        if self.style:
+            self.Zs = zt(Ra, P(self.z))
+            self.Hs, self.dZs = chain_bufs(self.style[:-1], Ra)
+            self.dStyle = zt(Ra, P(self.z))
+            self.new_z = zt(M, self.z, f32)
+            self.rng_state = torch.tensor([0x5EED, 0], dtype=torch.int64, device=dev)
+        if self.has_disc:
+            Rd = 3 * AMB
+            self.Xd = zt(Rd, self.disc[0].k_pad)
+            self.Hd, self.dZd = chain_bufs(self.disc, Rd)
+            self.HD = zt(Rd, self.disc_head.n_pad, f32)
+            self.dHD = zt(Rd, self.disc_head.n_pad)
+            # gradient penalty chain on the demo rows
+            self.Gp = [zt(AMB, d.n_pad) for d in self.disc]            # g_l  (grad of logit w.r.t. Z_l)
+            self.G0 = zt(AMB, self.disc[0].k_pad)
+            self.dGp = [zt(AMB, d.n_pad) for d in self.disc]           # d J / d g_l (masked)
+            if self.enc_chain:
+                self.He, self.dZe = chain_bufs(self.enc_chain, AMB)
+                self.E = zt(AMB, self.enc_head.n_pad, f32)
+                self.dE = zt(AMB, self.enc_head.n_pad)
+            self.amp_sums = torch.zeros(3, 2 * self.amp, dtype=torch.float64, device=dev)
+            self.amp_mean = zt(3, self.amp, f32)
+            self.amp_std = zt(3, self.amp, f32)
+            self.amp_state = torch.zeros(2 * self.amp + 1, dtype=torch.float64, device=dev)
+            self.amp_state[self.amp:] = 1.0
+        self.obs_sums = torch.zeros(2 * self.obs, dtype=torch.float64, device=dev)
+        self.obs_mean = zt(1, self.obs, f32)
+        self.obs_std = zt(1, self.obs, f32)
+        self.obs_state = torch.zeros(2 * self.obs + 1, dtype=torch.float64, device=dev)
+        self.obs_state[self.obs:] = 1.0
+        self.val_state = torch.tensor([0.0, 1.0, 1.0], dtype=torch.float64, device=dev)
+        self.acc = torch.zeros(L.ACC_COUNT, dtype=torch.float64, device=dev)
+        self.res = torch.zeros(L.RES_COUNT, dtype=torch.float32, device=dev)
+        # packed f32 minibatch fields
+        self.mb = {'actions': zt(M, self.act, f32), 'mu': zt(M, self.act, f32), 'sigma': zt(M, self.act, f32),
+                   'old_logp_actions': zt(M, 1, f32), 'advantages': zt(M, 1, f32), 'old_values': zt(M, 1, f32),
+                   'returns': zt(M, 1, f32)}
+        if self.masked:
+            self.mb['rand_action_mask'] = zt(M, 1, f32)
+        if self.z:
+            self.mb['ase_latents'] = zt(M, self.z, f32)
+
+    # ------------------------------------------------------------------ shadows
+    def refresh_shadows(self):
+        be = self.be
+        for d in self.layers:
+            for (name, nr, off), W, b in zip(d.parts, d.W, d.b):
+                be.refresh_shadow(W, d.Ws[off:], d.Wts[:, off:], d.split_src, d.split_dst)
+                be.gather_rows(b.view(1, nr), nr, None, (0, 0), 1, d.bs[off:off + nr].view(1, nr))
+
+    # ------------------------------------------------------------------ primitive layer ops
+    def _fwd(self, d, X, Y, rows, act=None):
+        self.be.gemm_nt(X, d.Ws, Y, rows, d.n_pad, d.k_pad, bias=d.bs, act=d.act if act is None else act)
+
+    def _fwd_chain(self, chain, X, H, rows):
+        for d, h in zip(chain, H):
+            self._fwd(d, X, h, rows)
+            X = h
+        return X
+
+    def _dgrad(self, d, dY, dX, rows, aux, aux_act, gb, gb_n, wts=None, n_out=None, alpha=1.0):
+        """dX = (dY @ W) * act'(aux);  gb += colsum(dX)  (bias gradient of the layer that produced aux)."""
+        wts = d.Wts if wts is None else wts
+        n_out = d.k_pad if n_out is None else n_out
+        self.be.gemm_nt(dY, wts, dX, rows, n_out, d.n_pad, aux=aux if _AUX[aux_act] else None, aux_mode=_AUX[aux_act],
+                        colsum=gb, colsum_n=gb_n, alpha=alpha)
+
+    def _wgrad(self, d, dY, X, rows, alpha=1.0):
+        for (name, nr, off), gW in zip(d.parts, d.gW):
+            self.be.gemm_tn(dY[:, off:], X, gW, rows, P(nr), d.k_pad, nr, d.K, d.split_src, d.split_dst, alpha=alpha)
+
+    def _bwd_chain(self, chain, X0, H, dZ, rows):
+        """dZ[-1] holds d loss / d Z of the last chain layer (its bias grad already accumulated)."""
+        for l in range(len(chain) - 1, -1, -1):
+            d = chain[l]
+            self._wgrad(d, dZ[l], H[l - 1] if l > 0 else X0, rows)
+            if l > 0:
+                p = chain[l - 1]
+                self._dgrad(d, dZ[l], dZ[l - 1], rows, H[l - 1], p.act, p.gb[0], p.N)
+
+    # ------------------------------------------------------------------ one optimisation step
+    def gather_minibatch(self, ds, idx, remap):
+        be, M = self.be, self.M
+        for k, dst in self.mb.items():
+            src = ds[k]
+            src2 = src.view(src.shape[0], -1)
+            be.gather_rows(src2, src2.shape[1], idx, remap, M, dst)
+
+    def step(self, ds, idx, remap, amp_streams=None, new_z=None, apply=True):
+        """ds: dataset dict of physical-order device tensors; idx int32 [M] (this rank's rows);
+        amp_streams: [(src, idx, remap)] x3 for agent / replay / demo (AMB rows each);
+        new_z: optional injected diversity latents f32 [M, z] (else drawn on device)."""
+        be, c, M, AMB = self.be, self.cfg, self.M, self.AMB
+        T = self.dtype
+        be.begin_step(self.opt_state, self.acc)
+        be.zero_(self.grads[:self.n_train])
+        be.zero_(self.obs_sums)
+        self.gather_minibatch(ds, idx, remap)
+        if self.masked:
+            be.reduce_sum(self.mb['rand_action_mask'], M, False, self.acc, L.ACC_MASK_SUM)
+        # ---- normaliser statistics (local partial sums; all-reduced over ranks when sharded)
+        norm_in = c.get('normalize_input', True)
+        if norm_in:
+            be.rms_moments(ds['obs'], self.obs, idx, remap, M, self.obs_state, self.obs_sums)
+        norm_amp = self.has_disc and c.get('normalize_amp_input', True)
+        if self.has_disc:
+            be.zero_(self.amp_sums)
+            if norm_amp:
+                for s, (src, sidx, srm) in enumerate(amp_streams):
+                    be.rms_moments(src, self.amp, sidx, srm, AMB, self.amp_state, self.amp_sums[s])
+        self._allreduce_stats()
+        # ---- merge + normalise (+ gather) straight into the GEMM input buffers
+        if norm_in:
+            be.rms_finalize(self.obs_state, self.obs, self.obs_sums, self.Mg, 1, self.obs_mean, self.obs_std)
+        else:
+            self._identity_stats(self.obs_mean, self.obs_std)
+        outs = [self.Xa[:M], self.Xc]
+        if self.div_on:
+            outs.append(self.Xa[M:])
+        be.rms_normalize(ds['obs'], self.obs, idx, remap, M, self.obs_mean[0], self.obs_std[0], outs)
+        if self.has_disc:
+            if norm_amp:
+                be.rms_finalize(self.amp_state, self.amp, self.amp_sums, self.AMBg, 3, self.amp_mean, self.amp_std)
+            else:
+                self._identity_stats(self.amp_mean, self.amp_std)
+            for s, (src, sidx, srm) in enumerate(amp_streams):
+                be.rms_normalize(src, self.amp, sidx, srm, AMB, self.amp_mean[s], self.amp_std[s],
+                                 [self.Xd[s * AMB:(s + 1) * AMB]])
+        if self.z:
+            zsrc = self.mb['ase_latents']
+            sd = self.actor[0].split_dst
+            be.gather_rows(zsrc, self.z, None, (0, 0), M, self.Zs[:M])
+            be.gather_rows(zsrc, self.z, None, (0, 0), M, self.Xc[:, sd:])
+            if self.div_on:
+                if new_z is not None:
+                    self.new_z.copy_(new_z)
+                else:
+                    be.sample_latents(self.new_z, M, self.z, self.rng_state)
+                be.gather_rows(self.new_z, self.z, None, (0, 0), M, self.Zs[M:])
+
+        # ---- forward
+        Ra = self.Ra
+        if self.style:
+            sd = self.actor[0].split_dst
+            h = self._fwd_chain(self.style[:-1], self.Zs, self.Hs, Ra)
+            self._fwd(self.style[-1], h, self.Xa[:, sd:], Ra)
+        ha = self._fwd_chain(self.actor, self.Xa, self.Ha, Ra)
+        self._fwd(self.mu_head, ha, self.MU, Ra)
+        hc = self._fwd_chain(self.critic, self.Xc, self.Hc, M)
+        self._fwd(self.value_head, hc, self.V, M)
+        if self.has_disc:
+            hd = self._fwd_chain(self.disc, self.Xd, self.Hd, 3 * AMB)
+            self._fwd(self.disc_head, hd, self.HD, 3 * AMB)
+            if self.enc_chain:
+                he = self._fwd_chain(self.enc_chain, self.Xd[:AMB], self.He, AMB)
+                self._fwd(self.enc_head, he, self.E, AMB)
+
+        # ---- loss heads (value + gradient w.r.t. head outputs + head bias gradients)
+        be.ppo_head(self.MU, self.V, self.mb, self.new_z if self.div_on else None, self.logstd, self.dMU, self.dV,
+                    self.mu_head.gb[0], self.value_head.gb[0], self.acc, M, self.Mg, self.act, self.z, self.masked,
+                    self.div_on, self.mu_tanh, c['clip_value'], c['e_clip'], c['critic_coef'],
+                    c['bounds_loss_coef'], c.get('amp_diversity_bonus', 0.0), c.get('amp_diversity_tar', 0.0))
+        if self.has_disc:
+            be.disc_head(self.HD, self.dHD, self.disc_head.gb[0], self.acc, AMB, self.AMBg, c['disc_coef'])
+            if self.has_enc:
+                if self.enc_sep:
+                    be.enc_head(self.E, self.mb['ase_latents'], self.dE, self.enc_head.gb[0], None, self.acc, AMB,
+                                self.AMBg, self.z, c['enc_coef'])
+                else:
+                    off = self.disc_head.parts[1][2]
+                    be.enc_head(self.HD[:AMB, off:], self.mb['ase_latents'], self.dHD[:AMB, off:],
+                                self.disc_head.gb[1], None, self.acc, AMB, self.AMBg, self.z, c['enc_coef'])
+
+        # ---- backward: actor (+ style), critic
+        self._wgrad(self.mu_head, self.dMU, ha, Ra)
+        last = self.actor[-1]
+        self._dgrad(self.mu_head, self.dMU, self.dZa[-1], Ra, self.Ha[-1], last.act, last.gb[0], last.N)
+        self._bwd_chain(self.actor, self.Xa, self.Ha, self.dZa, Ra)
+        if self.style:
+            a0, sdn = self.actor[0], self.style[-1]
+            sd = a0.split_dst
+            self._dgrad(a0, self.dZa[0], self.dStyle, Ra, self.Xa[:, sd:], sdn.act, sdn.gb[0], sdn.N,
+                        wts=a0.Wts[sd:], n_out=P(self.z))
+            hs_last = self.Hs[-1] if self.Hs else self.Zs
+            self._wgrad(sdn, self.dStyle, hs_last, Ra)
+            if self.Hs:
+                p = self.style[-2]
+                self._dgrad(sdn, self.dStyle, self.dZs[-1], Ra, self.Hs[-1], p.act, p.gb[0], p.N)
+                self._bwd_chain(self.style[:-1], self.Zs, self.Hs, self.dZs, Ra)
+        self._wgrad(self.value_head, self.dV, hc, M)
+        last = self.critic[-1]
+        self._dgrad(self.value_head, self.dV, self.dZc[-1], M, self.Hc[-1], last.act, last.gb[0], last.N)
+        self._bwd_chain(self.critic, self.Xc, self.Hc, self.dZc, M)
+
+        # ---- backward: discriminator (+ encoder) and the gradient penalty
+        if self.has_disc:
+            Rd = 3 * AMB
+            self._wgrad(self.disc_head, self.dHD, hd, Rd)
+            last = self.disc[-1]
+            self._dgrad(self.disc_head, self.dHD, self.dZd[-1], Rd, self.Hd[-1], last.act, last.gb[0], last.N)
+            self._bwd_chain(self.disc, self.Xd, self.Hd, self.dZd, Rd)
+            if self.enc_chain:
+                self._wgrad(self.enc_head, self.dE, he, AMB)
+                last = self.enc_chain[-1]
+                self._dgrad(self.enc_head, self.dE, self.dZe[-1], AMB, self.He[-1], last.act, last.gb[0], last.N)
+                self._bwd_chain(self.enc_chain, self.Xd[:AMB], self.He, self.dZe, AMB)
+            self._grad_penalty()
+
+        self._allreduce_grads()
+        if self.has_disc:
+            # weight-only loss terms, added once after the gradient reduction
+            for W, gW, coef, slot in self.l2_terms:
+                if coef != 0:
+                    be.axpy(gW.view(-1), W.view(-1), coef)
+            wl = self.disc_head.W[0]
+            be.reduce_sum(wl.view(-1), wl.numel(), True, self.acc, L.ACC_LOGIT_W2)
+            if c['disc_weight_decay'] != 0:
+                for d in self.disc:
+                    be.reduce_sum(d.W[0].view(-1), d.W[0].numel(), True, self.acc, L.ACC_DISC_W2)
+                be.reduce_sum(wl.view(-1), wl.numel(), True, self.acc, L.ACC_DISC_W2)
+            if self.has_enc and c.get('enc_weight_decay', 0) != 0:
+                for W, gW, coef, slot in self.l2_terms:
+                    if slot == L.ACC_ENC_W2:
+                        be.reduce_sum(W.view(-1), W.numel(), True, self.acc, L.ACC_ENC_W2)
+        if apply:
+            be.adam(self.params[:self.n_train], self.grads[:self.n_train], self.adam_m[:self.n_train],
+                    self.adam_v[:self.n_train], self.opt_state)
+            self.refresh_shadows()
+        be.finalize_scalars(self.acc, self.res, self.Mg, self.AMBg, self.masked, self.has_disc, self.has_enc,
+                            self.div_on, c)
+        return self.res
+
+    def _grad_penalty(self):
+        """J = coef * mean_rows |d logit / d x_demo|^2 with ReLU layers (learning/amp_agent.py:453-459):
+        g_L = m_L * w_logit ; g_{l-1} = m_{l-1} * (g_l @ W_l) ; g_0 = g_1 @ W_1 ; then the backward of that chain."""
+        be, c, AMB = self.be, self.cfg, self.AMB
+        gp_coef = c['disc_coef'] * c['disc_grad_penalty']
+        lo = 2 * AMB
+        Hdemo = [h[lo:lo + AMB] for h in self.Hd]
+        nl = len(self.disc)
+        for d in self.disc:
+            assert d.act == L.ACT_RELU, "analytic gradient penalty needs ReLU discriminator layers"
+        assert nl >= 2, "gradient penalty with a single discriminator layer is not implemented"
+        top = self.disc[-1]
+        be.gp_seed(Hdemo[-1], self.disc_head.W[0].view(-1), self.Gp[-1], AMB, top.N)
+        for l in range(nl - 1, 0, -1):
+            d = self.disc[l]
+            be.gemm_nt(self.Gp[l], d.Wts, self.Gp[l - 1], AMB, d.k_pad, d.n_pad, aux=Hdemo[l - 1],
+                       aux_mode=L.AUX_RELU_MASK)
+        d0 = self.disc[0]
+        be.gemm_nt(self.Gp[0], d0.Wts, self.G0, AMB, d0.k_pad, d0.n_pad)
+        be.sqnorm(self.G0, AMB, d0.k_pad, self.acc, L.ACC_GP)
+        if gp_coef == 0:
+            return
+        cg = gp_coef * 2.0 / self.AMBg          # d J / d g_0 = cg * g_0
+        # layer 1: g_0 = g_1 @ W_1
+        be.gemm_tn(self.Gp[0], self.G0, d0.gW[0], AMB, d0.n_pad, d0.k_pad, d0.N, d0.K, d0.split_src, d0.split_dst, alpha=cg)
+        be.gemm_nt(self.G0, d0.Ws, self.dGp[0], AMB, d0.n_pad, d0.k_pad, aux=Hdemo[0], aux_mode=L.AUX_RELU_MASK, alpha=cg)
+        for l in range(1, nl):
+            d = self.disc[l]                     # g_{l-1} = m_{l-1} * (g_l @ W_l)   [dGp[l-1] is already masked]
+            be.gemm_tn(self.Gp[l], self.dGp[l - 1], d.gW[0], AMB, d.n_pad, d.k_pad, d.N, d.K, d.split_src, d.split_dst)
+            last = l == nl - 1
+            be.gemm_nt(self.dGp[l - 1], d.Ws, self.dGp[l], AMB, d.n_pad, d.k_pad, aux=Hdemo[l], aux_mode=L.AUX_RELU_MASK,
+                       colsum=self.disc_head.gW[0].view(-1) if last else None, colsum_n=d.N if last else 0)
+
+    # ------------------------------------------------------------------ collectives (single rank: no-ops)
+    def _allreduce_stats(self):
+        if self.R > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.obs_sums)
+            if self.has_disc:
+                dist.all_reduce(self.amp_sums)
+            if self.masked:
+                dist.all_reduce(self.acc[L.ACC_MASK_SUM:L.ACC_MASK_SUM + 1])
+
+    def _allreduce_grads(self):
+        if self.R > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.grads[:self.n_train])     # SUM of per-rank partials (global denominators inside)
+            dist.all_reduce(self.acc[1:])                  # slot 0 (mask sum) is already global
+
+    def _identity_stats(self, mean, std):
+        mean.zero_()
+        std.fill_(1.0)
+
+    # ------------------------------------------------------------------ results
+    def results(self):
+        """train_result with the reference's keys (learning/ase_agent.py:296-306) as device scalars."""
+        r = self.res
+        out = {'entropy': r[L.RES_ENTROPY], 'kl': r[L.RES_KL], 'b_loss': r[L.RES_B_LOSS], 'actor_loss': r[L.RES_A_LOSS],
+               'actor_clip_frac': r[L.RES_CLIP_FRAC], 'critic_loss': r[L.RES_C_LOSS], 'loss': r[L.RES_LOSS]}
+        if self.has_disc:
+            AMB = self.AMB
+            out.update({'disc_loss': r[L.RES_DISC_LOSS], 'disc_grad_penalty': r[L.RES_DISC_GP],
+                        'disc_logit_loss': r[L.RES_DISC_LOGIT_LOSS], 'disc_agent_acc': r[L.RES_DISC_AGENT_ACC],
+                        'disc_demo_acc': r[L.RES_DISC_DEMO_ACC], 'disc_agent_logit': self.HD[:2 * AMB, 0:1],
+                        'disc_demo_logit': self.HD[2 * AMB:, 0:1]})
+        if self.has_enc:
+            out['enc_loss'] = r[L.RES_ENC_LOSS]
+        if self.div_on:
+            out['amp_diversity_loss'] = r[L.RES_DIV_LOSS]
+        return out
+
+    def export_grads(self):
+        return {name: self.grads[o:o + math.prod(shp)].view(shp) for name, (o, shp) in self.net.param_slices.items()
+                if o < self.n_train}

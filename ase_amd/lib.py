@@ -1,0 +1,91 @@
+"""ctypes binding of ``libase_hip.so`` (C ABI declared in ``include/ase_hip.h``).
+
+The library is the product: there is NO fallback.  Importing this module without the built
+shared object raises; creating a ``HipBackend`` without a GPU raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libase_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+AUX_NONE, AUX_RELU_MASK, AUX_TANH_GRAD = 0, 1, 2
+
+# accumulator slots (ASE_ACC_*)
+(ACC_MASK_SUM, ACC_A_LOSS, ACC_B_LOSS, ACC_ENTROPY, ACC_CLIPPED, ACC_C_LOSS, ACC_KL, ACC_DIV, ACC_BCE_AGENT,
+ ACC_BCE_DEMO, ACC_AGENT_ACC, ACC_DEMO_ACC, ACC_GP, ACC_ENC, ACC_LOGIT_W2, ACC_DISC_W2, ACC_ENC_W2) = range(17)
+ACC_COUNT = 24
+# result slots (ASE_RES_*)
+(RES_A_LOSS, RES_C_LOSS, RES_B_LOSS, RES_ENTROPY, RES_CLIP_FRAC, RES_KL, RES_DISC_LOSS, RES_DISC_GP,
+ RES_DISC_LOGIT_LOSS, RES_DISC_AGENT_ACC, RES_DISC_DEMO_ACC, RES_ENC_LOSS, RES_DIV_LOSS, RES_LOSS,
+ RES_MASK_SUM) = range(15)
+RES_COUNT = 16
+
+_p, _i, _i64, _f, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
+
+# name -> argtypes; every function returns int.  Keep in lock-step with include/ase_hip.h
+# (tests/test_abi.py parses the header and checks names + arity against this table).
+SIGNATURES = {
+    "ase_hip_gemm_nt": [_p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
+    "ase_hip_gemm_tn": [_p, _i64, _p, _i64, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
+    "ase_hip_refresh_shadow": [_p, _i, _i, _p, _i64, _p, _i64, _i, _i, _i, _p],
+    "ase_hip_rms_moments": [_p, _i64, _i, _p, _i, _i, _i, _p, _p, _p],
+    "ase_hip_rms_finalize": [_p, _i, _p, _p, _i, _p, _p, _p],
+    "ase_hip_rms_normalize": [_p, _i64, _i, _p, _i, _i, _i, _p, _p, _p, _i64, _p, _i64, _p, _i64, _i, _p],
+    "ase_hip_rms_unnormalize": [_p, _p, _p, _i64, _p],
+    "ase_hip_gather_rows": [_p, _i64, _i, _p, _i, _i, _i, _p, _i64, _i, _p],
+    "ase_hip_reduce_sum": [_p, _i64, _i, _p, _i, _p],
+    "ase_hip_ppo_head": [_p, _i64, _p, _i64] + [_p] * 11 + [_p, _i64, _p, _i64, _p, _p, _p, _p] + [_i] * 8 + [_f] * 5 + [_i, _p],
+    "ase_hip_disc_head": [_p, _i64, _p, _i64, _p, _p, _i, _i, _f, _i, _p],
+    "ase_hip_enc_head": [_p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _i, _i, _i, _f, _i, _p],
+    "ase_hip_gp_seed": [_p, _i64, _p, _p, _i64, _i, _i, _i, _p],
+    "ase_hip_sqnorm": [_p, _i64, _i, _i, _p, _i, _i, _p],
+    "ase_hip_finalize_scalars": [_p, _p, _i, _i, _i, _i, _i, _i] + [_f] * 10 + [_p],
+    "ase_hip_begin_step": [_p, _p, _i, _p],
+    "ase_hip_adam": [_p, _p, _p, _p, _i64, _p, _p],
+    "ase_hip_axpy": [_p, _p, _i64, _f, _p],
+    "ase_hip_disc_reward": [_p, _i64, _p, _i64, _f, _p],
+    "ase_hip_enc_reward": [_p, _i64, _p, _i64, _p, _i64, _i, _f, _p],
+    "ase_hip_gae": [_p, _p, _p, _p, _p, _p, _f, _f, _f, _d, _d, _p, _p, _i, _i, _p],
+    "ase_hip_adv_norm": [_p, _p, _p, _p, _p, _i64, _i, _i, _p],
+    "ase_hip_ring_store": [_p, _i64, _i, _p, _i, _i, _i, _p, _i64, _i64, _p],
+    "ase_hip_sample_latents": [_p, _i, _i, _p, _p],
+}
+
+
+class AseHipError(RuntimeError):
+    pass
+
+
+def load():
+    if not os.path.exists(LIB_PATH):
+        raise AseHipError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C ase_amd/csrc`.  There is no CPU or PyTorch fallback for the update path.")
+    lib = C.CDLL(LIB_PATH)
+    lib.ase_hip_abi_version.restype = C.c_int
+    lib.ase_hip_last_error.restype = C.c_char_p
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError if the library does not export it
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    if lib.ase_hip_abi_version() != 1:
+        raise AseHipError("libase_hip.so ABI version mismatch")
+    return lib
+
+
+_lib = None
+
+
+def get():
+    global _lib
+    if _lib is None:
+        _lib = load()
+    return _lib
+
+
+def check(rc, name):
+    if rc != 0:
+        raise AseHipError(f"{name} failed ({rc}): {get().ase_hip_last_error().decode()}")

@@ -1,0 +1,241 @@
+/* ase_hip.h — C ABI of libase_hip.so: the MI355X (gfx950) kernels behind the ASE/AMP PPO update.
+ *
+ * The reference (nv-tlabs/ASE) is pure Python on stock PyTorch ops; it has no FFI.  Each entry
+ * point below therefore cites the reference *Python* statement(s) it replaces (paths relative to
+ * /root/reference/ase/).  INTEGRATION.md shows the ctypes binding a maintainer of the reference
+ * would add for each.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative ASE_E* code otherwise
+ *     (ase_hip_last_error() gives the text); nothing allocates, frees or synchronises;
+ *     work is enqueued on `stream` (a hipStream_t), so calls are hipGraph-capturable.
+ *   - matrices are row-major with an explicit leading dimension in ELEMENTS.
+ *   - `dtype` selects the storage type of activations / shadow weights that feed the matrix
+ *     cores: ASE_F32 (exact f32 MFMA, parity mode) or ASE_BF16 (bf16 MFMA, f32 accumulate).
+ *     Running statistics are f64, master weights / gradients / Adam state / loss math are f32.
+ *   - GEMM operands live in "padded" buffers: K (the contracted, contiguous dimension) is a
+ *     multiple of 128 bytes / sizeof(type) and the padding is zero.
+ *   - row index maps: a logical minibatch row r reads dataset row p = idx ? idx[r] : r; when
+ *     remap_h > 0 the dataset is the time-major experience buffer [H=remap_h, N=remap_n, ...] and
+ *     p is the env-major flat index (p = env*H + t, rl_games swap_and_flatten01), i.e. the
+ *     physical row is (p % H) * N + p / H.  This is how learning/ase_agent.py:108-113 and
+ *     learning/amp_datasets.py:14-27 are applied without materialising copies.
+ */
+#ifndef ASE_HIP_H
+#define ASE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASE_HIP_ABI_VERSION 1
+
+enum { ASE_F32 = 0, ASE_BF16 = 1 };
+enum { ASE_ACT_NONE = 0, ASE_ACT_RELU = 1, ASE_ACT_TANH = 2 };
+enum { ASE_AUX_NONE = 0, ASE_AUX_RELU_MASK = 1, ASE_AUX_TANH_GRAD = 2 };
+enum { ASE_OK = 0, ASE_EINVAL = -1, ASE_ELAUNCH = -2, ASE_EUNSUPPORTED = -3 };
+
+int ase_hip_abi_version(void);
+const char* ase_hip_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense layers (matrix cores).
+ * ------------------------------------------------------------------------------------------- */
+
+/* C[m,n] = mask( act( alpha * sum_k A[m,k] * B[n,k] + bias[n] ) )       "NT" GEMM
+ *   A [M,K] dtype, B [N,K] dtype (weights, K contiguous), C [M,N] dtype or f32 (out_f32).
+ *   aux [M,N] dtype: ASE_AUX_RELU_MASK multiplies by (aux > 0), ASE_AUX_TANH_GRAD by (1 - aux^2).
+ *   colsum (nullable, f32[colsum_n]) += column sums of the stored values for n < colsum_n (atomic):
+ *   the bias gradient of the producing layer.
+ * Replaces: nn.Linear + activation forward  (learning/ase_network_builder.py:255-259,305-324,
+ *   learning/amp_network_builder.py:81-84), and autograd's data-gradient of the same layers
+ *   (B = the transposed weight shadow; mask = derivative of the previous activation), and the
+ *   transposed-MLP chain of the gradient penalty (learning/amp_agent.py:453-459). */
+int ase_hip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                    const float* bias, const void* aux, int64_t ldaux, float* colsum, int colsum_n,
+                    int M, int N, int K, int act, int aux_mode, int out_f32, float alpha,
+                    int dtype, void* stream);
+
+/* G[n, kmap(k)] += alpha * sum_m A[m,n] * B[m,k]   for n < n_real, kmap(k) valid     "TN" GEMM
+ *   A [M,N] dtype (output gradients), B [M,K] dtype (layer inputs), G f32 [n_real, k_real]
+ *   (master-layout weight gradient, accumulated with f32 atomics; split over M internally).
+ *   kmap undoes the padded-concat layout of the first actor/critic layer: k < split_src -> k;
+ *   k >= split_dst -> k - (split_dst - split_src); columns in between are padding.
+ *   (layers without a concat pass split_src = split_dst = k_real).
+ * Replaces: autograd's weight gradient of nn.Linear inside loss.backward()
+ *   (learning/ase_agent.py:271). */
+int ase_hip_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* G,
+                    int M, int N, int K, int n_real, int k_real, int split_src, int split_dst,
+                    float alpha, int dtype, void* stream);
+
+/* Shadow copies of one weight matrix for the matrix cores: W_s [n_pad,k_pad] and its transpose
+ * Wt_s [k_pad,n_pad] (both dtype, zero padded, concat columns moved to split_dst).  Run after
+ * every optimizer step.  (No reference counterpart: the reference multiplies f32 masters.) */
+int ase_hip_refresh_shadow(const float* W, int n_real, int k_real, void* Ws, int64_t ldws,
+                           void* Wts, int64_t ldwts, int split_src, int split_dst, int dtype,
+                           void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Running mean/std normaliser (rl_games RunningMeanStd; learning/common_agent.py:49,323-325,
+ * learning/amp_agent.py:26,535-538, learning/ase_agent.py:170-181) fused with the minibatch
+ * gather (learning/amp_datasets.py:14-27).
+ * state: f64[2*D+1] = running_mean[D], running_var[D], count.
+ * ------------------------------------------------------------------------------------------- */
+
+/* sums[2*D] (f64, atomic) += { sum_r (x[r,j]-shift[j]), sum_r (x[r,j]-shift[j])^2 }, shift = f32(running_mean) */
+int ase_hip_rms_moments(const float* src, int64_t ld_src, int D, const int32_t* idx, int remap_h,
+                        int remap_n, int M, const double* state, double* sums, void* stream);
+
+/* Sequentially merge n_streams batches (sums[s][2*D], counts[s] rows each; counts are the GLOBAL
+ * row counts) into `state` exactly as RunningMeanStd.forward does in training mode, and after
+ * each merge emit mean_f32[s][D] and std_f32[s][D] = sqrt(f32(var)+1e-5).  n_streams == 0 emits
+ * one pair from the current state (eval mode). */
+int ase_hip_rms_finalize(double* state, int D, const double* sums, const int32_t* counts /* HOST */,
+                         int n_streams, float* mean_out, float* std_out, void* stream);
+
+/* out_i[r, col_off_i + j] = clamp((x[map(r), j] - mean[j]) / std[j], -5, 5), i < 3 destinations. */
+int ase_hip_rms_normalize(const float* src, int64_t ld_src, int D, const int32_t* idx, int remap_h,
+                          int remap_n, int M, const float* mean, const float* std,
+                          void* out0, int64_t ld0, void* out1, int64_t ld1, void* out2, int64_t ld2,
+                          int dtype, void* stream);
+
+/* y = sqrt(f32(var)+1e-5) * clamp(x,-5,5) + f32(mean): RunningMeanStd(..., unnorm=True)
+ * (learning/ase_agent.py:140-141,391-392), D == 1. */
+int ase_hip_rms_unnormalize(const double* state, const float* x, float* y, int64_t n, void* stream);
+
+/* Generic row gather + cast: dst[r, 0:D] = src[map(r), 0:D]; dst dtype = dst_dtype
+ * (learning/amp_datasets.py:21-22 for the small per-row tensors). */
+int ase_hip_gather_rows(const float* src, int64_t ld_src, int D, const int32_t* idx, int remap_h,
+                        int remap_n, int M, void* dst, int64_t ld_dst, int dst_dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Loss heads: forward value + analytic gradient w.r.t. the head inputs, in one pass.
+ * `acc` is a device array of f64 partial sums (layout ASE_ACC_* below), zeroed by begin_step.
+ * ------------------------------------------------------------------------------------------- */
+enum {
+    ASE_ACC_MASK_SUM = 0,   /* sum rand_action_mask                         */
+    ASE_ACC_A_LOSS,         /* sum mask * ppo surrogate                      */
+    ASE_ACC_B_LOSS,         /* sum mask * bound loss                         */
+    ASE_ACC_ENTROPY,        /* sum mask * entropy                            */
+    ASE_ACC_CLIPPED,        /* sum mask * 1[|ratio-1| > e_clip]              */
+    ASE_ACC_C_LOSS,         /* sum (return - value)^2                        */
+    ASE_ACC_KL,             /* sum_rows policy_kl                            */
+    ASE_ACC_DIV,            /* sum mask * diversity loss                     */
+    ASE_ACC_BCE_AGENT,      /* sum softplus(l) over agent+replay rows        */
+    ASE_ACC_BCE_DEMO,       /* sum softplus(-l) over demo rows               */
+    ASE_ACC_AGENT_ACC,      /* count l < 0 (agent+replay)                    */
+    ASE_ACC_DEMO_ACC,       /* count l > 0 (demo)                            */
+    ASE_ACC_GP,             /* sum_rows |d logit / d x_demo|^2               */
+    ASE_ACC_ENC,            /* sum_rows -<enc, z>                            */
+    ASE_ACC_LOGIT_W2,       /* sum w_logit^2                                 */
+    ASE_ACC_DISC_W2,        /* sum over all disc weights^2                   */
+    ASE_ACC_ENC_W2,         /* sum over all enc weights^2                    */
+    ASE_ACC_COUNT = 24
+};
+
+/* acc[slot] += sum_i x[i] (f32 in, f64 atomic out); square != 0 sums x^2. */
+int ase_hip_reduce_sum(const float* x, int64_t n, int square, double* acc, int slot, void* stream);
+
+/* PPO actor/critic head for one minibatch (learning/common_agent.py:505-534,456-464,
+ * learning/ase_agent.py:228-241,252-258,290-294,445-467; rl_games neglogp / policy_kl).
+ *   mu      f32 [rows_mu, ld_mu]   rows [0,M) main pass, rows [M,2M) diversity pass (if div_on)
+ *   value   f32 [M, ld_v] (column 0)
+ *   mb_*    packed f32 minibatch fields (see ase_hip_gather_rows)
+ *   d_mu    dtype [rows_mu, ld_dmu], d_value dtype [M, ld_dv]: d loss / d mu, d loss / d value
+ *   db_mu f32[act_dim], db_value f32[1] (nullable): += their column sums (head bias gradients)
+ *   masked: 1 -> sum(mask*x)/sum(mask) reductions (AMP/ASE), 0 -> plain means over m_global (PPO)
+ *   mu_tanh: 1 -> mu_out = tanh(mu) precedes the losses (HRL high-level policy,
+ *            learning/hrl_network_builder.py:26-29)
+ *   acc[ASE_ACC_MASK_SUM] must already hold the GLOBAL mask sum. */
+int ase_hip_ppo_head(const float* mu, int64_t ld_mu, const float* value, int64_t ld_v,
+                     const float* mb_actions, const float* mb_old_mu, const float* mb_old_sigma,
+                     const float* mb_old_logp, const float* mb_adv, const float* mb_old_value,
+                     const float* mb_return, const float* mb_mask, const float* mb_z,
+                     const float* new_z, const float* logstd,
+                     void* d_mu, int64_t ld_dmu, void* d_value, int64_t ld_dv,
+                     float* db_mu, float* db_value, float* mu_out, double* acc,
+                     int M, int m_global, int act_dim, int z_dim, int masked, int div_on, int mu_tanh,
+                     int clip_value, float e_clip, float critic_coef, float bounds_coef,
+                     float div_coef, float div_tar, int dtype, void* stream);
+
+/* Discriminator logit losses (learning/amp_agent.py:442-447,481-496): rows [0,2*amb) agent+replay
+ * (target 0), rows [2*amb,3*amb) demo (target 1).  d_logit dtype [3*amb, ld_d] column 0. */
+int ase_hip_disc_head(const float* logit, int64_t ld_l, void* d_logit, int64_t ld_d, float* db_logit,
+                      double* acc, int amb, int amb_global, float disc_coef, int dtype, void* stream);
+
+/* Encoder head (learning/ase_network_builder.py:217, learning/ase_agent.py:413-418,469-472):
+ * e f32 [amb, ld_e] pre-normalisation output, z f32 [amb, z_dim]; d_e dtype [amb, ld_de].
+ * enc_out (nullable) f32 [amb, z_dim] receives normalize(e). */
+int ase_hip_enc_head(const float* e, int64_t ld_e, const float* z, int64_t ld_z, void* d_e,
+                     int64_t ld_de, float* db_enc, float* enc_out, double* acc, int amb, int amb_global,
+                     int z_dim, float enc_coef, int dtype, void* stream);
+
+/* Gradient-penalty seed: g[r,j] = (h[r,j] > 0) ? w[j] : 0  (d logit / d last hidden, ReLU). */
+int ase_hip_gp_seed(const void* h, int64_t ld_h, const float* w, void* g, int64_t ld_g, int rows,
+                    int width, int dtype, void* stream);
+
+/* acc[slot] += sum_{r,j} x[r,j]^2 over a dtype matrix [rows, cols]. */
+int ase_hip_sqnorm(const void* x, int64_t ld, int rows, int cols, double* acc, int slot, int dtype,
+                   void* stream);
+
+/* train_result scalars from the accumulators (same keys as learning/ase_agent.py:296-306).
+ * out f32[ASE_RES_COUNT]. */
+enum {
+    ASE_RES_A_LOSS = 0, ASE_RES_C_LOSS, ASE_RES_B_LOSS, ASE_RES_ENTROPY, ASE_RES_CLIP_FRAC, ASE_RES_KL,
+    ASE_RES_DISC_LOSS, ASE_RES_DISC_GP, ASE_RES_DISC_LOGIT_LOSS, ASE_RES_DISC_AGENT_ACC,
+    ASE_RES_DISC_DEMO_ACC, ASE_RES_ENC_LOSS, ASE_RES_DIV_LOSS, ASE_RES_LOSS, ASE_RES_MASK_SUM,
+    ASE_RES_COUNT = 16
+};
+int ase_hip_finalize_scalars(const double* acc, float* out, int m_global, int amb_global, int masked,
+                             int has_disc, int has_enc, int has_div, float critic_coef,
+                             float entropy_coef, float bounds_coef, float disc_coef, float disc_logit_reg,
+                             float disc_grad_penalty, float disc_weight_decay, float enc_coef,
+                             float enc_weight_decay, float div_coef, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Optimizer (torch.optim.Adam(lr, eps=1e-8, weight_decay=0): learning/common_agent.py:45,
+ * learning/ase_agent.py:265-269,287).
+ * opt_state: DEVICE f64[8] = {step, lr, beta1, beta2, eps, bias_corr1, bias_corr2, _}; step is
+ * advanced and the bias corrections recomputed on device by ase_hip_begin_step (graph-replay safe),
+ * which also zeroes the n_acc accumulators.
+ * ------------------------------------------------------------------------------------------- */
+int ase_hip_begin_step(double* opt_state, double* acc, int n_acc, void* stream);
+int ase_hip_adam(float* w, const float* g, float* m, float* v, int64_t n, const double* opt_state,
+                 void* stream);
+/* g[i] += c * w[i]  (the weight-only loss terms: learning/amp_agent.py:449-466) */
+int ase_hip_axpy(float* g, const float* w, int64_t n, float c, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Once-per-epoch rollout tail.
+ * ------------------------------------------------------------------------------------------- */
+
+/* r = -log(max(1 - sigmoid(l), 1e-4)) * scale   (learning/amp_agent.py:570-577) */
+int ase_hip_disc_reward(const float* logit, int64_t ld_l, float* r, int64_t n, float scale, void* stream);
+/* r = max(<normalize(e), z>, 0) * scale          (learning/ase_agent.py:404-411) */
+int ase_hip_enc_reward(const float* e, int64_t ld_e, const float* z, int64_t ld_z, float* r, int64_t n,
+                       int z_dim, float scale, void* stream);
+/* GAE (learning/common_agent.py:437-449, learning/ase_agent.py:484-490,105-106):
+ * rewards = w_task*task + w_disc*disc + w_enc*enc (disc/enc nullable); all [H,N] time-major. */
+int ase_hip_gae(const uint8_t* dones, const float* values, const float* next_values,
+                const float* r_task, const float* r_disc, const float* r_enc, float w_task, float w_disc,
+                float w_enc, double gamma, double tau, float* advs, float* returns, int H, int N, void* stream);
+/* advantages = returns - values, masked normalisation (learning/amp_agent.py:551-561 with rl_games
+ * normalization_with_masks; mask nullable -> learning/common_agent.py:536-546).
+ * Two calls: phase 0 accumulates moments into acc3 (f64[3], zeroed by the caller), phase 1 writes. */
+int ase_hip_adv_norm(const float* returns, const float* values, const float* mask, float* adv,
+                     double* acc3, int64_t n, int normalize, int phase, void* stream);
+
+/* dst[(head + i) % size, :] = src[map(i), :]  (learning/replay_buffer.py:27-49) */
+int ase_hip_ring_store(const float* src, int64_t ld_src, int D, const int32_t* idx, int remap_h,
+                       int remap_n, int n, float* dst, int64_t size, int64_t head, void* stream);
+
+/* z[r,:] = normalize(N(0,I))  (learning/ase_network_builder.py:221-225); counter-based Philox,
+ * stream position read from and advanced in rng_state (u64[2] = {seed, offset}). */
+int ase_hip_sample_latents(float* z, int rows, int dim, uint64_t* rng_state, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASE_HIP_H */

@@ -1,0 +1,342 @@
+"""CPU emulation of the libase_hip C-ABI operations — TEST INFRASTRUCTURE ONLY.
+
+Same method names and argument conventions as ``ase_amd.backend.HipBackend`` so that the engine's
+HOST logic (buffer layout, launch sequence, analytic backward, index maps) can be checked against
+the oracle on a machine without a GPU, and so that the GPU tests have a per-op reference with the
+SAME semantics as the kernels (including padding, concat-column maps and the analytic — not
+autograd — head gradients).  The product never imports this file.
+"""
+import math
+
+import torch
+
+from ase_amd import lib as L
+
+
+def _rows(idx, remap, M):
+    p = torch.arange(M) if idx is None else idx[:M].long()
+    if remap[0] > 0:
+        H, N = remap
+        env = p // H
+        t = p - env * H
+        p = t * N + env
+    return p
+
+
+class EmuBackend:
+    name = "emu"
+
+    def __init__(self):
+        self.rng = torch.Generator().manual_seed(99)
+
+    def zero_(self, t):
+        t.zero_()
+
+    # ------------------------------------------------------------------ GEMMs
+    def gemm_nt(self, A, B, Cm, M, N, K, bias=None, aux=None, aux_mode=L.AUX_NONE, colsum=None, colsum_n=0,
+                act=L.ACT_NONE, alpha=1.0):
+        a = A[:M, :K].float()
+        b = B[:N, :K].float()
+        v = alpha * (a @ b.t())
+        if bias is not None:
+            v = v + bias[:N]
+        if act == L.ACT_RELU:
+            v = torch.relu(v)
+        elif act == L.ACT_TANH:
+            v = torch.tanh(v)
+        if aux_mode == L.AUX_RELU_MASK:
+            v = v * (aux[:M, :N].float() > 0)
+        elif aux_mode == L.AUX_TANH_GRAD:
+            x = aux[:M, :N].float()
+            v = v * (1 - x * x)
+        out = v.to(Cm.dtype)
+        Cm[:M, :N] = out
+        if colsum is not None and colsum_n > 0:
+            colsum[:colsum_n] += out.float().sum(0)[:colsum_n]
+
+    def gemm_tn(self, A, B, G, M, N, K, n_real, k_real, split_src, split_dst, alpha=1.0):
+        full = alpha * (A[:M, :N].float().t() @ B[:M, :K].float())       # [N, K] padded layout
+        gap = split_dst - split_src
+        cols = list(range(split_src)) + [k for k in range(split_dst, K) if k - gap < k_real]
+        G[:n_real, :] += full[:n_real][:, cols]
+
+    def refresh_shadow(self, W, Ws, Wts, split_src, split_dst):
+        n, k = W.shape
+        gap = split_dst - split_src
+        kd = torch.tensor([j if j < split_src else j + gap for j in range(k)])
+        if Ws is not None:
+            Ws[:n, kd] = W.to(Ws.dtype)
+        if Wts is not None:
+            Wts[kd, :n] = W.t().to(Wts.dtype)
+
+    # ------------------------------------------------------------------ normaliser / gather
+    def rms_moments(self, src, D, idx, remap, M, state, sums):
+        x = src[_rows(idx, remap, M), :D]
+        shift = state[:D].float()
+        d = (x - shift).double()
+        sums[:D] += d.sum(0)
+        sums[D:2 * D] += (d * d).sum(0)
+
+    def rms_finalize(self, state, D, sums, count, n_streams, mean_out, std_out):
+        mean, var, cnt = state[:D].clone(), state[D:2 * D].clone(), state[2 * D].clone()
+        shift = mean.float().double()
+        mo, so = mean_out.view(-1, D), std_out.view(-1, D)
+        if n_streams == 0:
+            mo[0] = mean.float()
+            so[0] = torch.sqrt(var.float() + 1e-5)
+        sm = sums.view(-1, 2 * D)
+        for s in range(n_streams):
+            n = float(count)
+            s1, s2 = sm[s, :D], sm[s, D:]
+            bm = (shift + s1 / n).float().double()
+            bv = ((s2 - s1 * s1 / n) / (n - 1.0)).float().double()
+            delta = bm - mean
+            tot = cnt + n
+            new_mean = mean + delta * n / tot
+            m2 = var * cnt + bv * n + delta * delta * cnt * n / tot
+            mean, var, cnt = new_mean, m2 / tot, tot
+            mo[s] = mean.float()
+            so[s] = torch.sqrt(var.float() + 1e-5)
+        state[:D], state[D:2 * D], state[2 * D] = mean, var, cnt
+
+    def rms_normalize(self, src, D, idx, remap, M, mean, std, outs):
+        x = src[_rows(idx, remap, M), :D]
+        y = torch.clamp((x - mean[:D]) / std[:D], -5.0, 5.0)
+        for o in outs:
+            if o is not None:
+                o[:M, :D] = y.to(o.dtype)
+
+    def rms_unnormalize(self, state, x, y):
+        y.copy_(torch.sqrt(state[1].float() + 1e-5) * torch.clamp(x, -5.0, 5.0) + state[0].float())
+
+    def gather_rows(self, src, D, idx, remap, M, dst):
+        dst[:M, :D] = src[_rows(idx, remap, M), :D].to(dst.dtype)
+
+    # ------------------------------------------------------------------ heads
+    def reduce_sum(self, x, n, square, acc, slot):
+        v = x.reshape(-1)[:n].double()
+        acc[slot] += (v * v).sum() if square else v.sum()
+
+    def ppo_head(self, mu, value, mb, new_z, logstd, d_mu, d_value, db_mu, db_value, acc, M, m_global, act_dim,
+                 z_dim, masked, div_on, mu_tanh, clip_value, e_clip, critic_coef, bounds_coef, div_coef, div_tar,
+                 mu_out=None):
+        D = act_dim
+        raw = mu[:M, :D]
+        m = torch.tanh(raw) if mu_tanh else raw
+        a, omu, osg = mb['actions'], mb['mu'], mb['sigma']
+        ls = logstd[:D]
+        sg = torch.exp(ls)
+        d = (a - m) / sg
+        nlp = 0.5 * (d * d).sum(-1) + 0.5 * math.log(2 * math.pi) * D + ls.sum()
+        ratio = torch.exp(mb['old_logp_actions'].view(-1) - nlp)
+        adv = mb['advantages'].view(-1)
+        rc = torch.clamp(ratio, 1 - e_clip, 1 + e_clip)
+        s1, s2 = -adv * ratio, -adv * rc
+        a_loss = torch.max(s1, s2)
+        g = torch.where(ratio == rc, -adv, torch.where(s1 > s2, -adv, torch.where(s1 == s2, -0.5 * adv, torch.zeros_like(adv))))
+        S = float(acc[L.ACC_MASK_SUM]) if masked else float(m_global)
+        mk = mb['rand_action_mask'].view(-1) if masked else torch.ones(M)
+        w = mk / S
+        bh, bl = torch.clamp_min(m - 1, 0), torch.clamp_max(m + 1, 0)
+        b_row = (bh * bh + bl * bl).sum(-1)
+        ent_row = (0.5 + 0.5 * math.log(2 * math.pi) + ls).sum().expand(M)
+        kl_row = (torch.log(osg / sg + 1e-5) + (sg * sg + (omu - m) ** 2) / (2 * (osg * osg + 1e-5)) - 0.5).sum(-1)
+        gm = (w * g * ratio).unsqueeze(-1) * d / sg + bounds_coef * w.unsqueeze(-1) * 2 * (bh + bl)
+        div_row = torch.zeros(M)
+        gm2 = None
+        if div_on:
+            raw2 = mu[M:2 * M, :D]
+            m2 = torch.tanh(raw2) if mu_tanh else raw2
+            cm, cm2 = torch.clamp(m, -1, 1), torch.clamp(m2, -1, 1)
+            diff = cm - cm2
+            a_diff = (diff * diff).sum(-1) / D
+            zz = (new_z[:M] * mb['ase_latents']).sum(-1)
+            inv = 1.0 / (0.5 - 0.5 * zz + 1e-5)
+            bonus = a_diff * inv
+            div_row = (div_tar - bonus) ** 2
+            dl = div_coef * w * 2 * (bonus - div_tar)
+            db = (dl * inv).unsqueeze(-1) * 2 * diff / D
+            gm = gm + db * ((m >= -1) & (m <= 1))
+            gm2 = -db * ((m2 >= -1) & (m2 <= 1))
+            if mu_tanh:
+                gm2 = gm2 * (1 - m2 * m2)
+        if mu_tanh:
+            gm = gm * (1 - m * m)
+        o1 = gm.to(d_mu.dtype)
+        d_mu[:M, :D] = o1
+        dbm = o1.float().sum(0)
+        if div_on:
+            o2 = gm2.to(d_mu.dtype)
+            d_mu[M:2 * M, :D] = o2
+            dbm = dbm + o2.float().sum(0)
+        v = value[:M, 0]
+        R = mb['returns'].view(-1)
+        if clip_value:
+            ov = mb['old_values'].view(-1)
+            dlt = v - ov
+            vpc = ov + torch.clamp(dlt, -e_clip, e_clip)
+            l1, l2 = (v - R) ** 2, (vpc - R) ** 2
+            c = torch.max(l1, l2)
+            g1, g2 = 2 * (v - R), 2 * (vpc - R) * ((dlt >= -e_clip) & (dlt <= e_clip))
+            dv = torch.where(l1 > l2, g1, torch.where(l1 < l2, g2, 0.5 * (g1 + g2)))
+        else:
+            c = (R - v) ** 2
+            dv = 2 * (v - R)
+        ov_ = (critic_coef * dv / m_global).to(d_value.dtype)
+        d_value[:M, 0] = ov_
+        if db_mu is not None:
+            db_mu[:D] += dbm
+            if db_value is not None:
+                db_value[0] += ov_.float().sum()
+        if mu_out is not None:
+            mu_out[:M, :D] = m
+        acc[L.ACC_A_LOSS] += (mk * a_loss).double().sum()
+        acc[L.ACC_B_LOSS] += (mk * b_row).double().sum()
+        acc[L.ACC_ENTROPY] += (mk * ent_row).double().sum()
+        acc[L.ACC_CLIPPED] += (mk * ((ratio - 1).abs() > e_clip)).double().sum()
+        acc[L.ACC_C_LOSS] += c.double().sum()
+        acc[L.ACC_KL] += kl_row.double().sum()
+        if div_on:
+            acc[L.ACC_DIV] += (mk * div_row).double().sum()
+
+    def disc_head(self, logit, d_logit, db_logit, acc, amb, amb_global, disc_coef):
+        l = logit[:3 * amb, 0]
+        la, ld = l[:2 * amb], l[2 * amb:]
+        sp = lambda x: torch.clamp_min(x, 0) + torch.log1p(torch.exp(-x.abs()))
+        acc[L.ACC_BCE_AGENT] += sp(la).double().sum()
+        acc[L.ACC_BCE_DEMO] += sp(-ld).double().sum()
+        acc[L.ACC_AGENT_ACC] += (la < 0).double().sum()
+        acc[L.ACC_DEMO_ACC] += (ld > 0).double().sum()
+        ga = disc_coef * 0.5 * torch.sigmoid(la) / (2.0 * amb_global)
+        gd = -disc_coef * 0.5 * torch.sigmoid(-ld) / amb_global
+        o = torch.cat([ga, gd]).to(d_logit.dtype)
+        d_logit[:3 * amb, 0] = o
+        if db_logit is not None:
+            db_logit[0] += o.float().sum()
+
+    def enc_head(self, e, z, d_e, db_enc, enc_out, acc, amb, amb_global, z_dim, enc_coef):
+        ev, zv = e[:amb, :z_dim], z[:amb, :z_dim]
+        nrm = ev.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+        h = ev / nrm
+        dot = (h * zv).sum(-1, keepdim=True)
+        o = (-(enc_coef / amb_global) * (zv - h * dot) / nrm).to(d_e.dtype)
+        d_e[:amb, :z_dim] = o
+        if db_enc is not None:
+            db_enc[:z_dim] += o.float().sum(0)
+        if enc_out is not None:
+            enc_out[:amb, :z_dim] = h
+        acc[L.ACC_ENC] += (-dot).double().sum()
+
+    def gp_seed(self, h, w, g, rows, width):
+        g[:rows, :width] = torch.where(h[:rows, :width].float() > 0, w[:width].expand(rows, width),
+                                       torch.zeros(rows, width)).to(g.dtype)
+
+    def sqnorm(self, x, rows, cols, acc, slot):
+        acc[slot] += (x[:rows, :cols].double() ** 2).sum()
+
+    def finalize_scalars(self, acc, out, m_global, amb_global, masked, has_disc, has_enc, has_div, c):
+        a = acc.tolist()
+        S = a[L.ACC_MASK_SUM]
+        den = S if masked else float(m_global)
+        al, bl, ent, cf = a[L.ACC_A_LOSS] / den, a[L.ACC_B_LOSS] / den, a[L.ACC_ENTROPY] / den, a[L.ACC_CLIPPED] / den
+        cl, kl = a[L.ACC_C_LOSS] / m_global, a[L.ACC_KL] / m_global
+        loss = al + c['critic_coef'] * cl - c['entropy_coef'] * ent + c['bounds_loss_coef'] * bl
+        out.zero_()
+        out[L.RES_A_LOSS], out[L.RES_C_LOSS], out[L.RES_B_LOSS] = al, cl, bl
+        out[L.RES_ENTROPY], out[L.RES_CLIP_FRAC], out[L.RES_KL], out[L.RES_MASK_SUM] = ent, cf, kl, S
+        if has_disc:
+            amb = float(amb_global)
+            bce = 0.5 * (a[L.ACC_BCE_AGENT] / (2 * amb) + a[L.ACC_BCE_DEMO] / amb)
+            gp = a[L.ACC_GP] / amb
+            dl = bce + c['disc_logit_reg'] * a[L.ACC_LOGIT_W2] + c['disc_grad_penalty'] * gp + \
+                c['disc_weight_decay'] * a[L.ACC_DISC_W2]
+            loss += c['disc_coef'] * dl
+            out[L.RES_DISC_LOSS], out[L.RES_DISC_GP], out[L.RES_DISC_LOGIT_LOSS] = dl, gp, a[L.ACC_LOGIT_W2]
+            out[L.RES_DISC_AGENT_ACC] = a[L.ACC_AGENT_ACC] / (2 * amb)
+            out[L.RES_DISC_DEMO_ACC] = a[L.ACC_DEMO_ACC] / amb
+        if has_enc:
+            el = a[L.ACC_ENC] / amb_global + c.get('enc_weight_decay', 0) * a[L.ACC_ENC_W2]
+            loss += c['enc_coef'] * el
+            out[L.RES_ENC_LOSS] = el
+        if has_div:
+            dv = a[L.ACC_DIV] / S
+            loss += c['amp_diversity_bonus'] * dv
+            out[L.RES_DIV_LOSS] = dv
+        out[L.RES_LOSS] = loss
+
+    # ------------------------------------------------------------------ optimizer
+    def begin_step(self, opt_state, acc):
+        if acc is not None:
+            acc.zero_()
+        if opt_state is not None:
+            opt_state[0] += 1
+            opt_state[5] = 1.0 - float(opt_state[2]) ** float(opt_state[0])
+            opt_state[6] = 1.0 - float(opt_state[3]) ** float(opt_state[0])
+
+    def adam(self, w, g, m, v, st):
+        s = st.tolist()
+        b1m, b2, b2m, eps = torch.tensor(1.0 - s[2]).float(), torch.tensor(s[3]).float(), torch.tensor(1.0 - s[3]).float(), s[4]
+        step_size = torch.tensor(s[1] / s[5]).float()
+        bc2s = torch.tensor(math.sqrt(s[6])).float()
+        m.add_(b1m * (g - m))
+        v.mul_(b2).add_(b2m * (g * g))
+        denom = v.sqrt() / bc2s + eps
+        w.sub_(step_size * (m / denom))
+
+    def axpy(self, g, w, c):
+        g.add_(c * w)
+
+    # ------------------------------------------------------------------ rollout tail
+    def disc_reward(self, logit, r, n, scale):
+        l = logit.reshape(-1, logit.shape[-1])[:n, 0]
+        prob = 1 / (1 + torch.exp(-l))
+        r.view(-1)[:n] = -torch.log(torch.clamp_min(1 - prob, 0.0001)) * scale
+
+    def enc_reward(self, e, z, r, n, z_dim, scale):
+        ev, zv = e[:n, :z_dim], z.reshape(-1, z.shape[-1])[:n, :z_dim]
+        h = ev / ev.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+        r.view(-1)[:n] = torch.clamp_min((h * zv).sum(-1), 0) * scale
+
+    def gae(self, dones, values, next_values, r_task, r_disc, r_enc, w_task, w_disc, w_enc, gamma, tau, advs, returns,
+            H, N):
+        d = dones.view(H, N).float()
+        v, nv = values.view(H, N), next_values.view(H, N)
+        r = w_task * r_task.view(H, N)
+        if r_disc is not None:
+            r = r + w_disc * r_disc.view(H, N)
+        if r_enc is not None:
+            r = r + w_enc * r_enc.view(H, N)
+        last = torch.zeros(N)
+        A, Rt = advs.view(H, N), returns.view(H, N)
+        gt = torch.tensor(gamma * tau).float()
+        for t in reversed(range(H)):
+            delta = r[t] + torch.tensor(gamma).float() * nv[t] - v[t]
+            last = delta + gt * (1 - d[t]) * last
+            A[t] = last
+            Rt[t] = last + v[t]
+
+    def adv_norm(self, returns, values, mask, adv, acc3, n, normalize, phase):
+        a = (returns.view(-1) - values.view(-1))[:n]
+        m = mask.view(-1)[:n] if mask is not None else torch.ones(n)
+        if phase == 0:
+            am = (a * m).double()
+            acc3[0] += m.double().sum()
+            acc3[1] += am.sum()
+            acc3[2] += (am * am).sum()
+            return
+        if normalize:
+            S, mu = float(acc3[0]), float(acc3[1]) / float(acc3[0])
+            min_sqr = float(acc3[2]) / S - mu * mu
+            denom = torch.tensor(math.sqrt(min_sqr * S / (S - 1))).float() + 1e-8
+            adv.view(-1)[:n] = (a - torch.tensor(mu).float()) / denom
+        else:
+            adv.view(-1)[:n] = a
+
+    def ring_store(self, src, D, idx, remap, n, dst, size, head):
+        q = (head + torch.arange(n)) % size
+        dst[q, :D] = src[_rows(idx, remap, n), :D]
+
+    def sample_latents(self, z, rows, dim, rng_state):
+        v = torch.randn(rows, dim, generator=self.rng)
+        z[:rows, :dim] = v / v.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+        rng_state[1] += 1
