@@ -78,6 +78,7 @@ class UpdateEngine:
         self.enc_sep = bool(getattr(net, 'enc_separate', False))
         assert cfg.get('enc_grad_penalty', 0) == 0, "enc_grad_penalty: not on the default path (SURVEY §8f N4)"
         self.mu_tanh = kind == 'ppo' and getattr(net, 'mu_tanh', False)
+        self._scratch = {}
         self._build_layers()
         self._bind_params()
         self._alloc(infer_rows)
@@ -495,6 +496,164 @@ class UpdateEngine:
         if self.div_on:
             out['amp_diversity_loss'] = r[L.RES_DIV_LOSS]
         return out
+
+    # ------------------------------------------------------------------ inference (rollout side, epoch tail)
+    def _scr(self, key, rows, cols, dt=None):
+        dt = self.dtype if dt is None else dt
+        k = (key, cols, dt)
+        t = self._scratch.get(k)
+        if t is None or t.shape[0] < rows:
+            t = torch.zeros(rows, cols, dtype=dt, device=self.dev)
+            self._scratch[k] = t
+        return t[:rows]
+
+    def _eval_stats(self, state, D, key):
+        mean, std = self._scr(key + '_m', 1, D, torch.float32), self._scr(key + '_s', 1, D, torch.float32)
+        self.be.rms_finalize(state, D, None, 0, 0, mean, std)
+        return mean[0], std[0]
+
+    def policy_forward(self, obs, z=None, normalize=True, unnorm_value=True, want=('mu', 'value')):
+        """Eval-mode actor / critic on raw observations [n, obs] (learning/ase_agent.py:117-148,385-393):
+        eval-mode obs normalisation -> nets -> (mu [n, act], value [n, 1] un-normalised)."""
+        be, n = self.be, obs.shape[0]
+        f32 = torch.float32
+        a0 = self.actor[0]
+        Xa, Xc = self._scr('Xa', n, a0.k_pad), self._scr('Xc', n, a0.k_pad)
+        if normalize and self.cfg.get('normalize_input', True):
+            mean, std = self._eval_stats(self.obs_state, self.obs, 'obs')
+        else:
+            mean, std = self._scr('one_m', 1, self.obs, f32)[0].zero_(), self._scr('one_s', 1, self.obs, f32)[0].fill_(1.0)
+        be.rms_normalize(obs, self.obs, None, (0, 0), n, mean, std, [Xa, Xc])
+        out = {}
+        if self.z:
+            sd = a0.split_dst
+            be.gather_rows(z, self.z, None, (0, 0), n, Xc[:, sd:])
+        if 'mu' in want:
+            if self.style:
+                Zs = self._scr('Zs', n, P(self.z))
+                be.gather_rows(z, self.z, None, (0, 0), n, Zs)
+                h = Zs
+                for i, d in enumerate(self.style[:-1]):
+                    y = self._scr(f'Hs{i}', n, d.n_pad)
+                    self._fwd(d, h, y, n)
+                    h = y
+                self._fwd(self.style[-1], h, Xa[:, a0.split_dst:], n)
+            h = Xa
+            for i, d in enumerate(self.actor):
+                y = self._scr(f'Ha{i}', n, d.n_pad)
+                self._fwd(d, h, y, n)
+                h = y
+            MU = self._scr('MU', n, self.mu_head.n_pad, f32)
+            self._fwd(self.mu_head, h, MU, n)
+            mu = MU[:, :self.act]
+            out['mu'] = torch.tanh(mu) if self.mu_tanh else mu.clone()
+        if 'value' in want:
+            h = Xc
+            for i, d in enumerate(self.critic):
+                y = self._scr(f'Hc{i}', n, d.n_pad)
+                self._fwd(d, h, y, n)
+                h = y
+            V = self._scr('V', n, self.value_head.n_pad, f32)
+            self._fwd(self.value_head, h, V, n)
+            v = V[:, 0:1].contiguous()
+            if unnorm_value and self.cfg.get('normalize_value', True):
+                vu = torch.empty_like(v)
+                be.rms_unnormalize(self.val_state, v, vu)
+                v = vu
+            out['value'] = v
+        return out
+
+    def amp_heads(self, amp_obs, normalize=True):
+        """Eval-mode discriminator logits [n,1] (+ un-normalised encoder output [n,z]) on raw amp obs
+        (learning/amp_agent.py:547-549, learning/ase_agent.py:480-482)."""
+        be, n = self.be, amp_obs.shape[0]
+        f32 = torch.float32
+        d0 = self.disc[0]
+        X = self._scr('Xd', n, d0.k_pad)
+        if normalize and self.cfg.get('normalize_amp_input', True):
+            mean, std = self._eval_stats(self.amp_state, self.amp, 'amp')
+        else:
+            mean, std = self._scr('one_am', 1, self.amp, f32)[0].zero_(), self._scr('one_as', 1, self.amp, f32)[0].fill_(1.0)
+        be.rms_normalize(amp_obs, self.amp, None, (0, 0), n, mean, std, [X])
+        h = X
+        for i, d in enumerate(self.disc):
+            y = self._scr(f'Hd{i}', n, d.n_pad)
+            self._fwd(d, h, y, n)
+            h = y
+        HD = self._scr('HD', n, self.disc_head.n_pad, f32)
+        self._fwd(self.disc_head, h, HD, n)
+        enc = None
+        if self.has_enc:
+            if self.enc_sep:
+                h = X
+                for i, d in enumerate(self.enc_chain):
+                    y = self._scr(f'He{i}', n, d.n_pad)
+                    self._fwd(d, h, y, n)
+                    h = y
+                E = self._scr('E', n, self.enc_head.n_pad, f32)
+                self._fwd(self.enc_head, h, E, n)
+                enc = E
+            else:
+                enc = HD[:, self.disc_head.parts[1][2]:]
+        return HD, enc
+
+    # ------------------------------------------------------------------ once-per-epoch rollout tail
+    def prepare_epoch(self, exp):
+        """Tail of play_steps + prepare_dataset on the time-major experience buffers (device tensors):
+        AMP/ASE rewards, GAE, advantage normalisation, value normalisation (two statistics updates:
+        values, then returns — learning/common_agent.py:323-325).  Returns the dataset dict in physical
+        (time-major) row order; minibatch rows are addressed with remap = (H, N)."""
+        be, c = self.be, self.cfg
+        H, N = exp['rewards'].shape[0], exp['rewards'].shape[1]
+        B = H * N
+        f32 = torch.float32
+        r_disc = r_enc = None
+        info = {}
+        if self.has_disc:
+            amp = exp['amp_obs'].view(B, self.amp)
+            HD, enc = self.amp_heads(amp)
+            r_disc = self._scr('r_disc', B, 1, f32)
+            be.disc_reward(HD, r_disc, B, c['disc_reward_scale'])
+            info['disc_rewards'] = r_disc
+            if self.has_enc:
+                r_enc = self._scr('r_enc', B, 1, f32)
+                be.enc_reward(enc, exp['ase_latents'].view(B, self.z), r_enc, B, self.z, c['enc_reward_scale'])
+                info['enc_rewards'] = r_enc
+        advs, rets = self._scr('advs', B, 1, f32), self._scr('rets', B, 1, f32)
+        be.gae(exp['dones'], exp['values'], exp['next_values'], exp['rewards'], r_disc, r_enc,
+               c.get('task_reward_w', 1.0) if self.has_disc else 1.0, c.get('disc_reward_w', 0.0),
+               c.get('enc_reward_w', 0.0), c['gamma'], c['tau'], advs, rets, H, N)
+        info['mb_advs'], info['mb_returns'] = advs, rets
+        values = exp['values'].view(B, 1)
+        mask = exp['rand_action_mask'].view(B, 1) if self.masked else None
+        adv = self._scr('adv_n', B, 1, f32)
+        acc3 = self._scr('acc3', 1, 3, torch.float64)
+        be.zero_(acc3)
+        be.adv_norm(rets, values, mask, adv, acc3, B, c['normalize_advantage'], 0)
+        be.adv_norm(rets, values, mask, adv, acc3, B, c['normalize_advantage'], 1)
+        if c.get('normalize_value', True):
+            nv, nr = self._scr('val_n', B, 1, f32), self._scr('ret_n', B, 1, f32)
+            sums = self._scr('val_sums', 1, 2, torch.float64)
+            m, s = self._scr('val_m', 1, 1, f32), self._scr('val_s', 1, 1, f32)
+            for src, dst in ((values, nv), (rets, nr)):
+                be.zero_(sums)
+                be.rms_moments(src, 1, None, (0, 0), B, self.val_state, sums)
+                if self.R > 1:
+                    import torch.distributed as dist
+                    pass  # the experience buffer is replicated across ranks in strong-scaling mode: no reduction
+                be.rms_finalize(self.val_state, 1, sums, B, 1, m, s)
+                be.rms_normalize(src, 1, None, (0, 0), B, m[0], s[0], [dst])
+        else:
+            nv, nr = values, rets
+        ds = {'obs': exp['obses'].view(B, self.obs), 'actions': exp['actions'].view(B, self.act),
+              'mu': exp['mus'].view(B, self.act), 'sigma': exp['sigmas'].view(B, self.act),
+              'old_logp_actions': exp['neglogpacs'].view(B, 1), 'advantages': adv, 'old_values': nv, 'returns': nr}
+        if self.masked:
+            ds['rand_action_mask'] = exp['rand_action_mask'].view(B, 1)
+            ds['amp_obs'] = exp['amp_obs'].view(B, self.amp)
+        if self.z:
+            ds['ase_latents'] = exp['ase_latents'].view(B, self.z)
+        return ds, info, (H, N)
 
     def export_grads(self):
         return {name: self.grads[o:o + math.prod(shp)].view(shp) for name, (o, shp) in self.net.param_slices.items()

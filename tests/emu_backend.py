@@ -84,7 +84,7 @@ class EmuBackend:
         if n_streams == 0:
             mo[0] = mean.float()
             so[0] = torch.sqrt(var.float() + 1e-5)
-        sm = sums.view(-1, 2 * D)
+        sm = sums.view(-1, 2 * D) if n_streams > 0 else None
         for s in range(n_streams):
             n = float(count)
             s1, s2 = sm[s, :D], sm[s, D:]

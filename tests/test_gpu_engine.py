@@ -1,0 +1,140 @@
+"""GPU parity tests, step level: the HIP update engine against (a) the golden vectors recorded from
+the reference's own code and (b) the CPU oracle at the real ASE shapes (obs 253, amp 1400, latent 64,
+[1024,1024,512] nets), in exact-f32 mode (rtol 1e-4 on losses and gradients — BASELINE.json's bar)
+and in bf16 mode (tolerance stated per check)."""
+import copy
+import os
+
+import pytest
+import torch
+
+from oracle import restated as R
+from tests.helpers import build_net, close, get_rms, set_rms
+from tests.test_engine_emu import CASES, check_first_step, first_step
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def be():
+    from ase_amd.backend import HipBackend
+    return HipBackend()
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_first_step_vs_reference_golden_f32(be, name, golden_dir):
+    G = torch.load(os.path.join(golden_dir, name + '.pt'), weights_only=False)
+    net, eng = first_step(G, be, torch.float32, device='cuda')
+    torch.cuda.synchronize()
+    check_first_step(G, net, eng, rtol=1e-4, gtol=1e-4, wtol=G['cfg']['learning_rate'] * 0.05)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_first_step_vs_reference_golden_bf16(be, name, golden_dir):
+    """bf16 storage / MFMA, f32 accumulate (8 mantissa bits on activations, shadow weights and
+    back-propagated gradients): losses within 8e-2 relative (+2e-2 abs), every gradient tensor within 30%
+    relative L2 error on this stress minibatch.  The realistic-ratio check is test_full_width_step_vs_oracle."""
+    G = torch.load(os.path.join(golden_dir, name + '.pt'), weights_only=False)
+    net, eng = first_step(G, be, torch.bfloat16, device='cuda')
+    torch.cuda.synchronize()
+    E = G['epochs'][0]
+    res, ref = eng.results(), E['steps'][0]
+    # the golden minibatches are a stress case (policy far from the behaviour policy: clip fraction 0.93,
+    # |a - mu| / sigma up to ~10), where the importance ratio amplifies any error in mu by ~1/sigma^2
+    for k in ('actor_loss', 'b_loss', 'disc_loss', 'disc_grad_penalty', 'enc_loss', 'amp_diversity_loss', 'kl'):
+        if k in ref:
+            close(res[k], ref[k], 8e-2, 2e-2, k)
+    close(res['critic_loss'], ref['critic_loss'].mean(), 3e-2, 1e-3, 'critic_loss')
+    grads = eng.export_grads()
+    for k, g in E['first_grads'].items():
+        rel = float((grads[k].cpu().double() - g.double()).norm() / (g.double().norm() + 1e-30))
+        assert rel < 0.3, ('grad ' + k, rel)
+
+
+def _ase_full_cfg():
+    import yaml
+    y = yaml.safe_load(open(os.path.join(os.path.dirname(__file__), '..', 'ase_amd', 'cfg', 'train_ase.yaml')))
+    return y['params']['network'], y['params']['config']
+
+
+@pytest.mark.parametrize('dt,M,AMB', [(torch.float32, 2048, 512), (torch.bfloat16, 2048, 512)])
+def test_full_width_step_vs_oracle(be, dt, M, AMB):
+    """Real ASE net (7,039,905 parameters), real feature sizes; minibatch reduced so the CPU oracle
+    finishes in seconds.  Same seeded inputs on both sides; oracle = oracle/restated.py (pinned to the
+    reference by tests/test_oracle_golden.py)."""
+    from ase_amd.engine import UpdateEngine
+    from ase_amd.learning.network_builder import ASEBuilder
+    net_p, cfg = _ase_full_cfg()
+    cfg = copy.deepcopy(cfg)
+    cfg['minibatch_size'], cfg['amp_minibatch_size'] = M, AMB
+    torch.manual_seed(0)
+    b = ASEBuilder()
+    b.load(net_p)
+    net = b.build('ase', actions_num=31, input_shape=(253,), num_seqs=1, value_size=1, amp_input_shape=(1400,),
+                  ase_latent_shape=(64,), device='cuda')
+    assert net.trainable_numel == 7039905
+    g = torch.Generator().manual_seed(1)
+    z = torch.randn(M, 64, generator=g)
+    nz = torch.randn(M, 64, generator=g)
+    mb = {'obs': torch.randn(M, 253, generator=g) * 1.5 + 0.2, 'actions': torch.randn(M, 31, generator=g) * 0.1,
+          'mu': torch.randn(M, 31, generator=g) * 0.05, 'sigma': torch.full((M, 31), 0.055023),
+          'advantages': torch.randn(M, generator=g), 'old_values': torch.randn(M, 1, generator=g),
+          'returns': torch.randn(M, 1, generator=g), 'rand_action_mask': (torch.rand(M, generator=g) < 0.8).float(),
+          'ase_latents': z / z.norm(dim=-1, keepdim=True), 'amp_obs': torch.randn(M, 1400, generator=g),
+          'amp_obs_replay': torch.randn(M, 1400, generator=g) * 1.1, 'amp_obs_demo': torch.randn(M, 1400, generator=g) + 0.3}
+    nz = nz / nz.norm(dim=-1, keepdim=True)
+    # oracle first (it also provides a consistent old_logp so that the ratio is near 1)
+    sd = R.canonical_sd(net.state_dict(), False, requires_grad=[k for k, p in net.named_parameters() if p.requires_grad])
+    sd = {k: v.cpu() if not v.requires_grad else v.detach().cpu().requires_grad_(True) for k, v in sd.items()}
+    rms = {'obs': R.rms_new(253), 'amp': R.rms_new(1400)}
+    with torch.no_grad():
+        o = R.rms_normalize(R.rms_update(R.rms_clone(rms['obs']), mb['obs']), mb['obs'])
+        mu0, ls0 = R.eval_actor('ase', sd, o, mb['ase_latents'])
+        mb['actions'] = mu0 + torch.exp(ls0) * torch.randn(M, 31, generator=g)
+        mb['mu'] = mu0 + 0.01 * torch.randn(M, 31, generator=g)
+        mb['old_logp_actions'] = R.neglogp(mb['actions'], mu0, torch.exp(ls0), ls0) + 0.1 * torch.randn(M, generator=g)
+    ref = R.calc_gradients('ase', sd, rms, mb, cfg, nz)          # the reference's arithmetic: f32 on CPU
+    sd64 = {k: (v.detach().double().requires_grad_(True) if v.requires_grad else v.double()) for k, v in sd.items()}
+    rms64 = {'obs': R.rms_new(253), 'amp': R.rms_new(1400)}
+    ref64 = R.calc_gradients('ase', sd64, rms64, {k: v.double() for k, v in mb.items()}, cfg, nz.double())
+
+    eng = UpdateEngine('ase', net, cfg, be, minibatch=M, amp_minibatch=AMB, dtype=dt)
+    idx = torch.arange(M, dtype=torch.int32, device='cuda')
+    mbg = {k: v.cuda() for k, v in mb.items()}
+    streams = [(mbg['amp_obs'], idx, (0, 0)), (mbg['amp_obs_replay'], idx, (0, 0)), (mbg['amp_obs_demo'], idx, (0, 0))]
+    eng.step(mbg, idx, (0, 0), streams, new_z=nz.cuda(), apply=False)
+    torch.cuda.synchronize()
+    res, grads = eng.results(), eng.export_grads()
+    f32 = dt == torch.float32
+    # loss scalars.  Scale = magnitude of the summands (actor_loss / enc_loss are means of signed O(1) terms)
+    scale = {'actor_loss': 1.0, 'enc_loss': 1.0}
+    for k in ('actor_loss', 'critic_loss', 'b_loss', 'disc_loss', 'disc_grad_penalty', 'enc_loss', 'amp_diversity_loss',
+              'kl', 'entropy', 'actor_clip_frac', 'disc_agent_acc', 'disc_demo_acc'):
+        sc = max(abs(float(ref64[k])), scale.get(k, 0.0))
+        err = abs(float(res[k]) - float(ref64[k]))
+        tol = (1e-4 if f32 else 1e-2) * sc + 1e-7
+        if not f32 and k == 'actor_clip_frac':
+            tol = 2e-2          # a counting statistic of the (bf16-noisy) importance ratio
+        assert err <= tol, (k, float(res[k]), float(ref64[k]), err, tol)
+    worst = 0.0
+    for k, p in sd64.items():
+        if not p.requires_grad:
+            continue
+        g64, g32, gh = p.grad, sd[k].grad.double(), grads[k].cpu().double()
+        mx = float(g64.abs().max())
+        e_hip, e_cpu = float((gh - g64).abs().max()) / mx, float((g32 - g64).abs().max()) / mx
+        rel = float((gh - g64).norm() / g64.norm())
+        worst = max(worst, rel)
+        if f32:
+            # BASELINE bar (1e-4), or — where f32 itself cannot reach it because the gradient is a cancelling sum
+            # (critic trunk: CPU f32 is 5e-4 from the exact result) — no worse than 3x the reference's own f32 error
+            assert e_hip <= max(1e-4, 3.0 * e_cpu), ('grad ' + k, e_hip, e_cpu)
+        else:
+            # bf16: measured 0.3% (disc head) ... 12% (actor trunk, importance-ratio amplification) relative L2
+            assert rel < 0.25, ('grad ' + k, rel)
+    print('dtype', dt, 'worst relative L2 gradient error', worst)
+    for nm, st in (('obs', eng.obs_state), ('amp', eng.amp_state)):
+        got = get_rms(st)
+        close(got['mean'], rms64[nm]['mean'], 1e-6, 1e-6, nm + ' mean')
+        close(got['var'], rms64[nm]['var'], 1e-5, 1e-6, nm + ' var')
+        close(got['count'], rms64[nm]['count'], 0, 0, nm + ' count')

@@ -1,0 +1,354 @@
+"""GPU parity tests, op level: every C-ABI entry point of libase_hip.so against the CPU emulation of the
+same op (tests/emu_backend.py) on identical seeded inputs.  Shapes include the odd sizes of the real
+nets (K = 253+64 -> 320 padded concat, 1400 -> 1408, N = 31 / 1 heads, ragged M).
+f32 storage = exact-f32 MFMA: tolerance is summation-order noise; bf16 storage: inputs are rounded to
+bf16 on both sides, products accumulate in f32, so only the output rounding (2^-8 relative) remains."""
+import math
+
+import pytest
+import torch
+
+from ase_amd import lib as L
+from tests.emu_backend import EmuBackend
+from tests.helpers import close
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+
+
+@pytest.fixture(scope='module')
+def be():
+    from ase_amd.backend import HipBackend
+    return HipBackend()
+
+
+def _pair(t):
+    return t.cuda(), t.clone()
+
+
+def _tol(dt):
+    return (2e-5, 2e-5) if dt == torch.float32 else (1.2e-2, 2e-3)
+
+
+@pytest.mark.parametrize('dt', DT)
+@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (200, 64, 320), (77, 32, 128), (513, 320, 1408), (1024, 1024, 1024),
+                                   (4096, 512, 1024), (33, 1408, 1024)])
+def test_gemm_nt_plain(be, dt, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(dt)
+    B = (torch.randn(N, K, generator=g) * 0.1).to(dt)
+    bias = torch.randn(N, generator=g)
+    Ag, Ac = _pair(A)
+    Bg, Bc = _pair(B)
+    bg, bc = _pair(bias)
+    Cg, Cc = torch.zeros(M, N, dtype=dt).cuda(), torch.zeros(M, N, dtype=dt)
+    be.gemm_nt(Ag, Bg, Cg, M, N, K, bias=bg, act=L.ACT_RELU)
+    EmuBackend().gemm_nt(Ac, Bc, Cc, M, N, K, bias=bc, act=L.ACT_RELU)
+    rt, at = _tol(dt)
+    close(Cg.float(), Cc.float(), rt, at * math.sqrt(K / 64), f'nt {M}x{N}x{K}')
+
+
+@pytest.mark.parametrize('dt', DT)
+@pytest.mark.parametrize('act,aux_mode', [(L.ACT_TANH, L.AUX_NONE), (L.ACT_NONE, L.AUX_RELU_MASK),
+                                          (L.ACT_NONE, L.AUX_TANH_GRAD)])
+def test_gemm_nt_epilogues(be, dt, act, aux_mode):
+    M, N, K = 300, 192, 256
+    g = torch.Generator().manual_seed(11)
+    A = (torch.randn(M, K + 64, generator=g) * 0.3).to(dt)[:, :K]          # lda > K
+    B = (torch.randn(N, K, generator=g) * 0.1).to(dt)
+    aux = (torch.randn(M, N, generator=g)).clamp(-0.9, 0.9).to(dt)
+    Cbig = torch.zeros(M, N + 64, dtype=dt)
+    cs = torch.zeros(N + 8)
+    outs = []
+    for dev in ('cuda', 'cpu'):
+        b = be if dev == 'cuda' else EmuBackend()
+        Ad, Bd, auxd = A.to(dev), B.to(dev), aux.to(dev)
+        Cd, csd = Cbig.to(dev).clone(), cs.to(dev).clone()
+        Cv = Cd[:, 64:]                                                      # column-offset output view
+        b.gemm_nt(Ad, Bd, Cv, M, N, K, aux=auxd if aux_mode else None, aux_mode=aux_mode, colsum=csd, colsum_n=N - 5,
+                  act=act, alpha=0.5)
+        outs.append((Cd.float().cpu(), csd.cpu()))
+    rt, at = _tol(dt)
+    close(outs[0][0], outs[1][0], rt, at * 2, 'C')
+    close(outs[0][1], outs[1][1], rt * 5, at * 40, 'colsum')
+    assert float(outs[0][1][N - 5:].abs().max()) == 0.0
+    assert float(outs[0][0][:, :64].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('dt', DT)
+def test_gemm_nt_f32_out(be, dt):
+    M, N, K = 257, 64, 512
+    g = torch.Generator().manual_seed(5)
+    A = (torch.randn(M, K, generator=g) * 0.3).to(dt)
+    B = (torch.randn(N, K, generator=g) * 0.1).to(dt)
+    Cg, Cc = torch.zeros(M, N).cuda(), torch.zeros(M, N)
+    be.gemm_nt(A.cuda(), B.cuda(), Cg, M, N, K)
+    EmuBackend().gemm_nt(A, B, Cc, M, N, K)
+    close(Cg, Cc, 2e-5, 2e-5, 'f32 out')
+
+
+@pytest.mark.parametrize('dt', DT)
+@pytest.mark.parametrize('M,N,K,nr,kr,ss,sd', [(256, 128, 128, 128, 128, 128, 128), (1000, 64, 320, 48, 317, 253, 256),
+                                               (4096, 1024, 1408, 1024, 1400, 1400, 1400), (130, 64, 64, 1, 40, 40, 40),
+                                               (16384, 512, 1024, 512, 1024, 1024, 1024), (50, 128, 64, 100, 53, 37, 40)])
+def test_gemm_tn(be, dt, M, N, K, nr, kr, ss, sd):
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn(M, N, generator=g) * 0.2).to(dt)
+    B = (torch.randn(M, K, generator=g) * 0.2).to(dt)
+    G0 = torch.randn(nr, kr, generator=g)
+    Gg, Gc = G0.cuda(), G0.clone()
+    be.gemm_tn(A.cuda(), B.cuda(), Gg, M, N, K, nr, kr, ss, sd, alpha=0.7)
+    EmuBackend().gemm_tn(A, B, Gc, M, N, K, nr, kr, ss, sd, alpha=0.7)
+    close(Gg, Gc, 3e-5, 3e-5 * math.sqrt(M), f'tn {M}x{N}x{K}')
+
+
+@pytest.mark.parametrize('dt', DT)
+def test_refresh_shadow(be, dt):
+    n, k, ss, sd = 48, 53, 37, 64
+    W = torch.randn(n, k)
+    outs = []
+    for dev in ('cuda', 'cpu'):
+        b = be if dev == 'cuda' else EmuBackend()
+        Ws, Wts = torch.zeros(64, 128, dtype=dt, device=dev), torch.zeros(128, 64, dtype=dt, device=dev)
+        b.refresh_shadow(W.to(dev), Ws, Wts, ss, sd)
+        outs.append((Ws.float().cpu(), Wts.float().cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][0].t(), outs[0][1])
+
+
+@pytest.mark.parametrize('dt', DT)
+def test_rms_pipeline(be, dt):
+    H, N, D, M = 8, 50, 253, 300
+    g = torch.Generator().manual_seed(3)
+    src = torch.randn(H * N, D, generator=g) * 2 + 0.5
+    idx = torch.randperm(H * N, generator=g)[:M].to(torch.int32)
+    outs = []
+    for dev in ('cuda', 'cpu'):
+        b = be if dev == 'cuda' else EmuBackend()
+        state = torch.zeros(2 * D + 1, dtype=torch.float64, device=dev)
+        state[D:] = 1.0
+        state[:D] = 0.1
+        sums = torch.zeros(3, 2 * D, dtype=torch.float64, device=dev)
+        mean, std = torch.zeros(3, D, device=dev), torch.zeros(3, D, device=dev)
+        o0 = torch.zeros(M, 320, dtype=dt, device=dev)
+        o1 = torch.zeros(M, 320, dtype=dt, device=dev)
+        for s in range(3):
+            b.rms_moments(src.to(dev), D, idx.to(dev), (H, N), M, state, sums[s])
+        b.rms_finalize(state, D, sums, M, 3, mean, std)
+        b.rms_normalize(src.to(dev), D, idx.to(dev), (H, N), M, mean[2], std[2], [o0, o1[:, 0:]])
+        outs.append((state.cpu(), mean.cpu(), std.cpu(), o0.float().cpu(), o1.float().cpu()))
+    close(outs[0][0], outs[1][0], 1e-9, 1e-12, 'state')
+    close(outs[0][1], outs[1][1], 1e-6, 1e-7, 'mean')
+    close(outs[0][2], outs[1][2], 1e-6, 1e-7, 'std')
+    tol = 1e-5 if dt == torch.float32 else 1e-2
+    close(outs[0][3], outs[1][3], tol, tol, 'normalised')
+    assert torch.equal(outs[0][3], outs[0][4])
+
+
+def test_rms_eval_and_unnorm(be):
+    D = 17
+    st = torch.rand(2 * D + 1, dtype=torch.float64) + 0.5
+    outs = []
+    for dev in ('cuda', 'cpu'):
+        b = be if dev == 'cuda' else EmuBackend()
+        mean, std = torch.zeros(1, D, device=dev), torch.zeros(1, D, device=dev)
+        b.rms_finalize(st.to(dev), D, None, 0, 0, mean, std)
+        x = torch.linspace(-7, 7, 1000).to(dev)
+        y = torch.zeros_like(x)
+        b.rms_unnormalize(st[[0, D, 2 * D]].contiguous().to(dev), x, y)
+        outs.append((mean.cpu(), std.cpu(), y.cpu()))
+    for a, c in zip(*outs):
+        close(a, c, 1e-6, 1e-7)
+
+
+def test_gather_rows(be):
+    src = torch.randn(640, 31)
+    idx = torch.randperm(640)[:200].to(torch.int32)
+    for dt in DT:
+        dg, dc = torch.zeros(200, 64, dtype=dt).cuda(), torch.zeros(200, 64, dtype=dt)
+        be.gather_rows(src.cuda(), 31, idx.cuda(), (16, 40), 200, dg)
+        EmuBackend().gather_rows(src, 31, idx, (16, 40), 200, dc)
+        assert torch.equal(dg.cpu(), dc)
+
+
+def _mb(M, D, Z, g, masked=True):
+    mb = {'actions': torch.randn(M, D, generator=g) * 0.3, 'mu': torch.randn(M, D, generator=g) * 0.3,
+          'sigma': torch.full((M, D), math.exp(-2.9)), 'old_logp_actions': torch.randn(M, 1, generator=g) * 2 - 60,
+          'advantages': torch.randn(M, 1, generator=g), 'old_values': torch.randn(M, 1, generator=g),
+          'returns': torch.randn(M, 1, generator=g)}
+    if masked:
+        mb['rand_action_mask'] = (torch.rand(M, 1, generator=g) < 0.8).float()
+    if Z:
+        z = torch.randn(M, Z, generator=g)
+        mb['ase_latents'] = z / z.norm(dim=-1, keepdim=True)
+    return mb
+
+
+@pytest.mark.parametrize('dt', DT)
+@pytest.mark.parametrize('masked,div_on,mu_tanh,clip_value', [(1, 1, 0, 0), (1, 0, 0, 1), (0, 0, 1, 0)])
+def test_ppo_head(be, dt, masked, div_on, mu_tanh, clip_value):
+    M, D, Z = 1003, 31, 64
+    g = torch.Generator().manual_seed(17 + masked + 2 * div_on)
+    mb = _mb(M, D, Z if div_on else 0, g, masked)
+    rows = 2 * M if div_on else M
+    mu = torch.zeros(rows, 64)
+    mu[:, :D] = torch.randn(rows, D, generator=g) * 0.7
+    # keep the importance ratio in a range where all three surrogate branches occur
+    logstd = torch.full((D,), -2.9)
+    with torch.no_grad():
+        m = torch.tanh(mu[:M, :D]) if mu_tanh else mu[:M, :D]
+        nlp = 0.5 * (((mb['actions'] - m) / math.exp(-2.9)) ** 2).sum(-1) + 0.5 * math.log(2 * math.pi) * D + logstd.sum()
+        mb['old_logp_actions'] = (nlp + torch.randn(M, generator=g) * 0.3).view(M, 1)
+    value = torch.zeros(M, 64)
+    value[:, 0] = torch.randn(M, generator=g)
+    new_z = None
+    if div_on:
+        nz = torch.randn(M, Z, generator=g)
+        new_z = nz / nz.norm(dim=-1, keepdim=True)
+    outs = []
+    for dev in ('cuda', 'cpu'):
+        b = be if dev == 'cuda' else EmuBackend()
+        d_mu, d_v = torch.zeros(rows, 64, dtype=dt, device=dev), torch.zeros(M, 64, dtype=dt, device=dev)
+        dbm, dbv = torch.zeros(D, device=dev), torch.zeros(1, device=dev)
+        acc = torch.zeros(L.ACC_COUNT, dtype=torch.float64, device=dev)
+        if masked:
+            acc[L.ACC_MASK_SUM] = float(mb['rand_action_mask'].sum())
+        mbd = {k: v.to(dev) for k, v in mb.items()}
+        b.ppo_head(mu.to(dev), value.to(dev), mbd, None if new_z is None else new_z.to(dev), logstd.to(dev), d_mu, d_v,
+                   dbm, dbv, acc, M, M, D, Z if div_on else 0, masked, div_on, mu_tanh, clip_value, 0.2, 5.0, 10.0, 0.01,
+                   1.0)
+        outs.append((d_mu.float().cpu(), d_v.float().cpu(), dbm.cpu(), dbv.cpu(), acc.cpu()))
+    t = 2e-5 if dt == torch.float32 else 1e-2
+    sc = float(outs[1][0].abs().max())
+    close(outs[0][0], outs[1][0], t * 5, t * sc, 'd_mu')
+    close(outs[0][1], outs[1][1], t * 5, t * float(outs[1][1].abs().max()), 'd_value')
+    close(outs[0][2], outs[1][2], t * 50, t * 50 * sc, 'db_mu')
+    close(outs[0][3], outs[1][3], t * 50, t * 5 * float(outs[1][1].abs().max()), 'db_value')
+    # sums of signed surrogate terms: expf/logf differ by an ulp between host and device and the sum cancels
+    close(outs[0][4], outs[1][4], 5e-4, 2e-2, 'acc')
+
+
+@pytest.mark.parametrize('dt', DT)
+def test_disc_enc_heads(be, dt):
+    amb, Z = 333, 64
+    g = torch.Generator().manual_seed(23)
+    HD = torch.zeros(3 * amb, 128)
+    HD[:, 0] = torch.randn(3 * amb, generator=g) * 3
+    HD[:amb, 64:] = torch.randn(amb, Z, generator=g)
+    z = torch.randn(amb, Z, generator=g)
+    z = z / z.norm(dim=-1, keepdim=True)
+    outs = []
+    for dev in ('cuda', 'cpu'):
+        b = be if dev == 'cuda' else EmuBackend()
+        dHD = torch.zeros(3 * amb, 128, dtype=dt, device=dev)
+        dbl, dbe = torch.zeros(1, device=dev), torch.zeros(Z, device=dev)
+        enc_out = torch.zeros(amb, Z, device=dev)
+        acc = torch.zeros(L.ACC_COUNT, dtype=torch.float64, device=dev)
+        hd = HD.to(dev)
+        b.disc_head(hd, dHD, dbl, acc, amb, amb, 5.0)
+        b.enc_head(hd[:amb, 64:], z.to(dev), dHD[:amb, 64:], dbe, enc_out, acc, amb, amb, Z, 5.0)
+        outs.append((dHD.float().cpu(), dbl.cpu(), dbe.cpu(), enc_out.cpu(), acc.cpu()))
+    t = 2e-5 if dt == torch.float32 else 1e-2
+    sc = float(outs[1][0].abs().max())
+    close(outs[0][0], outs[1][0], t * 5, t * sc, 'dHD')
+    close(outs[0][1], outs[1][1], t * 50, t * 20 * sc, 'db_logit')
+    close(outs[0][2], outs[1][2], t * 50, t * 20 * sc, 'db_enc')
+    close(outs[0][3], outs[1][3], 1e-5, 1e-6, 'enc_out')
+    close(outs[0][4], outs[1][4], 2e-5, 1e-6, 'acc')
+
+
+@pytest.mark.parametrize('dt', DT)
+def test_gp_seed_sqnorm_reduce(be, dt):
+    rows, width = 200, 512
+    h = torch.randn(rows, 576).to(dt)
+    w = torch.randn(width)
+    x = torch.randn(300, 1408).to(dt)
+    v = torch.randn(100000)
+    outs = []
+    for dev in ('cuda', 'cpu'):
+        b = be if dev == 'cuda' else EmuBackend()
+        g = torch.zeros(rows, 512, dtype=dt, device=dev)
+        acc = torch.zeros(L.ACC_COUNT, dtype=torch.float64, device=dev)
+        b.gp_seed(h.to(dev), w.to(dev), g, rows, width)
+        b.sqnorm(x.to(dev), 300, 1400, acc, L.ACC_GP)
+        b.reduce_sum(v.to(dev), v.numel(), False, acc, 0)
+        b.reduce_sum(v.to(dev), v.numel(), True, acc, 1)
+        outs.append((g.float().cpu(), acc.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    close(outs[0][1], outs[1][1], 1e-10, 1e-9, 'acc')
+
+
+def test_finalize_begin_adam_axpy(be):
+    cfg = dict(critic_coef=5, entropy_coef=0.0, bounds_loss_coef=10, disc_coef=5, disc_logit_reg=0.01,
+               disc_grad_penalty=5, disc_weight_decay=1e-4, enc_coef=5, enc_weight_decay=0.0, amp_diversity_bonus=0.01)
+    n = 100003
+    g = torch.Generator().manual_seed(2)
+    w0, gr = torch.randn(n, generator=g), torch.randn(n, generator=g) * 1e-3
+    outs = []
+    for dev in ('cuda', 'cpu'):
+        b = be if dev == 'cuda' else EmuBackend()
+        acc = (torch.arange(L.ACC_COUNT, dtype=torch.float64) + 1.5).to(dev)
+        res = torch.zeros(L.RES_COUNT, device=dev)
+        b.finalize_scalars(acc, res, 1000, 250, 1, 1, 1, 1, cfg)
+        st = torch.tensor([0.0, 2e-5, 0.9, 0.999, 1e-8, 1.0, 1.0, 0.0], dtype=torch.float64, device=dev)
+        w, m, v, gd = w0.to(dev).clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev), gr.to(dev).clone()
+        for _ in range(3):
+            b.begin_step(st, acc)
+            b.axpy(gd, w, 1e-3)
+            b.adam(w, gd, m, v, st)
+        outs.append((res.cpu(), st.cpu(), acc.cpu(), w.cpu(), m.cpu(), v.cpu()))
+    close(outs[0][0], outs[1][0], 1e-6, 1e-7, 'res')
+    close(outs[0][1], outs[1][1], 1e-12, 1e-15, 'opt_state')
+    assert float(outs[0][2].abs().max()) == 0.0
+    close(outs[0][3], outs[1][3], 1e-6, 1e-9, 'w')
+    close(outs[0][4], outs[1][4], 1e-6, 1e-12, 'm')
+    close(outs[0][5], outs[1][5], 1e-6, 1e-15, 'v')
+
+
+def test_rollout_tail_ops(be):
+    H, N, Z, A = 32, 300, 64, 140
+    g = torch.Generator().manual_seed(8)
+    HD = torch.randn(H * N, 128, generator=g) * 3
+    z = torch.randn(H * N, Z, generator=g)
+    z = z / z.norm(dim=-1, keepdim=True)
+    dones = (torch.rand(H, N, generator=g) < 0.05).to(torch.uint8)
+    val, nval, rt = torch.randn(H, N, 1, generator=g), torch.randn(H, N, 1, generator=g), torch.ones(H, N, 1)
+    mask = (torch.rand(H, N, generator=g) < 0.7).float()
+    amp = torch.randn(H * N, A, generator=g)
+    idx = torch.randperm(H * N, generator=g)[:500].to(torch.int32)
+    outs = []
+    for dev in ('cuda', 'cpu'):
+        b = be if dev == 'cuda' else EmuBackend()
+        rd, re = torch.zeros(H * N, device=dev), torch.zeros(H * N, device=dev)
+        hd = HD.to(dev)
+        b.disc_reward(hd, rd, H * N, 2.0)
+        b.enc_reward(hd[:, 64:], z.to(dev), re, H * N, Z, 1.0)
+        advs, rets = torch.zeros(H, N, 1, device=dev), torch.zeros(H, N, 1, device=dev)
+        b.gae(dones.to(dev), val.to(dev), nval.to(dev), rt.to(dev), rd, re, 0.0, 0.5, 0.5, 0.99, 0.95, advs, rets, H, N)
+        acc3 = torch.zeros(3, dtype=torch.float64, device=dev)
+        adv = torch.zeros(H * N, device=dev)
+        b.adv_norm(rets, val.to(dev), mask.to(dev), adv, acc3, H * N, 1, 0)
+        b.adv_norm(rets, val.to(dev), mask.to(dev), adv, acc3, H * N, 1, 1)
+        ring = torch.zeros(700, A, device=dev)
+        b.ring_store(amp.to(dev), A, idx.to(dev), (H, N), 500, ring, 700, 450)
+        outs.append((rd.cpu(), re.cpu(), advs.cpu(), rets.cpu(), adv.cpu(), ring.cpu()))
+    names = ['disc_r', 'enc_r', 'advs', 'returns', 'adv_norm', 'ring']
+    for a, c, nm in zip(outs[0], outs[1], names):
+        close(a, c, 2e-5, 2e-5, nm)
+    assert torch.equal(outs[0][5], outs[1][5])
+
+
+def test_sample_latents(be):
+    z = torch.zeros(20000, 64).cuda()
+    st = torch.tensor([1234, 0], dtype=torch.int64).cuda()
+    be.sample_latents(z, 20000, 64, st)
+    z2 = torch.zeros(20000, 64).cuda()
+    be.sample_latents(z2, 20000, 64, st)
+    assert int(st[1]) == 2
+    zc = z.cpu()
+    close(zc.norm(dim=-1), torch.ones(20000), 1e-5, 1e-5, 'unit rows')
+    assert not torch.equal(zc, z2.cpu())
+    # isotropy: component mean ~ 0, second moment ~ 1/64
+    assert float(zc.mean(0).abs().max()) < 0.01
+    close((zc * zc).mean(0), torch.full((64,), 1 / 64), 0.08, 0.0, 'second moment')
