@@ -627,13 +627,13 @@ class UpdateEngine:
         values = exp['values'].view(B, 1)
         mask = exp['rand_action_mask'].view(B, 1) if self.masked else None
         adv = self._scr('adv_n', B, 1, f32)
-        acc3 = self._scr('acc3', 1, 3, torch.float64)
+        acc3 = self._scr('acc3', 1, 3, torch.float64)[0]
         be.zero_(acc3)
         be.adv_norm(rets, values, mask, adv, acc3, B, c['normalize_advantage'], 0)
         be.adv_norm(rets, values, mask, adv, acc3, B, c['normalize_advantage'], 1)
         if c.get('normalize_value', True):
             nv, nr = self._scr('val_n', B, 1, f32), self._scr('ret_n', B, 1, f32)
-            sums = self._scr('val_sums', 1, 2, torch.float64)
+            sums = self._scr('val_sums', 1, 2, torch.float64)[0]
             m, s = self._scr('val_m', 1, 1, f32), self._scr('val_s', 1, 1, f32)
             for src, dst in ((values, nv), (rets, nr)):
                 be.zero_(sums)

@@ -1,0 +1,306 @@
+"""Benchmark of the ASE PPO-update hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision bf16|f32] [--no-graph]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): ASE PPO-update samples/sec, 4096 envs x horizon 32 (config 2 = the reference's
+ase_humanoid.yaml verbatim: [1024,1024,512] actor/critic/disc MLPs, latent 64, obs 253, amp obs 1400,
+minibatch 16384, amp minibatch 4096, 6 mini-epochs => 48 optimisation steps).
+
+One "step" = one whole update of one rollout batch = everything ``train_epoch`` does after the simulator
+loop: AMP/encoder rewards, GAE, advantage + value normalisation, demo/replay sampling, 48 minibatch
+optimisation steps (normalisers, 4 MLPs forward/backward, losses incl. gradient penalty + diversity, Adam),
+replay store.  Inputs (the synthetic experience buffer) are resident in HBM before the timed
+region.  With N > 1 every minibatch is row-sharded over the ranks (strong scaling, BASELINE config 3) and the
+flat gradient buffer is all-reduced over RCCL/xGMI each optimisation step.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}        # /opt/skills/guides/MI355X_MICROARCH.md (dense)
+
+
+def load_cfg():
+    import yaml
+    y = yaml.safe_load(open(os.path.join(ROOT, 'ase_amd', 'cfg', 'train_ase.yaml')))
+    cfg = y['params']['config']
+    cfg['learning_rate'] = float(cfg['learning_rate'])       # PyYAML reads '2e-5' (no dot) as a string
+    return y['params']['network'], cfg
+
+
+def host_cores():
+    """CPU cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+class TimedBackend:
+    """Wraps a HipBackend: brackets every matrix-core launch with HIP events on the launch stream."""
+
+    def __init__(self, be):
+        self._be = be
+        self.records = []          # (kind, flops, start_event, end_event)
+
+    def __getattr__(self, k):
+        return getattr(self._be, k)
+
+    def _timed(self, kind, flops, fn, *a, **kw):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn(*a, **kw)
+        e.record()
+        self.records.append((kind, flops, s, e, self._shape))
+
+    def gemm_nt(self, A, B, Cm, M, N, K, **kw):
+        self._shape = (M, N, K)
+        self._timed('nt', 2.0 * M * N * K, self._be.gemm_nt, A, B, Cm, M, N, K, **kw)
+
+    def gemm_tn(self, A, B, G, M, N, K, n_real, k_real, split_src, split_dst, alpha=1.0):
+        self._shape = (M, N, K)
+        self._timed('tn', 2.0 * M * n_real * k_real, self._be.gemm_tn, A, B, G, M, N, K, n_real, k_real, split_src,
+                    split_dst, alpha=alpha)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for kind in ('nt', 'tn'):
+            rs = [r for r in self.records if r[0] == kind]
+            if rs:
+                ms = sum(r[2].elapsed_time(r[3]) for r in rs)
+                out[kind] = {'launches': len(rs), 'ms': ms, 'flops': sum(r[1] for r in rs)}
+        return out
+
+    def breakdown(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for kind, flops, s, e, shape in self.records:
+            a = agg.setdefault((kind,) + shape, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += s.elapsed_time(e)
+            a[2] += flops
+        rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+        return [f'{k[0]} M={k[1]:6d} N={k[2]:5d} K={k[3]:5d}  n={v[0]:4d}  {v[1]:8.2f} ms  {v[2] / (v[1] * 1e-3) / 1e12:7.1f} TF/s'
+                for k, v in rows]
+
+
+def algorithmic_flops_per_step(eng):
+    """2*M*N*K over the real (unpadded) layer shapes, forward + data-gradient + weight-gradient, the
+    gradient-penalty chain included; the shared-trunk encoder costs only its head (SURVEY §8d 'minimal')."""
+    M, AMB, Ra = eng.M, eng.AMB, eng.Ra
+
+    def chain(layers, rows, first_dgrad=False):
+        f = 0.0
+        for i, d in enumerate(layers):
+            n = sum(p[1] for p in d.parts)
+            f += 2.0 * rows * n * d.K * (3 if (i > 0 or first_dgrad) else 2)
+        return f
+    f = chain(eng.style, Ra) + chain(eng.actor + [eng.mu_head], Ra) + 2.0 * Ra * eng.z * eng.actor[0].N   # style-column dgrad
+    f += chain(eng.critic + [eng.value_head], M)
+    if eng.has_disc:
+        f += chain(eng.disc, 3 * AMB) + 2.0 * 3 * AMB * 1 * eng.disc_head.K * 3
+        if eng.has_enc and not eng.enc_sep:
+            f += 2.0 * AMB * eng.z * eng.disc_head.K * 3
+        gp = sum(2.0 * AMB * d.N * d.K for d in eng.disc)
+        f += gp * 3 - 0        # chain forward + its backward (data + weight)
+    return f
+
+
+def make_agent(device, precision, use_graph, world, rank, seed=0):
+    from ase_amd.learning import agents, models
+    from ase_amd.learning.network_builder import ASEBuilder
+    from ase_amd.synthetic import EnvSpec, SyntheticSource
+    import types
+    net_p, cfg = load_cfg()
+    spec = EnvSpec(num_envs=4096, horizon=cfg['horizon_length'], obs_size=253, act_size=31, amp_obs_size=1400,
+                   latent_dim=cfg['latent_dim'], latent_steps_min=cfg['latent_steps_min'],
+                   latent_steps_max=cfg['latent_steps_max'])
+    torch.manual_seed(seed)
+    b = ASEBuilder()
+    b.load(net_p)
+    sp = lambda n: types.SimpleNamespace(shape=(n,))
+    src = SyntheticSource(spec, seed=1234 + 2)
+    cfg = dict(cfg)
+    cfg.update(network=models.ModelASEContinuous(b), num_actors=spec.num_envs, device=device, precision=precision,
+               graph_capture=use_graph, world_size=world, rank=rank, vec_env=src,
+               env_info={'observation_space': sp(253), 'action_space': sp(31), 'amp_observation_space': sp(1400)})
+    return agents.ASEAgent('bench', cfg), cfg, spec
+
+
+def cpu_baseline(agent, cfg, steps=2):
+    """The reference's arithmetic (oracle/restated.py, f32, torch CPU threads = host cores) on a bounded sample
+    of the SAME workload: `steps` full-size optimisation steps (minibatch 16384 / amp 4096); the update rate is
+    extrapolated to the 48 steps of one update (the once-per-epoch tail is < 2% and left out)."""
+    from oracle import restated as R
+    ncpu = host_cores()
+    torch.set_num_threads(ncpu)
+    B, MB = agent.batch_size, agent.minibatch_size
+    H, N = agent._remap
+    env_major = lambda t: t.view(H, N, -1).transpose(0, 1).reshape(H * N, -1)
+    ds = {k: env_major(v).cpu() for k, v in agent._ds.items()}
+    for k in ('old_logp_actions', 'advantages', 'rand_action_mask'):
+        ds[k] = ds[k].view(-1)
+    ds['amp_obs_replay'] = ds['amp_obs']
+    g = torch.Generator().manual_seed(0)
+    demo = agent._amp_obs_demo_buffer.data.cpu()
+    ds['amp_obs_demo'] = demo[torch.randint(0, demo.shape[0], (B,), generator=g)]
+    sd = R.canonical_sd(agent.model.state_dict(), False,
+                        requires_grad=[k.replace('a2c_network.', '', 1) for k, p in agent.model.named_parameters() if p.requires_grad])
+    sd = {k: (v.cpu().detach().requires_grad_(True) if v.requires_grad else v.cpu()) for k, v in sd.items()}
+    rms = {'obs': R.rms_new(253), 'amp': R.rms_new(1400)}
+    adam = R.adam_new()
+    perm = torch.randperm(B, generator=g)
+    times = []
+    for i in range(steps + 1):
+        idx = perm[i * MB:(i + 1) * MB]
+        mb = {k: v[idx] for k, v in ds.items()}
+        z = R.sample_latents(MB, 64, g)
+        t0 = time.time()
+        R.calc_gradients('ase', sd, rms, mb, cfg, z)
+        R.adam_step(sd, adam, cfg['learning_rate'])
+        times.append(time.time() - t0)
+    t_step = sum(times[1:]) / steps            # first call = warm-up
+    n_steps = cfg['mini_epochs'] * (B // MB)
+    return {'value': B / (n_steps * t_step), 'unit': 'samples/s', 'cores': ncpu, 'kind': 'port',
+            'sample': f'{steps} of the {n_steps} optimisation steps of one update at full size (minibatch {MB}, amp '
+                      f'{cfg["amp_minibatch_size"]}), {t_step:.2f} s/step on {ncpu} threads, extrapolated x{n_steps}; '
+                      'oracle/restated.py (f32 torch CPU)'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--breakdown', action='store_true', help='per-shape GEMM time table on stderr')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    torch.cuda.set_device(local)
+    device = f'cuda:{local}'
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device(device))
+
+    use_graph = (not args.no_graph) and world == 1
+    t_setup = time.time()
+    agent, cfg, spec = make_agent(device, args.precision, use_graph, world, rank)
+    B = agent.batch_size
+
+    # ---- untimed: synthetic rollout into HBM (the policy outputs come from the engine's own inference path)
+    with torch.no_grad():
+        agent.set_eval()
+        exp = agent.vec_env.experience(agent._cpu_policy())
+        for k, v in exp.items():
+            if k in agent.experience:
+                agent.experience[k].copy_(v.to(device))
+        agent._init_amp_demo_buf()
+    torch.cuda.synchronize()
+    if rank == 0:
+        print(f'[bench] setup + synthetic rollout: {time.time() - t_setup:.1f} s', file=sys.stderr)
+
+    def one_update():
+        batch = agent._play_steps_tail()
+        return agent.update(batch)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_update()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        info = one_update()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = B * args.steps / dt
+    last = {k: float(v[-1]) for k, v in info.items() if torch.is_tensor(v[-1]) and v[-1].numel() == 1}
+
+    # ---- roofline of the dominant kernel class (matrix-core GEMMs): HIP events around every launch of one
+    # additional, eager (un-graphed) update on the same stream the kernels are launched on.
+    eng = agent.engine
+    roof = None
+    if rank == 0:
+        tb = TimedBackend(eng.be)
+        eng.be = tb
+        agent.use_graph = False
+        one_update()
+        summ = tb.summary()
+        if args.breakdown:
+            print('\n'.join(tb.breakdown()), file=sys.stderr)
+        eng.be = tb._be
+        agent.use_graph = use_graph
+        n_opt = cfg['mini_epochs'] * (B // cfg['minibatch_size'])
+        alg = algorithmic_flops_per_step(eng) * n_opt + 2.0 * B * sum(d.N * d.K for d in eng.disc) \
+            + 2.0 * B * (1 + eng.z) * eng.disc_head.K
+        gemm_ms = sum(v['ms'] for v in summ.values())
+        launches = sum(v['launches'] for v in summ.values())
+        achieved = alg / (gemm_ms * 1e-3) / 1e12
+        peak = MFMA_PEAK_TFLOPS[args.precision]
+        roof = {'bound': 'mfma', 'kernel': 'gemm_nt + gemm_tn (all dense layers of one update)',
+                'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
+                'traffic': None, 'launches_per_update': launches, 'avg_launch_us': round(gemm_ms * 1e3 / launches, 2),
+                'gemm_ms_per_update': round(gemm_ms, 3), 'algorithmic_tflop_per_update': round(alg / 1e12, 3),
+                'per_kind': {k: {'launches': v['launches'], 'ms': round(v['ms'], 3),
+                                 'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1)} for k, v in summ.items()}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(agent, cfg, steps=args.cpu_steps)
+
+    if rank == 0:
+        out = {'metric': 'ASE PPO-update samples/sec (4096 envs x horizon 32)', 'value': round(value, 1),
+               'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+               'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'strong',
+               'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
+               'config': {'workload': 'BASELINE configs[1]: ASE agent, 4096 envs x horizon 32, obs 253 / act 31 / amp obs '
+                                      '1400 / latent 64, [1024,1024,512] MLPs + disc + shared-trunk encoder, minibatch 16384 '
+                                      '(amp 4096) x 6 mini-epochs = 48 optimisation steps per update; random-init weights',
+                          'samples_per_step': B, 'optimisation_steps_per_step': cfg['mini_epochs'] * (B // cfg['minibatch_size']),
+                          'hipgraph': use_graph, 'parallelism': f'dp{world} (minibatch rows sharded, RCCL grad all-reduce)'
+                          if world > 1 else 'single GPU'},
+               'roofline': roof, 'cpu_baseline': cpu, 'last_train_result': {k: round(v, 6) for k, v in last.items()}}
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

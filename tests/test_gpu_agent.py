@@ -1,0 +1,70 @@
+"""GPU parity tests, epoch level: the agents' train_epoch update on the HIP backend replayed against the two
+full train_epoch calls of the reference recorded in the golden vectors (same inputs, same injected random
+draws): per-step losses, final weights after 8 optimisation steps per epoch, running statistics, replay ring."""
+import os
+
+import pytest
+import torch
+
+from tests.test_agent_emu import make_agent, replay_epochs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def be():
+    from ase_amd.backend import HipBackend
+    return HipBackend()
+
+
+@pytest.mark.parametrize('name', ['ase_tiny', 'amp_tiny', 'ppo_tiny', 'ase_sep_tiny'])
+def test_two_epochs_f32(be, name, golden_dir):
+    G = torch.load(os.path.join(golden_dir, name + '.pt'), weights_only=False)
+    ag = make_agent(G, be, device='cuda', precision='f32')
+    replay_epochs(G, ag, rtol=3e-4, wtol=G['cfg']['learning_rate'] * 0.25)
+
+
+@pytest.mark.parametrize('name', ['amp_tiny', 'ppo_tiny'])
+def test_two_epochs_f32_hipgraph(be, name, golden_dir):
+    """Same, with every optimisation step replayed from a captured hipGraph (no injected latents needed)."""
+    G = torch.load(os.path.join(golden_dir, name + '.pt'), weights_only=False)
+    ag = make_agent(G, be, device='cuda', precision='f32', graph_capture=True)
+    replay_epochs(G, ag, rtol=3e-4, wtol=G['cfg']['learning_rate'] * 0.25)
+    assert len(ag._graphs) >= 1
+
+
+@pytest.mark.parametrize('name', ['ase_tiny', 'amp_tiny'])
+def test_two_epochs_bf16_runs(be, name, golden_dir):
+    """bf16 mode end to end: finite, and the losses of every step within 10% (+0.05) of the reference's."""
+    G = torch.load(os.path.join(golden_dir, name + '.pt'), weights_only=False)
+    ag = make_agent(G, be, device='cuda', precision='bf16')
+    infos = replay_epochs(G, ag, rtol=0, wtol=0, check=False)
+    for info, E in zip(infos, G['epochs']):
+        for i, ref in enumerate(E['steps']):
+            for k in ('disc_loss', 'enc_loss', 'critic_loss', 'amp_diversity_loss'):
+                if k in ref:
+                    a, b = float(info[k][i]), float(ref[k].mean())
+                    assert a == a and abs(a - b) <= 0.1 * abs(b) + 0.05, (k, i, a, b)
+
+
+def test_graph_and_eager_agree_ase(be, golden_dir):
+    """ASE step under hipGraph replay (latents drawn on device) == eager step with the same latents injected."""
+    G = torch.load(os.path.join(golden_dir, 'ase_tiny.pt'), weights_only=False)
+    res = []
+    for graph in (False, True):
+        ag = make_agent(G, be, device='cuda', precision='f32', graph_capture=graph)
+        ag.engine.rng_state[0] = 777
+        E = G['epochs'][0]
+        ag.vec_env.q.append(G['demo_init'].clone())
+        for k, v in E['exp'].items():
+            if k in ag.experience:
+                ag.experience[k].copy_(v)
+        batch = ag._play_steps_tail()
+        ag.vec_env.q.append(E['demo_fetched'].clone())
+        ag._amp_obs_demo_buffer._sample_idx = E['demo_sample_perm'].cuda()
+        info = ag.update(batch, perms=E['dataset_perms'])
+        res.append(({k: torch.stack([x.float() for x in v]).cpu() for k, v in info.items() if torch.is_tensor(v[0]) and v[0].numel() == 1},
+                    ag.model.a2c_network.flat_params.clone().cpu()))
+    for k in res[0][0]:
+        assert torch.allclose(res[0][0][k], res[1][0][k], rtol=1e-4, atol=1e-6), k
+    assert torch.allclose(res[0][1], res[1][1], rtol=1e-5, atol=2e-6)

@@ -54,6 +54,7 @@ def test_first_step_vs_reference_golden_bf16(be, name, golden_dir):
 def _ase_full_cfg():
     import yaml
     y = yaml.safe_load(open(os.path.join(os.path.dirname(__file__), '..', 'ase_amd', 'cfg', 'train_ase.yaml')))
+    y['params']['config']['learning_rate'] = float(y['params']['config']['learning_rate'])
     return y['params']['network'], y['params']['config']
 
 
