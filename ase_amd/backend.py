@@ -66,6 +66,15 @@ class HipBackend:
         L.check(self.lib.ase_hip_refresh_shadow(_ptr(W), n, k, _ptr(Ws), _ld(Ws), _ptr(Wts), _ld(Wts), split_src,
                                                 split_dst, _code(ref.dtype), self._stream()), "refresh_shadow")
 
+    def refresh_shadow_multi(self, desc, items, dtype):
+        """desc: device int64 [n, 12] pointer table (see ase_hip.h); items: the same tensors (kept alive by the caller)."""
+        L.check(self.lib.ase_hip_refresh_shadow_multi(_ptr(desc), desc.shape[0], _code(dtype), self._stream()),
+                "refresh_shadow_multi")
+
+    def gather_multi(self, desc, items, idx, remap, M):
+        L.check(self.lib.ase_hip_gather_multi(_ptr(desc), desc.shape[0], _ptr(idx), remap[0], remap[1], M,
+                                              self._stream()), "gather_multi")
+
     # ------------------------------------------------------------------ normaliser / gather
     def rms_moments(self, src, D, idx, remap, M, state, sums):
         L.check(self.lib.ase_hip_rms_moments(_ptr(src), _ld(src), D, _ptr(idx), remap[0], remap[1], M, _ptr(state),

@@ -151,42 +151,85 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(NTParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (e&3) + 8*(e>>2) + 4*(lane>>5), i.e. a
+    // lane owns ONE column: storing from registers would be 2-byte scattered stores.  Phase 1 applies bias +
+    // activation (per-column bias = per-lane scalar) and transposes the wave's sub-tile through a wave-private f32
+    // LDS slab [rows][FN*32] (row pitch 64 dwords: ds_write_b32 and ds_read_b128 are both conflict-free); phase 2
+    // lets every lane pick up 4 consecutive columns of a row, applies the derivative mask from 8/16-byte aux loads,
+    // issues 8/16-byte row-contiguous stores (full 128-byte lines per row) and keeps per-column partial sums for
+    // the bias gradient.  (The last loop iteration ended with a barrier: nobody still reads the staging buffers.)
+    constexpr int WCOLS = FN * 32, WROWS = FM * 32;
+    float* slab = reinterpret_cast<float*>(smem) + wid * (WROWS * WCOLS);
     const int col_in = lane & 31, row_hi = (lane >> 5) * 4;
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
         const int n = bn0 + (wn * FN + j) * 32 + col_in;
-        const bool n_ok = n < p.N;
-        const float bias = (p.bias && n_ok) ? p.bias[n] : 0.f;
-        float csum = 0.f;
+        const float bias = (p.bias && n < p.N) ? p.bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
-            const int mbase = bm0 + (wm * FM + i) * 32 + row_hi;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int m = mbase + (e & 3) + 8 * (e >> 2);
-                if (m < p.M && n_ok) {
-                    float v = p.alpha * acc[i][j][e] + bias;
-                    if (p.act == ASE_ACT_RELU) v = fmaxf(v, 0.f);
-                    else if (p.act == ASE_ACT_TANH) v = tanhf(v);
-                    if (p.aux_mode != ASE_AUX_NONE) {
-                        const float a = to_f32(*reinterpret_cast<const T*>(p.aux + (int64_t)m * p.ldaux + (int64_t)n * sizeof(T)));
-                        v = (p.aux_mode == ASE_AUX_RELU_MASK) ? (a > 0.f ? v : 0.f) : v * (1.f - a * a);
-                    }
-                    if (p.out_f32) {
-                        *reinterpret_cast<float*>(p.C + (int64_t)m * p.ldc + (int64_t)n * 4) = v;
-                    } else {
-                        const T o = from_f32<T>(v);
-                        *reinterpret_cast<T*>(p.C + (int64_t)m * p.ldc + (int64_t)n * sizeof(T)) = o;
-                        v = to_f32(o);
-                    }
-                    csum += v;
-                }
+                float v = p.alpha * acc[i][j][e] + bias;
+                if (p.act == ASE_ACT_RELU) v = fmaxf(v, 0.f);
+                else if (p.act == ASE_ACT_TANH) v = tanhf(v);
+                slab[(i * 32 + row_hi + (e & 3) + 8 * (e >> 2)) * WCOLS + j * 32 + col_in] = v;
             }
         }
-        if (p.colsum) {
-            csum += __shfl_xor(csum, 32, 64);
-            if (lane < 32 && n < p.colsum_n) atomic_add_f32(p.colsum + n, csum);
+    }
+    constexpr int LPR = WCOLS / 4;                 // lanes per row (4 columns each)
+    constexpr int RPI = 64 / LPR;                  // rows per iteration
+    const int c4 = lane % LPR, rsub = lane / LPR;
+    const int n0 = bn0 + wn * WCOLS + c4 * 4;
+    const int mrow0 = bm0 + wm * WROWS;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    if (n0 < p.N) {                                // N is a multiple of 4 (checked on the host)
+#pragma unroll 4
+        for (int it = 0; it < WROWS / RPI; ++it) {
+            const int row = it * RPI + rsub;
+            const int m = mrow0 + row;
+            if (m >= p.M) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * WCOLS + c4 * 4);
+            if (p.aux_mode != ASE_AUX_NONE) {
+                float a[4];
+                const char* ap = p.aux + (int64_t)m * p.ldaux + (int64_t)n0 * sizeof(T);
+                if constexpr (sizeof(T) == 2) {
+                    const bf16x4 av = *reinterpret_cast<const bf16x4*>(ap);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a[q] = (float)av[q];
+                } else {
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(ap);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a[q] = av[q];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    v[q] = (p.aux_mode == ASE_AUX_RELU_MASK) ? (a[q] > 0.f ? v[q] : 0.f) : v[q] * (1.f - a[q] * a[q]);
+            }
+            if (p.out_f32 || sizeof(T) == 4) {
+                *reinterpret_cast<f32x4*>(p.C + (int64_t)m * p.ldc + (int64_t)n0 * 4) = v;
+            } else {
+                bf16x4 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    o[q] = (bf16_t)v[q];
+                    v[q] = (float)o[q];
+                }
+                *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + (int64_t)n0 * 2) = o;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cs[q] += v[q];
+        }
+    }
+    if (p.colsum) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int o = LPR; o < 64; o <<= 1) cs[q] += __shfl_xor(cs[q], o, 64);
+        }
+        if (lane < LPR) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (n0 + q < p.colsum_n) atomic_add_f32(p.colsum + n0 + q, cs[q]);
         }
     }
 }
@@ -441,7 +484,64 @@ __global__ void refresh_shadow_kernel(const float* __restrict__ W, int n_real, i
     }
 }
 
+// All layers in one launch: desc[l] = {W, n_real, k_real, Ws, ldws, Wts, ldwts, split_src, gap, bias, bias_shadow, tiles_k}
+// (int64 each); blockIdx.y = layer, blockIdx.x = 32x32 tile (grid-stride), bias copied by the first workgroup.
+template <typename T>
+__global__ __launch_bounds__(256) void refresh_multi_kernel(const int64_t* __restrict__ desc) {
+    __shared__ float tile[32][33];
+    const int64_t* d = desc + 12 * blockIdx.y;
+    const float* W = reinterpret_cast<const float*>(d[0]);
+    const int n_real = (int)d[1], k_real = (int)d[2];
+    T* Ws = reinterpret_cast<T*>(d[3]);
+    const int64_t ldws = d[4];
+    T* Wts = reinterpret_cast<T*>(d[5]);
+    const int64_t ldwts = d[6];
+    const int split_src = (int)d[7], gap = (int)d[8];
+    const int tiles_k = (int)d[11];
+    const int tiles = tiles_k * ((n_real + 31) / 32);
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    if (blockIdx.x == 0 && d[9]) {
+        const float* b = reinterpret_cast<const float*>(d[9]);
+        float* bs = reinterpret_cast<float*>(d[10]);
+        for (int i = threadIdx.x; i < n_real; i += 256) bs[i] = b[i];
+    }
+    for (int t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const int k0 = (t % tiles_k) * 32, n0 = (t / tiles_k) * 32;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + ty + 8 * i, k = k0 + tx;
+            float v = 0.f;
+            if (n < n_real && k < k_real) {
+                v = W[(int64_t)n * k_real + k];
+                Ws[(int64_t)n * ldws + ((k < split_src) ? k : k + gap)] = from_f32<T>(v);
+            }
+            tile[ty + 8 * i][tx] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + ty + 8 * i, n = n0 + tx;
+            if (k < k_real && n < n_real)
+                Wts[(int64_t)((k < split_src) ? k : k + gap) * ldwts + n] = from_f32<T>(tile[tx][ty + 8 * i]);
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int ase_hip_refresh_shadow_multi(const int64_t* desc, int n_layers, int dtype, void* stream) {
+    ASE_CHECK_ARG(desc && n_layers > 0, "refresh_shadow_multi: null/empty operand");
+    const dim3 grid(256, n_layers);
+    if (dtype == ASE_BF16)
+        hipLaunchKernelGGL(refresh_multi_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, desc);
+    else if (dtype == ASE_F32)
+        hipLaunchKernelGGL(refresh_multi_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, desc);
+    else
+        ASE_CHECK_ARG(false, "refresh_shadow_multi: bad dtype %d", dtype);
+    ASE_CHECK_LAUNCH("refresh_shadow_multi");
+    return ASE_OK;
+}
 
 extern "C" int ase_hip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                                const float* bias, const void* aux, int64_t ldaux, float* colsum, int colsum_n,
@@ -454,6 +554,9 @@ extern "C" int ase_hip_gemm_nt(const void* A, int64_t lda, const void* B, int64_
     ASE_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && (lda * es) % 16 == 0 && (ldb * es) % 16 == 0,
                   "gemm_nt: A/B must be 16-byte aligned with 16-byte row pitch");
     ASE_CHECK_ARG(aux_mode == ASE_AUX_NONE || aux != nullptr, "gemm_nt: aux_mode %d without aux", aux_mode);
+    ASE_CHECK_ARG(N % 4 == 0 && ((uintptr_t)C % 16) == 0 && (ldc * (out_f32 ? 4 : es)) % 8 == 0 &&
+                      (aux == nullptr || (((uintptr_t)aux % 8) == 0 && (ldaux * es) % 8 == 0)),
+                  "gemm_nt: C / aux must allow 8/16-byte row-vector access (N %% 4 == 0, aligned pitches)");
     NTParams p;
     p.A = (const char*)A; p.lda = lda * es;
     p.B = (const char*)B; p.ldb = ldb * es;

@@ -37,13 +37,12 @@ __global__ __launch_bounds__(256) void ppo_head_kernel(PpoArgs p) {
     __shared__ float sdb[8][33];
     const int lane = threadIdx.x & 31;
     float gm_out = 0.f, gm2_out = 0.f, dv_out = 0.f;
-    const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
-    const bool row_ok = i < p.M;
-    const bool act_ok = row_ok && lane < p.act_dim;
     const int D = p.act_dim;
     double part[7] = {0, 0, 0, 0, 0, 0, 0};  // a_loss, b_loss, entropy, clipped, c_loss, kl, div
 
-    if (row_ok) {
+    // grid-stride over rows: few workgroups => few contended f64 atomics on the 7 accumulators
+    for (int i = blockIdx.x * 8 + (threadIdx.x >> 5); i < p.M; i += gridDim.x * 8) {
+        const bool act_ok = lane < p.act_dim;
         const float S = p.masked ? (float)p.acc[ASE_ACC_MASK_SUM] : (float)p.m_global;
         const float mk = p.masked ? p.mask[i] : 1.f;
         const float w = mk / S;
@@ -121,8 +120,8 @@ __global__ __launch_bounds__(256) void ppo_head_kernel(PpoArgs p) {
             const T o1 = from_f32<T>(gm), o2 = from_f32<T>(gm2);
             reinterpret_cast<T*>(p.d_mu)[(int64_t)i * p.ld_dmu + lane] = o1;
             if (p.div_on) reinterpret_cast<T*>(p.d_mu)[(int64_t)(p.M + i) * p.ld_dmu + lane] = o2;
-            gm_out = to_f32(o1);
-            gm2_out = p.div_on ? to_f32(o2) : 0.f;
+            gm_out += to_f32(o1);
+            gm2_out += p.div_on ? to_f32(o2) : 0.f;
         }
 
         if (lane == 0) {
@@ -145,14 +144,14 @@ __global__ __launch_bounds__(256) void ppo_head_kernel(PpoArgs p) {
             }
             const T ov = from_f32<T>(p.critic_coef * dv / (float)p.m_global);
             reinterpret_cast<T*>(p.d_value)[(int64_t)i * p.ld_dv] = ov;
-            dv_out = to_f32(ov);
-            part[0] = (double)(mk * a_loss);
-            part[1] = (double)(mk * b_row);
-            part[2] = (double)(mk * ent_row);
-            part[3] = (double)(mk * ((fabsf(ratio - 1.f) > p.e_clip) ? 1.f : 0.f));
-            part[4] = (double)c;
-            part[5] = (double)kl_row;
-            part[6] = (double)(mk * div_row);
+            dv_out += to_f32(ov);
+            part[0] += (double)(mk * a_loss);
+            part[1] += (double)(mk * b_row);
+            part[2] += (double)(mk * ent_row);
+            part[3] += (double)(mk * ((fabsf(ratio - 1.f) > p.e_clip) ? 1.f : 0.f));
+            part[4] += (double)c;
+            part[5] += (double)kl_row;
+            part[6] += (double)(mk * div_row);
         }
     }
     if (p.db_mu) {  // head bias gradients: column sums over this block's 8 rows, one atomic per column
@@ -352,7 +351,7 @@ inline int grid_for(int64_t n, int block = 256, int cap = 2048) {
 
 extern "C" int ase_hip_reduce_sum(const float* x, int64_t n, int square, double* acc, int slot, void* stream) {
     ASE_CHECK_ARG(x && acc && n > 0 && slot >= 0, "reduce_sum: null/empty operand");
-    hipLaunchKernelGGL(reduce_sum_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, x, n, square,
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(grid_for(n, 1024, 128)), dim3(256), 0, (hipStream_t)stream, x, n, square,
                        acc + slot);
     ASE_CHECK_LAUNCH("reduce_sum");
     return ASE_OK;
@@ -381,7 +380,7 @@ extern "C" int ase_hip_ppo_head(const float* mu, int64_t ld_mu, const float* val
     p.acc = acc; p.M = M; p.m_global = m_global; p.act_dim = act_dim; p.z_dim = z_dim; p.masked = masked;
     p.div_on = div_on; p.mu_tanh = mu_tanh; p.clip_value = clip_value; p.e_clip = e_clip; p.critic_coef = critic_coef;
     p.bounds_coef = bounds_coef; p.div_coef = div_coef; p.div_tar = div_tar;
-    const dim3 grid((M + 7) / 8);
+    const dim3 grid(min((M + 7) / 8, 256));
     if (dtype == ASE_BF16) hipLaunchKernelGGL(ppo_head_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, p);
     else if (dtype == ASE_F32) hipLaunchKernelGGL(ppo_head_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, p);
     else ASE_CHECK_ARG(false, "ppo_head: bad dtype %d", dtype);
@@ -439,7 +438,7 @@ extern "C" int ase_hip_gp_seed(const void* h, int64_t ld_h, const float* w, void
 extern "C" int ase_hip_sqnorm(const void* x, int64_t ld, int rows, int cols, double* acc, int slot, int dtype,
                               void* stream) {
     ASE_CHECK_ARG(x && acc && rows > 0 && cols > 0 && slot >= 0, "sqnorm: null/empty operand");
-    const dim3 grid(grid_for((int64_t)rows * cols, 256, 1024));
+    const dim3 grid(grid_for((int64_t)rows * cols, 2048, 256));
     if (dtype == ASE_BF16)
         hipLaunchKernelGGL(sqnorm_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, rows,
                            cols, acc + slot);

@@ -6,7 +6,7 @@
 namespace {
 
 // ---- batch moments: grid (col tiles of 64, row chunks); block 64 x 4 ---------------------------
-constexpr int kRowsPerBlock = 256;
+constexpr int kRowsPerBlock = 64;
 
 __global__ __launch_bounds__(256) void rms_moments_kernel(const float* __restrict__ src, int64_t ld_src, int D,
                                                           const int32_t* __restrict__ idx, int remap_h, int remap_n,
@@ -20,11 +20,20 @@ __global__ __launch_bounds__(256) void rms_moments_kernel(const float* __restric
     double s1 = 0.0, s2 = 0.0;
     if (j < D) {
         const float shift = (float)state[j];
-        for (int r = r0 + ty; r < r1; r += 4) {
-            const int64_t p = map_row(r, idx, remap_h, remap_n);
-            const double d = (double)(src[p * ld_src + j] - shift);
-            s1 += d;
-            s2 += d * d;
+        // 4 independent row loads in flight per thread (the gather makes every row a dependent index -> data chain)
+        for (int r = r0 + ty; r < r1; r += 16) {
+            float x[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rr = r + 4 * q;
+                x[q] = (rr < r1) ? src[map_row(rr, idx, remap_h, remap_n) * ld_src + j] : shift;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double d = (double)(x[q] - shift);
+                s1 += d;
+                s2 += d * d;
+            }
         }
     }
     red[0][ty][tx] = s1;
@@ -120,7 +129,36 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
     for (int j = threadIdx.x; j < D; j += W) dst[(int64_t)r * ld_dst + j] = from_f32<T>(src[p * ld_src + j]);
 }
 
+// fields of one minibatch gathered by ONE launch: desc[f] = {src, ld_src, D, dst, ld_dst, dst_dtype} (int64 each)
+__global__ __launch_bounds__(256) void gather_multi_kernel(const int64_t* __restrict__ desc, const int32_t* __restrict__ idx,
+                                                           int remap_h, int remap_n, int M) {
+    const int64_t* d = desc + 6 * blockIdx.y;
+    const float* src = reinterpret_cast<const float*>(d[0]);
+    const int64_t ld_src = d[1];
+    const int D = (int)d[2];
+    const int64_t ld_dst = d[4];
+    const int dt = (int)d[5];
+    const int lane = threadIdx.x & 63;
+    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < M; r += gridDim.x * 4) {
+        const int64_t p = map_row(r, idx, remap_h, remap_n);
+        for (int j = lane; j < D; j += 64) {
+            const float v = src[p * ld_src + j];
+            if (dt == ASE_BF16) reinterpret_cast<bf16_t*>(d[3])[(int64_t)r * ld_dst + j] = (bf16_t)v;
+            else reinterpret_cast<float*>(d[3])[(int64_t)r * ld_dst + j] = v;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int ase_hip_gather_multi(const int64_t* desc, int n_fields, const int32_t* idx, int remap_h, int remap_n,
+                                    int M, void* stream) {
+    ASE_CHECK_ARG(desc && n_fields > 0 && M > 0, "gather_multi: null/empty operand");
+    const dim3 grid(min((M + 3) / 4, 512), n_fields);
+    hipLaunchKernelGGL(gather_multi_kernel, grid, dim3(256), 0, (hipStream_t)stream, desc, idx, remap_h, remap_n, M);
+    ASE_CHECK_LAUNCH("gather_multi");
+    return ASE_OK;
+}
 
 extern "C" int ase_hip_rms_moments(const float* src, int64_t ld_src, int D, const int32_t* idx, int remap_h,
                                    int remap_n, int M, const double* state, double* sums, void* stream) {

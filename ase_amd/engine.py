@@ -79,6 +79,9 @@ class UpdateEngine:
         assert cfg.get('enc_grad_penalty', 0) == 0, "enc_grad_penalty: not on the default path (SURVEY §8f N4)"
         self.mu_tanh = kind == 'ppo' and getattr(net, 'mu_tanh', False)
         self._scratch = {}
+        self._refresh_desc = None
+        self._mb_desc = None
+        self._mb_desc_key = None
         self._build_layers()
         self._bind_params()
         self._alloc(infer_rows)
@@ -238,11 +241,18 @@ class UpdateEngine:
 
     # ------------------------------------------------------------------ shadows
     def refresh_shadows(self):
-        be = self.be
-        for d in self.layers:
-            for (name, nr, off), W, b in zip(d.parts, d.W, d.b):
-                be.refresh_shadow(W, d.Ws[off:], d.Wts[:, off:], d.split_src, d.split_dst)
-                be.gather_rows(b.view(1, nr), nr, None, (0, 0), 1, d.bs[off:off + nr].view(1, nr))
+        """Master f32 weights -> compute-dtype shadows (W, W^T, padded bias) for every layer: one launch."""
+        if self._refresh_desc is None:
+            rows, items = [], []
+            for d in self.layers:
+                for (name, nr, off), W, b in zip(d.parts, d.W, d.b):
+                    ws, wts, bs = d.Ws[off:], d.Wts[:, off:], d.bs[off:off + nr]
+                    rows.append([W.data_ptr(), nr, d.K, ws.data_ptr(), ws.stride(0), wts.data_ptr(), wts.stride(0),
+                                 d.split_src, d.split_dst - d.split_src, b.data_ptr(), bs.data_ptr(), (d.K + 31) // 32])
+                    items.append((W, ws, wts, d.split_src, d.split_dst, b, bs))
+            self._refresh_desc = torch.tensor(rows, dtype=torch.int64, device=self.dev)
+            self._refresh_items = items
+        self.be.refresh_shadow_multi(self._refresh_desc, self._refresh_items, self.dtype)
 
     # ------------------------------------------------------------------ primitive layer ops
     def _fwd(self, d, X, Y, rows, act=None):
@@ -276,11 +286,18 @@ class UpdateEngine:
 
     # ------------------------------------------------------------------ one optimisation step
     def gather_minibatch(self, ds, idx, remap):
-        be, M = self.be, self.M
-        for k, dst in self.mb.items():
-            src = ds[k]
-            src2 = src.view(src.shape[0], -1)
-            be.gather_rows(src2, src2.shape[1], idx, remap, M, dst)
+        """All small per-row fields of the minibatch (learning/amp_datasets.py:21-22) in one launch."""
+        key = tuple(ds[k].data_ptr() for k in self.mb)
+        if self._mb_desc_key != key:
+            rows, items = [], []
+            for k, dst in self.mb.items():
+                src = ds[k].view(ds[k].shape[0], -1)
+                rows.append([src.data_ptr(), src.stride(0), src.shape[1], dst.data_ptr(), dst.stride(0), L.F32])
+                items.append((src, src.shape[1], dst))
+            self._mb_desc = torch.tensor(rows, dtype=torch.int64, device=self.dev)
+            self._mb_items = items
+            self._mb_desc_key = key
+        self.be.gather_multi(self._mb_desc, self._mb_items, idx, remap, self.M)
 
     def step(self, ds, idx, remap, amp_streams=None, new_z=None, apply=True):
         """ds: dataset dict of physical-order device tensors; idx int32 [M] (this rank's rows);

@@ -31,6 +31,8 @@ SIGNATURES = {
     "ase_hip_gemm_nt": [_p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
     "ase_hip_gemm_tn": [_p, _i64, _p, _i64, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
     "ase_hip_refresh_shadow": [_p, _i, _i, _p, _i64, _p, _i64, _i, _i, _i, _p],
+    "ase_hip_refresh_shadow_multi": [_p, _i, _i, _p],
+    "ase_hip_gather_multi": [_p, _i, _p, _i, _i, _i, _p],
     "ase_hip_rms_moments": [_p, _i64, _i, _p, _i, _i, _i, _p, _p, _p],
     "ase_hip_rms_finalize": [_p, _i, _p, _p, _i, _p, _p, _p],
     "ase_hip_rms_normalize": [_p, _i64, _i, _p, _i, _i, _i, _p, _p, _p, _i64, _p, _i64, _p, _i64, _i, _p],

@@ -77,6 +77,11 @@ int ase_hip_refresh_shadow(const float* W, int n_real, int k_real, void* Ws, int
                            void* Wts, int64_t ldwts, int split_src, int split_dst, int dtype,
                            void* stream);
 
+/* The same for every layer in ONE launch.  desc: DEVICE int64[n_layers][12] =
+ * {W, n_real, k_real, Ws, ldws, Wts, ldwts, split_src, split_dst - split_src, bias, bias_shadow, ceil(k_real/32)}
+ * (pointers as integers; bias_shadow f32[n_pad] feeds ase_hip_gemm_nt's bias). */
+int ase_hip_refresh_shadow_multi(const int64_t* desc, int n_layers, int dtype, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Running mean/std normaliser (rl_games RunningMeanStd; learning/common_agent.py:49,323-325,
  * learning/amp_agent.py:26,535-538, learning/ase_agent.py:170-181) fused with the minibatch
@@ -109,6 +114,10 @@ int ase_hip_rms_unnormalize(const double* state, const float* x, float* y, int64
  * (learning/amp_datasets.py:21-22 for the small per-row tensors). */
 int ase_hip_gather_rows(const float* src, int64_t ld_src, int D, const int32_t* idx, int remap_h,
                         int remap_n, int M, void* dst, int64_t ld_dst, int dst_dtype, void* stream);
+
+/* Several fields by ONE launch.  desc: DEVICE int64[n_fields][6] = {src, ld_src, D, dst, ld_dst, dst_dtype}. */
+int ase_hip_gather_multi(const int64_t* desc, int n_fields, const int32_t* idx, int remap_h, int remap_n,
+                         int M, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Loss heads: forward value + analytic gradient w.r.t. the head inputs, in one pass.

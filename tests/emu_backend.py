@@ -69,6 +69,15 @@ class EmuBackend:
         if Wts is not None:
             Wts[kd, :n] = W.t().to(Wts.dtype)
 
+    def refresh_shadow_multi(self, desc, items, dtype):
+        for W, ws, wts, ss, sd, b, bs in items:       # the pointer table `desc` describes exactly these tensors
+            self.refresh_shadow(W, ws, wts, ss, sd)
+            bs[:b.numel()] = b
+
+    def gather_multi(self, desc, items, idx, remap, M):
+        for src, D, dst in items:
+            self.gather_rows(src, D, idx, remap, M, dst)
+
     # ------------------------------------------------------------------ normaliser / gather
     def rms_moments(self, src, D, idx, remap, M, state, sums):
         x = src[_rows(idx, remap, M), :D]

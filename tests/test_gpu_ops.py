@@ -357,3 +357,37 @@ def test_sample_latents(be):
     # isotropy: component mean ~ 0, second moment ~ 1/64
     assert float(zc.mean(0).abs().max()) < 0.01
     close((zc * zc).mean(0), torch.full((64,), 1 / 64), 0.08, 0.0, 'second moment')
+
+
+def test_multi_ops(be):
+    """Pointer-table launches (all layers' shadows / all minibatch fields in one kernel) == the per-item ops."""
+    dev = 'cuda'
+    g = torch.Generator().manual_seed(4)
+    items, rows = [], []
+    for n, k, ss, sd, kp in [(48, 53, 37, 64, 128), (1, 24, 24, 24, 64), (100, 1400, 1400, 1400, 1408)]:
+        W = torch.randn(n, k, generator=g).to(dev)
+        b = torch.randn(n, generator=g).to(dev)
+        npad = (n + 63) // 64 * 64
+        ws, wts = torch.zeros(npad, kp, dtype=torch.bfloat16, device=dev), torch.zeros(kp, npad, dtype=torch.bfloat16, device=dev)
+        bs = torch.zeros(npad, device=dev)
+        rows.append([W.data_ptr(), n, k, ws.data_ptr(), ws.stride(0), wts.data_ptr(), wts.stride(0), ss, sd - ss, b.data_ptr(),
+                     bs.data_ptr(), (k + 31) // 32])
+        items.append((W, ws, wts, ss, sd, b, bs))
+    be.refresh_shadow_multi(torch.tensor(rows, dtype=torch.int64, device=dev), items, torch.bfloat16)
+    for W, ws, wts, ss, sd, b, bs in items:
+        rw, rwt = torch.zeros_like(ws), torch.zeros_like(wts)
+        be.refresh_shadow(W, rw, rwt, ss, sd)
+        assert torch.equal(ws, rw) and torch.equal(wts, rwt) and torch.equal(bs[:b.numel()], b)
+    H, N, M = 8, 40, 123
+    idx = torch.randperm(H * N, generator=g)[:M].to(torch.int32).to(dev)
+    fields, rows = [], []
+    for D in (31, 1, 64):
+        src = torch.randn(H * N, D, generator=g).to(dev)
+        dst = torch.zeros(M, D, device=dev)
+        rows.append([src.data_ptr(), src.stride(0), D, dst.data_ptr(), dst.stride(0), L.F32])
+        fields.append((src, D, dst))
+    be.gather_multi(torch.tensor(rows, dtype=torch.int64, device=dev), fields, idx, (H, N), M)
+    for src, D, dst in fields:
+        ref = torch.zeros_like(dst)
+        be.gather_rows(src, D, idx, (H, N), M, ref)
+        assert torch.equal(dst, ref)
