@@ -8,6 +8,7 @@
 // are 128 bytes (+16 B pad => conflict-free ds_read_b128), register-staged double buffering with
 // one barrier per K-tile, XCD-aware tile order (8 XCDs, private L2s).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -280,8 +281,10 @@ struct TNParams {
 };
 
 template <typename T> struct TNGeom;
-template <> struct TNGeom<bf16_t> { static constexpr int BKM = 64, ROWB = 256, STRIDE = 256 + 16, CPR = 16; };
-template <> struct TNGeom<float>  { static constexpr int BKM = 16, ROWB = 512, STRIDE = 512 + 16, CPR = 32; };
+// bf16 row pitch 256 + 64 B: the 8 (row, 16-column-group) blocks that the 32 lanes of one ds_read_b64_tr_b16 group
+// touch land on 8 distinct 32-byte bank slots (pitch = 16 dwords mod 64)
+template <> struct TNGeom<bf16_t> { static constexpr int BKM = 64, STRIDE = 256 + 64, CPR = 16; };
+template <> struct TNGeom<float>  { static constexpr int BKM = 16, STRIDE = 512 + 16, CPR = 32; };
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
@@ -324,7 +327,6 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(TNParams p) {
     constexpr int BKM = Gm::BKM, STRIDE = Gm::STRIDE, CPR = Gm::CPR;
     constexpr int LOADS = BKM * CPR / kThreads;          // 16-B chunks per thread per operand
     constexpr int kOp = BKM * STRIDE;                    // bytes per operand tile
-    constexpr int EPC = 16 / (int)sizeof(T);             // elements per chunk
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -438,7 +440,14 @@ template <typename T> int launch_tn(TNParams p, hipStream_t stream) {
     p.tiles_n = (p.n_real + 127) / 128;
     p.tiles_k = (p.K + 127) / 128;
     const int tiles = p.tiles_n * p.tiles_k;
-    int splits = (1024 + tiles - 1) / tiles;                       // aim at >= 1024 workgroups (256 CUs)
+    // Split M so that the grid is ONE resident wave of workgroups: 80 KB of LDS => 2 workgroups per CU => 512 slots
+    // on 256 CUs.  More splits only add f32 atomics (splits x N x K of them) and a partial second wave.
+    static int target_wg = 0;
+    if (target_wg == 0) {
+        const char* e = getenv("ASE_TN_TARGET_WG");
+        target_wg = e ? atoi(e) : 512;
+    }
+    int splits = target_wg / tiles;
     const int max_splits = (p.M + 4 * Gm::BKM - 1) / (4 * Gm::BKM); // >= 4 staged tiles per split
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;

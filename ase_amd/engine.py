@@ -217,6 +217,8 @@ class UpdateEngine:
                 self.He, self.dZe = chain_bufs(self.enc_chain, AMB)
                 self.E = zt(AMB, self.enc_head.n_pad, f32)
                 self.dE = zt(AMB, self.enc_head.n_pad)
+            if self.has_enc:
+                self.enc_z = zt(AMB, self.z, f32)     # latents of the amp rows (first amp_minibatch rows of the GLOBAL minibatch)
             self.amp_sums = torch.zeros(3, 2 * self.amp, dtype=torch.float64, device=dev)
             self.amp_mean = zt(3, self.amp, f32)
             self.amp_std = zt(3, self.amp, f32)
@@ -376,12 +378,15 @@ class UpdateEngine:
         if self.has_disc:
             be.disc_head(self.HD, self.dHD, self.disc_head.gb[0], self.acc, AMB, self.AMBg, c['disc_coef'])
             if self.has_enc:
+                src, sidx, srm = amp_streams[0]       # enc_latents = ase_latents[0:amp_minibatch] (learning/ase_agent.py:247)
+                zsrc = ds['ase_latents'].view(ds['ase_latents'].shape[0], -1)
+                be.gather_rows(zsrc, self.z, sidx, srm, AMB, self.enc_z)
                 if self.enc_sep:
-                    be.enc_head(self.E, self.mb['ase_latents'], self.dE, self.enc_head.gb[0], None, self.acc, AMB,
+                    be.enc_head(self.E, self.enc_z, self.dE, self.enc_head.gb[0], None, self.acc, AMB,
                                 self.AMBg, self.z, c['enc_coef'])
                 else:
                     off = self.disc_head.parts[1][2]
-                    be.enc_head(self.HD[:AMB, off:], self.mb['ase_latents'], self.dHD[:AMB, off:],
+                    be.enc_head(self.HD[:AMB, off:], self.enc_z, self.dHD[:AMB, off:],
                                 self.disc_head.gb[1], None, self.acc, AMB, self.AMBg, self.z, c['enc_coef'])
 
         # ---- backward: actor (+ style), critic
