@@ -56,8 +56,8 @@ class HipBackend:
                                          _ld(aux), _ptr(colsum), int(colsum_n), M, N, K, act, aux_mode, out_f32,
                                          float(alpha), dt, self._stream()), "gemm_nt")
 
-    def gemm_tn(self, A, B, G, M, N, K, n_real, k_real, split_src, split_dst, alpha=1.0):
-        L.check(self.lib.ase_hip_gemm_tn(_ptr(A), _ld(A), _ptr(B), _ld(B), _ptr(G), M, N, K, n_real, k_real,
+    def gemm_tn(self, A, B, G, M, N, K, n_real, k_real, split_src, split_dst, alpha=1.0, gbias=None):
+        L.check(self.lib.ase_hip_gemm_tn(_ptr(A), _ld(A), _ptr(B), _ld(B), _ptr(G), _ptr(gbias), M, N, K, n_real, k_real,
                                          split_src, split_dst, float(alpha), _code(A.dtype), self._stream()), "gemm_tn")
 
     def refresh_shadow(self, W, Ws, Wts, split_src, split_dst):

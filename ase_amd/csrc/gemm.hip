@@ -4,9 +4,13 @@
 //   gemm_tn : G += alpha * Aᵀ·B                        weight gradient (split over M, f32 atomics)
 //
 // Both come in two storage types: bf16 (v_mfma_f32_32x32x16_bf16, f32 accumulate) and exact f32
-// (v_mfma_f32_32x32x2_f32).  Wave64, 256-thread workgroups (4 waves), LDS-staged tiles whose rows
-// are 128 bytes (+16 B pad => conflict-free ds_read_b128), register-staged double buffering with
-// one barrier per K-tile, XCD-aware tile order (8 XCDs, private L2s).
+// (v_mfma_f32_32x32x2_f32).  Wave64, 256-thread workgroups (4 waves), XCD-aware tile order (8 XCDs, private L2s).
+//   NT: tiles go HBM -> LDS directly with global_load_lds_dwordx4 (no staging VGPRs, no ds_write pass); LDS rows
+//       are 128 bytes, unpadded (the DMA writes lane-linear), with the 16-byte chunks of row r stored at slot
+//       chunk ^ ((r >> 1) & 7): the permutation is applied to the per-lane SOURCE address and again on the
+//       fragment read, which makes every ds_read_b128 lane group hit 16 distinct bank slots.  Two LDS buffers,
+//       one barrier per K-tile (the next tile's DMA runs under the current tile's MFMAs).
+//   TN: register-staged double buffering, 16-byte-padded rows.
 #include "common.h"
 #include <stdlib.h>
 
@@ -14,7 +18,6 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kRowBytes = 128;               // one staged tile row (64 bf16 / 32 f32)
-constexpr int kLdsStride = kRowBytes + 16;   // bytes
 
 // Bijective XCD-aware remap: workgroup b runs on XCD b % 8; give each XCD a contiguous tile range.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -29,16 +32,17 @@ template <> struct Mma<bf16_t> {
     // one staged row = 64 k-values = 4 steps of 16
     template <int FM, int FN>
     static __device__ __forceinline__ void tile(const char* sA, const char* sB, int lane, f32x16 (&acc)[FM][FN]) {
-        const int r = lane & 31, h = lane >> 5;
+        const int r = lane & 31, h = lane >> 5, sw = (r >> 1) & 7;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             bf16x8 a[FM], b[FN];
+            const int off = r * kRowBytes + (((ks * 2 + h) ^ sw) << 4);
 #pragma unroll
             for (int i = 0; i < FM; ++i)
-                a[i] = *reinterpret_cast<const bf16x8*>(sA + (i * 32 + r) * kLdsStride + (ks * 2 + h) * 16);
+                a[i] = *reinterpret_cast<const bf16x8*>(sA + i * 32 * kRowBytes + off);
 #pragma unroll
             for (int j = 0; j < FN; ++j)
-                b[j] = *reinterpret_cast<const bf16x8*>(sB + (j * 32 + r) * kLdsStride + (ks * 2 + h) * 16);
+                b[j] = *reinterpret_cast<const bf16x8*>(sB + j * 32 * kRowBytes + off);
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -53,16 +57,17 @@ template <> struct Mma<float> {
     // and MFMA j multiplies element j of both operands (any k order is fine if A and B agree).
     template <int FM, int FN>
     static __device__ __forceinline__ void tile(const char* sA, const char* sB, int lane, f32x16 (&acc)[FM][FN]) {
-        const int r = lane & 31, h = lane >> 5;
+        const int r = lane & 31, h = lane >> 5, sw = (r >> 1) & 7;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
             f32x4 a[FM], b[FN];
+            const int off = r * kRowBytes + (((kb * 2 + h) ^ sw) << 4);
 #pragma unroll
             for (int i = 0; i < FM; ++i)
-                a[i] = *reinterpret_cast<const f32x4*>(sA + (i * 32 + r) * kLdsStride + (kb * 2 + h) * 16);
+                a[i] = *reinterpret_cast<const f32x4*>(sA + i * 32 * kRowBytes + off);
 #pragma unroll
             for (int j = 0; j < FN; ++j)
-                b[j] = *reinterpret_cast<const f32x4*>(sB + (j * 32 + r) * kLdsStride + (kb * 2 + h) * 16);
+                b[j] = *reinterpret_cast<const f32x4*>(sB + j * 32 * kRowBytes + off);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -74,19 +79,15 @@ template <> struct Mma<float> {
     }
 };
 
-// 32 rows x 8 chunks per pass: thread (lrow, lchunk) stages rows lrow + 32*i.
-template <int LOADS>
-__device__ __forceinline__ void nt_gload(uint4 (&r)[LOADS], const char* g, int64_t ld, int row0, int rows, int64_t koff) {
+// HBM -> LDS DMA of one operand tile: pass i moves rows [32 i, 32 i + 32); wave w of the pass owns the 8 rows
+// 32 i + 8 w .. + 7 = one 1-KiB lane-linear LDS piece (M0 = wave-uniform base, lane l lands at base + 16 l).
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+template <int PASSES>
+__device__ __forceinline__ void nt_stage(const char* const (&src)[PASSES], int64_t koff, char* lds_wave_base) {
 #pragma unroll
-    for (int i = 0; i < LOADS; ++i) {
-        r[i] = make_uint4(0, 0, 0, 0);
-        if (row0 + 32 * i < rows) r[i] = *reinterpret_cast<const uint4*>(g + (int64_t)(32 * i) * ld + koff);
-    }
-}
-template <int LOADS>
-__device__ __forceinline__ void nt_sstore(const uint4 (&r)[LOADS], char* s) {
-#pragma unroll
-    for (int i = 0; i < LOADS; ++i) *reinterpret_cast<uint4*>(s + (32 * i) * kLdsStride) = r[i];
+    for (int i = 0; i < PASSES; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t*)(src[i] + koff), (lptr_t*)(lds_wave_base + i * 32 * kRowBytes), 16, 0, 0);
 }
 
 struct NTParams {
@@ -106,9 +107,9 @@ template <typename T, int WGM, int WGN, int FM, int FN>
 __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(NTParams p) {
     constexpr int BM = WGM * FM * 32, BN = WGN * FN * 32;
     constexpr int BK = kRowBytes / (int)sizeof(T);
-    constexpr int A_LOADS = BM / 32, B_LOADS = BN / 32;
+    constexpr int A_PASSES = BM / 32, B_PASSES = BN / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int kBuf = (BM + BN) * kLdsStride;
+    constexpr int kBuf = (BM + BN) * kRowBytes;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WGN, wn = wid % WGN;
@@ -116,8 +117,24 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(NTParams p) {
     const int tile = xcd_remap(blockIdx.x, nwg);
     const int bm0 = (tile / p.tiles_n) * BM, bn0 = (tile % p.tiles_n) * BN;
 
-    const int lrow = tid >> 3, lchunk = tid & 7;
-    uint4 ra[A_LOADS], rb[B_LOADS];
+    // per-lane DMA sources: tile row 32 i + (tid >> 3), LDS slot tid & 7 receives chunk slot ^ ((row >> 1) & 7).
+    // Rows past M / N are clamped to the last valid row: their products only reach output rows / columns that are
+    // never stored.
+    const int srow = tid >> 3, sslot = tid & 7;
+    const char* srcA[A_PASSES];
+    const char* srcB[B_PASSES];
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+        const int r = i * 32 + srow;
+        srcA[i] = p.A + (int64_t)min(bm0 + r, p.M - 1) * p.lda + ((sslot ^ ((r >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i) {
+        const int r = i * 32 + srow;
+        srcB[i] = p.B + (int64_t)min(bn0 + r, p.N - 1) * p.ldb + ((sslot ^ ((r >> 1) & 7)) << 4);
+    }
+    char* const ldsA = smem + (wid * 8) * kRowBytes;
+    char* const ldsB = ldsA + BM * kRowBytes;
 
     f32x16 acc[FM][FN];
 #pragma unroll
@@ -128,27 +145,18 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(NTParams p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nk = p.K / BK;
-    const char* gA = p.A + (int64_t)(bm0 + lrow) * p.lda + lchunk * 16;
-    const char* gB = p.B + (int64_t)(bn0 + lrow) * p.ldb + lchunk * 16;
-    char* const lds_st = smem + lrow * kLdsStride + lchunk * 16;
-    nt_gload<A_LOADS>(ra, gA, p.lda, bm0 + lrow, p.M, 0);
-    nt_gload<B_LOADS>(rb, gB, p.ldb, bn0 + lrow, p.N, 0);
-    nt_sstore<A_LOADS>(ra, lds_st);
-    nt_sstore<B_LOADS>(rb, lds_st + BM * kLdsStride);
-    __syncthreads();
+    nt_stage<A_PASSES>(srcA, 0, ldsA);
+    nt_stage<B_PASSES>(srcB, 0, ldsB);
+    __syncthreads();                                   // (drains the DMA: vmcnt(0) + barrier)
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) {
-            nt_gload<A_LOADS>(ra, gA, p.lda, bm0 + lrow, p.M, (int64_t)(kt + 1) * kRowBytes);
-            nt_gload<B_LOADS>(rb, gB, p.ldb, bn0 + lrow, p.N, (int64_t)(kt + 1) * kRowBytes);
+            nt_stage<A_PASSES>(srcA, (int64_t)(kt + 1) * kRowBytes, ldsA + (buf ^ 1) * kBuf);
+            nt_stage<B_PASSES>(srcB, (int64_t)(kt + 1) * kRowBytes, ldsB + (buf ^ 1) * kBuf);
         }
-        const char* sA = smem + buf * kBuf + (wm * FM * 32) * kLdsStride;
-        const char* sB = smem + buf * kBuf + BM * kLdsStride + (wn * FN * 32) * kLdsStride;
+        const char* sA = smem + buf * kBuf + (wm * FM * 32) * kRowBytes;
+        const char* sB = smem + buf * kBuf + (BM + wn * FN * 32) * kRowBytes;
         Mma<T>::template tile<FM, FN>(sA, sB, lane, acc);
-        if (kt + 1 < nk) {
-            nt_sstore<A_LOADS>(ra, lds_st + (buf ^ 1) * kBuf);
-            nt_sstore<B_LOADS>(rb, lds_st + (buf ^ 1) * kBuf + BM * kLdsStride);
-        }
         __syncthreads();
     }
 
@@ -238,7 +246,7 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(NTParams p) {
 template <typename T, int WGM, int WGN, int FM, int FN>
 int launch_nt(const NTParams& p0, hipStream_t stream) {
     constexpr int BM = WGM * FM * 32, BN = WGN * FN * 32;
-    constexpr int lds = 2 * (BM + BN) * kLdsStride;
+    constexpr int lds = 2 * (BM + BN) * kRowBytes;
     static bool attr_done = false;
     auto kern = gemm_nt_kernel<T, WGM, WGN, FM, FN>;
     if (!attr_done) {
@@ -259,9 +267,8 @@ int launch_nt(const NTParams& p0, hipStream_t stream) {
 }
 
 template <typename T> int dispatch_nt(const NTParams& p, hipStream_t s) {
-    if (p.N > 64) return launch_nt<T, 2, 2, 2, 2>(p, s);   // 128 x 128
-    if (p.N > 32) return launch_nt<T, 4, 1, 1, 2>(p, s);   // 128 x 64
-    return launch_nt<T, 4, 1, 1, 1>(p, s);                 // 128 x 32
+    if (p.N > 64) return launch_nt<T, 2, 2, 2, 2>(p, s);   // 128 x 128 tile, 64 x 64 per wave
+    return launch_nt<T, 2, 2, 1, 1>(p, s);                 //  64 x  64 tile (narrow heads: more workgroups)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -274,6 +281,7 @@ struct TNParams {
     const char* A; int64_t lda;   // bytes
     const char* B; int64_t ldb;   // bytes
     float* G;
+    float* gbias;                 // nullable: += column sums of A (bias gradient), n < n_real
     int M, N, K;                  // padded widths N (of A), K (of B), in elements
     int n_real, k_real, split_src, split_dst;
     float alpha;
@@ -321,6 +329,23 @@ __device__ __forceinline__ void tn_sstore(const uint4 (&ra)[LOADS], const uint4 
     }
 }
 
+// running column sums of the staged A chunks (each thread always stages the same 16-byte column chunk)
+template <typename T, int LOADS>
+__device__ __forceinline__ void tn_colsum(const uint4 (&ra)[LOADS], float (&cs)[8]) {
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+        if constexpr (sizeof(T) == 2) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(&ra[i]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) cs[q] += (float)v[q];
+        } else {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&ra[i]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cs[q] += v[q];
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(TNParams p) {
     using Gm = TNGeom<T>;
@@ -348,7 +373,10 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(TNParams p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nt = (m_end - m_begin + BKM - 1) / BKM;
+    const bool do_bias = p.gbias != nullptr && bk0 == 0;      // one k-tile column of workgroups also reduces A
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     tn_gload<T, LOADS>(ra, rb, p, tid, m_begin, m_end, bn0, bk0);
+    if (do_bias) tn_colsum<T, LOADS>(ra, cs);
     tn_sstore<T, LOADS>(ra, rb, smem, tid);
     __syncthreads();
     for (int mt = 0; mt < nt; ++mt) {
@@ -398,10 +426,27 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(TNParams p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
             }
         }
-        if (mt + 1 < nt) tn_sstore<T, LOADS>(ra, rb, smem + (buf ^ 1) * 2 * kOp, tid);
+        if (mt + 1 < nt) {
+            if (do_bias) tn_colsum<T, LOADS>(ra, cs);
+            tn_sstore<T, LOADS>(ra, rb, smem + (buf ^ 1) * 2 * kOp, tid);
+        }
         __syncthreads();
     }
 
+    if (do_bias) {   // block-level reduction over the threads that staged the same column chunk, then one atomic per column
+        constexpr int EPC = 16 / (int)sizeof(T);
+        float* red = reinterpret_cast<float*>(smem);           // [256][EPC]  (the loop ended with a barrier)
+#pragma unroll
+        for (int q = 0; q < EPC; ++q) red[tid * EPC + q] = cs[q];
+        __syncthreads();
+        if (tid < 128) {
+            const int ch = tid / EPC, q = tid % EPC;
+            float t = 0.f;
+            for (int j = ch; j < kThreads; j += CPR) t += red[j * EPC + q];
+            const int n = bn0 + tid;
+            if (n < p.n_real) atomic_add_f32(p.gbias + n, p.alpha * t);
+        }
+    }
     const int col_in = lane & 31, row_hi = (lane >> 5) * 4;
     const int gap = p.split_dst - p.split_src;
 #pragma unroll
@@ -576,8 +621,8 @@ extern "C" int ase_hip_gemm_nt(const void* A, int64_t lda, const void* B, int64_
     return dtype == ASE_BF16 ? dispatch_nt<bf16_t>(p, (hipStream_t)stream) : dispatch_nt<float>(p, (hipStream_t)stream);
 }
 
-extern "C" int ase_hip_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* G, int M, int N, int K,
-                               int n_real, int k_real, int split_src, int split_dst, float alpha, int dtype,
+extern "C" int ase_hip_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* G, float* gbias, int M,
+                               int N, int K, int n_real, int k_real, int split_src, int split_dst, float alpha, int dtype,
                                void* stream) {
     const int es = (dtype == ASE_BF16) ? 2 : 4;
     ASE_CHECK_ARG(dtype == ASE_F32 || dtype == ASE_BF16, "gemm_tn: bad dtype %d", dtype);
@@ -589,7 +634,7 @@ extern "C" int ase_hip_gemm_tn(const void* A, int64_t lda, const void* B, int64_
     ASE_CHECK_ARG(n_real > 0 && n_real <= N && k_real > 0 && split_src <= split_dst && split_src <= k_real,
                   "gemm_tn: bad real dims / split");
     TNParams p;
-    p.A = (const char*)A; p.lda = lda * es; p.B = (const char*)B; p.ldb = ldb * es; p.G = G;
+    p.A = (const char*)A; p.lda = lda * es; p.B = (const char*)B; p.ldb = ldb * es; p.G = G; p.gbias = gbias;
     p.M = M; p.N = N; p.K = K; p.n_real = n_real; p.k_real = k_real; p.split_src = split_src; p.split_dst = split_dst;
     p.alpha = alpha; p.tiles_n = p.tiles_k = p.m_chunk = 0;
     return dtype == ASE_BF16 ? launch_tn<bf16_t>(p, (hipStream_t)stream) : launch_tn<float>(p, (hipStream_t)stream);

@@ -266,16 +266,20 @@ class UpdateEngine:
             X = h
         return X
 
-    def _dgrad(self, d, dY, dX, rows, aux, aux_act, gb, gb_n, wts=None, n_out=None, alpha=1.0):
-        """dX = (dY @ W) * act'(aux);  gb += colsum(dX)  (bias gradient of the layer that produced aux)."""
+    def _dgrad(self, d, dY, dX, rows, aux, aux_act, wts=None, n_out=None, alpha=1.0):
+        """dX = (dY @ W) * act'(aux): gradient w.r.t. the pre-activation of the layer that produced aux."""
         wts = d.Wts if wts is None else wts
         n_out = d.k_pad if n_out is None else n_out
         self.be.gemm_nt(dY, wts, dX, rows, n_out, d.n_pad, aux=aux if _AUX[aux_act] else None, aux_mode=_AUX[aux_act],
-                        colsum=gb, colsum_n=gb_n, alpha=alpha)
+                        alpha=alpha)
 
-    def _wgrad(self, d, dY, X, rows, alpha=1.0):
-        for (name, nr, off), gW in zip(d.parts, d.gW):
-            self.be.gemm_tn(dY[:, off:], X, gW, rows, P(nr), d.k_pad, nr, d.K, d.split_src, d.split_dst, alpha=alpha)
+    def _wgrad(self, d, dY, X, rows, alpha=1.0, bias=True):
+        """gW += dY^T X and (bias) gb += colsum(dY) from the same staged tiles.  Head groups computed their bias
+        gradients in the loss-head kernels already."""
+        heads = len(d.parts) > 1 or d in (self.mu_head, self.value_head, self.disc_head, self.enc_head)
+        for (name, nr, off), gW, gb in zip(d.parts, d.gW, d.gb):
+            self.be.gemm_tn(dY[:, off:], X, gW, rows, P(nr), d.k_pad, nr, d.K, d.split_src, d.split_dst, alpha=alpha,
+                            gbias=gb if (bias and not heads) else None)
 
     def _bwd_chain(self, chain, X0, H, dZ, rows):
         """dZ[-1] holds d loss / d Z of the last chain layer (its bias grad already accumulated)."""
@@ -284,7 +288,7 @@ class UpdateEngine:
             self._wgrad(d, dZ[l], H[l - 1] if l > 0 else X0, rows)
             if l > 0:
                 p = chain[l - 1]
-                self._dgrad(d, dZ[l], dZ[l - 1], rows, H[l - 1], p.act, p.gb[0], p.N)
+                self._dgrad(d, dZ[l], dZ[l - 1], rows, H[l - 1], p.act)
 
     # ------------------------------------------------------------------ one optimisation step
     def gather_minibatch(self, ds, idx, remap):
@@ -392,22 +396,21 @@ class UpdateEngine:
         # ---- backward: actor (+ style), critic
         self._wgrad(self.mu_head, self.dMU, ha, Ra)
         last = self.actor[-1]
-        self._dgrad(self.mu_head, self.dMU, self.dZa[-1], Ra, self.Ha[-1], last.act, last.gb[0], last.N)
+        self._dgrad(self.mu_head, self.dMU, self.dZa[-1], Ra, self.Ha[-1], last.act)
         self._bwd_chain(self.actor, self.Xa, self.Ha, self.dZa, Ra)
         if self.style:
             a0, sdn = self.actor[0], self.style[-1]
             sd = a0.split_dst
-            self._dgrad(a0, self.dZa[0], self.dStyle, Ra, self.Xa[:, sd:], sdn.act, sdn.gb[0], sdn.N,
-                        wts=a0.Wts[sd:], n_out=P(self.z))
+            self._dgrad(a0, self.dZa[0], self.dStyle, Ra, self.Xa[:, sd:], sdn.act, wts=a0.Wts[sd:], n_out=P(self.z))
             hs_last = self.Hs[-1] if self.Hs else self.Zs
             self._wgrad(sdn, self.dStyle, hs_last, Ra)
             if self.Hs:
                 p = self.style[-2]
-                self._dgrad(sdn, self.dStyle, self.dZs[-1], Ra, self.Hs[-1], p.act, p.gb[0], p.N)
+                self._dgrad(sdn, self.dStyle, self.dZs[-1], Ra, self.Hs[-1], p.act)
                 self._bwd_chain(self.style[:-1], self.Zs, self.Hs, self.dZs, Ra)
         self._wgrad(self.value_head, self.dV, hc, M)
         last = self.critic[-1]
-        self._dgrad(self.value_head, self.dV, self.dZc[-1], M, self.Hc[-1], last.act, last.gb[0], last.N)
+        self._dgrad(self.value_head, self.dV, self.dZc[-1], M, self.Hc[-1], last.act)
         self._bwd_chain(self.critic, self.Xc, self.Hc, self.dZc, M)
 
         # ---- backward: discriminator (+ encoder) and the gradient penalty
@@ -415,12 +418,12 @@ class UpdateEngine:
             Rd = 3 * AMB
             self._wgrad(self.disc_head, self.dHD, hd, Rd)
             last = self.disc[-1]
-            self._dgrad(self.disc_head, self.dHD, self.dZd[-1], Rd, self.Hd[-1], last.act, last.gb[0], last.N)
+            self._dgrad(self.disc_head, self.dHD, self.dZd[-1], Rd, self.Hd[-1], last.act)
             self._bwd_chain(self.disc, self.Xd, self.Hd, self.dZd, Rd)
             if self.enc_chain:
                 self._wgrad(self.enc_head, self.dE, he, AMB)
                 last = self.enc_chain[-1]
-                self._dgrad(self.enc_head, self.dE, self.dZe[-1], AMB, self.He[-1], last.act, last.gb[0], last.N)
+                self._dgrad(self.enc_head, self.dE, self.dZe[-1], AMB, self.He[-1], last.act)
                 self._bwd_chain(self.enc_chain, self.Xd[:AMB], self.He, self.dZe, AMB)
             self._grad_penalty()
 

@@ -73,10 +73,10 @@ class TimedBackend:
         self._shape = (M, N, K)
         self._timed('nt', 2.0 * M * N * K, self._be.gemm_nt, A, B, Cm, M, N, K, **kw)
 
-    def gemm_tn(self, A, B, G, M, N, K, n_real, k_real, split_src, split_dst, alpha=1.0):
+    def gemm_tn(self, A, B, G, M, N, K, n_real, k_real, split_src, split_dst, alpha=1.0, gbias=None):
         self._shape = (M, N, K)
         self._timed('tn', 2.0 * M * n_real * k_real, self._be.gemm_tn, A, B, G, M, N, K, n_real, k_real, split_src,
-                    split_dst, alpha=alpha)
+                    split_dst, alpha=alpha, gbias=gbias)
 
     def summary(self):
         torch.cuda.synchronize()

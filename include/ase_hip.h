@@ -64,9 +64,11 @@ int ase_hip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void
  *   kmap undoes the padded-concat layout of the first actor/critic layer: k < split_src -> k;
  *   k >= split_dst -> k - (split_dst - split_src); columns in between are padding.
  *   (layers without a concat pass split_src = split_dst = k_real).
+ *   gbias (nullable, f32[n_real]) += alpha * sum_m A[m,n]: the bias gradient of the same layer, reduced from
+ *   the A tiles the kernel stages anyway (a handful of atomics per column instead of one per row tile).
  * Replaces: autograd's weight gradient of nn.Linear inside loss.backward()
  *   (learning/ase_agent.py:271). */
-int ase_hip_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* G,
+int ase_hip_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* G, float* gbias,
                     int M, int N, int K, int n_real, int k_real, int split_src, int split_dst,
                     float alpha, int dtype, void* stream);
 

@@ -54,7 +54,9 @@ class EmuBackend:
         if colsum is not None and colsum_n > 0:
             colsum[:colsum_n] += out.float().sum(0)[:colsum_n]
 
-    def gemm_tn(self, A, B, G, M, N, K, n_real, k_real, split_src, split_dst, alpha=1.0):
+    def gemm_tn(self, A, B, G, M, N, K, n_real, k_real, split_src, split_dst, alpha=1.0, gbias=None):
+        if gbias is not None:
+            gbias[:n_real] += alpha * A[:M, :n_real].float().sum(0)
         full = alpha * (A[:M, :N].float().t() @ B[:M, :K].float())       # [N, K] padded layout
         gap = split_dst - split_src
         cols = list(range(split_src)) + [k for k in range(split_dst, K) if k - gap < k_real]

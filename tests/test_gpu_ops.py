@@ -97,10 +97,13 @@ def test_gemm_tn(be, dt, M, N, K, nr, kr, ss, sd):
     A = (torch.randn(M, N, generator=g) * 0.2).to(dt)
     B = (torch.randn(M, K, generator=g) * 0.2).to(dt)
     G0 = torch.randn(nr, kr, generator=g)
+    b0 = torch.randn(nr, generator=g)
     Gg, Gc = G0.cuda(), G0.clone()
-    be.gemm_tn(A.cuda(), B.cuda(), Gg, M, N, K, nr, kr, ss, sd, alpha=0.7)
-    EmuBackend().gemm_tn(A, B, Gc, M, N, K, nr, kr, ss, sd, alpha=0.7)
+    bg, bc = b0.cuda(), b0.clone()
+    be.gemm_tn(A.cuda(), B.cuda(), Gg, M, N, K, nr, kr, ss, sd, alpha=0.7, gbias=bg)
+    EmuBackend().gemm_tn(A, B, Gc, M, N, K, nr, kr, ss, sd, alpha=0.7, gbias=bc)
     close(Gg, Gc, 3e-5, 3e-5 * math.sqrt(M), f'tn {M}x{N}x{K}')
+    close(bg, bc, 3e-5, 3e-5 * math.sqrt(M), f'tn bias {M}x{N}')
 
 
 @pytest.mark.parametrize('dt', DT)
