@@ -79,6 +79,9 @@ class UpdateEngine:
         assert cfg.get('enc_grad_penalty', 0) == 0, "enc_grad_penalty: not on the default path (SURVEY §8f N4)"
         self.mu_tanh = kind == 'ppo' and getattr(net, 'mu_tanh', False)
         self._scratch = {}
+        self.multi_stream = bool(cfg.get('multi_stream', True)) and getattr(backend, 'name', '') == 'hip'
+        self._side_streams = None
+        self.force_dist = bool(cfg.get('force_dist', False))   # exercise the collectives with a 1-rank group
         self._refresh_desc = None
         self._mb_desc = None
         self._mb_desc_key = None
@@ -308,27 +311,69 @@ class UpdateEngine:
     def step(self, ds, idx, remap, amp_streams=None, new_z=None, apply=True):
         """ds: dataset dict of physical-order device tensors; idx int32 [M] (this rank's rows);
         amp_streams: [(src, idx, remap)] x3 for agent / replay / demo (AMB rows each);
-        new_z: optional injected diversity latents f32 [M, z] (else drawn on device)."""
+        new_z: optional injected diversity latents f32 [M, z] (else drawn on device).
+        Three phases separated by the only two exchange points of the data-parallel update
+        (normaliser moments + mask sum; gradients) — each phase is hipGraph-capturable on its own."""
+        self.phase_stats(ds, idx, remap, amp_streams)
+        self._allreduce_stats()
+        self.phase_main(ds, idx, remap, amp_streams, new_z)
+        self._allreduce_grads()
+        self.phase_apply(apply)
+        return self.res
+
+    # ---- phase A: local partial statistics -------------------------------------------------------
+    def phase_stats(self, ds, idx, remap, amp_streams=None):
         be, c, M, AMB = self.be, self.cfg, self.M, self.AMB
-        T = self.dtype
         be.begin_step(self.opt_state, self.acc)
         be.zero_(self.grads[:self.n_train])
         be.zero_(self.obs_sums)
         self.gather_minibatch(ds, idx, remap)
         if self.masked:
             be.reduce_sum(self.mb['rand_action_mask'], M, False, self.acc, L.ACC_MASK_SUM)
-        # ---- normaliser statistics (local partial sums; all-reduced over ranks when sharded)
-        norm_in = c.get('normalize_input', True)
-        if norm_in:
+        if c.get('normalize_input', True):
             be.rms_moments(ds['obs'], self.obs, idx, remap, M, self.obs_state, self.obs_sums)
-        norm_amp = self.has_disc and c.get('normalize_amp_input', True)
         if self.has_disc:
             be.zero_(self.amp_sums)
-            if norm_amp:
+            if c.get('normalize_amp_input', True):
                 for s, (src, sidx, srm) in enumerate(amp_streams):
                     be.rms_moments(src, self.amp, sidx, srm, AMB, self.amp_state, self.amp_sums[s])
-        self._allreduce_stats()
-        # ---- merge + normalise (+ gather) straight into the GEMM input buffers
+
+    # ---- fork / join of the independent actor / critic / discriminator branches -------------------
+    def _side(self, k):
+        """k-th side stream (HIP backend only; the branches are independent until the loss heads / the optimizer,
+        and the small tail-heavy kernels of one branch fill the CUs another leaves idle)."""
+        if not self.multi_stream:
+            return None
+        if self._side_streams is None:
+            self._side_streams = [torch.cuda.Stream(device=self.dev) for _ in range(2)]
+        return self._side_streams[k]
+
+    class _Branch:
+        def __init__(self, stream):
+            self.stream = stream
+
+        def __enter__(self):
+            if self.stream is not None:
+                self.stream.wait_stream(torch.cuda.current_stream())
+                self.ctx = torch.cuda.stream(self.stream)
+                self.ctx.__enter__()
+            return self
+
+        def __exit__(self, *a):
+            if self.stream is not None:
+                self.ctx.__exit__(*a)
+
+    def _join(self, k):
+        st = self._side(k)
+        if st is not None:
+            torch.cuda.current_stream().wait_stream(st)
+
+    # ---- phase B: normalise, forward, loss heads, backward -----------------------------------------
+    def phase_main(self, ds, idx, remap, amp_streams=None, new_z=None):
+        be, c, M, AMB = self.be, self.cfg, self.M, self.AMB
+        norm_in = c.get('normalize_input', True)
+        norm_amp = self.has_disc and c.get('normalize_amp_input', True)
+        Ra = self.Ra
         if norm_in:
             be.rms_finalize(self.obs_state, self.obs, self.obs_sums, self.Mg, 1, self.obs_mean, self.obs_std)
         else:
@@ -337,14 +382,6 @@ class UpdateEngine:
         if self.div_on:
             outs.append(self.Xa[M:])
         be.rms_normalize(ds['obs'], self.obs, idx, remap, M, self.obs_mean[0], self.obs_std[0], outs)
-        if self.has_disc:
-            if norm_amp:
-                be.rms_finalize(self.amp_state, self.amp, self.amp_sums, self.AMBg, 3, self.amp_mean, self.amp_std)
-            else:
-                self._identity_stats(self.amp_mean, self.amp_std)
-            for s, (src, sidx, srm) in enumerate(amp_streams):
-                be.rms_normalize(src, self.amp, sidx, srm, AMB, self.amp_mean[s], self.amp_std[s],
-                                 [self.Xd[s * AMB:(s + 1) * AMB]])
         if self.z:
             zsrc = self.mb['ase_latents']
             sd = self.actor[0].split_dst
@@ -357,43 +394,69 @@ class UpdateEngine:
                     be.sample_latents(self.new_z, M, self.z, self.rng_state)
                 be.gather_rows(self.new_z, self.z, None, (0, 0), M, self.Zs[M:])
 
-        # ---- forward
-        Ra = self.Ra
+        # -- discriminator (+ encoder) branch: normalise, forward, heads, backward, gradient penalty
+        with self._Branch(self._side(1) if self.has_disc else None):
+            if self.has_disc:
+                if norm_amp:
+                    be.rms_finalize(self.amp_state, self.amp, self.amp_sums, self.AMBg, 3, self.amp_mean, self.amp_std)
+                else:
+                    self._identity_stats(self.amp_mean, self.amp_std)
+                for s, (src, sidx, srm) in enumerate(amp_streams):
+                    be.rms_normalize(src, self.amp, sidx, srm, AMB, self.amp_mean[s], self.amp_std[s],
+                                     [self.Xd[s * AMB:(s + 1) * AMB]])
+                Rd = 3 * AMB
+                hd = self._fwd_chain(self.disc, self.Xd, self.Hd, Rd)
+                self._fwd(self.disc_head, hd, self.HD, Rd)
+                if self.enc_chain:
+                    he = self._fwd_chain(self.enc_chain, self.Xd[:AMB], self.He, AMB)
+                    self._fwd(self.enc_head, he, self.E, AMB)
+                be.disc_head(self.HD, self.dHD, self.disc_head.gb[0], self.acc, AMB, self.AMBg, c['disc_coef'])
+                if self.has_enc:
+                    src, sidx, srm = amp_streams[0]   # enc_latents = ase_latents[0:amp_minibatch] (learning/ase_agent.py:247)
+                    zsrc = ds['ase_latents'].view(ds['ase_latents'].shape[0], -1)
+                    be.gather_rows(zsrc, self.z, sidx, srm, AMB, self.enc_z)
+                    if self.enc_sep:
+                        be.enc_head(self.E, self.enc_z, self.dE, self.enc_head.gb[0], None, self.acc, AMB, self.AMBg,
+                                    self.z, c['enc_coef'])
+                    else:
+                        off = self.disc_head.parts[1][2]
+                        be.enc_head(self.HD[:AMB, off:], self.enc_z, self.dHD[:AMB, off:], self.disc_head.gb[1], None,
+                                    self.acc, AMB, self.AMBg, self.z, c['enc_coef'])
+                self._wgrad(self.disc_head, self.dHD, hd, Rd)
+                last = self.disc[-1]
+                self._dgrad(self.disc_head, self.dHD, self.dZd[-1], Rd, self.Hd[-1], last.act)
+                self._bwd_chain(self.disc, self.Xd, self.Hd, self.dZd, Rd)
+                if self.enc_chain:
+                    self._wgrad(self.enc_head, self.dE, he, AMB)
+                    last = self.enc_chain[-1]
+                    self._dgrad(self.enc_head, self.dE, self.dZe[-1], AMB, self.He[-1], last.act)
+                    self._bwd_chain(self.enc_chain, self.Xd[:AMB], self.He, self.dZe, AMB)
+                self._grad_penalty()
+
+        # -- critic forward (side stream 0) next to the actor forward (main stream)
+        with self._Branch(self._side(0)):
+            hc = self._fwd_chain(self.critic, self.Xc, self.Hc, M)
+            self._fwd(self.value_head, hc, self.V, M)
         if self.style:
             sd = self.actor[0].split_dst
             h = self._fwd_chain(self.style[:-1], self.Zs, self.Hs, Ra)
             self._fwd(self.style[-1], h, self.Xa[:, sd:], Ra)
         ha = self._fwd_chain(self.actor, self.Xa, self.Ha, Ra)
         self._fwd(self.mu_head, ha, self.MU, Ra)
-        hc = self._fwd_chain(self.critic, self.Xc, self.Hc, M)
-        self._fwd(self.value_head, hc, self.V, M)
-        if self.has_disc:
-            hd = self._fwd_chain(self.disc, self.Xd, self.Hd, 3 * AMB)
-            self._fwd(self.disc_head, hd, self.HD, 3 * AMB)
-            if self.enc_chain:
-                he = self._fwd_chain(self.enc_chain, self.Xd[:AMB], self.He, AMB)
-                self._fwd(self.enc_head, he, self.E, AMB)
+        self._join(0)
 
-        # ---- loss heads (value + gradient w.r.t. head outputs + head bias gradients)
+        # -- PPO loss head (value + gradient w.r.t. mu / value + head bias gradients)
         be.ppo_head(self.MU, self.V, self.mb, self.new_z if self.div_on else None, self.logstd, self.dMU, self.dV,
                     self.mu_head.gb[0], self.value_head.gb[0], self.acc, M, self.Mg, self.act, self.z, self.masked,
                     self.div_on, self.mu_tanh, c['clip_value'], c['e_clip'], c['critic_coef'],
                     c['bounds_loss_coef'], c.get('amp_diversity_bonus', 0.0), c.get('amp_diversity_tar', 0.0))
-        if self.has_disc:
-            be.disc_head(self.HD, self.dHD, self.disc_head.gb[0], self.acc, AMB, self.AMBg, c['disc_coef'])
-            if self.has_enc:
-                src, sidx, srm = amp_streams[0]       # enc_latents = ase_latents[0:amp_minibatch] (learning/ase_agent.py:247)
-                zsrc = ds['ase_latents'].view(ds['ase_latents'].shape[0], -1)
-                be.gather_rows(zsrc, self.z, sidx, srm, AMB, self.enc_z)
-                if self.enc_sep:
-                    be.enc_head(self.E, self.enc_z, self.dE, self.enc_head.gb[0], None, self.acc, AMB,
-                                self.AMBg, self.z, c['enc_coef'])
-                else:
-                    off = self.disc_head.parts[1][2]
-                    be.enc_head(self.HD[:AMB, off:], self.enc_z, self.dHD[:AMB, off:],
-                                self.disc_head.gb[1], None, self.acc, AMB, self.AMBg, self.z, c['enc_coef'])
 
-        # ---- backward: actor (+ style), critic
+        # -- critic backward (side stream 0) next to the actor (+ style) backward
+        with self._Branch(self._side(0)):
+            self._wgrad(self.value_head, self.dV, hc, M)
+            last = self.critic[-1]
+            self._dgrad(self.value_head, self.dV, self.dZc[-1], M, self.Hc[-1], last.act)
+            self._bwd_chain(self.critic, self.Xc, self.Hc, self.dZc, M)
         self._wgrad(self.mu_head, self.dMU, ha, Ra)
         last = self.actor[-1]
         self._dgrad(self.mu_head, self.dMU, self.dZa[-1], Ra, self.Ha[-1], last.act)
@@ -408,26 +471,13 @@ class UpdateEngine:
                 p = self.style[-2]
                 self._dgrad(sdn, self.dStyle, self.dZs[-1], Ra, self.Hs[-1], p.act)
                 self._bwd_chain(self.style[:-1], self.Zs, self.Hs, self.dZs, Ra)
-        self._wgrad(self.value_head, self.dV, hc, M)
-        last = self.critic[-1]
-        self._dgrad(self.value_head, self.dV, self.dZc[-1], M, self.Hc[-1], last.act)
-        self._bwd_chain(self.critic, self.Xc, self.Hc, self.dZc, M)
-
-        # ---- backward: discriminator (+ encoder) and the gradient penalty
+        self._join(0)
         if self.has_disc:
-            Rd = 3 * AMB
-            self._wgrad(self.disc_head, self.dHD, hd, Rd)
-            last = self.disc[-1]
-            self._dgrad(self.disc_head, self.dHD, self.dZd[-1], Rd, self.Hd[-1], last.act)
-            self._bwd_chain(self.disc, self.Xd, self.Hd, self.dZd, Rd)
-            if self.enc_chain:
-                self._wgrad(self.enc_head, self.dE, he, AMB)
-                last = self.enc_chain[-1]
-                self._dgrad(self.enc_head, self.dE, self.dZe[-1], AMB, self.He[-1], last.act)
-                self._bwd_chain(self.enc_chain, self.Xd[:AMB], self.He, self.dZe, AMB)
-            self._grad_penalty()
+            self._join(1)
 
-        self._allreduce_grads()
+    # ---- phase C: weight-only loss terms, optimizer, shadows, reported scalars --------------------
+    def phase_apply(self, apply=True):
+        be, c = self.be, self.cfg
         if self.has_disc:
             # weight-only loss terms, added once after the gradient reduction
             for W, gW, coef, slot in self.l2_terms:
@@ -449,7 +499,6 @@ class UpdateEngine:
             self.refresh_shadows()
         be.finalize_scalars(self.acc, self.res, self.Mg, self.AMBg, self.masked, self.has_disc, self.has_enc,
                             self.div_on, c)
-        return self.res
 
     def _grad_penalty(self):
         """J = coef * mean_rows |d logit / d x_demo|^2 with ReLU layers (learning/amp_agent.py:453-459):
@@ -485,20 +534,33 @@ class UpdateEngine:
                        colsum=self.disc_head.gW[0].view(-1) if last else None, colsum_n=d.N if last else 0)
 
     # ------------------------------------------------------------------ collectives (single rank: no-ops)
+    def _ar(self, t):
+        """SUM all-reduce of a device tensor over the data-parallel group: RCCL over xGMI in production (backend
+        'nccl').  With the 'gloo' backend (CPU test rigs, or several ranks sharing one GPU) device tensors are staged
+        through the host."""
+        import torch.distributed as dist
+        if t.is_cuda and dist.get_backend() == 'gloo':
+            h = t.cpu()
+            dist.all_reduce(h)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t)
+
+    def _dist_on(self):
+        return self.R > 1 or self.force_dist
+
     def _allreduce_stats(self):
-        if self.R > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.obs_sums)
+        if self._dist_on():
+            self._ar(self.obs_sums)
             if self.has_disc:
-                dist.all_reduce(self.amp_sums)
+                self._ar(self.amp_sums)
             if self.masked:
-                dist.all_reduce(self.acc[L.ACC_MASK_SUM:L.ACC_MASK_SUM + 1])
+                self._ar(self.acc[L.ACC_MASK_SUM:L.ACC_MASK_SUM + 1])
 
     def _allreduce_grads(self):
-        if self.R > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.grads[:self.n_train])     # SUM of per-rank partials (global denominators inside)
-            dist.all_reduce(self.acc[1:])                  # slot 0 (mask sum) is already global
+        if self._dist_on():
+            self._ar(self.grads[:self.n_train])     # SUM of per-rank partials (global denominators inside)
+            self._ar(self.acc[1:])                  # slot 0 (mask sum) is already global
 
     def _identity_stats(self, mean, std):
         mean.zero_()

@@ -283,36 +283,54 @@ class CommonAgent:
 
     def _step(self, idx, new_z=None):
         streams = self._amp_streams(idx)
-        if self.use_graph and new_z is None and self.world_size == 1:
+        if self.use_graph and new_z is None:
             return self._graph_step(idx, streams)
         return self.engine.step(self._ds, idx, self._remap, streams, new_z=new_z)
 
     def _graph_step(self, idx, streams):
+        """Replay the optimisation step from captured hipGraphs.  Single GPU: one graph for the whole step.
+        Data parallel: three graphs (local statistics | forward-backward | optimizer) with the two RCCL all-reduces
+        issued between them.  Index tensors are copied into the static buffers the graphs were captured with."""
+        eng = self.engine
         key = tuple(int(s[0].data_ptr()) for s in streams) if streams else ()
         g = self._graphs.get(key)
         if g is None:
             st = {'idx': idx.clone()}
+            st_streams = None
             if streams:
                 st['sidx'] = [s[1].clone() for s in streams]
                 st_streams = [(s[0], st['sidx'][i], s[2]) for i, s in enumerate(streams)]
-            else:
-                st_streams = None
-            self.engine.step(self._ds, st['idx'], self._remap, st_streams)          # warm-up (module load, attributes)
+            eng.step(self._ds, st['idx'], self._remap, st_streams)      # this call's real step; also warms up lazies
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                self.engine.step(self._ds, st['idx'], self._remap, st_streams)
-            st['graph'] = graph
-            self._graphs[key] = g = st
-            # the warm-up + capture executed two real optimisation steps' worth of state changes only once:
-            # capture itself does not run kernels, the warm-up step is this call's step
-            return self.engine.res
+            if self.world_size == 1 and not eng.force_dist:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    eng.step(self._ds, st['idx'], self._remap, st_streams)
+                st['graphs'] = [graph]
+            else:
+                ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga):
+                    eng.phase_stats(self._ds, st['idx'], self._remap, st_streams)
+                with torch.cuda.graph(gb):
+                    eng.phase_main(self._ds, st['idx'], self._remap, st_streams)
+                with torch.cuda.graph(gc):
+                    eng.phase_apply(True)
+                st['graphs'] = [ga, gb, gc]
+            self._graphs[key] = st
+            return eng.res
         g['idx'].copy_(idx)
         if streams:
             for d, s in zip(g['sidx'], streams):
                 d.copy_(s[1])
-        g['graph'].replay()
-        return self.engine.res
+        if len(g['graphs']) == 1:
+            g['graphs'][0].replay()
+        else:
+            g['graphs'][0].replay()
+            eng._allreduce_stats()
+            g['graphs'][1].replay()
+            eng._allreduce_grads()
+            g['graphs'][2].replay()
+        return eng.res
 
     def calc_gradients(self, input_dict):
         """Reference-compatible single step on an already gathered minibatch dict (learning/ase_agent.py:159)."""

@@ -123,7 +123,7 @@ def algorithmic_flops_per_step(eng):
     return f
 
 
-def make_agent(device, precision, use_graph, world, rank, seed=0):
+def make_agent(device, precision, use_graph, world, rank, seed=0, force_dist=False):
     from ase_amd.learning import agents, models
     from ase_amd.learning.network_builder import ASEBuilder
     from ase_amd.synthetic import EnvSpec, SyntheticSource
@@ -139,7 +139,7 @@ def make_agent(device, precision, use_graph, world, rank, seed=0):
     src = SyntheticSource(spec, seed=1234 + 2)
     cfg = dict(cfg)
     cfg.update(network=models.ModelASEContinuous(b), num_actors=spec.num_envs, device=device, precision=precision,
-               graph_capture=use_graph, world_size=world, rank=rank, vec_env=src,
+               graph_capture=use_graph, world_size=world, rank=rank, vec_env=src, force_dist=force_dist,
                env_info={'observation_space': sp(253), 'action_space': sp(31), 'amp_observation_space': sp(1400)})
     return agents.ASEAgent('bench', cfg), cfg, spec
 
@@ -184,7 +184,14 @@ def cpu_baseline(agent, cfg, steps=2):
                       'oracle/restated.py (f32 torch CPU)'}
 
 
+def _dbg(msg):
+    if os.environ.get('ASE_BENCH_DEBUG'):
+        print(f'[rank {os.environ.get("RANK", 0)}] {msg}', file=sys.stderr, flush=True)
+
+
 def main():
+    import faulthandler
+    faulthandler.enable()
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
@@ -193,6 +200,8 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--force-dist', action='store_true', help='run the collectives even with one rank (RCCL smoke)')
+    ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'])
     ap.add_argument('--breakdown', action='store_true', help='per-shape GEMM time table on stderr')
     args = ap.parse_args()
 
@@ -200,17 +209,26 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = f'cuda:{local}'
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device(device))
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+        if args.dist_backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device(device))      # RCCL over xGMI
+        else:
+            dist.init_process_group(args.dist_backend)                            # (test rigs without one GPU per rank)
 
-    use_graph = (not args.no_graph) and world == 1
+    use_graph = not args.no_graph
     t_setup = time.time()
-    agent, cfg, spec = make_agent(device, args.precision, use_graph, world, rank)
+    _dbg('init done')
+    agent, cfg, spec = make_agent(device, args.precision, use_graph, world, rank, force_dist=args.force_dist)
     B = agent.batch_size
+    _dbg('agent built')
 
     # ---- untimed: synthetic rollout into HBM (the policy outputs come from the engine's own inference path)
     with torch.no_grad():
@@ -221,6 +239,7 @@ def main():
                 agent.experience[k].copy_(v.to(device))
         agent._init_amp_demo_buf()
     torch.cuda.synchronize()
+    _dbg('rollout in HBM')
     if rank == 0:
         print(f'[bench] setup + synthetic rollout: {time.time() - t_setup:.1f} s', file=sys.stderr)
 
@@ -256,15 +275,17 @@ def main():
     # additional, eager (un-graphed) update on the same stream the kernels are launched on.
     eng = agent.engine
     roof = None
-    if rank == 0:
+    if True:      # every rank runs the instrumented update (it contains collectives); rank 0 reports
         tb = TimedBackend(eng.be)
         eng.be = tb
         agent.use_graph = False
+        ms_flag, eng.multi_stream = eng.multi_stream, False       # serial launches: clean per-kernel durations
         one_update()
         summ = tb.summary()
         if args.breakdown:
             print('\n'.join(tb.breakdown()), file=sys.stderr)
         eng.be = tb._be
+        eng.multi_stream = ms_flag
         agent.use_graph = use_graph
         n_opt = cfg['mini_epochs'] * (B // cfg['minibatch_size'])
         alg = algorithmic_flops_per_step(eng) * n_opt + 2.0 * B * sum(d.N * d.K for d in eng.disc) \
@@ -297,7 +318,7 @@ def main():
                           if world > 1 else 'single GPU'},
                'roofline': roof, 'cpu_baseline': cpu, 'last_train_result': {k: round(v, 6) for k, v in last.items()}}
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -68,3 +68,31 @@ def test_graph_and_eager_agree_ase(be, golden_dir):
     for k in res[0][0]:
         assert torch.allclose(res[0][0][k], res[1][0][k], rtol=1e-4, atol=1e-6), k
     assert torch.allclose(res[0][1], res[1][1], rtol=1e-5, atol=2e-6)
+
+
+def _dp_worker(rank, world, port, name, precision, graph):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from ase_amd.backend import HipBackend
+    G = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', name + '.pt'), weights_only=False)
+    ag = make_agent(G, HipBackend('cuda:0'), device='cuda:0', precision=precision, world_size=world, rank=rank,
+                    graph_capture=graph)
+    replay_epochs(G, ag, rtol=3e-4, wtol=G['cfg']['learning_rate'] * 0.25)       # against the REFERENCE's run
+    torch.cuda.synchronize()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('name,graph', [('ase_tiny', False), ('amp_tiny', True)])
+def test_two_ranks_sharded_update_matches_reference(name, graph):
+    """Data-parallel HIP path: two ranks (sharing this box's single GPU; collectives staged through gloo) shard every
+    minibatch, all-reduce normaliser moments, mask sums and the flat gradient buffer, and must reproduce the
+    reference's two train_epochs.  With graph=True each rank replays the three per-phase hipGraphs."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_dp_worker, args=(2, port, name, 'f32', graph), nprocs=2, join=True)
