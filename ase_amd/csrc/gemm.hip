@@ -79,15 +79,16 @@ template <> struct Mma<float> {
     }
 };
 
-// HBM -> LDS DMA of one operand tile: pass i moves rows [32 i, 32 i + 32); wave w of the pass owns the 8 rows
-// 32 i + 8 w .. + 7 = one 1-KiB lane-linear LDS piece (M0 = wave-uniform base, lane l lands at base + 16 l).
+// HBM -> LDS DMA of one operand tile: pass i moves rows [RPP i, RPP i + RPP) (RPP = 8 rows per wave); wave w of the
+// pass owns the 8 rows RPP i + 8 w .. + 7 = one 1-KiB lane-linear LDS piece (M0 = wave-uniform base, lane l lands at
+// base + 16 l).
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
-template <int PASSES>
+template <int PASSES, int RPP>
 __device__ __forceinline__ void nt_stage(const char* const (&src)[PASSES], int64_t koff, char* lds_wave_base) {
 #pragma unroll
     for (int i = 0; i < PASSES; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t*)(src[i] + koff), (lptr_t*)(lds_wave_base + i * 32 * kRowBytes), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t*)(src[i] + koff), (lptr_t*)(lds_wave_base + i * RPP * kRowBytes), 16, 0, 0);
 }
 
 struct NTParams {
@@ -104,10 +105,12 @@ struct NTParams {
 };
 
 template <typename T, int WGM, int WGN, int FM, int FN>
-__global__ __launch_bounds__(kThreads) void gemm_nt_kernel(NTParams p) {
+__global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(NTParams p) {
     constexpr int BM = WGM * FM * 32, BN = WGN * FN * 32;
     constexpr int BK = kRowBytes / (int)sizeof(T);
-    constexpr int A_PASSES = BM / 32, B_PASSES = BN / 32;
+    constexpr int RPP = WGM * WGN * 8;                       // tile rows staged per pass (8 per wave)
+    constexpr int A_PASSES = BM / RPP, B_PASSES = BN / RPP;
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the rows staged per pass");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int kBuf = (BM + BN) * kRowBytes;
 
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(NTParams p) {
     const int tile = xcd_remap(blockIdx.x, nwg);
     const int bm0 = (tile / p.tiles_n) * BM, bn0 = (tile % p.tiles_n) * BN;
 
-    // per-lane DMA sources: tile row 32 i + (tid >> 3), LDS slot tid & 7 receives chunk slot ^ ((row >> 1) & 7).
+    // per-lane DMA sources: tile row RPP i + (tid >> 3), LDS slot tid & 7 receives chunk slot ^ ((row >> 1) & 7).
     // Rows past M / N are clamped to the last valid row: their products only reach output rows / columns that are
     // never stored.
     const int srow = tid >> 3, sslot = tid & 7;
@@ -125,12 +128,12 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(NTParams p) {
     const char* srcB[B_PASSES];
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
-        const int r = i * 32 + srow;
+        const int r = i * RPP + srow;
         srcA[i] = p.A + (int64_t)min(bm0 + r, p.M - 1) * p.lda + ((sslot ^ ((r >> 1) & 7)) << 4);
     }
 #pragma unroll
     for (int i = 0; i < B_PASSES; ++i) {
-        const int r = i * 32 + srow;
+        const int r = i * RPP + srow;
         srcB[i] = p.B + (int64_t)min(bn0 + r, p.N - 1) * p.ldb + ((sslot ^ ((r >> 1) & 7)) << 4);
     }
     char* const ldsA = smem + (wid * 8) * kRowBytes;
@@ -145,14 +148,14 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(NTParams p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nk = p.K / BK;
-    nt_stage<A_PASSES>(srcA, 0, ldsA);
-    nt_stage<B_PASSES>(srcB, 0, ldsB);
+    nt_stage<A_PASSES, RPP>(srcA, 0, ldsA);
+    nt_stage<B_PASSES, RPP>(srcB, 0, ldsB);
     __syncthreads();                                   // (drains the DMA: vmcnt(0) + barrier)
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) {
-            nt_stage<A_PASSES>(srcA, (int64_t)(kt + 1) * kRowBytes, ldsA + (buf ^ 1) * kBuf);
-            nt_stage<B_PASSES>(srcB, (int64_t)(kt + 1) * kRowBytes, ldsB + (buf ^ 1) * kBuf);
+            nt_stage<A_PASSES, RPP>(srcA, (int64_t)(kt + 1) * kRowBytes, ldsA + (buf ^ 1) * kBuf);
+            nt_stage<B_PASSES, RPP>(srcB, (int64_t)(kt + 1) * kRowBytes, ldsB + (buf ^ 1) * kBuf);
         }
         const char* sA = smem + buf * kBuf + (wm * FM * 32) * kRowBytes;
         const char* sB = smem + buf * kBuf + (BM + wn * FN * 32) * kRowBytes;
@@ -167,78 +170,83 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(NTParams p) {
     // lets every lane pick up 4 consecutive columns of a row, applies the derivative mask from 8/16-byte aux loads,
     // issues 8/16-byte row-contiguous stores (full 128-byte lines per row) and keeps per-column partial sums for
     // the bias gradient.  (The last loop iteration ended with a barrier: nobody still reads the staging buffers.)
-    constexpr int WCOLS = FN * 32, WROWS = FM * 32;
+    constexpr int FNC = (FN > 2) ? 2 : FN;          // column fragments per epilogue round (slab = [FM*32][FNC*32] f32)
+    constexpr int WCOLS = FNC * 32, WROWS = FM * 32;
     float* slab = reinterpret_cast<float*>(smem) + wid * (WROWS * WCOLS);
     const int col_in = lane & 31, row_hi = (lane >> 5) * 4;
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-        const int n = bn0 + (wn * FN + j) * 32 + col_in;
-        const float bias = (p.bias && n < p.N) ? p.bias[n] : 0.f;
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float v = p.alpha * acc[i][j][e] + bias;
-                if (p.act == ASE_ACT_RELU) v = fmaxf(v, 0.f);
-                else if (p.act == ASE_ACT_TANH) v = tanhf(v);
-                slab[(i * 32 + row_hi + (e & 3) + 8 * (e >> 2)) * WCOLS + j * 32 + col_in] = v;
-            }
-        }
-    }
     constexpr int LPR = WCOLS / 4;                 // lanes per row (4 columns each)
     constexpr int RPI = 64 / LPR;                  // rows per iteration
     const int c4 = lane % LPR, rsub = lane / LPR;
-    const int n0 = bn0 + wn * WCOLS + c4 * 4;
     const int mrow0 = bm0 + wm * WROWS;
-    float cs[4] = {0.f, 0.f, 0.f, 0.f};
-    if (n0 < p.N) {                                // N is a multiple of 4 (checked on the host)
-#pragma unroll 4
-        for (int it = 0; it < WROWS / RPI; ++it) {
-            const int row = it * RPI + rsub;
-            const int m = mrow0 + row;
-            if (m >= p.M) continue;
-            f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * WCOLS + c4 * 4);
-            if (p.aux_mode != ASE_AUX_NONE) {
-                float a[4];
-                const char* ap = p.aux + (int64_t)m * p.ldaux + (int64_t)n0 * sizeof(T);
-                if constexpr (sizeof(T) == 2) {
-                    const bf16x4 av = *reinterpret_cast<const bf16x4*>(ap);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) a[q] = (float)av[q];
-                } else {
-                    const f32x4 av = *reinterpret_cast<const f32x4*>(ap);
+    for (int jc = 0; jc < FN; jc += FNC) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) a[q] = av[q];
+        for (int jj = 0; jj < FNC; ++jj) {
+            const int j = jc + jj;
+            const int n = bn0 + (wn * FN + j) * 32 + col_in;
+            const float bias = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float v = p.alpha * acc[i][j][e] + bias;
+                    if (p.act == ASE_ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (p.act == ASE_ACT_TANH) v = tanhf(v);
+                    slab[(i * 32 + row_hi + (e & 3) + 8 * (e >> 2)) * WCOLS + jj * 32 + col_in] = v;
                 }
+            }
+        }
+        const int n0 = bn0 + (wn * FN + jc) * 32 + c4 * 4;
+        float cs[4] = {0.f, 0.f, 0.f, 0.f};
+        if (n0 < p.N) {                                // N is a multiple of 4 (checked on the host)
+#pragma unroll 4
+            for (int it = 0; it < WROWS / RPI; ++it) {
+                const int row = it * RPI + rsub;
+                const int m = mrow0 + row;
+                if (m >= p.M) continue;
+                f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * WCOLS + c4 * 4);
+                if (p.aux_mode != ASE_AUX_NONE) {
+                    float a[4];
+                    const char* ap = p.aux + (int64_t)m * p.ldaux + (int64_t)n0 * sizeof(T);
+                    if constexpr (sizeof(T) == 2) {
+                        const bf16x4 av = *reinterpret_cast<const bf16x4*>(ap);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) a[q] = (float)av[q];
+                    } else {
+                        const f32x4 av = *reinterpret_cast<const f32x4*>(ap);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) a[q] = av[q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        v[q] = (p.aux_mode == ASE_AUX_RELU_MASK) ? (a[q] > 0.f ? v[q] : 0.f) : v[q] * (1.f - a[q] * a[q]);
+                }
+                if (p.out_f32 || sizeof(T) == 4) {
+                    *reinterpret_cast<f32x4*>(p.C + (int64_t)m * p.ldc + (int64_t)n0 * 4) = v;
+                } else {
+                    bf16x4 o;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        o[q] = (bf16_t)v[q];
+                        v[q] = (float)o[q];
+                    }
+                    *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + (int64_t)n0 * 2) = o;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cs[q] += v[q];
+            }
+        }
+        if (p.colsum) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int o = LPR; o < 64; o <<= 1) cs[q] += __shfl_xor(cs[q], o, 64);
+            }
+            if (lane < LPR) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    v[q] = (p.aux_mode == ASE_AUX_RELU_MASK) ? (a[q] > 0.f ? v[q] : 0.f) : v[q] * (1.f - a[q] * a[q]);
+                    if (n0 + q < p.colsum_n) atomic_add_f32(p.colsum + n0 + q, cs[q]);
             }
-            if (p.out_f32 || sizeof(T) == 4) {
-                *reinterpret_cast<f32x4*>(p.C + (int64_t)m * p.ldc + (int64_t)n0 * 4) = v;
-            } else {
-                bf16x4 o;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    o[q] = (bf16_t)v[q];
-                    v[q] = (float)o[q];
-                }
-                *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + (int64_t)n0 * 2) = o;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) cs[q] += v[q];
-        }
-    }
-    if (p.colsum) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-#pragma unroll
-            for (int o = LPR; o < 64; o <<= 1) cs[q] += __shfl_xor(cs[q], o, 64);
-        }
-        if (lane < LPR) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (n0 + q < p.colsum_n) atomic_add_f32(p.colsum + n0 + q, cs[q]);
         }
     }
 }
@@ -261,14 +269,24 @@ int launch_nt(const NTParams& p0, hipStream_t stream) {
     NTParams p = p0;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
-    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(kThreads), lds, stream, p);
+    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(WGM * WGN * 64), lds, stream, p);
     ASE_CHECK_LAUNCH("gemm_nt");
     return ASE_OK;
 }
 
 template <typename T> int dispatch_nt(const NTParams& p, hipStream_t s) {
-    if (p.N > 64) return launch_nt<T, 2, 2, 2, 2>(p, s);   // 128 x 128 tile, 64 x 64 per wave
-    return launch_nt<T, 2, 2, 1, 1>(p, s);                 //  64 x  64 tile (narrow heads: more workgroups)
+    static int force = -1;
+    if (force < 0) {
+        const char* e = getenv("ASE_NT_TILE");
+        force = e ? atoi(e) : 0;
+    }
+    if (p.N <= 64) return launch_nt<T, 2, 2, 1, 1>(p, s);                 //  64 x  64 tile (narrow heads: more workgroups)
+    // 256 x 256 tile, 8 waves of 64 x 128: half the L2->LDS bytes per flop of the 128 x 128 tile (the main-loop limiter),
+    // one workgroup per CU.  Used when the grid still fills the 256 CUs in whole rounds.
+    const int t256 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    const bool big = (force == 256) || (force == 0 && p.N % 256 == 0 && t256 >= 240 && (t256 % 256 == 0 || t256 >= 1024));
+    if (big && force != 128) return launch_nt<T, 4, 2, 2, 4>(p, s);
+    return launch_nt<T, 2, 2, 2, 2>(p, s);                                // 128 x 128 tile, 64 x 64 per wave
 }
 
 // ------------------------------------------------------------------------------------------------

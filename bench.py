@@ -58,6 +58,7 @@ class TimedBackend:
     def __init__(self, be):
         self._be = be
         self.records = []          # (kind, flops, start_event, end_event)
+        self.nt_bytes = 0.0        # algorithmic operand bytes of the NT launches (A + B + C [+ aux])
 
     def __getattr__(self, k):
         return getattr(self._be, k)
@@ -71,6 +72,8 @@ class TimedBackend:
 
     def gemm_nt(self, A, B, Cm, M, N, K, **kw):
         self._shape = (M, N, K)
+        es = A.element_size()
+        self.nt_bytes += (M * K + N * K) * es + M * N * Cm.element_size() + (M * N * es if kw.get('aux') is not None else 0)
         self._timed('nt', 2.0 * M * N * K, self._be.gemm_nt, A, B, Cm, M, N, K, **kw)
 
     def gemm_tn(self, A, B, G, M, N, K, n_real, k_real, split_src, split_dst, alpha=1.0, gbias=None):
@@ -294,9 +297,19 @@ def main():
         launches = sum(v['launches'] for v in summ.values())
         achieved = alg / (gemm_ms * 1e-3) / 1e12
         peak = MFMA_PEAK_TFLOPS[args.precision]
+        # HBM traffic of the dominant kernel per launch: PMC measurement committed under profiles/ (rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE in separate passes, FETCH doubled per the gfx950 note); bench cannot profile itself
+        traffic, traffic_src = None, None
+        pmc = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_pmc.json')) \
+            if os.path.isdir(os.path.join(ROOT, 'profiles')) else []
+        if pmc and args.precision == 'bf16':
+            j = json.load(open(os.path.join(ROOT, 'profiles', pmc[-1])))
+            traffic, traffic_src = j['hbm_bytes_per_launch'], 'profiles/' + pmc[-1]
         roof = {'bound': 'mfma', 'kernel': 'gemm_nt + gemm_tn (all dense layers of one update)',
                 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
-                'traffic': None, 'launches_per_update': launches, 'avg_launch_us': round(gemm_ms * 1e3 / launches, 2),
+                'traffic': traffic, 'traffic_unit': 'HBM bytes per gemm_nt launch (PMC)', 'traffic_source': traffic_src,
+                'algorithmic_bytes_per_nt_launch': round(tb.nt_bytes / max(1, summ['nt']['launches'])),
+                'launches_per_update': launches, 'avg_launch_us': round(gemm_ms * 1e3 / launches, 2),
                 'gemm_ms_per_update': round(gemm_ms, 3), 'algorithmic_tflop_per_update': round(alg / 1e12, 3),
                 'per_kind': {k: {'launches': v['launches'], 'ms': round(v['ms'], 3),
                                  'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1)} for k, v in summ.items()}}
