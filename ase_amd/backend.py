@@ -38,6 +38,7 @@ class HipBackend:
                                 "the update path has no CPU fallback")
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.lib = L.get()
+        self._head_scratch = torch.zeros(8192, dtype=torch.float64, device=self.device)
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
@@ -48,16 +49,18 @@ class HipBackend:
 
     # ------------------------------------------------------------------ GEMMs
     def gemm_nt(self, A, B, Cm, M, N, K, bias=None, aux=None, aux_mode=L.AUX_NONE, colsum=None, colsum_n=0,
-                act=L.ACT_NONE, alpha=1.0):
+                act=L.ACT_NONE, alpha=1.0, aux_split=0, aux_delta=0):
         dt = _code(A.dtype)
         assert B.dtype == A.dtype and (aux is None or aux.dtype == A.dtype)
         out_f32 = int(Cm.dtype == torch.float32 and A.dtype != torch.float32)
         L.check(self.lib.ase_hip_gemm_nt(_ptr(A), _ld(A), _ptr(B), _ld(B), _ptr(Cm), _ld(Cm), _ptr(bias), _ptr(aux),
-                                         _ld(aux), _ptr(colsum), int(colsum_n), M, N, K, act, aux_mode, out_f32,
+                                         _ld(aux), int(aux_split), int(aux_delta), _ptr(colsum), int(colsum_n), M, N, K, act,
+                                         aux_mode, out_f32,
                                          float(alpha), dt, self._stream()), "gemm_nt")
 
-    def gemm_tn(self, A, B, G, M, N, K, n_real, k_real, split_src, split_dst, alpha=1.0, gbias=None):
-        L.check(self.lib.ase_hip_gemm_tn(_ptr(A), _ld(A), _ptr(B), _ld(B), _ptr(G), _ptr(gbias), M, N, K, n_real, k_real,
+    def gemm_tn(self, A, B, G, M, N, K, n_real, k_real, split_src, split_dst, alpha=1.0, gbias=None, bias_rows=0):
+        L.check(self.lib.ase_hip_gemm_tn(_ptr(A), _ld(A), _ptr(B), _ld(B), _ptr(G), _ptr(gbias), int(bias_rows), M, N, K,
+                                         n_real, k_real,
                                          split_src, split_dst, float(alpha), _code(A.dtype), self._stream()), "gemm_tn")
 
     def refresh_shadow(self, W, Ws, Wts, split_src, split_dst):
@@ -112,6 +115,7 @@ class HipBackend:
             _ptr(mb['old_logp_actions']), _ptr(mb['advantages']), _ptr(mb.get('old_values')), _ptr(mb['returns']),
             _ptr(mb.get('rand_action_mask')), _ptr(mb.get('ase_latents')), _ptr(new_z), _ptr(logstd),
             _ptr(d_mu), _ld(d_mu), _ptr(d_value), _ld(d_value), _ptr(db_mu), _ptr(db_value), _ptr(mu_out), _ptr(acc),
+            _ptr(self._head_scratch),
             M, m_global, act_dim, z_dim, int(masked), int(div_on), int(mu_tanh), int(clip_value),
             float(e_clip), float(critic_coef), float(bounds_coef), float(div_coef), float(div_tar),
             _code(d_mu.dtype), self._stream()), "ppo_head")
@@ -126,12 +130,13 @@ class HipBackend:
                                           _ptr(enc_out), _ptr(acc), amb, amb_global, z_dim, float(enc_coef),
                                           _code(d_e.dtype), self._stream()), "enc_head")
 
-    def gp_seed(self, h, w, g, rows, width):
-        L.check(self.lib.ase_hip_gp_seed(_ptr(h), _ld(h), _ptr(w), _ptr(g), _ld(g), rows, width, _code(h.dtype),
+    def gp_seed(self, h, w, g, rows, width, scale=1.0):
+        L.check(self.lib.ase_hip_gp_seed(_ptr(h), _ld(h), _ptr(w), _ptr(g), _ld(g), rows, width, float(scale), _code(h.dtype),
                                          self._stream()), "gp_seed")
 
-    def sqnorm(self, x, rows, cols, acc, slot):
-        L.check(self.lib.ase_hip_sqnorm(_ptr(x), _ld(x), rows, cols, _ptr(acc), slot, _code(x.dtype), self._stream()),
+    def sqnorm(self, x, rows, cols, acc, slot, scale=1.0):
+        L.check(self.lib.ase_hip_sqnorm(_ptr(x), _ld(x), rows, cols, _ptr(acc), slot, float(scale), _code(x.dtype),
+                                        self._stream()),
                 "sqnorm")
 
     def finalize_scalars(self, acc, out, m_global, amb_global, masked, has_disc, has_enc, has_div, c):

@@ -28,21 +28,27 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 template <typename T> struct Mma;
 
+// LDS rows are RB = 64 or 128 bytes, unpadded; chunk c (16 B) of row r lives at slot c ^ swz(r):
+//   RB = 128: swz = (r >> 1) & 7   (a 256-byte bank window holds 2 rows x 8 slots)
+//   RB =  64: swz = (r >> 2) & 3   (4 rows x 4 slots)
+// either way the 16 rows (distinct mod 16) of a ds_read_b128 lane group land on 16 distinct slots.
+template <int RB> __device__ __forceinline__ int lds_swz(int r) { return RB == 128 ? ((r >> 1) & 7) : ((r >> 2) & 3); }
+
 template <> struct Mma<bf16_t> {
-    // one staged row = 64 k-values = 4 steps of 16
-    template <int FM, int FN>
+    // one staged row = RB/2 k-values = RB/32 steps of 16
+    template <int FM, int FN, int RB>
     static __device__ __forceinline__ void tile(const char* sA, const char* sB, int lane, f32x16 (&acc)[FM][FN]) {
-        const int r = lane & 31, h = lane >> 5, sw = (r >> 1) & 7;
+        const int r = lane & 31, h = lane >> 5, sw = lds_swz<RB>(r);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < RB / 32; ++ks) {
             bf16x8 a[FM], b[FN];
-            const int off = r * kRowBytes + (((ks * 2 + h) ^ sw) << 4);
+            const int off = r * RB + (((ks * 2 + h) ^ sw) << 4);
 #pragma unroll
             for (int i = 0; i < FM; ++i)
-                a[i] = *reinterpret_cast<const bf16x8*>(sA + i * 32 * kRowBytes + off);
+                a[i] = *reinterpret_cast<const bf16x8*>(sA + i * 32 * RB + off);
 #pragma unroll
             for (int j = 0; j < FN; ++j)
-                b[j] = *reinterpret_cast<const bf16x8*>(sB + j * 32 * kRowBytes + off);
+                b[j] = *reinterpret_cast<const bf16x8*>(sB + j * 32 * RB + off);
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -53,21 +59,21 @@ template <> struct Mma<bf16_t> {
 };
 
 template <> struct Mma<float> {
-    // one staged row = 32 k-values = 4 blocks of 8; within a block lane-half h holds k = 4h..4h+3
+    // one staged row = RB/4 k-values = RB/32 blocks of 8; within a block lane-half h holds k = 4h..4h+3
     // and MFMA j multiplies element j of both operands (any k order is fine if A and B agree).
-    template <int FM, int FN>
+    template <int FM, int FN, int RB>
     static __device__ __forceinline__ void tile(const char* sA, const char* sB, int lane, f32x16 (&acc)[FM][FN]) {
-        const int r = lane & 31, h = lane >> 5, sw = (r >> 1) & 7;
+        const int r = lane & 31, h = lane >> 5, sw = lds_swz<RB>(r);
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
+        for (int kb = 0; kb < RB / 32; ++kb) {
             f32x4 a[FM], b[FN];
-            const int off = r * kRowBytes + (((kb * 2 + h) ^ sw) << 4);
+            const int off = r * RB + (((kb * 2 + h) ^ sw) << 4);
 #pragma unroll
             for (int i = 0; i < FM; ++i)
-                a[i] = *reinterpret_cast<const f32x4*>(sA + i * 32 * kRowBytes + off);
+                a[i] = *reinterpret_cast<const f32x4*>(sA + i * 32 * RB + off);
 #pragma unroll
             for (int j = 0; j < FN; ++j)
-                b[j] = *reinterpret_cast<const f32x4*>(sB + j * 32 * kRowBytes + off);
+                b[j] = *reinterpret_cast<const f32x4*>(sB + j * 32 * RB + off);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -84,12 +90,13 @@ template <> struct Mma<float> {
 // base + 16 l).
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
-template <int PASSES, int RPP>
+template <int PASSES, int RPP, int RB>
 __device__ __forceinline__ void nt_stage(const char* const (&src)[PASSES], int64_t koff, char* lds_wave_base) {
 #pragma unroll
     for (int i = 0; i < PASSES; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t*)(src[i] + koff), (lptr_t*)(lds_wave_base + i * RPP * kRowBytes), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t*)(src[i] + koff), (lptr_t*)(lds_wave_base + i * RPP * RB), 16, 0, 0);
 }
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 struct NTParams {
     const char* A; int64_t lda;     // leading dims in BYTES
@@ -97,6 +104,7 @@ struct NTParams {
     char* C; int64_t ldc;           // bytes
     const float* bias;
     const char* aux; int64_t ldaux; // bytes
+    int aux_split, aux_delta;       // rows m >= aux_split read aux row m - aux_delta (stacked row blocks sharing a mask)
     float* colsum; int colsum_n;
     int M, N, K;                    // K in elements (multiple of 128/sizeof(T))
     int act, aux_mode, out_f32;
@@ -104,15 +112,18 @@ struct NTParams {
     int tiles_m, tiles_n;
 };
 
-template <typename T, int WGM, int WGN, int FM, int FN>
+template <typename T, int WGM, int WGN, int FM, int FN, int RB, int S>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(NTParams p) {
     constexpr int BM = WGM * FM * 32, BN = WGN * FN * 32;
-    constexpr int BK = kRowBytes / (int)sizeof(T);
-    constexpr int RPP = WGM * WGN * 8;                       // tile rows staged per pass (8 per wave)
+    constexpr int BK = RB / (int)sizeof(T);
+    constexpr int LPR = RB / 16;                             // lanes (16-byte chunks) per staged row
+    constexpr int RPW = 64 / LPR;                            // rows per wave-instruction of the DMA
+    constexpr int RPP = WGM * WGN * RPW;                     // tile rows staged per pass
     constexpr int A_PASSES = BM / RPP, B_PASSES = BN / RPP;
+    constexpr int P = A_PASSES + B_PASSES;                   // DMA instructions per lane per K-tile
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the rows staged per pass");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int kBuf = (BM + BN) * kRowBytes;
+    constexpr int kBuf = (BM + BN) * RB;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WGN, wn = wid % WGN;
@@ -120,24 +131,24 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(NTParams p) {
     const int tile = xcd_remap(blockIdx.x, nwg);
     const int bm0 = (tile / p.tiles_n) * BM, bn0 = (tile % p.tiles_n) * BN;
 
-    // per-lane DMA sources: tile row RPP i + (tid >> 3), LDS slot tid & 7 receives chunk slot ^ ((row >> 1) & 7).
+    // per-lane DMA sources: tile row RPP i + tid / LPR, LDS slot tid % LPR receives chunk slot ^ swz(row).
     // Rows past M / N are clamped to the last valid row: their products only reach output rows / columns that are
     // never stored.
-    const int srow = tid >> 3, sslot = tid & 7;
+    const int srow = tid / LPR, sslot = tid % LPR;
     const char* srcA[A_PASSES];
     const char* srcB[B_PASSES];
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
         const int r = i * RPP + srow;
-        srcA[i] = p.A + (int64_t)min(bm0 + r, p.M - 1) * p.lda + ((sslot ^ ((r >> 1) & 7)) << 4);
+        srcA[i] = p.A + (int64_t)min(bm0 + r, p.M - 1) * p.lda + ((sslot ^ lds_swz<RB>(r)) << 4);
     }
 #pragma unroll
     for (int i = 0; i < B_PASSES; ++i) {
         const int r = i * RPP + srow;
-        srcB[i] = p.B + (int64_t)min(bn0 + r, p.N - 1) * p.ldb + ((sslot ^ ((r >> 1) & 7)) << 4);
+        srcB[i] = p.B + (int64_t)min(bn0 + r, p.N - 1) * p.ldb + ((sslot ^ lds_swz<RB>(r)) << 4);
     }
-    char* const ldsA = smem + (wid * 8) * kRowBytes;
-    char* const ldsB = ldsA + BM * kRowBytes;
+    char* const ldsA = smem + (wid * RPW) * RB;
+    char* const ldsB = ldsA + BM * RB;
 
     f32x16 acc[FM][FN];
 #pragma unroll
@@ -147,21 +158,34 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(NTParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    // S-stage ring of LDS buffers, DMA prefetch distance S-1 tiles, ONE barrier per K-tile:
+    //   wait (counted vmcnt: only the newest S-2 tiles may still be in flight) -> barrier (tile kt has landed for
+    //   every wave AND every wave is done reading tile kt-1) -> issue the DMA of tile kt+S-1 into the buffer tile
+    //   kt-1 occupied -> MFMAs on tile kt.
     const int nk = p.K / BK;
-    nt_stage<A_PASSES, RPP>(srcA, 0, ldsA);
-    nt_stage<B_PASSES, RPP>(srcB, 0, ldsB);
-    __syncthreads();                                   // (drains the DMA: vmcnt(0) + barrier)
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) {
-            nt_stage<A_PASSES, RPP>(srcA, (int64_t)(kt + 1) * kRowBytes, ldsA + (buf ^ 1) * kBuf);
-            nt_stage<B_PASSES, RPP>(srcB, (int64_t)(kt + 1) * kRowBytes, ldsB + (buf ^ 1) * kBuf);
+#pragma unroll
+    for (int t = 0; t < S - 1; ++t) {
+        if (t < nk) {
+            nt_stage<A_PASSES, RPP, RB>(srcA, (int64_t)t * RB, ldsA + t * kBuf);
+            nt_stage<B_PASSES, RPP, RB>(srcB, (int64_t)t * RB, ldsB + t * kBuf);
         }
-        const char* sA = smem + buf * kBuf + (wm * FM * 32) * kRowBytes;
-        const char* sB = smem + buf * kBuf + (BM + wn * FN * 32) * kRowBytes;
-        Mma<T>::template tile<FM, FN>(sA, sB, lane, acc);
-        __syncthreads();
     }
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + S - 2 < nk) wait_vmcnt<P*(S - 2)>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + S - 1 < nk) {
+            const int nb = (buf == 0) ? S - 1 : buf - 1;           // (kt + S - 1) % S
+            nt_stage<A_PASSES, RPP, RB>(srcA, (int64_t)(kt + S - 1) * RB, ldsA + nb * kBuf);
+            nt_stage<B_PASSES, RPP, RB>(srcB, (int64_t)(kt + S - 1) * RB, ldsB + nb * kBuf);
+        }
+        const char* sA = smem + buf * kBuf + (wm * FM * 32) * RB;
+        const char* sB = smem + buf * kBuf + (BM + wn * FN * 32) * RB;
+        Mma<T>::template tile<FM, FN, RB>(sA, sB, lane, acc);
+        buf = (buf + 1 == S) ? 0 : buf + 1;
+    }
+    __syncthreads();                                   // everyone is done with the ring before it becomes the epilogue slab
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (e&3) + 8*(e>>2) + 4*(lane>>5), i.e. a
     // lane owns ONE column: storing from registers would be 2-byte scattered stores.  Phase 1 applies bias +
@@ -174,9 +198,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(NTParams p) {
     constexpr int WCOLS = FNC * 32, WROWS = FM * 32;
     float* slab = reinterpret_cast<float*>(smem) + wid * (WROWS * WCOLS);
     const int col_in = lane & 31, row_hi = (lane >> 5) * 4;
-    constexpr int LPR = WCOLS / 4;                 // lanes per row (4 columns each)
-    constexpr int RPI = 64 / LPR;                  // rows per iteration
-    const int c4 = lane % LPR, rsub = lane / LPR;
+    constexpr int ELPR = WCOLS / 4;                // lanes per row (4 columns each)
+    constexpr int RPI = 64 / ELPR;                 // rows per iteration
+    const int c4 = lane % ELPR, rsub = lane / ELPR;
     const int mrow0 = bm0 + wm * WROWS;
 #pragma unroll
     for (int jc = 0; jc < FN; jc += FNC) {
@@ -207,7 +231,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(NTParams p) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * WCOLS + c4 * 4);
                 if (p.aux_mode != ASE_AUX_NONE) {
                     float a[4];
-                    const char* ap = p.aux + (int64_t)m * p.ldaux + (int64_t)n0 * sizeof(T);
+                    const int ma = (m >= p.aux_split) ? m - p.aux_delta : m;
+                    const char* ap = p.aux + (int64_t)ma * p.ldaux + (int64_t)n0 * sizeof(T);
                     if constexpr (sizeof(T) == 2) {
                         const bf16x4 av = *reinterpret_cast<const bf16x4*>(ap);
 #pragma unroll
@@ -240,9 +265,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(NTParams p) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
 #pragma unroll
-                for (int o = LPR; o < 64; o <<= 1) cs[q] += __shfl_xor(cs[q], o, 64);
+                for (int o = ELPR; o < 64; o <<= 1) cs[q] += __shfl_xor(cs[q], o, 64);
             }
-            if (lane < LPR) {
+            if (lane < ELPR) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     if (n0 + q < p.colsum_n) atomic_add_f32(p.colsum + n0 + q, cs[q]);
@@ -251,12 +276,15 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(NTParams p) {
     }
 }
 
-template <typename T, int WGM, int WGN, int FM, int FN>
+template <typename T, int WGM, int WGN, int FM, int FN, int RB, int S>
 int launch_nt(const NTParams& p0, hipStream_t stream) {
     constexpr int BM = WGM * FM * 32, BN = WGN * FN * 32;
-    constexpr int lds = 2 * (BM + BN) * kRowBytes;
+    constexpr int ring = S * (BM + BN) * RB;
+    constexpr int slab = WGM * WGN * (FM * 32) * ((FN > 2 ? 2 : FN) * 32) * 4;
+    constexpr int lds = ring > slab ? ring : slab;
+    static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
-    auto kern = gemm_nt_kernel<T, WGM, WGN, FM, FN>;
+    auto kern = gemm_nt_kernel<T, WGM, WGN, FM, FN, RB, S>;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -275,18 +303,26 @@ int launch_nt(const NTParams& p0, hipStream_t stream) {
 }
 
 template <typename T> int dispatch_nt(const NTParams& p, hipStream_t s) {
-    static int force = -1;
+    static int force = -1, variant = 0;
     if (force < 0) {
         const char* e = getenv("ASE_NT_TILE");
         force = e ? atoi(e) : 0;
+        const char* v = getenv("ASE_NT_VARIANT");
+        variant = v ? atoi(v) : 1;   // 1: 128-byte rows, 2-stage ring (measured best); 0: 64-byte rows, 4-stage ring; 2: 3-stage
     }
-    if (p.N <= 64) return launch_nt<T, 2, 2, 1, 1>(p, s);                 //  64 x  64 tile (narrow heads: more workgroups)
-    // 256 x 256 tile, 8 waves of 64 x 128: half the L2->LDS bytes per flop of the 128 x 128 tile (the main-loop limiter),
-    // one workgroup per CU.  Used when the grid still fills the 256 CUs in whole rounds.
+    const bool k128 = (p.K * (int)sizeof(T)) % 128 == 0;       // 128-byte staged rows need K in whole 128-byte steps
+    if (p.N <= 64) return launch_nt<T, 2, 2, 1, 1, 64, 4>(p, s);          //  64 x  64 tile (narrow heads: more workgroups)
+    // 256 x 256 tile, 8 waves of 64 x 128: half the L2->LDS bytes per flop of the 128 x 128 tile, one workgroup per
+    // CU.  Used when the grid still fills the 256 CUs in whole rounds.
     const int t256 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     const bool big = (force == 256) || (force == 0 && p.N % 256 == 0 && t256 >= 240 && (t256 % 256 == 0 || t256 >= 1024));
-    if (big && force != 128) return launch_nt<T, 4, 2, 2, 4>(p, s);
-    return launch_nt<T, 2, 2, 2, 2>(p, s);                                // 128 x 128 tile, 64 x 64 per wave
+    if (big && force != 128) {
+        if (variant == 1 && k128) return launch_nt<T, 4, 2, 2, 4, 128, 2>(p, s);
+        return launch_nt<T, 4, 2, 2, 4, 64, 4>(p, s);                     // 64-byte rows, 4-stage ring (128 KB)
+    }
+    if (variant == 1 && k128) return launch_nt<T, 2, 2, 2, 2, 128, 2>(p, s);
+    if (variant == 2 && k128) return launch_nt<T, 2, 2, 2, 2, 128, 3>(p, s);
+    return launch_nt<T, 2, 2, 2, 2, 64, 4>(p, s);                         // 128 x 128 tile, 4-stage ring (64 KB)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -299,7 +335,8 @@ struct TNParams {
     const char* A; int64_t lda;   // bytes
     const char* B; int64_t ldb;   // bytes
     float* G;
-    float* gbias;                 // nullable: += column sums of A (bias gradient), n < n_real
+    float* gbias;                 // nullable: += column sums of A rows < bias_rows (bias gradient), n < n_real
+    int bias_rows;
     int M, N, K;                  // padded widths N (of A), K (of B), in elements
     int n_real, k_real, split_src, split_dst;
     float alpha;
@@ -349,9 +386,11 @@ __device__ __forceinline__ void tn_sstore(const uint4 (&ra)[LOADS], const uint4 
 
 // running column sums of the staged A chunks (each thread always stages the same 16-byte column chunk)
 template <typename T, int LOADS>
-__device__ __forceinline__ void tn_colsum(const uint4 (&ra)[LOADS], float (&cs)[8]) {
+__device__ __forceinline__ void tn_colsum(const uint4 (&ra)[LOADS], float (&cs)[8], int tid, int m0, int bias_rows) {
+    constexpr int CPR = TNGeom<T>::CPR;
 #pragma unroll
     for (int i = 0; i < LOADS; ++i) {
+        if (m0 + (tid + kThreads * i) / CPR >= bias_rows) continue;
         if constexpr (sizeof(T) == 2) {
             const bf16x8 v = *reinterpret_cast<const bf16x8*>(&ra[i]);
 #pragma unroll
@@ -394,7 +433,7 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(TNParams p) {
     const bool do_bias = p.gbias != nullptr && bk0 == 0;      // one k-tile column of workgroups also reduces A
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     tn_gload<T, LOADS>(ra, rb, p, tid, m_begin, m_end, bn0, bk0);
-    if (do_bias) tn_colsum<T, LOADS>(ra, cs);
+    if (do_bias) tn_colsum<T, LOADS>(ra, cs, tid, m_begin, p.bias_rows);
     tn_sstore<T, LOADS>(ra, rb, smem, tid);
     __syncthreads();
     for (int mt = 0; mt < nt; ++mt) {
@@ -445,7 +484,7 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(TNParams p) {
             }
         }
         if (mt + 1 < nt) {
-            if (do_bias) tn_colsum<T, LOADS>(ra, cs);
+            if (do_bias) tn_colsum<T, LOADS>(ra, cs, tid, m_begin + (mt + 1) * BKM, p.bias_rows);
             tn_sstore<T, LOADS>(ra, rb, smem + (buf ^ 1) * 2 * kOp, tid);
         }
         __syncthreads();
@@ -616,12 +655,12 @@ extern "C" int ase_hip_refresh_shadow_multi(const int64_t* desc, int n_layers, i
 }
 
 extern "C" int ase_hip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
-                               const float* bias, const void* aux, int64_t ldaux, float* colsum, int colsum_n,
-                               int M, int N, int K, int act, int aux_mode, int out_f32, float alpha, int dtype, void* stream) {
+                               const float* bias, const void* aux, int64_t ldaux, int aux_split, int aux_delta,
+                               float* colsum, int colsum_n, int M, int N, int K, int act, int aux_mode, int out_f32, float alpha, int dtype, void* stream) {
     const int es = (dtype == ASE_BF16) ? 2 : 4;
     ASE_CHECK_ARG(dtype == ASE_F32 || dtype == ASE_BF16, "gemm_nt: bad dtype %d", dtype);
     ASE_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0, "gemm_nt: null/empty operand (M=%d N=%d K=%d)", M, N, K);
-    ASE_CHECK_ARG((K * es) % kRowBytes == 0, "gemm_nt: K=%d is not a multiple of %d elements", K, kRowBytes / es);
+    ASE_CHECK_ARG((K * es) % 64 == 0, "gemm_nt: K=%d is not a multiple of %d elements", K, 64 / es);
     ASE_CHECK_ARG(lda >= K && ldb >= K && ldc >= N, "gemm_nt: leading dimension too small");
     ASE_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && (lda * es) % 16 == 0 && (ldb * es) % 16 == 0,
                   "gemm_nt: A/B must be 16-byte aligned with 16-byte row pitch");
@@ -633,14 +672,14 @@ extern "C" int ase_hip_gemm_nt(const void* A, int64_t lda, const void* B, int64_
     p.A = (const char*)A; p.lda = lda * es;
     p.B = (const char*)B; p.ldb = ldb * es;
     p.C = (char*)C; p.ldc = ldc * (out_f32 ? 4 : es);
-    p.bias = bias; p.aux = (const char*)aux; p.ldaux = ldaux * es; p.colsum = colsum; p.colsum_n = colsum ? colsum_n : 0;
+    p.bias = bias; p.aux = (const char*)aux; p.ldaux = ldaux * es; p.aux_split = aux_split > 0 ? aux_split : M; p.aux_delta = aux_delta; p.colsum = colsum; p.colsum_n = colsum ? colsum_n : 0;
     p.M = M; p.N = N; p.K = K; p.act = act; p.aux_mode = aux_mode; p.out_f32 = out_f32; p.alpha = alpha;
     p.tiles_m = p.tiles_n = 0;
     return dtype == ASE_BF16 ? dispatch_nt<bf16_t>(p, (hipStream_t)stream) : dispatch_nt<float>(p, (hipStream_t)stream);
 }
 
-extern "C" int ase_hip_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* G, float* gbias, int M,
-                               int N, int K, int n_real, int k_real, int split_src, int split_dst, float alpha, int dtype,
+extern "C" int ase_hip_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* G, float* gbias,
+                               int bias_rows, int M, int N, int K, int n_real, int k_real, int split_src, int split_dst, float alpha, int dtype,
                                void* stream) {
     const int es = (dtype == ASE_BF16) ? 2 : 4;
     ASE_CHECK_ARG(dtype == ASE_F32 || dtype == ASE_BF16, "gemm_tn: bad dtype %d", dtype);
@@ -652,7 +691,7 @@ extern "C" int ase_hip_gemm_tn(const void* A, int64_t lda, const void* B, int64_
     ASE_CHECK_ARG(n_real > 0 && n_real <= N && k_real > 0 && split_src <= split_dst && split_src <= k_real,
                   "gemm_tn: bad real dims / split");
     TNParams p;
-    p.A = (const char*)A; p.lda = lda * es; p.B = (const char*)B; p.ldb = ldb * es; p.G = G; p.gbias = gbias;
+    p.A = (const char*)A; p.lda = lda * es; p.B = (const char*)B; p.ldb = ldb * es; p.G = G; p.gbias = gbias; p.bias_rows = bias_rows > 0 ? bias_rows : M;
     p.M = M; p.N = N; p.K = K; p.n_real = n_real; p.k_real = k_real; p.split_src = split_src; p.split_dst = split_dst;
     p.alpha = alpha; p.tiles_n = p.tiles_k = p.m_chunk = 0;
     return dtype == ASE_BF16 ? launch_tn<bf16_t>(p, (hipStream_t)stream) : launch_tn<float>(p, (hipStream_t)stream);

@@ -26,6 +26,7 @@ struct PpoArgs {
     void* d_value; int64_t ld_dv;
     float *db_mu, *db_value, *mu_out;
     double* acc;
+    double* scratch;              // [gridDim.x][8] per-workgroup partial sums (no contended atomics)
     int M, m_global, act_dim, z_dim, masked, div_on, mu_tanh, clip_value;
     float e_clip, critic_coef, bounds_coef, div_coef, div_tar;
 };
@@ -168,13 +169,29 @@ __global__ __launch_bounds__(256) void ppo_head_kernel(PpoArgs p) {
     }
     block_sum<7>(part, sm);
     if (threadIdx.x == 0) {
-        atomic_add_f64(p.acc + ASE_ACC_A_LOSS, part[0]);
-        atomic_add_f64(p.acc + ASE_ACC_B_LOSS, part[1]);
-        atomic_add_f64(p.acc + ASE_ACC_ENTROPY, part[2]);
-        atomic_add_f64(p.acc + ASE_ACC_CLIPPED, part[3]);
-        atomic_add_f64(p.acc + ASE_ACC_C_LOSS, part[4]);
-        atomic_add_f64(p.acc + ASE_ACC_KL, part[5]);
-        if (p.div_on) atomic_add_f64(p.acc + ASE_ACC_DIV, part[6]);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) p.scratch[(int64_t)blockIdx.x * 8 + k] = part[k];
+    }
+}
+
+// second stage: one workgroup folds the per-workgroup partials into the accumulators
+__global__ __launch_bounds__(256) void ppo_head_fold_kernel(const double* __restrict__ scratch, int nblocks,
+                                                            double* __restrict__ acc, int div_on) {
+    __shared__ double sm[7 * 16];
+    double part[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) part[k] += scratch[(int64_t)b * 8 + k];
+    }
+    block_sum<7>(part, sm);
+    if (threadIdx.x == 0) {
+        acc[ASE_ACC_A_LOSS] += part[0];
+        acc[ASE_ACC_B_LOSS] += part[1];
+        acc[ASE_ACC_ENTROPY] += part[2];
+        acc[ASE_ACC_CLIPPED] += part[3];
+        acc[ASE_ACC_C_LOSS] += part[4];
+        acc[ASE_ACC_KL] += part[5];
+        if (div_on) acc[ASE_ACC_DIV] += part[6];
     }
 }
 
@@ -270,18 +287,18 @@ __global__ __launch_bounds__(256) void enc_head_kernel(const float* __restrict__
 
 template <typename T>
 __global__ __launch_bounds__(256) void gp_seed_kernel(const T* __restrict__ h, int64_t ld_h, const float* __restrict__ w,
-                                                      T* __restrict__ g, int64_t ld_g, int rows, int width) {
+                                                      T* __restrict__ g, int64_t ld_g, int rows, int width, float scale) {
     const int64_t n = (int64_t)rows * width;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / width), j = (int)(i - (int64_t)r * width);
         const float hv = to_f32(h[(int64_t)r * ld_h + j]);
-        g[(int64_t)r * ld_g + j] = from_f32<T>(hv > 0.f ? w[j] : 0.f);
+        g[(int64_t)r * ld_g + j] = from_f32<T>(hv > 0.f ? scale * w[j] : 0.f);
     }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void sqnorm_kernel(const T* __restrict__ x, int64_t ld, int rows, int cols,
-                                                     double* __restrict__ acc) {
+                                                     double* __restrict__ acc, double scale) {
     __shared__ double sm[16];
     const int64_t n = (int64_t)rows * cols;
     double v[1] = {0.0};
@@ -291,7 +308,7 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const T* __restrict__ x, in
         v[0] += t * t;
     }
     block_sum<1>(v, sm);
-    if (threadIdx.x == 0) atomic_add_f64(acc, v[0]);
+    if (threadIdx.x == 0) atomic_add_f64(acc, v[0] * scale);
 }
 
 struct FinArgs {
@@ -362,11 +379,11 @@ extern "C" int ase_hip_ppo_head(const float* mu, int64_t ld_mu, const float* val
                                 const float* mb_old_logp, const float* mb_adv, const float* mb_old_value,
                                 const float* mb_return, const float* mb_mask, const float* mb_z, const float* new_z,
                                 const float* logstd, void* d_mu, int64_t ld_dmu, void* d_value, int64_t ld_dv,
-                                float* db_mu, float* db_value, float* mu_out, double* acc, int M, int m_global, int act_dim, int z_dim, int masked,
+                                float* db_mu, float* db_value, float* mu_out, double* acc, double* scratch, int M, int m_global, int act_dim, int z_dim, int masked,
                                 int div_on, int mu_tanh, int clip_value, float e_clip, float critic_coef,
                                 float bounds_coef, float div_coef, float div_tar, int dtype, void* stream) {
     ASE_CHECK_ARG(mu && value && mb_actions && mb_old_mu && mb_old_sigma && mb_old_logp && mb_adv && mb_return &&
-                      logstd && d_mu && d_value && acc && M > 0 && m_global >= M,
+                      logstd && d_mu && d_value && acc && scratch && M > 0 && m_global >= M,
                   "ppo_head: null/empty operand");
     ASE_CHECK_ARG(act_dim >= 1 && act_dim <= 32, "ppo_head: act_dim %d not in [1,32]", act_dim);
     ASE_CHECK_ARG(!masked || mb_mask, "ppo_head: masked reduction without a mask");
@@ -377,13 +394,14 @@ extern "C" int ase_hip_ppo_head(const float* mu, int64_t ld_mu, const float* val
     p.actions = mb_actions; p.old_mu = mb_old_mu; p.old_sigma = mb_old_sigma; p.old_logp = mb_old_logp;
     p.adv = mb_adv; p.old_value = mb_old_value; p.ret = mb_return; p.mask = mb_mask; p.z = mb_z; p.new_z = new_z;
     p.logstd = logstd; p.d_mu = d_mu; p.ld_dmu = ld_dmu; p.d_value = d_value; p.ld_dv = ld_dv; p.db_mu = db_mu; p.db_value = db_value; p.mu_out = mu_out;
-    p.acc = acc; p.M = M; p.m_global = m_global; p.act_dim = act_dim; p.z_dim = z_dim; p.masked = masked;
+    p.acc = acc; p.scratch = scratch; p.M = M; p.m_global = m_global; p.act_dim = act_dim; p.z_dim = z_dim; p.masked = masked;
     p.div_on = div_on; p.mu_tanh = mu_tanh; p.clip_value = clip_value; p.e_clip = e_clip; p.critic_coef = critic_coef;
     p.bounds_coef = bounds_coef; p.div_coef = div_coef; p.div_tar = div_tar;
-    const dim3 grid(min((M + 7) / 8, 256));
+    const dim3 grid(min((M + 7) / 8, 1024));       // scratch holds 1024 x 8 doubles
     if (dtype == ASE_BF16) hipLaunchKernelGGL(ppo_head_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, p);
     else if (dtype == ASE_F32) hipLaunchKernelGGL(ppo_head_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, p);
     else ASE_CHECK_ARG(false, "ppo_head: bad dtype %d", dtype);
+    hipLaunchKernelGGL(ppo_head_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, (int)grid.x, acc, div_on);
     ASE_CHECK_LAUNCH("ppo_head");
     return ASE_OK;
 }
@@ -421,30 +439,30 @@ extern "C" int ase_hip_enc_head(const float* e, int64_t ld_e, const float* z, in
 }
 
 extern "C" int ase_hip_gp_seed(const void* h, int64_t ld_h, const float* w, void* g, int64_t ld_g, int rows, int width,
-                               int dtype, void* stream) {
+                               float scale, int dtype, void* stream) {
     ASE_CHECK_ARG(h && w && g && rows > 0 && width > 0, "gp_seed: null/empty operand");
     const dim3 grid(grid_for((int64_t)rows * width));
     if (dtype == ASE_BF16)
         hipLaunchKernelGGL(gp_seed_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h, ld_h, w,
-                           (bf16_t*)g, ld_g, rows, width);
+                           (bf16_t*)g, ld_g, rows, width, scale);
     else if (dtype == ASE_F32)
         hipLaunchKernelGGL(gp_seed_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)h, ld_h, w,
-                           (float*)g, ld_g, rows, width);
+                           (float*)g, ld_g, rows, width, scale);
     else ASE_CHECK_ARG(false, "gp_seed: bad dtype %d", dtype);
     ASE_CHECK_LAUNCH("gp_seed");
     return ASE_OK;
 }
 
-extern "C" int ase_hip_sqnorm(const void* x, int64_t ld, int rows, int cols, double* acc, int slot, int dtype,
-                              void* stream) {
+extern "C" int ase_hip_sqnorm(const void* x, int64_t ld, int rows, int cols, double* acc, int slot, double scale,
+                              int dtype, void* stream) {
     ASE_CHECK_ARG(x && acc && rows > 0 && cols > 0 && slot >= 0, "sqnorm: null/empty operand");
     const dim3 grid(grid_for((int64_t)rows * cols, 2048, 256));
     if (dtype == ASE_BF16)
         hipLaunchKernelGGL(sqnorm_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, rows,
-                           cols, acc + slot);
+                           cols, acc + slot, scale);
     else if (dtype == ASE_F32)
         hipLaunchKernelGGL(sqnorm_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ld, rows,
-                           cols, acc + slot);
+                           cols, acc + slot, scale);
     else ASE_CHECK_ARG(false, "sqnorm: bad dtype %d", dtype);
     ASE_CHECK_LAUNCH("sqnorm");
     return ASE_OK;

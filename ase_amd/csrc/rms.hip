@@ -138,14 +138,14 @@ __global__ __launch_bounds__(256) void gather_multi_kernel(const int64_t* __rest
     const int D = (int)d[2];
     const int64_t ld_dst = d[4];
     const int dt = (int)d[5];
-    const int lane = threadIdx.x & 63;
-    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < M; r += gridDim.x * 4) {
+    // flat (row, element) index: consecutive threads take consecutive elements of a row, or consecutive rows when D = 1
+    const int64_t total = (int64_t)M * D;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / D), j = (int)(i - (int64_t)r * D);
         const int64_t p = map_row(r, idx, remap_h, remap_n);
-        for (int j = lane; j < D; j += 64) {
-            const float v = src[p * ld_src + j];
-            if (dt == ASE_BF16) reinterpret_cast<bf16_t*>(d[3])[(int64_t)r * ld_dst + j] = (bf16_t)v;
-            else reinterpret_cast<float*>(d[3])[(int64_t)r * ld_dst + j] = v;
-        }
+        const float v = src[p * ld_src + j];
+        if (dt == ASE_BF16) reinterpret_cast<bf16_t*>(d[3])[(int64_t)r * ld_dst + j] = (bf16_t)v;
+        else reinterpret_cast<float*>(d[3])[(int64_t)r * ld_dst + j] = v;
     }
 }
 
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void gather_multi_kernel(const int64_t* __rest
 extern "C" int ase_hip_gather_multi(const int64_t* desc, int n_fields, const int32_t* idx, int remap_h, int remap_n,
                                     int M, void* stream) {
     ASE_CHECK_ARG(desc && n_fields > 0 && M > 0, "gather_multi: null/empty operand");
-    const dim3 grid(min((M + 3) / 4, 512), n_fields);
+    const dim3 grid(min((M + 7) / 8, 256), n_fields);
     hipLaunchKernelGGL(gather_multi_kernel, grid, dim3(256), 0, (hipStream_t)stream, desc, idx, remap_h, remap_n, M);
     ASE_CHECK_LAUNCH("gather_multi");
     return ASE_OK;

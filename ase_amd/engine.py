@@ -208,14 +208,20 @@ class UpdateEngine:
             self.rng_state = torch.tensor([0x5EED, 0], dtype=torch.int64, device=dev)
         if self.has_disc:
             Rd = 3 * AMB
-            self.Xd = zt(Rd, self.disc[0].k_pad)
-            self.Hd, self.dZd = chain_bufs(self.disc, Rd)
+            # Rows [0, 3 AMB) = agent | replay | demo.  A 4th block of AMB rows carries the gradient-penalty chain of
+            # the demo rows through the SAME launches: the chain g_l = m_l * (g_{l+1} @ W_{l+1}) is a data-gradient
+            # with the demo rows' masks, and its weight-gradient terms g_l^T (dJ/dU_{l-1}) stack under dZ_l^T H_{l-1}.
+            self.Xd4 = zt(4 * AMB, self.disc[0].k_pad)                   # [Xd ; s*g_0]
+            self.Xd = self.Xd4[:Rd]
+            self.G0 = self.Xd4[Rd:]
+            self.Hd4 = [zt(4 * AMB, d.n_pad) for d in self.disc]         # [H_l ; dJ/dU_l (masked)]
+            self.dZd4 = [zt(4 * AMB, d.n_pad) for d in self.disc]        # [dZ_l ; s*g_l]
+            self.Hd = [h[:Rd] for h in self.Hd4]
+            self.dGp = [h[Rd:] for h in self.Hd4]
+            self.dZd = [z[:Rd] for z in self.dZd4]
+            self.Gp = [z[Rd:] for z in self.dZd4]
             self.HD = zt(Rd, self.disc_head.n_pad, f32)
             self.dHD = zt(Rd, self.disc_head.n_pad)
-            # gradient penalty chain on the demo rows
-            self.Gp = [zt(AMB, d.n_pad) for d in self.disc]            # g_l  (grad of logit w.r.t. Z_l)
-            self.G0 = zt(AMB, self.disc[0].k_pad)
-            self.dGp = [zt(AMB, d.n_pad) for d in self.disc]           # d J / d g_l (masked)
             if self.enc_chain:
                 self.He, self.dZe = chain_bufs(self.enc_chain, AMB)
                 self.E = zt(AMB, self.enc_head.n_pad, f32)
@@ -425,13 +431,12 @@ class UpdateEngine:
                 self._wgrad(self.disc_head, self.dHD, hd, Rd)
                 last = self.disc[-1]
                 self._dgrad(self.disc_head, self.dHD, self.dZd[-1], Rd, self.Hd[-1], last.act)
-                self._bwd_chain(self.disc, self.Xd, self.Hd, self.dZd, Rd)
+                self._disc_backward()
                 if self.enc_chain:
                     self._wgrad(self.enc_head, self.dE, he, AMB)
                     last = self.enc_chain[-1]
                     self._dgrad(self.enc_head, self.dE, self.dZe[-1], AMB, self.He[-1], last.act)
                     self._bwd_chain(self.enc_chain, self.Xd[:AMB], self.He, self.dZe, AMB)
-                self._grad_penalty()
 
         # -- critic forward (side stream 0) next to the actor forward (main stream)
         with self._Branch(self._side(0)):
@@ -500,38 +505,52 @@ class UpdateEngine:
         be.finalize_scalars(self.acc, self.res, self.Mg, self.AMBg, self.masked, self.has_disc, self.has_enc,
                             self.div_on, c)
 
-    def _grad_penalty(self):
-        """J = coef * mean_rows |d logit / d x_demo|^2 with ReLU layers (learning/amp_agent.py:453-459):
-        g_L = m_L * w_logit ; g_{l-1} = m_{l-1} * (g_l @ W_l) ; g_0 = g_1 @ W_1 ; then the backward of that chain."""
+    def _disc_backward(self):
+        """Discriminator trunk backward with the gradient penalty riding on the same launches.
+
+        J = coef * mean_rows |d logit / d x_demo|^2 with ReLU layers (learning/amp_agent.py:453-459):
+        g_L = m_L * w_logit ; g_{l-1} = m_{l-1} * (g_l @ W_l) ; g_0 = g_1 @ W_1, then the backward of that chain.
+        The chain is carried scaled by s = sqrt(2 coef / AMB) so that every weight-gradient term needs alpha = 1:
+          rows [3 AMB, 4 AMB) of dZd4[l] hold s*g_l        (data-gradient launches, demo rows' masks via aux row wrap)
+          rows [3 AMB, 4 AMB) of Xd4 / Hd4[l] hold s*g_0 / the masked dJ/dU_l   (3 small NT launches)
+          gW_l += [dZ_l ; s g_l]^T [H_{l-1} ; dJ/dU_{l-1}]                        (ONE weight-gradient launch per layer)."""
         be, c, AMB = self.be, self.cfg, self.AMB
-        gp_coef = c['disc_coef'] * c['disc_grad_penalty']
-        lo = 2 * AMB
-        Hdemo = [h[lo:lo + AMB] for h in self.Hd]
+        Rd = 3 * AMB
         nl = len(self.disc)
+        gp_coef = c['disc_coef'] * c['disc_grad_penalty']
+        if gp_coef == 0:
+            be.zero_(self.G0)     # keeps the reported penalty at 0 without the chain
+            self._bwd_chain(self.disc, self.Xd, self.Hd, self.dZd, Rd)
+            return
         for d in self.disc:
             assert d.act == L.ACT_RELU, "analytic gradient penalty needs ReLU discriminator layers"
         assert nl >= 2, "gradient penalty with a single discriminator layer is not implemented"
+        cg = gp_coef * 2.0 / self.AMBg
+        s = math.sqrt(cg)
         top = self.disc[-1]
-        be.gp_seed(Hdemo[-1], self.disc_head.W[0].view(-1), self.Gp[-1], AMB, top.N)
+        be.gp_seed(self.Hd[-1][2 * AMB:], self.disc_head.W[0].view(-1), self.Gp[-1], AMB, top.N, scale=s)
+        # data-gradient chain on 4 AMB rows: [dZ_l ; s g_l] -> [dZ_{l-1} ; s g_{l-1}]
         for l in range(nl - 1, 0, -1):
-            d = self.disc[l]
-            be.gemm_nt(self.Gp[l], d.Wts, self.Gp[l - 1], AMB, d.k_pad, d.n_pad, aux=Hdemo[l - 1],
-                       aux_mode=L.AUX_RELU_MASK)
+            d, pl = self.disc[l], self.disc[l - 1]
+            be.gemm_nt(self.dZd4[l], d.Wts, self.dZd4[l - 1], 4 * AMB, d.k_pad, d.n_pad, aux=self.Hd4[l - 1],
+                       aux_mode=_AUX[pl.act], aux_split=Rd, aux_delta=AMB)
         d0 = self.disc[0]
-        be.gemm_nt(self.Gp[0], d0.Wts, self.G0, AMB, d0.k_pad, d0.n_pad)
-        be.sqnorm(self.G0, AMB, d0.k_pad, self.acc, L.ACC_GP)
-        if gp_coef == 0:
-            return
-        cg = gp_coef * 2.0 / self.AMBg          # d J / d g_0 = cg * g_0
-        # layer 1: g_0 = g_1 @ W_1
-        be.gemm_tn(self.Gp[0], self.G0, d0.gW[0], AMB, d0.n_pad, d0.k_pad, d0.N, d0.K, d0.split_src, d0.split_dst, alpha=cg)
-        be.gemm_nt(self.G0, d0.Ws, self.dGp[0], AMB, d0.n_pad, d0.k_pad, aux=Hdemo[0], aux_mode=L.AUX_RELU_MASK, alpha=cg)
+        be.gemm_nt(self.Gp[0], d0.Wts, self.G0, AMB, d0.k_pad, d0.n_pad)                 # s * g_0
+        be.sqnorm(self.G0, AMB, d0.k_pad, self.acc, L.ACC_GP, scale=1.0 / cg)
+        # backward of the chain (values scaled by s; see the docstring): dJ/dU_l, masked by the demo rows' ReLU masks
+        be.gemm_nt(self.G0, d0.Ws, self.dGp[0], AMB, d0.n_pad, d0.k_pad, aux=self.Hd[0][2 * AMB:], aux_mode=L.AUX_RELU_MASK)
         for l in range(1, nl):
-            d = self.disc[l]                     # g_{l-1} = m_{l-1} * (g_l @ W_l)   [dGp[l-1] is already masked]
-            be.gemm_tn(self.Gp[l], self.dGp[l - 1], d.gW[0], AMB, d.n_pad, d.k_pad, d.N, d.K, d.split_src, d.split_dst)
+            d = self.disc[l]
             last = l == nl - 1
-            be.gemm_nt(self.dGp[l - 1], d.Ws, self.dGp[l], AMB, d.n_pad, d.k_pad, aux=Hdemo[l], aux_mode=L.AUX_RELU_MASK,
+            be.gemm_nt(self.dGp[l - 1], d.Ws, self.dGp[l], AMB, d.n_pad, d.k_pad, aux=self.Hd[l][2 * AMB:],
+                       aux_mode=L.AUX_RELU_MASK, alpha=s if last else 1.0,
                        colsum=self.disc_head.gW[0].view(-1) if last else None, colsum_n=d.N if last else 0)
+        # weight (+ bias) gradients: one launch per layer over the stacked rows
+        for l in range(nl):
+            d = self.disc[l]
+            X = self.Xd4 if l == 0 else self.Hd4[l - 1]
+            be.gemm_tn(self.dZd4[l], X, d.gW[0], 4 * AMB, d.n_pad, d.k_pad, d.N, d.K, d.split_src, d.split_dst,
+                       gbias=d.gb[0], bias_rows=Rd)
 
     # ------------------------------------------------------------------ collectives (single rank: no-ops)
     def _ar(self, t):

@@ -281,6 +281,12 @@ class CommonAgent:
     def _amp_streams(self, idx):
         return None
 
+    def _set_epoch_perm(self, perm):
+        """Copy the mini-epoch permutation into persistent device storage (hipGraphs bind to slices of it)."""
+        if getattr(self, '_perm_buf', None) is None:
+            self._perm_buf = torch.empty(self.batch_size, dtype=torch.int32, device=self.ppo_device)
+        self._perm_buf.copy_(perm)
+
     def _step(self, idx, new_z=None):
         streams = self._amp_streams(idx)
         if self.use_graph and new_z is None:
@@ -290,38 +296,31 @@ class CommonAgent:
     def _graph_step(self, idx, streams):
         """Replay the optimisation step from captured hipGraphs.  Single GPU: one graph for the whole step.
         Data parallel: three graphs (local statistics | forward-backward | optimizer) with the two RCCL all-reduces
-        issued between them.  Index tensors are copied into the static buffers the graphs were captured with."""
+        issued between them.  One graph (set) per minibatch position: the index tensors are slices of persistent
+        per-mini-epoch buffers (permutation, composed demo / replay indices), so a replay needs no copies."""
         eng = self.engine
-        key = tuple(int(s[0].data_ptr()) for s in streams) if streams else ()
+        key = (int(idx.data_ptr()),) + (tuple((int(s[0].data_ptr()), int(s[1].data_ptr())) for s in streams) if streams else ())
         g = self._graphs.get(key)
         if g is None:
-            st = {'idx': idx.clone()}
-            st_streams = None
-            if streams:
-                st['sidx'] = [s[1].clone() for s in streams]
-                st_streams = [(s[0], st['sidx'][i], s[2]) for i, s in enumerate(streams)]
-            eng.step(self._ds, st['idx'], self._remap, st_streams)      # this call's real step; also warms up lazies
+            eng.step(self._ds, idx, self._remap, streams)                # this call's real step; also warms up lazies
             torch.cuda.synchronize()
             if self.world_size == 1 and not eng.force_dist:
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
-                    eng.step(self._ds, st['idx'], self._remap, st_streams)
-                st['graphs'] = [graph]
+                    eng.step(self._ds, idx, self._remap, streams)
+                graphs = [graph]
             else:
                 ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 with torch.cuda.graph(ga):
-                    eng.phase_stats(self._ds, st['idx'], self._remap, st_streams)
+                    eng.phase_stats(self._ds, idx, self._remap, streams)
                 with torch.cuda.graph(gb):
-                    eng.phase_main(self._ds, st['idx'], self._remap, st_streams)
+                    eng.phase_main(self._ds, idx, self._remap, streams)
                 with torch.cuda.graph(gc):
                     eng.phase_apply(True)
-                st['graphs'] = [ga, gb, gc]
-            self._graphs[key] = st
+                graphs = [ga, gb, gc]
+            # keep the captured index views alive: the graphs read through their addresses on every replay
+            self._graphs[key] = {'graphs': graphs, 'keep': (idx, streams)}
             return eng.res
-        g['idx'].copy_(idx)
-        if streams:
-            for d, s in zip(g['sidx'], streams):
-                d.copy_(s[1])
         if len(g['graphs']) == 1:
             g['graphs'][0].replay()
         else:
@@ -387,12 +386,14 @@ class CommonAgent:
         step = 0
         for ep in range(self.mini_epochs_num):
             perm = self.dataset_perm if perms is None else perms[ep].to(self.ppo_device, torch.int32)
-            self._epoch_perm = perm
+            self._set_epoch_perm(perm)
+            perm = self._perm_buf                      # persistent storage: minibatch slices keep stable addresses
             for i in range(self.num_minibatches):
                 if max_steps is not None and step >= max_steps:
                     break
                 mb_idx = perm[i * MB:(i + 1) * MB]
                 self._mb_idx_full = mb_idx
+                self._mb_pos = i
                 idx = mb_idx[rk * m:(rk + 1) * m]
                 self._step(idx, None if new_zs is None else new_zs[step].to(self.ppo_device)[rk * m:(rk + 1) * m])
                 cur = self._collect_result()
@@ -501,19 +502,32 @@ class AMPAgent(CommonAgent):
     def _post_update(self, batch_dict):
         self._store_replay_amp_obs(self.experience['amp_obs'])
 
+    def _set_epoch_perm(self, perm):
+        """+ demo / replay ring indices composed with the permutation, once per mini-epoch:
+        amp_obs_demo[perm[j]] = demo_ring[demo_idx[perm[j]]] (learning/amp_agent.py:196, learning/amp_datasets.py:21-22)."""
+        super()._set_epoch_perm(perm)
+        if getattr(self, '_demo_comp', None) is None:
+            self._demo_comp = torch.empty_like(self._perm_buf)
+            self._replay_comp = torch.empty_like(self._perm_buf)
+        pl = self._perm_buf.long()
+        self._demo_comp.copy_(self._demo_idx[pl])
+        if self._replay_idx is not None:
+            self._replay_comp.copy_(self._replay_idx[pl])
+
     def _amp_streams(self, idx):
         """agent / replay / demo rows of this minibatch as (source, index, remap) — the first amp_minibatch rows
         of the minibatch (learning/ase_agent.py:172-181), this rank's share of them."""
         R, rk = self.world_size, self.rank
         amb = self._amp_minibatch_size
         a = amb // R
-        rows = self._mb_idx_full[:amb][rk * a:(rk + 1) * a]
+        lo = self._mb_pos * self.minibatch_size + rk * a          # position of this rank's amp rows in the permutation
+        rows = self._perm_buf[lo:lo + a]
         agent = (self._ds['amp_obs'], rows, self._remap)
-        demo = (self._amp_obs_demo_buffer.data, self._demo_idx[rows.long()], (0, 0))
+        demo = (self._amp_obs_demo_buffer.data, self._demo_comp[lo:lo + a], (0, 0))
         if self._replay_idx is None:
             replay = (self._ds['amp_obs'], rows, self._remap)
         else:
-            replay = (self._amp_replay_buffer.data, self._replay_idx[rows.long()], (0, 0))
+            replay = (self._amp_replay_buffer.data, self._replay_comp[lo:lo + a], (0, 0))
         return [agent, replay, demo]
 
     def _calc_disc_rewards(self, amp_obs):

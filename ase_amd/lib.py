@@ -28,8 +28,8 @@ _p, _i, _i64, _f, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 # name -> argtypes; every function returns int.  Keep in lock-step with include/ase_hip.h
 # (tests/test_abi.py parses the header and checks names + arity against this table).
 SIGNATURES = {
-    "ase_hip_gemm_nt": [_p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
-    "ase_hip_gemm_tn": [_p, _i64, _p, _i64, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
+    "ase_hip_gemm_nt": [_p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
+    "ase_hip_gemm_tn": [_p, _i64, _p, _i64, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
     "ase_hip_refresh_shadow": [_p, _i, _i, _p, _i64, _p, _i64, _i, _i, _i, _p],
     "ase_hip_refresh_shadow_multi": [_p, _i, _i, _p],
     "ase_hip_gather_multi": [_p, _i, _p, _i, _i, _i, _p],
@@ -39,11 +39,11 @@ SIGNATURES = {
     "ase_hip_rms_unnormalize": [_p, _p, _p, _i64, _p],
     "ase_hip_gather_rows": [_p, _i64, _i, _p, _i, _i, _i, _p, _i64, _i, _p],
     "ase_hip_reduce_sum": [_p, _i64, _i, _p, _i, _p],
-    "ase_hip_ppo_head": [_p, _i64, _p, _i64] + [_p] * 11 + [_p, _i64, _p, _i64, _p, _p, _p, _p] + [_i] * 8 + [_f] * 5 + [_i, _p],
+    "ase_hip_ppo_head": [_p, _i64, _p, _i64] + [_p] * 11 + [_p, _i64, _p, _i64, _p, _p, _p, _p, _p] + [_i] * 8 + [_f] * 5 + [_i, _p],
     "ase_hip_disc_head": [_p, _i64, _p, _i64, _p, _p, _i, _i, _f, _i, _p],
     "ase_hip_enc_head": [_p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _i, _i, _i, _f, _i, _p],
-    "ase_hip_gp_seed": [_p, _i64, _p, _p, _i64, _i, _i, _i, _p],
-    "ase_hip_sqnorm": [_p, _i64, _i, _i, _p, _i, _i, _p],
+    "ase_hip_gp_seed": [_p, _i64, _p, _p, _i64, _i, _i, _f, _i, _p],
+    "ase_hip_sqnorm": [_p, _i64, _i, _i, _p, _i, _d, _i, _p],
     "ase_hip_finalize_scalars": [_p, _p, _i, _i, _i, _i, _i, _i] + [_f] * 10 + [_p],
     "ase_hip_begin_step": [_p, _p, _i, _p],
     "ase_hip_adam": [_p, _p, _p, _p, _i64, _p, _p],

@@ -76,10 +76,10 @@ class TimedBackend:
         self.nt_bytes += (M * K + N * K) * es + M * N * Cm.element_size() + (M * N * es if kw.get('aux') is not None else 0)
         self._timed('nt', 2.0 * M * N * K, self._be.gemm_nt, A, B, Cm, M, N, K, **kw)
 
-    def gemm_tn(self, A, B, G, M, N, K, n_real, k_real, split_src, split_dst, alpha=1.0, gbias=None):
+    def gemm_tn(self, A, B, G, M, N, K, n_real, k_real, split_src, split_dst, **kw):
         self._shape = (M, N, K)
         self._timed('tn', 2.0 * M * n_real * k_real, self._be.gemm_tn, A, B, G, M, N, K, n_real, k_real, split_src,
-                    split_dst, alpha=alpha, gbias=gbias)
+                    split_dst, **kw)
 
     def summary(self):
         torch.cuda.synchronize()

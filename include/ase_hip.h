@@ -46,7 +46,9 @@ const char* ase_hip_last_error(void);
 
 /* C[m,n] = mask( act( alpha * sum_k A[m,k] * B[n,k] + bias[n] ) )       "NT" GEMM
  *   A [M,K] dtype, B [N,K] dtype (weights, K contiguous), C [M,N] dtype or f32 (out_f32).
- *   aux [M,N] dtype: ASE_AUX_RELU_MASK multiplies by (aux > 0), ASE_AUX_TANH_GRAD by (1 - aux^2).
+ *   aux [M,N] dtype: ASE_AUX_RELU_MASK multiplies by (aux > 0), ASE_AUX_TANH_GRAD by (1 - aux^2);
+ *   rows m >= aux_split (> 0) read aux row m - aux_delta (a stacked block of rows re-using another block's mask:
+ *   the gradient-penalty chain rides on the discriminator's data-gradient launches).
  *   colsum (nullable, f32[colsum_n]) += column sums of the stored values for n < colsum_n (atomic):
  *   the bias gradient of the producing layer.
  * Replaces: nn.Linear + activation forward  (learning/ase_network_builder.py:255-259,305-324,
@@ -54,8 +56,8 @@ const char* ase_hip_last_error(void);
  *   (B = the transposed weight shadow; mask = derivative of the previous activation), and the
  *   transposed-MLP chain of the gradient penalty (learning/amp_agent.py:453-459). */
 int ase_hip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
-                    const float* bias, const void* aux, int64_t ldaux, float* colsum, int colsum_n,
-                    int M, int N, int K, int act, int aux_mode, int out_f32, float alpha,
+                    const float* bias, const void* aux, int64_t ldaux, int aux_split, int aux_delta,
+                    float* colsum, int colsum_n, int M, int N, int K, int act, int aux_mode, int out_f32, float alpha,
                     int dtype, void* stream);
 
 /* G[n, kmap(k)] += alpha * sum_m A[m,n] * B[m,k]   for n < n_real, kmap(k) valid     "TN" GEMM
@@ -64,12 +66,12 @@ int ase_hip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void
  *   kmap undoes the padded-concat layout of the first actor/critic layer: k < split_src -> k;
  *   k >= split_dst -> k - (split_dst - split_src); columns in between are padding.
  *   (layers without a concat pass split_src = split_dst = k_real).
- *   gbias (nullable, f32[n_real]) += alpha * sum_m A[m,n]: the bias gradient of the same layer, reduced from
+ *   gbias (nullable, f32[n_real]) += alpha * sum_{m < bias_rows} A[m,n] (bias_rows <= 0: all rows): the bias gradient of the same layer, reduced from
  *   the A tiles the kernel stages anyway (a handful of atomics per column instead of one per row tile).
  * Replaces: autograd's weight gradient of nn.Linear inside loss.backward()
  *   (learning/ase_agent.py:271). */
 int ase_hip_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* G, float* gbias,
-                    int M, int N, int K, int n_real, int k_real, int split_src, int split_dst,
+                    int bias_rows, int M, int N, int K, int n_real, int k_real, int split_src, int split_dst,
                     float alpha, int dtype, void* stream);
 
 /* Shadow copies of one weight matrix for the matrix cores: W_s [n_pad,k_pad] and its transpose
@@ -159,14 +161,15 @@ int ase_hip_reduce_sum(const float* x, int64_t n, int square, double* acc, int s
  *   masked: 1 -> sum(mask*x)/sum(mask) reductions (AMP/ASE), 0 -> plain means over m_global (PPO)
  *   mu_tanh: 1 -> mu_out = tanh(mu) precedes the losses (HRL high-level policy,
  *            learning/hrl_network_builder.py:26-29)
- *   acc[ASE_ACC_MASK_SUM] must already hold the GLOBAL mask sum. */
+ *   acc[ASE_ACC_MASK_SUM] must already hold the GLOBAL mask sum.
+ *   scratch: device f64[8192] workspace (per-workgroup partial sums, folded by a second tiny kernel). */
 int ase_hip_ppo_head(const float* mu, int64_t ld_mu, const float* value, int64_t ld_v,
                      const float* mb_actions, const float* mb_old_mu, const float* mb_old_sigma,
                      const float* mb_old_logp, const float* mb_adv, const float* mb_old_value,
                      const float* mb_return, const float* mb_mask, const float* mb_z,
                      const float* new_z, const float* logstd,
                      void* d_mu, int64_t ld_dmu, void* d_value, int64_t ld_dv,
-                     float* db_mu, float* db_value, float* mu_out, double* acc,
+                     float* db_mu, float* db_value, float* mu_out, double* acc, double* scratch,
                      int M, int m_global, int act_dim, int z_dim, int masked, int div_on, int mu_tanh,
                      int clip_value, float e_clip, float critic_coef, float bounds_coef,
                      float div_coef, float div_tar, int dtype, void* stream);
@@ -183,13 +186,13 @@ int ase_hip_enc_head(const float* e, int64_t ld_e, const float* z, int64_t ld_z,
                      int64_t ld_de, float* db_enc, float* enc_out, double* acc, int amb, int amb_global,
                      int z_dim, float enc_coef, int dtype, void* stream);
 
-/* Gradient-penalty seed: g[r,j] = (h[r,j] > 0) ? w[j] : 0  (d logit / d last hidden, ReLU). */
+/* Gradient-penalty seed: g[r,j] = (h[r,j] > 0) ? scale * w[j] : 0  (d logit / d last hidden, ReLU). */
 int ase_hip_gp_seed(const void* h, int64_t ld_h, const float* w, void* g, int64_t ld_g, int rows,
-                    int width, int dtype, void* stream);
+                    int width, float scale, int dtype, void* stream);
 
-/* acc[slot] += sum_{r,j} x[r,j]^2 over a dtype matrix [rows, cols]. */
-int ase_hip_sqnorm(const void* x, int64_t ld, int rows, int cols, double* acc, int slot, int dtype,
-                   void* stream);
+/* acc[slot] += scale * sum_{r,j} x[r,j]^2 over a dtype matrix [rows, cols]. */
+int ase_hip_sqnorm(const void* x, int64_t ld, int rows, int cols, double* acc, int slot, double scale,
+                   int dtype, void* stream);
 
 /* train_result scalars from the accumulators (same keys as learning/ase_agent.py:296-306).
  * out f32[ASE_RES_COUNT]. */

@@ -34,7 +34,11 @@ class EmuBackend:
 
     # ------------------------------------------------------------------ GEMMs
     def gemm_nt(self, A, B, Cm, M, N, K, bias=None, aux=None, aux_mode=L.AUX_NONE, colsum=None, colsum_n=0,
-                act=L.ACT_NONE, alpha=1.0):
+                act=L.ACT_NONE, alpha=1.0, aux_split=0, aux_delta=0):
+        if aux is not None and aux_split > 0:
+            rows = torch.arange(M)
+            rows = torch.where(rows >= aux_split, rows - aux_delta, rows)
+            aux = aux[rows]
         a = A[:M, :K].float()
         b = B[:N, :K].float()
         v = alpha * (a @ b.t())
@@ -54,9 +58,10 @@ class EmuBackend:
         if colsum is not None and colsum_n > 0:
             colsum[:colsum_n] += out.float().sum(0)[:colsum_n]
 
-    def gemm_tn(self, A, B, G, M, N, K, n_real, k_real, split_src, split_dst, alpha=1.0, gbias=None):
+    def gemm_tn(self, A, B, G, M, N, K, n_real, k_real, split_src, split_dst, alpha=1.0, gbias=None, bias_rows=0):
         if gbias is not None:
-            gbias[:n_real] += alpha * A[:M, :n_real].float().sum(0)
+            br = bias_rows if bias_rows > 0 else M
+            gbias[:n_real] += alpha * A[:br, :n_real].float().sum(0)
         full = alpha * (A[:M, :N].float().t() @ B[:M, :K].float())       # [N, K] padded layout
         gap = split_dst - split_src
         cols = list(range(split_src)) + [k for k in range(split_dst, K) if k - gap < k_real]
@@ -238,12 +243,12 @@ class EmuBackend:
             enc_out[:amb, :z_dim] = h
         acc[L.ACC_ENC] += (-dot).double().sum()
 
-    def gp_seed(self, h, w, g, rows, width):
-        g[:rows, :width] = torch.where(h[:rows, :width].float() > 0, w[:width].expand(rows, width),
+    def gp_seed(self, h, w, g, rows, width, scale=1.0):
+        g[:rows, :width] = torch.where(h[:rows, :width].float() > 0, (scale * w[:width]).expand(rows, width),
                                        torch.zeros(rows, width)).to(g.dtype)
 
-    def sqnorm(self, x, rows, cols, acc, slot):
-        acc[slot] += (x[:rows, :cols].double() ** 2).sum()
+    def sqnorm(self, x, rows, cols, acc, slot, scale=1.0):
+        acc[slot] += scale * (x[:rows, :cols].double() ** 2).sum()
 
     def finalize_scalars(self, acc, out, m_global, amb_global, masked, has_disc, has_enc, has_div, c):
         a = acc.tolist()

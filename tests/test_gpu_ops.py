@@ -394,3 +394,27 @@ def test_multi_ops(be):
         ref = torch.zeros_like(dst)
         be.gather_rows(src, D, idx, (H, N), M, ref)
         assert torch.equal(dst, ref)
+
+
+@pytest.mark.parametrize('dt', DT)
+def test_stacked_rows_aux_wrap_and_bias_rows(be, dt):
+    """Row blocks stacked under one launch: aux rows wrap back (m >= split reads aux[m - delta]); the bias gradient
+    of the TN kernel only sums the first bias_rows rows."""
+    M, N, K, split, delta = 512, 128, 256, 384, 128
+    g = torch.Generator().manual_seed(31)
+    A = (torch.randn(M, K, generator=g) * 0.3).to(dt)
+    B = (torch.randn(N, K, generator=g) * 0.1).to(dt)
+    aux = torch.randn(M, N, generator=g).to(dt)
+    X = (torch.randn(M, 192, generator=g) * 0.3).to(dt)
+    outs = []
+    for dev in ('cuda', 'cpu'):
+        b = be if dev == 'cuda' else EmuBackend()
+        C = torch.zeros(M, N, dtype=dt, device=dev)
+        b.gemm_nt(A.to(dev), B.to(dev), C, M, N, K, aux=aux.to(dev), aux_mode=L.AUX_RELU_MASK, aux_split=split, aux_delta=delta)
+        G, gb = torch.zeros(N, 192, device=dev), torch.zeros(N, device=dev)
+        b.gemm_tn(C, X.to(dev), G, M, N, 192, N, 192, 192, 192, gbias=gb, bias_rows=split)
+        outs.append((C.float().cpu(), G.cpu(), gb.cpu()))
+    rt, at = _tol(dt)
+    close(outs[0][0], outs[1][0], rt, at * 2, 'C')
+    close(outs[0][1], outs[1][1], 1e-3 if dt == torch.bfloat16 else 3e-5, 2e-3, 'G')
+    close(outs[0][2], outs[1][2], 1e-3 if dt == torch.bfloat16 else 3e-5, 2e-3, 'gbias')
