@@ -32,7 +32,9 @@ def _code(dtype):
 class HipBackend:
     name = "hip"
 
-    def __init__(self, device=None):
+    def __init__(self, device=None, x3=False):
+        # x3: f32-stored GEMM operands are multiplied as three bf16 MFMAs on a hi/lo split (ASE_F32X3)
+        self.x3 = bool(x3)
         if not torch.cuda.is_available():
             raise L.AseHipError("HipBackend needs a ROCm GPU (torch.cuda.is_available() is False); "
                                 "the update path has no CPU fallback")
@@ -47,10 +49,14 @@ class HipBackend:
     def zero_(self, t):
         t.zero_()
 
+    def _gemm_code(self, dtype):
+        c = _code(dtype)
+        return L.F32X3 if (self.x3 and c == L.F32) else c
+
     # ------------------------------------------------------------------ GEMMs
     def gemm_nt(self, A, B, Cm, M, N, K, bias=None, aux=None, aux_mode=L.AUX_NONE, colsum=None, colsum_n=0,
                 act=L.ACT_NONE, alpha=1.0, aux_split=0, aux_delta=0):
-        dt = _code(A.dtype)
+        dt = self._gemm_code(A.dtype)
         assert B.dtype == A.dtype and (aux is None or aux.dtype == A.dtype)
         out_f32 = int(Cm.dtype == torch.float32 and A.dtype != torch.float32)
         L.check(self.lib.ase_hip_gemm_nt(_ptr(A), _ld(A), _ptr(B), _ld(B), _ptr(Cm), _ld(Cm), _ptr(bias), _ptr(aux),
@@ -61,7 +67,7 @@ class HipBackend:
     def gemm_tn(self, A, B, G, M, N, K, n_real, k_real, split_src, split_dst, alpha=1.0, gbias=None, bias_rows=0):
         L.check(self.lib.ase_hip_gemm_tn(_ptr(A), _ld(A), _ptr(B), _ld(B), _ptr(G), _ptr(gbias), int(bias_rows), M, N, K,
                                          n_real, k_real,
-                                         split_src, split_dst, float(alpha), _code(A.dtype), self._stream()), "gemm_tn")
+                                         split_src, split_dst, float(alpha), self._gemm_code(A.dtype), self._stream()), "gemm_tn")
 
     def refresh_shadow(self, W, Ws, Wts, split_src, split_dst):
         n, k = W.shape

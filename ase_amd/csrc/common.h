@@ -31,13 +31,20 @@ void ase_set_error(const char* fmt, ...);
         }                                                                   \
     } while (0)
 
+// f32 storage whose matrix products run as THREE bf16 MFMAs on a hi/lo split (a = hi + lo, hi = bf16(a),
+// lo = bf16(a - hi); a*b ~= hi*hi + hi*lo + lo*hi): ~16 mantissa bits per operand at 1/3 of the bf16 MFMA rate
+// instead of the 1/16 of the exact-f32 MFMA (gfx950 has no TF32).
+struct f32s_t { float v; };
+
 // ---- storage type conversion --------------------------------------------------------------
 __device__ __forceinline__ float to_f32(float x) { return x; }
 __device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }
+__device__ __forceinline__ float to_f32(f32s_t x) { return x.v; }
 
 template <typename T> __device__ __forceinline__ T from_f32(float x);
 template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }  // RNE
+template <> __device__ __forceinline__ f32s_t from_f32<f32s_t>(float x) { return f32s_t{x}; }
 
 // ---- dataset row map (see ase_hip.h) -------------------------------------------------------
 __device__ __forceinline__ int64_t map_row(int r, const int32_t* __restrict__ idx, int remap_h, int remap_n) {

@@ -13,6 +13,7 @@
 //   TN: register-staged double buffering, 16-byte-padded rows.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -81,6 +82,46 @@ template <> struct Mma<float> {
 #pragma unroll
                     for (int j = 0; j < FN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+        }
+    }
+};
+
+__device__ __forceinline__ void split_bf16(const f32x4& x0, const f32x4& x1, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        hi[q] = (bf16_t)x0[q];
+        hi[q + 4] = (bf16_t)x1[q];
+        lo[q] = (bf16_t)(x0[q] - (float)hi[q]);
+        lo[q + 4] = (bf16_t)(x1[q] - (float)hi[q + 4]);
+    }
+}
+
+template <> struct Mma<f32s_t> {
+    // f32 rows (RB/4 k-values = RB/64 steps of 16): a lane needs 8 consecutive k per step = 2 chunks.
+    template <int FM, int FN, int RB>
+    static __device__ __forceinline__ void tile(const char* sA, const char* sB, int lane, f32x16 (&acc)[FM][FN]) {
+        const int r = lane & 31, h = lane >> 5, sw = lds_swz<RB>(r);
+#pragma unroll
+        for (int ks = 0; ks < RB / 64; ++ks) {
+            bf16x8 ah[FM], al[FM], bh[FN], bl[FN];
+            const int c0 = ks * 4 + h * 2;
+            const int o0 = r * RB + ((c0 ^ sw) << 4), o1 = r * RB + (((c0 + 1) ^ sw) << 4);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+                split_bf16(*reinterpret_cast<const f32x4*>(sA + i * 32 * RB + o0),
+                           *reinterpret_cast<const f32x4*>(sA + i * 32 * RB + o1), ah[i], al[i]);
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                split_bf16(*reinterpret_cast<const f32x4*>(sB + j * 32 * RB + o0),
+                           *reinterpret_cast<const f32x4*>(sB + j * 32 * RB + o1), bh[j], bl[j]);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
         }
     }
 };
@@ -348,6 +389,7 @@ template <typename T> struct TNGeom;
 // touch land on 8 distinct 32-byte bank slots (pitch = 16 dwords mod 64)
 template <> struct TNGeom<bf16_t> { static constexpr int BKM = 64, STRIDE = 256 + 64, CPR = 16; };
 template <> struct TNGeom<float>  { static constexpr int BKM = 16, STRIDE = 512 + 16, CPR = 32; };
+template <> struct TNGeom<f32s_t> { static constexpr int BKM = 16, STRIDE = 512 + 16, CPR = 32; };
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
@@ -466,6 +508,31 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(TNParams p) {
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
             }
+        } else if constexpr (std::is_same<T, f32s_t>::value) {
+            // one 16-deep step per staged tile (BKM = 16): lane (r, h) gathers rows 8 h .. 8 h + 7 of its column
+            const int r = lane & 31, h = lane >> 5;
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                f32x4 x0, x1, y0, y1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    x0[q] = *reinterpret_cast<const float*>(sA + (h * 8 + q) * STRIDE + ((wi * 2 + f) * 32 + r) * 4);
+                    x1[q] = *reinterpret_cast<const float*>(sA + (h * 8 + 4 + q) * STRIDE + ((wi * 2 + f) * 32 + r) * 4);
+                    y0[q] = *reinterpret_cast<const float*>(sB + (h * 8 + q) * STRIDE + ((wj * 2 + f) * 32 + r) * 4);
+                    y1[q] = *reinterpret_cast<const float*>(sB + (h * 8 + 4 + q) * STRIDE + ((wj * 2 + f) * 32 + r) * 4);
+                }
+                split_bf16(x0, x1, ah[f], al[f]);
+                split_bf16(y0, y1, bh[f], bl[f]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
         } else {
             const int r = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -658,7 +725,7 @@ extern "C" int ase_hip_gemm_nt(const void* A, int64_t lda, const void* B, int64_
                                const float* bias, const void* aux, int64_t ldaux, int aux_split, int aux_delta,
                                float* colsum, int colsum_n, int M, int N, int K, int act, int aux_mode, int out_f32, float alpha, int dtype, void* stream) {
     const int es = (dtype == ASE_BF16) ? 2 : 4;
-    ASE_CHECK_ARG(dtype == ASE_F32 || dtype == ASE_BF16, "gemm_nt: bad dtype %d", dtype);
+    ASE_CHECK_ARG(dtype == ASE_F32 || dtype == ASE_BF16 || dtype == ASE_F32X3, "gemm_nt: bad dtype %d", dtype);
     ASE_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0, "gemm_nt: null/empty operand (M=%d N=%d K=%d)", M, N, K);
     ASE_CHECK_ARG((K * es) % 64 == 0, "gemm_nt: K=%d is not a multiple of %d elements", K, 64 / es);
     ASE_CHECK_ARG(lda >= K && ldb >= K && ldc >= N, "gemm_nt: leading dimension too small");
@@ -675,14 +742,16 @@ extern "C" int ase_hip_gemm_nt(const void* A, int64_t lda, const void* B, int64_
     p.bias = bias; p.aux = (const char*)aux; p.ldaux = ldaux * es; p.aux_split = aux_split > 0 ? aux_split : M; p.aux_delta = aux_delta; p.colsum = colsum; p.colsum_n = colsum ? colsum_n : 0;
     p.M = M; p.N = N; p.K = K; p.act = act; p.aux_mode = aux_mode; p.out_f32 = out_f32; p.alpha = alpha;
     p.tiles_m = p.tiles_n = 0;
-    return dtype == ASE_BF16 ? dispatch_nt<bf16_t>(p, (hipStream_t)stream) : dispatch_nt<float>(p, (hipStream_t)stream);
+    if (dtype == ASE_BF16) return dispatch_nt<bf16_t>(p, (hipStream_t)stream);
+    if (dtype == ASE_F32X3) return dispatch_nt<f32s_t>(p, (hipStream_t)stream);
+    return dispatch_nt<float>(p, (hipStream_t)stream);
 }
 
 extern "C" int ase_hip_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* G, float* gbias,
                                int bias_rows, int M, int N, int K, int n_real, int k_real, int split_src, int split_dst, float alpha, int dtype,
                                void* stream) {
     const int es = (dtype == ASE_BF16) ? 2 : 4;
-    ASE_CHECK_ARG(dtype == ASE_F32 || dtype == ASE_BF16, "gemm_tn: bad dtype %d", dtype);
+    ASE_CHECK_ARG(dtype == ASE_F32 || dtype == ASE_BF16 || dtype == ASE_F32X3, "gemm_tn: bad dtype %d", dtype);
     ASE_CHECK_ARG(A && B && G && M > 0 && N > 0 && K > 0, "gemm_tn: null/empty operand");
     ASE_CHECK_ARG((N * es) % 16 == 0 && (K * es) % 16 == 0, "gemm_tn: N=%d / K=%d must cover whole 16-byte chunks", N, K);
     ASE_CHECK_ARG(lda >= N && ldb >= K, "gemm_tn: leading dimension too small");
@@ -694,7 +763,9 @@ extern "C" int ase_hip_gemm_tn(const void* A, int64_t lda, const void* B, int64_
     p.A = (const char*)A; p.lda = lda * es; p.B = (const char*)B; p.ldb = ldb * es; p.G = G; p.gbias = gbias; p.bias_rows = bias_rows > 0 ? bias_rows : M;
     p.M = M; p.N = N; p.K = K; p.n_real = n_real; p.k_real = k_real; p.split_src = split_src; p.split_dst = split_dst;
     p.alpha = alpha; p.tiles_n = p.tiles_k = p.m_chunk = 0;
-    return dtype == ASE_BF16 ? launch_tn<bf16_t>(p, (hipStream_t)stream) : launch_tn<float>(p, (hipStream_t)stream);
+    if (dtype == ASE_BF16) return launch_tn<bf16_t>(p, (hipStream_t)stream);
+    if (dtype == ASE_F32X3) return launch_tn<f32s_t>(p, (hipStream_t)stream);
+    return launch_tn<float>(p, (hipStream_t)stream);
 }
 
 extern "C" int ase_hip_refresh_shadow(const float* W, int n_real, int k_real, void* Ws, int64_t ldws, void* Wts,

@@ -75,12 +75,14 @@ class CommonAgent:
         self.network = config['network']
         self.model = self.network.build(self._build_net_config())
         self.model.to(self.ppo_device)
+        # precision: 'bf16' (bf16 storage + MFMA, throughput mode) | 'f32' (exact f32 MFMA) |
+        #            'bf16x3' (f32 storage, every product as three bf16 MFMAs on a hi/lo split: f32-grade results)
         precision = config.get('precision', 'bf16')
-        dtype = {'bf16': torch.bfloat16, 'f32': torch.float32}[precision]
+        dtype = {'bf16': torch.bfloat16, 'f32': torch.float32, 'bf16x3': torch.float32}[precision]
         backend = config.get('backend', None)
         if backend is None:
             from ..backend import HipBackend
-            backend = HipBackend(self.ppo_device)
+            backend = HipBackend(self.ppo_device, x3=(precision == 'bf16x3'))
         self.backend = backend
         self.engine = UpdateEngine(self.kind, self.model.a2c_network, config, backend, minibatch=self.minibatch_size,
                                    amp_minibatch=getattr(self, '_amp_minibatch_size', 0), dtype=dtype,

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libase_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, F32X3 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 AUX_NONE, AUX_RELU_MASK, AUX_TANH_GRAD = 0, 1, 2
 

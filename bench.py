@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}        # /opt/skills/guides/MI355X_MICROARCH.md (dense)
+MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3, 'bf16x3': 2500.0 / 3}   # x3: three bf16 MFMAs per product        # /opt/skills/guides/MI355X_MICROARCH.md (dense)
 
 
 def load_cfg():
@@ -199,7 +199,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'f32', 'bf16x3'])
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=2)

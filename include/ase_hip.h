@@ -11,7 +11,8 @@
  *     work is enqueued on `stream` (a hipStream_t), so calls are hipGraph-capturable.
  *   - matrices are row-major with an explicit leading dimension in ELEMENTS.
  *   - `dtype` selects the storage type of activations / shadow weights that feed the matrix
- *     cores: ASE_F32 (exact f32 MFMA, parity mode) or ASE_BF16 (bf16 MFMA, f32 accumulate).
+ *     cores: ASE_F32 (exact f32 MFMA, parity mode), ASE_BF16 (bf16 MFMA, f32 accumulate) or — for the two GEMM
+ *     entry points only — ASE_F32X3 (f32 storage like ASE_F32, each product as three bf16 MFMAs on a hi/lo split).
  *     Running statistics are f64, master weights / gradients / Adam state / loss math are f32.
  *   - GEMM operands live in "padded" buffers: K (the contracted, contiguous dimension) is a
  *     multiple of 128 bytes / sizeof(type) and the padding is zero.
@@ -32,7 +33,7 @@ extern "C" {
 
 #define ASE_HIP_ABI_VERSION 1
 
-enum { ASE_F32 = 0, ASE_BF16 = 1 };
+enum { ASE_F32 = 0, ASE_BF16 = 1, ASE_F32X3 = 2 /* f32 storage, products as 3 bf16 MFMAs on a hi/lo split (GEMMs only) */ };
 enum { ASE_ACT_NONE = 0, ASE_ACT_RELU = 1, ASE_ACT_TANH = 2 };
 enum { ASE_AUX_NONE = 0, ASE_AUX_RELU_MASK = 1, ASE_AUX_TANH_GRAD = 2 };
 enum { ASE_OK = 0, ASE_EINVAL = -1, ASE_ELAUNCH = -2, ASE_EUNSUPPORTED = -3 };

@@ -3,8 +3,8 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ase_amd.backend import HipBackend
 from ase_amd import lib as L
-be = HipBackend()
-dts = [torch.bfloat16] + ([torch.float32] if '--f32' in sys.argv else [])
+be = HipBackend(x3='--x3' in sys.argv)
+dts = ([torch.bfloat16] if '--x3' not in sys.argv else []) + ([torch.float32] if ('--f32' in sys.argv or '--x3' in sys.argv) else [])
 NT = [(32768, 1024, 320), (32768, 1024, 1024), (32768, 512, 1024), (32768, 64, 512), (16384, 1024, 1024), (12288, 1024, 1408),
       (12288, 1024, 1024), (12288, 512, 1024), (32768, 512, 64), (32768, 256, 512), (4096, 1408, 1024), (8192, 8192, 8192)]
 TN = [(32768, 1024, 1024), (32768, 1024, 320), (32768, 512, 1024), (12288, 1024, 1408), (16384, 1024, 1024), (32768, 64, 512),

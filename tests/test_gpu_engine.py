@@ -58,13 +58,17 @@ def _ase_full_cfg():
     return y['params']['network'], y['params']['config']
 
 
-@pytest.mark.parametrize('dt,M,AMB', [(torch.float32, 2048, 512), (torch.bfloat16, 2048, 512)])
-def test_full_width_step_vs_oracle(be, dt, M, AMB):
+@pytest.mark.parametrize('dt,M,AMB,x3', [(torch.float32, 2048, 512, False), (torch.bfloat16, 2048, 512, False),
+                                         (torch.float32, 2048, 512, True)])
+def test_full_width_step_vs_oracle(be, dt, M, AMB, x3):
     """Real ASE net (7,039,905 parameters), real feature sizes; minibatch reduced so the CPU oracle
     finishes in seconds.  Same seeded inputs on both sides; oracle = oracle/restated.py (pinned to the
     reference by tests/test_oracle_golden.py)."""
     from ase_amd.engine import UpdateEngine
     from ase_amd.learning.network_builder import ASEBuilder
+    if x3:      # 'bf16x3' mode: f32 storage, every product as three bf16 MFMAs (~16 mantissa bits per operand)
+        from ase_amd.backend import HipBackend
+        be = HipBackend(x3=True)
     net_p, cfg = _ase_full_cfg()
     cfg = copy.deepcopy(cfg)
     cfg['minibatch_size'], cfg['amp_minibatch_size'] = M, AMB
@@ -113,7 +117,7 @@ def test_full_width_step_vs_oracle(be, dt, M, AMB):
               'kl', 'entropy', 'actor_clip_frac', 'disc_agent_acc', 'disc_demo_acc'):
         sc = max(abs(float(ref64[k])), scale.get(k, 0.0))
         err = abs(float(res[k]) - float(ref64[k]))
-        tol = (1e-4 if f32 else 1e-2) * sc + 1e-7
+        tol = ((1e-3 if x3 else 1e-4) if f32 else 1e-2) * sc + 1e-7
         if not f32 and k == 'actor_clip_frac':
             tol = 2e-2          # a counting statistic of the (bf16-noisy) importance ratio
         assert err <= tol, (k, float(res[k]), float(ref64[k]), err, tol)
@@ -129,7 +133,12 @@ def test_full_width_step_vs_oracle(be, dt, M, AMB):
         if f32:
             # BASELINE bar (1e-4), or — where f32 itself cannot reach it because the gradient is a cancelling sum
             # (critic trunk: CPU f32 is 5e-4 from the exact result) — no worse than 3x the reference's own f32 error
-            assert e_hip <= max(1e-4, 3.0 * e_cpu), ('grad ' + k, e_hip, e_cpu)
+            if x3:
+                # measured: 2e-5 (discriminator) ... 1.7e-3 (actor trunk: the importance ratio amplifies the 2^-17
+                # operand error by |a-mu|/sigma^2, like it does for bf16) of each tensor's max
+                assert e_hip <= max(5e-3, 3.0 * e_cpu), ('grad ' + k, e_hip, e_cpu)
+            else:
+                assert e_hip <= max(1e-4, 3.0 * e_cpu), ('grad ' + k, e_hip, e_cpu)
         else:
             # bf16: measured 0.3% (disc head) ... 12% (actor trunk, importance-ratio amplification) relative L2
             assert rel < 0.25, ('grad ' + k, rel)

@@ -418,3 +418,26 @@ def test_stacked_rows_aux_wrap_and_bias_rows(be, dt):
     close(outs[0][0], outs[1][0], rt, at * 2, 'C')
     close(outs[0][1], outs[1][1], 1e-3 if dt == torch.bfloat16 else 3e-5, 2e-3, 'G')
     close(outs[0][2], outs[1][2], 1e-3 if dt == torch.bfloat16 else 3e-5, 2e-3, 'gbias')
+
+
+@pytest.mark.parametrize('M,N,K', [(513, 320, 1408), (1024, 1024, 1024), (77, 64, 128), (2048, 1024, 320)])
+def test_gemm_x3_split_mode(M, N, K):
+    """ASE_F32X3: f32 storage, products as three bf16 MFMAs on a hi/lo split: results within ~1e-5 of exact f32
+    (relative to the row/column scale), forward-type and weight-gradient-type."""
+    from ase_amd.backend import HipBackend
+    b3 = HipBackend(x3=True)
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g) * 0.5
+    B = torch.randn(N, K, generator=g) * 0.1
+    bias = torch.randn(N, generator=g)
+    Cg = torch.zeros(M, N).cuda()
+    b3.gemm_nt(A.cuda(), B.cuda(), Cg, M, N, K, bias=bias.cuda(), act=L.ACT_NONE)
+    ref = A.double() @ B.double().t() + bias.double()
+    scale = float((A.abs().double() @ B.abs().double().t()).max())
+    assert float((Cg.cpu().double() - ref).abs().max()) <= 3e-5 * scale
+    X = torch.randn(M, 192, generator=g) * 0.3
+    G = torch.zeros(N, 192).cuda()
+    b3.gemm_tn(Cg, X.cuda(), G, M, N, 192, N, 192, 192, 192)
+    gref = Cg.cpu().double().t() @ X.double()
+    gscale = float((Cg.cpu().abs().double().t() @ X.abs().double()).max())
+    assert float((G.cpu().double() - gref).abs().max()) <= 3e-5 * gscale
