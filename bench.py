@@ -33,11 +33,8 @@ MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3, 'bf16x3': 2500.0 / 3}   # x3: 
 
 
 def load_cfg():
-    import yaml
-    y = yaml.safe_load(open(os.path.join(ROOT, 'ase_amd', 'cfg', 'train_ase.yaml')))
-    cfg = y['params']['config']
-    cfg['learning_rate'] = float(cfg['learning_rate'])       # PyYAML reads '2e-5' (no dot) as a string
-    return y['params']['network'], cfg
+    from ase_amd import cfg as defaults
+    return defaults.get('ase')
 
 
 def host_cores():
