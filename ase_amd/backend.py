@@ -69,6 +69,37 @@ class HipBackend:
                                          n_real, k_real,
                                          split_src, split_dst, float(alpha), self._gemm_code(A.dtype), self._stream()), "gemm_tn")
 
+    # grouped weight gradients: one launch for every (eligible) dense layer of a step
+    def grouped_tn_ok(self, dtype, M, n_real, K, bias_rows):
+        """Problems the phased bf16 kernel takes: whole 64-row K-tiles, and an output wide enough to be worth a 256 x 256 tile."""
+        return (dtype == torch.bfloat16 and M % 64 == 0 and bias_rows % 64 == 0 and n_real >= 128 and K >= 128
+                and n_real * K >= 512 * 512)
+
+    def make_tn_plan(self, problems):
+        """problems: [(A, B, G, gbias|None, bias_rows, M, N, K, n_real, k_real, split_src, split_dst, alpha)] -> plan
+        (device tables + the tensors they point to, kept alive)."""
+        import struct
+        n = len(problems)
+        tab = (C.c_int64 * (16 * n))()
+        for i, (A, B, G, gb, br, M, N, K, nr, kr, ss, sd, alpha) in enumerate(problems):
+            assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and G.dtype == torch.float32
+            row = [A.data_ptr(), _ld(A), B.data_ptr(), _ld(B), G.data_ptr(), 0 if gb is None else gb.data_ptr(), int(br),
+                   M, N, K, nr, kr, ss, sd, struct.unpack('<i', struct.pack('<f', float(alpha)))[0], 0]
+            for j, v in enumerate(row):
+                tab[16 * i + j] = int(v)
+        max_work = 8192
+        work = (C.c_int32 * (4 * max_work))()
+        n_work = C.c_int(0)
+        L.check(self.lib.ase_hip_gemm_tn_grouped_plan(tab, n, 0, work, max_work, C.byref(n_work)), "gemm_tn_grouped_plan")
+        nw = n_work.value
+        dev_tab = torch.tensor(list(tab), dtype=torch.int64, device=self.device)
+        dev_work = torch.tensor(list(work[:4 * nw]), dtype=torch.int32, device=self.device)
+        return {'problems': dev_tab, 'work': dev_work, 'n_work': nw, 'keep': problems}
+
+    def gemm_tn_grouped(self, plan):
+        L.check(self.lib.ase_hip_gemm_tn_grouped(_ptr(plan['problems']), _ptr(plan['work']), plan['n_work'], L.BF16,
+                                                 self._stream()), "gemm_tn_grouped")
+
     def refresh_shadow(self, W, Ws, Wts, split_src, split_dst):
         n, k = W.shape
         ref = Ws if Ws is not None else Wts

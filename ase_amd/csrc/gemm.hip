@@ -17,8 +17,9 @@
 
 namespace {
 
+unsigned long long* g_nt_prof = nullptr;      // tuning aid, see ase_hip_debug_nt_profile
+
 constexpr int kThreads = 256;
-constexpr int kRowBytes = 128;               // one staged tile row (64 bf16 / 32 f32)
 
 // Bijective XCD-aware remap: workgroup b runs on XCD b % 8; give each XCD a contiguous tile range.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -151,7 +152,100 @@ struct NTParams {
     int act, aux_mode, out_f32;
     float alpha;
     int tiles_m, tiles_n;
+    unsigned long long* prof;       // debug: per-workgroup phase timestamps (ase_hip_debug_nt_profile), else null
 };
+
+// ---- epilogue of the NT kernels.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (e&3) + 8*(e>>2) + 4*(lane>>5),
+// i.e. a lane owns ONE column: storing from registers would be 2-byte scattered stores.  Phase 1 applies bias +
+// activation (per-column bias = per-lane scalar) and transposes FMC x FNC fragments of the wave's sub-tile through a
+// wave-private f32 LDS slab [FMC*32][FNC*32] (row pitch 64 dwords: ds_write_b32 and ds_read_b128 are both
+// conflict-free); phase 2 lets every lane pick up 4 consecutive columns of a row, applies the derivative mask from
+// 8/16-byte aux loads, issues 8/16-byte row-contiguous stores (full 128-byte lines per row) and keeps per-column
+// partial sums for the bias gradient.  The caller guarantees that nobody still reads the staging ring (barrier).
+template <typename T, int FM, int FN, int FMC, int FNC>
+__device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x16 (&acc)[FM][FN], float* slab, int lane, int mrow0,
+                                            int ncol0) {
+    constexpr int WCOLS = FNC * 32, WROWS = FMC * 32;
+    const int col_in = lane & 31, row_hi = (lane >> 5) * 4;
+    constexpr int ELPR = WCOLS / 4;                // lanes per row (4 columns each)
+    constexpr int RPI = 64 / ELPR;                 // rows per iteration
+    const int c4 = lane % ELPR, rsub = lane / ELPR;
+#pragma unroll
+    for (int jc = 0; jc < FN; jc += FNC) {
+        const int n0 = ncol0 + jc * 32 + c4 * 4;
+        float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ic = 0; ic < FM; ic += FMC) {
+#pragma unroll
+            for (int jj = 0; jj < FNC; ++jj) {
+                const int j = jc + jj;
+                const int n = ncol0 + j * 32 + col_in;
+                const float bias = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+                for (int ii = 0; ii < FMC; ++ii) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float v = p.alpha * acc[ic + ii][j][e] + bias;
+                        if (p.act == ASE_ACT_RELU) v = fmaxf(v, 0.f);
+                        else if (p.act == ASE_ACT_TANH) v = tanhf(v);
+                        slab[(ii * 32 + row_hi + (e & 3) + 8 * (e >> 2)) * WCOLS + jj * 32 + col_in] = v;
+                    }
+                }
+            }
+            if (n0 < p.N) {                                // N is a multiple of 4 (checked on the host)
+#pragma unroll 4
+                for (int it = 0; it < WROWS / RPI; ++it) {
+                    const int row = it * RPI + rsub;
+                    const int m = mrow0 + ic * 32 + row;
+                    if (m >= p.M) continue;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * WCOLS + c4 * 4);
+                    if (p.aux_mode != ASE_AUX_NONE) {
+                        float a[4];
+                        const int ma = (m >= p.aux_split) ? m - p.aux_delta : m;
+                        const char* ap = p.aux + (int64_t)ma * p.ldaux + (int64_t)n0 * sizeof(T);
+                        if constexpr (sizeof(T) == 2) {
+                            const bf16x4 av = *reinterpret_cast<const bf16x4*>(ap);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) a[q] = (float)av[q];
+                        } else {
+                            const f32x4 av = *reinterpret_cast<const f32x4*>(ap);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) a[q] = av[q];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            v[q] = (p.aux_mode == ASE_AUX_RELU_MASK) ? (a[q] > 0.f ? v[q] : 0.f) : v[q] * (1.f - a[q] * a[q]);
+                    }
+                    if (p.out_f32 || sizeof(T) == 4) {
+                        *reinterpret_cast<f32x4*>(p.C + (int64_t)m * p.ldc + (int64_t)n0 * 4) = v;
+                    } else {
+                        bf16x4 o;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            o[q] = (bf16_t)v[q];
+                            v[q] = (float)o[q];
+                        }
+                        *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + (int64_t)n0 * 2) = o;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) cs[q] += v[q];
+                }
+            }
+        }
+        if (p.colsum) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int o = ELPR; o < 64; o <<= 1) cs[q] += __shfl_xor(cs[q], o, 64);
+            }
+            if (lane < ELPR) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (n0 + q < p.colsum_n) atomic_add_f32(p.colsum + n0 + q, cs[q]);
+            }
+        }
+    }
+}
 
 template <typename T, int WGM, int WGN, int FM, int FN, int RB, int S>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(NTParams p) {
@@ -228,93 +322,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(NTParams p) {
     }
     __syncthreads();                                   // everyone is done with the ring before it becomes the epilogue slab
 
-    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (e&3) + 8*(e>>2) + 4*(lane>>5), i.e. a
-    // lane owns ONE column: storing from registers would be 2-byte scattered stores.  Phase 1 applies bias +
-    // activation (per-column bias = per-lane scalar) and transposes the wave's sub-tile through a wave-private f32
-    // LDS slab [rows][FN*32] (row pitch 64 dwords: ds_write_b32 and ds_read_b128 are both conflict-free); phase 2
-    // lets every lane pick up 4 consecutive columns of a row, applies the derivative mask from 8/16-byte aux loads,
-    // issues 8/16-byte row-contiguous stores (full 128-byte lines per row) and keeps per-column partial sums for
-    // the bias gradient.  (The last loop iteration ended with a barrier: nobody still reads the staging buffers.)
-    constexpr int FNC = (FN > 2) ? 2 : FN;          // column fragments per epilogue round (slab = [FM*32][FNC*32] f32)
-    constexpr int WCOLS = FNC * 32, WROWS = FM * 32;
-    float* slab = reinterpret_cast<float*>(smem) + wid * (WROWS * WCOLS);
-    const int col_in = lane & 31, row_hi = (lane >> 5) * 4;
-    constexpr int ELPR = WCOLS / 4;                // lanes per row (4 columns each)
-    constexpr int RPI = 64 / ELPR;                 // rows per iteration
-    const int c4 = lane % ELPR, rsub = lane / ELPR;
-    const int mrow0 = bm0 + wm * WROWS;
-#pragma unroll
-    for (int jc = 0; jc < FN; jc += FNC) {
-#pragma unroll
-        for (int jj = 0; jj < FNC; ++jj) {
-            const int j = jc + jj;
-            const int n = bn0 + (wn * FN + j) * 32 + col_in;
-            const float bias = (p.bias && n < p.N) ? p.bias[n] : 0.f;
-#pragma unroll
-            for (int i = 0; i < FM; ++i) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    float v = p.alpha * acc[i][j][e] + bias;
-                    if (p.act == ASE_ACT_RELU) v = fmaxf(v, 0.f);
-                    else if (p.act == ASE_ACT_TANH) v = tanhf(v);
-                    slab[(i * 32 + row_hi + (e & 3) + 8 * (e >> 2)) * WCOLS + jj * 32 + col_in] = v;
-                }
-            }
-        }
-        const int n0 = bn0 + (wn * FN + jc) * 32 + c4 * 4;
-        float cs[4] = {0.f, 0.f, 0.f, 0.f};
-        if (n0 < p.N) {                                // N is a multiple of 4 (checked on the host)
-#pragma unroll 4
-            for (int it = 0; it < WROWS / RPI; ++it) {
-                const int row = it * RPI + rsub;
-                const int m = mrow0 + row;
-                if (m >= p.M) continue;
-                f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * WCOLS + c4 * 4);
-                if (p.aux_mode != ASE_AUX_NONE) {
-                    float a[4];
-                    const int ma = (m >= p.aux_split) ? m - p.aux_delta : m;
-                    const char* ap = p.aux + (int64_t)ma * p.ldaux + (int64_t)n0 * sizeof(T);
-                    if constexpr (sizeof(T) == 2) {
-                        const bf16x4 av = *reinterpret_cast<const bf16x4*>(ap);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) a[q] = (float)av[q];
-                    } else {
-                        const f32x4 av = *reinterpret_cast<const f32x4*>(ap);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) a[q] = av[q];
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        v[q] = (p.aux_mode == ASE_AUX_RELU_MASK) ? (a[q] > 0.f ? v[q] : 0.f) : v[q] * (1.f - a[q] * a[q]);
-                }
-                if (p.out_f32 || sizeof(T) == 4) {
-                    *reinterpret_cast<f32x4*>(p.C + (int64_t)m * p.ldc + (int64_t)n0 * 4) = v;
-                } else {
-                    bf16x4 o;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        o[q] = (bf16_t)v[q];
-                        v[q] = (float)o[q];
-                    }
-                    *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + (int64_t)n0 * 2) = o;
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) cs[q] += v[q];
-            }
-        }
-        if (p.colsum) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                for (int o = ELPR; o < 64; o <<= 1) cs[q] += __shfl_xor(cs[q], o, 64);
-            }
-            if (lane < ELPR) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (n0 + q < p.colsum_n) atomic_add_f32(p.colsum + n0 + q, cs[q]);
-            }
-        }
-    }
+    constexpr int FNC = (FN > 2) ? 2 : FN;
+    float* slab = reinterpret_cast<float*>(smem) + wid * (FM * 32 * FNC * 32);
+    nt_epilogue<T, FM, FN, FM, FNC>(p, acc, slab, lane, bm0 + wm * FM * 32, bn0 + wn * FN * 32);
 }
 
 template <typename T, int WGM, int WGN, int FM, int FN, int RB, int S>
@@ -343,6 +353,242 @@ int launch_nt(const NTParams& p0, hipStream_t stream) {
     return ASE_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// NT, phased 256 x 256 kernel (bf16).  512 threads = 8 waves as 2 (M) x 4 (N); a wave owns 128 x 64 outputs = four
+// 64 x 32 quadrants.  One K-tile (64 k-values, 128-byte rows, the swizzle of the kernel above) is FOUR phases, each
+//     ds_read the fragments of one quadrant | issue one 16-KiB DMA unit (2 global_load_lds per lane) | counted vmcnt
+//     s_barrier | lgkmcnt(0) | 8 MFMAs 32x32x16 | s_barrier
+// and the two wave groups (waves 0-3 / 4-7: the two waves of every SIMD sit in different groups) run ONE BARRIER
+// APART, so that on each SIMD one wave is in its MFMA block while its partner reads LDS and issues the DMA.
+//   DMA units of K-tile t, in issue order = order of first use:
+//     A0 = A rows {0-63, 128-191} (sub-tile 0 of both wave rows)     read in phase 0
+//     B0 = B rows {64 c .. 64 c + 31, c = 0..3} (fragment 0 of every wave column)   phase 0 (kept in registers to phase 3)
+//     B1 = B rows {64 c + 32 .. 64 c + 63}                            phase 1
+//     A1 = A rows {64-127, 192-255}                                   phase 2
+//   unit u = 4 t + kind is issued in phase (t', p) with 4 t' + p + 6 = u: six units ahead, into the buffer (t & 1) whose
+//   previous occupant (K-tile t - 2) was last read >= 2 phases earlier (the WAR distance two staggered groups need);
+//   a unit is read one phase after the counted wait + barrier that retires it (RAW across the stagger).
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+template <int UNITS> __device__ __forceinline__ void wait_dma_units() { wait_vmcnt<2 * UNITS>(); }
+__device__ __forceinline__ void wait_dma_units_rt(int units) {      // wave-uniform runtime count (loop tail)
+    if (units >= 4) wait_vmcnt<8>();
+    else if (units == 3) wait_vmcnt<6>();
+    else if (units == 2) wait_vmcnt<4>();
+    else if (units == 1) wait_vmcnt<2>();
+    else wait_vmcnt<0>();
+}
+
+struct NT8Lane {
+    const char* src[4][2];     // per-lane DMA source (row base + swizzled chunk) of unit kind x piece
+    int dst[4][2];             // wave-uniform LDS byte offset of the piece inside a K-tile buffer
+    int roff[4];               // per-lane fragment read offsets (row * 128 + swizzled chunk) for the 4 k-steps
+};
+
+template <int KIND>
+__device__ __forceinline__ void nt8_issue(const NT8Lane& L, char* smem, int tile) {
+    constexpr int kBuf = 512 * 128;
+    char* buf = smem + (tile & 1) * kBuf;
+    const int64_t koff = (int64_t)tile * 128;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+        __builtin_amdgcn_global_load_lds((gptr_t*)(L.src[KIND][g] + koff), (lptr_t*)(buf + L.dst[KIND][g]), 16, 0, 0);
+}
+
+// fragment registers of one 32-row operand block: 4 k-steps x 16 bytes
+__device__ __forceinline__ void nt8_read(i32x4 (&f)[4], const char* base, const NT8Lane& L) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) f[ks] = *reinterpret_cast<const i32x4*>(base + L.roff[ks]);
+}
+
+__device__ __forceinline__ void nt8_mma(f32x16& c0, f32x16& c1, const i32x4 (&a0)[4], const i32x4 (&a1)[4],
+                                        const i32x4 (&b)[4]) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 bv = __builtin_bit_cast(bf16x8, b[ks]);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0[ks]), bv, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1[ks]), bv, c1, 0, 0, 0);
+    }
+}
+
+#define NT8_BARRIER()                        \
+    do {                                     \
+        __builtin_amdgcn_sched_barrier(0);   \
+        __builtin_amdgcn_s_barrier();        \
+        __builtin_amdgcn_sched_barrier(0);   \
+    } while (0)
+
+// schedule variants (bit mask V): 1 = retire the LDS reads BEFORE the first barrier; 2 = no s_setprio around the MFMAs.
+// (The DMA is always issued AFTER the phase's fragment reads: hipcc puts a vmcnt(0) in front of any LDS read that
+// follows a global_load_lds without a barrier in between.)
+template <int V> __device__ __forceinline__ void nt8_sync_in() {      // end of the read / issue half of a phase
+    if constexpr (V & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    NT8_BARRIER();
+    if constexpr (!(V & 1)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (!(V & 2)) __builtin_amdgcn_s_setprio(1);
+}
+template <int V> __device__ __forceinline__ void nt8_sync_out() {     // end of the MFMA half
+    if constexpr (!(V & 2)) __builtin_amdgcn_s_setprio(0);
+    NT8_BARRIER();
+}
+
+// one K-tile = 4 phases.  TAIL = false: every issued unit exists (t + 2 < nk) and the waits are compile-time counts.
+template <bool TAIL, int V>
+__device__ __forceinline__ void nt8_ktile(int t, int nk, const NT8Lane& L, char* smem, const char* aP, const char* bP,
+                                          f32x16 (&acc)[4][2], i32x4 (&a0)[4], i32x4 (&a1)[4], i32x4 (&b0)[4],
+                                          i32x4 (&b1)[4]) {
+    constexpr int RB = 128;
+    constexpr bool IF = false;
+    const int U = 4 * nk;
+    // ---- phase 0: A sub-tile 0, B fragment 0 -> quadrant (0, 0)
+    if (IF && (!TAIL || t + 1 < nk)) nt8_issue<2>(L, smem, t + 1);
+    nt8_read(b0, bP, L);
+    nt8_read(a0, aP, L);
+    nt8_read(a1, aP + 32 * RB, L);
+    if (!IF && (!TAIL || t + 1 < nk)) nt8_issue<2>(L, smem, t + 1);
+    if (!TAIL) wait_dma_units<4>();
+    else wait_dma_units_rt(min(U, 4 * t + 7) - (4 * t + 3));
+    nt8_sync_in<V>();
+    nt8_mma(acc[0][0], acc[1][0], a0, a1, b0);
+    nt8_sync_out<V>();
+    // ---- phase 1: B fragment 1 -> quadrant (0, 1)
+    if (IF && (!TAIL || t + 1 < nk)) nt8_issue<3>(L, smem, t + 1);
+    nt8_read(b1, bP + 32 * RB, L);
+    if (!IF && (!TAIL || t + 1 < nk)) nt8_issue<3>(L, smem, t + 1);
+    if (!TAIL) wait_dma_units<4>();
+    else wait_dma_units_rt(min(U, 4 * t + 8) - (4 * t + 4));
+    nt8_sync_in<V>();
+    nt8_mma(acc[0][1], acc[1][1], a0, a1, b1);
+    nt8_sync_out<V>();
+    // ---- phase 2: A sub-tile 1 -> quadrant (1, 1)
+    if (IF && (!TAIL || t + 2 < nk)) nt8_issue<0>(L, smem, t + 2);
+    nt8_read(a0, aP + 64 * RB, L);
+    nt8_read(a1, aP + 96 * RB, L);
+    if (!IF && (!TAIL || t + 2 < nk)) nt8_issue<0>(L, smem, t + 2);
+    nt8_sync_in<V>();
+    nt8_mma(acc[2][1], acc[3][1], a0, a1, b1);
+    nt8_sync_out<V>();
+    // ---- phase 3: quadrant (1, 0); the wait retires A0 / B0 of K-tile t + 1 for the next phase 0
+    if (!TAIL || t + 2 < nk) nt8_issue<1>(L, smem, t + 2);
+    if (!TAIL) wait_dma_units<4>();
+    else if (t + 1 < nk) wait_dma_units_rt(min(U, 4 * t + 10) - (4 * t + 6));
+    nt8_sync_in<V>();
+    nt8_mma(acc[2][0], acc[3][0], a0, a1, b0);
+    nt8_sync_out<V>();
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(512) void gemm_nt8_kernel(NTParams p) {
+    static_assert(sizeof(T) == 2, "the phased kernel is bf16 only");
+    constexpr int RB = 128, BM = 256, BN = 256, BK = 64;
+    constexpr int kBuf = (BM + BN) * RB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int tile = xcd_remap(blockIdx.x, nwg);
+    const int bm0 = (tile / p.tiles_n) * BM, bn0 = (tile % p.tiles_n) * BN;
+
+    if (p.prof && tid == 0) p.prof[blockIdx.x * 4 + 0] = wall_clock64();
+    NT8Lane L;
+    {
+        const int lr = lane >> 3, slot = lane & 7;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int ra = g * 128 + wid * 8;                           // A0 piece (A1: + 64)
+            const int rb = (g * 2 + (wid >> 2)) * 64 + (wid & 3) * 8;   // B0 piece (B1: + 32)
+            const int rows[4] = {ra, rb, rb + 32, ra + 64};             // kind 0..3 = A0, B0, B1, A1
+#pragma unroll
+            for (int kind = 0; kind < 4; ++kind) {
+                const int r = rows[kind] + lr;
+                const bool isB = (kind == 1 || kind == 2);
+                const int64_t grow = isB ? min(bn0 + r, p.N - 1) : min(bm0 + r, p.M - 1);
+                L.src[kind][g] = (isB ? p.B + grow * p.ldb : p.A + grow * p.lda) + ((slot ^ lds_swz<RB>(r)) << 4);
+                L.dst[kind][g] = (isB ? BM * RB : 0) + rows[kind] * RB;
+            }
+        }
+        const int r = lane & 31, h = lane >> 5, sw = lds_swz<RB>(r);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) L.roff[ks] = r * RB + (((ks * 2 + h) ^ sw) << 4);
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = p.K / BK;
+    // prologue: units 0..5 (K-tile 0 and A0, B0 of K-tile 1); A0 / B0 of K-tile 0 must have landed for phase 0
+    nt8_issue<0>(L, smem, 0);
+    nt8_issue<1>(L, smem, 0);
+    nt8_issue<2>(L, smem, 0);
+    nt8_issue<3>(L, smem, 0);
+    if (nk > 1) {
+        nt8_issue<0>(L, smem, 1);
+        nt8_issue<1>(L, smem, 1);
+        wait_dma_units<4>();
+    } else {
+        wait_dma_units<2>();
+    }
+    NT8_BARRIER();
+    if (p.prof && tid == 0) p.prof[blockIdx.x * 4 + 1] = wall_clock64();
+    if (wr == 1) NT8_BARRIER();                  // the second wave group runs one barrier behind
+
+    i32x4 a0[4], a1[4], b0[4], b1[4];
+    const int aoff = wr * 128 * RB, boff = BM * RB + wc * 64 * RB;
+    int t = 0;
+    for (; t + 2 < nk; ++t) {
+        const char* buf = smem + (t & 1) * kBuf;
+        nt8_ktile<false, V>(t, nk, L, smem, buf + aoff, buf + boff, acc, a0, a1, b0, b1);
+    }
+    for (; t < nk; ++t) {
+        const char* buf = smem + (t & 1) * kBuf;
+        nt8_ktile<true, V>(t, nk, L, smem, buf + aoff, buf + boff, acc, a0, a1, b0, b1);
+    }
+    if (wr == 0) NT8_BARRIER();
+    __syncthreads();                             // the ring becomes the epilogue slab
+    if (p.prof && tid == 0) p.prof[blockIdx.x * 4 + 2] = wall_clock64();
+
+    float* slab = reinterpret_cast<float*>(smem) + wid * (64 * 64);
+    nt_epilogue<T, 4, 2, 2, 2>(p, acc, slab, lane, bm0 + wr * 128, bn0 + wc * 64);
+    if (p.prof) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) p.prof[blockIdx.x * 4 + 3] = wall_clock64();
+    }
+}
+
+template <typename T, int V> int launch_nt8(const NTParams& p0, hipStream_t stream) {
+    constexpr int lds = 2 * 512 * 128;
+    static bool attr_done = false;
+    auto kern = gemm_nt8_kernel<T, V>;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            ase_set_error("gemm_nt8: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return ASE_ELAUNCH;
+        }
+        attr_done = true;
+    }
+    NTParams p = p0;
+    p.prof = g_nt_prof;
+    p.tiles_m = (p.M + 255) / 256;
+    p.tiles_n = (p.N + 255) / 256;
+    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(512), lds, stream, p);
+    ASE_CHECK_LAUNCH("gemm_nt8");
+    return ASE_OK;
+}
+
 template <typename T> int dispatch_nt(const NTParams& p, hipStream_t s) {
     static int force = -1, variant = 0;
     if (force < 0) {
@@ -358,7 +604,19 @@ template <typename T> int dispatch_nt(const NTParams& p, hipStream_t s) {
     const int t256 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     const bool big = (force == 256) || (force == 0 && p.N % 256 == 0 && t256 >= 240 && (t256 % 256 == 0 || t256 >= 1024));
     if (big && force != 128) {
-        if (variant == 1 && k128) return launch_nt<T, 4, 2, 2, 4, 128, 2>(p, s);
+        if constexpr (sizeof(T) == 2) {
+            if (variant != 3 && k128) {                                  // phased kernel (ASE_NT_VARIANT=3: the lock-step one)
+                static int sched = -1;
+                if (sched < 0) { const char* e = getenv("ASE_NT8_SCHED"); sched = e ? atoi(e) : 0; }
+                switch (sched) {
+                    case 1: return launch_nt8<T, 1>(p, s);
+                    case 2: return launch_nt8<T, 2>(p, s);
+                    case 3: return launch_nt8<T, 3>(p, s);
+                    default: return launch_nt8<T, 0>(p, s);
+                }
+            }
+        }
+        if ((variant == 1 || variant == 3) && k128) return launch_nt<T, 4, 2, 2, 4, 128, 2>(p, s);
         return launch_nt<T, 4, 2, 2, 4, 64, 4>(p, s);                     // 64-byte rows, 4-stage ring (128 KB)
     }
     if (variant == 1 && k128) return launch_nt<T, 2, 2, 2, 2, 128, 2>(p, s);
@@ -382,6 +640,7 @@ struct TNParams {
     int n_real, k_real, split_src, split_dst;
     float alpha;
     int tiles_n, tiles_k, m_chunk;
+    unsigned long long* prof;     // debug stamps (ase_hip_debug_nt_profile), else null
 };
 
 template <typename T> struct TNGeom;
@@ -592,6 +851,344 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(TNParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// TN, phased 256 x 256 kernel (bf16): the weight-gradient twin of gemm_nt8_kernel.  Output tile 256 (n) x 256 (k), 8
+// waves as 2 (n) x 4 (k), contraction over 64 rows m per K-tile.  Both staged tiles are row-major [64 m][512 B] images
+// written by the DMA (2 rows per 1-KiB piece) with the 16-byte chunks of row m at slot chunk ^ ((m & 3) << 2): the four
+// rows that one 32-lane group of ds_read_b64_tr_b16 touches land in the four 64-byte quarters of the bank window.
+//   DMA units (16 KiB = 32 rows of one operand), in issue order: B-lo, A-lo, B-hi, A-hi  (lo / hi = rows 0-31 / 32-63)
+//   phase 0: read A-lo (n fragments 0, 1) + B-lo -> acc[0..1][*]      phase 1: A-lo (fragments 2, 3) -> acc[2..3][*]
+//   phase 2: A-hi (0, 1) + B-hi                                      phase 3: A-hi (2, 3)
+//   issue / wait arithmetic exactly as in the NT kernel (unit 4 t + p + 6 in phase (t, p); waits in phases 1 and 3).
+// Bias gradient: workgroups of the first k-tile column multiply one A fragment per wave by a constant all-ones B
+// fragment (wave column c owns n fragment c: 4 extra MFMAs per K-tile), so the column sums never leave the matrix pipe.
+//
+// The split-M partial sums meet in f32 atomics, which run memory-side on this chip (~1.4 TB/s measured: 47 us for the
+// 16 x 4 MB of a 1024 x 1024 gradient split 16 ways, against 27 us of main loop).  Hence the GROUPED launch: all weight
+// gradients of one optimisation step (they only depend on buffers the data-gradient chain has already written) go
+// out as ONE grid whose work items {problem, tile, m range} are sized so that ~256 workgroups each run a long
+// contraction (100+ K-tiles): the same 256 x 256 KB of partial sums are then paid once per step, not once per layer.
+// ------------------------------------------------------------------------------------------------
+struct TN8Lane {
+    const char* src[4][2];     // per-lane DMA source of unit kind (B-lo, A-lo, B-hi, A-hi) x piece, at K-tile 0
+    int dst[4][2];             // wave-uniform LDS byte offset of the piece inside a K-tile buffer
+    int rbase;                 // per-lane tr-read base: row, 16-byte sub-chunk and half of the lane
+    int foffA[4], foffB[2];    // swizzled 64-byte fragment-column offsets
+    int64_t kstep[2];          // bytes per K-tile (64 rows) of B / A
+};
+
+template <int KIND>
+__device__ __forceinline__ void tn8_issue(const TN8Lane& L, char* smem, int tile) {
+    char* buf = smem + (tile & 1) * 65536;
+    const int64_t koff = (int64_t)tile * L.kstep[KIND & 1];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+        __builtin_amdgcn_global_load_lds((gptr_t*)(L.src[KIND][g] + koff), (lptr_t*)(buf + L.dst[KIND][g]), 16, 0, 0);
+}
+
+// fragment (32 columns) x k-step (16 rows): two transposed 8-byte reads = the lane's 8 consecutive m of its column.
+// Inline asm on purpose: behind the builtin hipcc drains the DMA queue (vmcnt(0)) in front of every transposed read
+// that follows a global_load_lds; the asm reads are ordered by the explicit lgkmcnt(0) + sched_barrier of the phase
+// (nt8_sync_in), and the two halves are only joined into the MFMA operand after that wait.
+struct tr_pair { bf16x4 lo, hi; };
+template <int OFF> __device__ __forceinline__ void tn8_read(tr_pair& f, uint32_t addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.lo) : "v"(addr), "n"(OFF) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.hi) : "v"(addr), "n"(OFF + 4 * 512) : "memory");
+}
+__device__ __forceinline__ bf16x8 tn8_join(const tr_pair& f) {
+    return __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// 8 MFMAs of one phase (+ 2 for the bias gradient when this wave owns one of the two live A fragments: bias_sel 0 / 1
+// picks it with VALU selects, bvec is all ones or - outside bias_rows - all zeros)
+template <bool BIAS>
+__device__ __forceinline__ void tn8_mma(f32x16& c00, f32x16& c01, f32x16& c10, f32x16& c11, f32x16& bacc,
+                                        const tr_pair (&a)[2][2], const tr_pair (&b)[2][2], int bias_sel, bf16x8 bvec) {
+    bf16x8 a0[2], a1[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        a0[ks] = tn8_join(a[0][ks]);
+        a1[ks] = tn8_join(a[1][ks]);
+        const bf16x8 b0 = tn8_join(b[0][ks]), b1 = tn8_join(b[1][ks]);
+        c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[ks], b0, c00, 0, 0, 0);
+        c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ks], b0, c10, 0, 0, 0);
+        c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[ks], b1, c01, 0, 0, 0);
+        c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ks], b1, c11, 0, 0, 0);
+    }
+    if (BIAS) {
+        if (bias_sel >= 0) {                         // wave-uniform
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const i32x4 x0 = __builtin_bit_cast(i32x4, a0[ks]), x1 = __builtin_bit_cast(i32x4, a1[ks]);
+                i32x4 xs;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xs[q] = bias_sel ? x1[q] : x0[q];
+                bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xs), bvec, bacc, 0, 0, 0);
+            }
+        }
+    }
+}
+
+// HALF = 0 / 1: phases 0, 1 (rows 0-31 of the K-tile) / phases 2, 3 (rows 32-63)
+template <bool TAIL, int V, bool BIAS, int HALF>
+__device__ __forceinline__ void tn8_half(int t, int nk, const TN8Lane& L, char* smem, const uint32_t (&adA)[4],
+                                         const uint32_t (&adB)[2], int bias_frag, bf16x8 bvec, f32x16 (&acc)[4][2],
+                                         f32x16& bacc) {
+    constexpr int RO = HALF * 2 * 8192;           // k-steps 2 HALF, 2 HALF + 1
+    const int U = 4 * nk;
+    const bool live = !TAIL || (HALF == 0 ? t + 1 < nk : t + 2 < nk);
+    tr_pair a[2][2], b[2][2];
+    // ---- even phase: A fragments 0, 1 + both B fragments of this half
+    tn8_read<32768 + RO>(b[0][0], adB[0]);
+    tn8_read<32768 + RO + 8192>(b[0][1], adB[0]);
+    tn8_read<32768 + RO>(b[1][0], adB[1]);
+    tn8_read<32768 + RO + 8192>(b[1][1], adB[1]);
+    tn8_read<RO>(a[0][0], adA[0]);
+    tn8_read<RO + 8192>(a[0][1], adA[0]);
+    tn8_read<RO>(a[1][0], adA[1]);
+    tn8_read<RO + 8192>(a[1][1], adA[1]);
+    // (the DMA is issued AFTER the fragment reads, as in the NT kernel)
+    if (live) {
+        if (HALF == 0) tn8_issue<2>(L, smem, t + 1);
+        else tn8_issue<0>(L, smem, t + 2);
+    }
+    nt8_sync_in<V>();
+    tn8_mma<BIAS>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], bacc, a, b, bias_frag < 2 ? bias_frag : -1, bvec);
+    nt8_sync_out<V>();
+    // ---- odd phase: A fragments 2, 3; the wait retires what the next phase reads
+    tn8_read<RO>(a[0][0], adA[2]);
+    tn8_read<RO + 8192>(a[0][1], adA[2]);
+    tn8_read<RO>(a[1][0], adA[3]);
+    tn8_read<RO + 8192>(a[1][1], adA[3]);
+    if (live) {
+        if (HALF == 0) tn8_issue<3>(L, smem, t + 1);
+        else tn8_issue<1>(L, smem, t + 2);
+    }
+    if (!TAIL) wait_dma_units<4>();
+    else if (HALF == 0) wait_dma_units_rt(min(U, 4 * t + 8) - (4 * t + 4));
+    else if (t + 1 < nk) wait_dma_units_rt(min(U, 4 * t + 10) - (4 * t + 6));
+    nt8_sync_in<V>();
+    tn8_mma<BIAS>(acc[2][0], acc[2][1], acc[3][0], acc[3][1], bacc, a, b, bias_frag >= 2 ? bias_frag - 2 : -1, bvec);
+    nt8_sync_out<V>();
+}
+
+template <bool TAIL, int V, bool BIAS>
+__device__ __forceinline__ void tn8_ktile(int t, int nk, const TN8Lane& L, char* smem, uint32_t lds0, int bias_frag,
+                                          bool bias_on, f32x16 (&acc)[4][2], f32x16& bacc) {
+    const uint32_t pa = lds0 + (t & 1) * 65536 + L.rbase;
+    uint32_t adA[4], adB[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) adA[i] = pa + L.foffA[i];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) adB[j] = pa + L.foffB[j];
+    bf16x8 bvec;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) bvec[q] = (bf16_t)(bias_on ? 1.0f : 0.0f);
+    tn8_half<TAIL, V, BIAS, 0>(t, nk, L, smem, adA, adB, bias_frag, bvec, acc, bacc);
+    tn8_half<TAIL, V, BIAS, 1>(t, nk, L, smem, adA, adB, bias_frag, bvec, acc, bacc);
+}
+
+// one work item: output tile (bn0, bk0) of problem p over the K-tiles [m_begin, m_begin + 64 nk)
+template <int V>
+__device__ __forceinline__ void tn8_body(const TNParams& p, char* smem, int bn0, int bk0, int m_begin, int nk,
+                                         unsigned long long* prof) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    if (prof && tid == 0) prof[0] = wall_clock64();
+
+    TN8Lane L;
+    {
+        const int lrow = lane >> 5, slot = lane & 31;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+#pragma unroll
+            for (int kind = 0; kind < 4; ++kind) {
+                const bool isA = kind & 1;
+                const int row0 = (kind >> 1) * 32 + 2 * (g * 8 + wid), row = row0 + lrow;
+                int chunk = slot ^ ((row & 3) << 2);
+                const int col0 = isA ? bn0 : bk0, width = isA ? p.N : p.K;
+                if (col0 + chunk * 8 >= width) chunk = 0;            // columns past the operand: products only reach unstored outputs
+                const char* base = isA ? p.A : p.B;
+                const int64_t ld = isA ? p.lda : p.ldb;
+                L.src[kind][g] = base + (int64_t)(m_begin + row) * ld + (int64_t)col0 * 2 + chunk * 16;
+                L.dst[kind][g] = (isA ? 0 : 32768) + row0 * 512;
+            }
+        }
+        L.kstep[0] = 64 * p.ldb;
+        L.kstep[1] = 64 * p.lda;
+        const int t = lane & 15, g4 = lane >> 4, h = g4 >> 1, cg = g4 & 1, s2 = (t >> 2) & 3;
+        L.rbase = (h * 8 + (t >> 2)) * 512 + (cg * 2 + ((t & 3) >> 1)) * 16 + (t & 1) * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) L.foffA[i] = ((wr * 4 + i) ^ s2) * 64;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) L.foffB[j] = ((wc * 2 + j) ^ s2) * 64;
+    }
+
+    f32x16 acc[4][2], bacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) bacc[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const bool do_bias = p.gbias != nullptr && bk0 == 0;
+    // whole K-tiles below bias_rows contribute to the bias gradient (the host checks bias_rows % 64 == 0)
+    const int bias_tiles = do_bias ? max(0, min(nk, (p.bias_rows - m_begin) / 64)) : 0;
+
+    tn8_issue<0>(L, smem, 0);
+    tn8_issue<1>(L, smem, 0);
+    tn8_issue<2>(L, smem, 0);
+    tn8_issue<3>(L, smem, 0);
+    if (nk > 1) {
+        tn8_issue<0>(L, smem, 1);
+        tn8_issue<1>(L, smem, 1);
+        wait_dma_units<4>();
+    } else {
+        wait_dma_units<2>();
+    }
+    NT8_BARRIER();
+    if (prof && tid == 0) prof[1] = wall_clock64();
+    if (wr == 1) NT8_BARRIER();
+
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;           // LDS byte address of the ring (low half of the flat address)
+    int t = 0;
+    if (bias_tiles > 0) {
+        for (; t + 2 < nk; ++t)
+            tn8_ktile<false, V, true>(t, nk, L, smem, lds0, wc, t < bias_tiles, acc, bacc);
+        for (; t < nk; ++t)
+            tn8_ktile<true, V, true>(t, nk, L, smem, lds0, wc, t < bias_tiles, acc, bacc);
+    } else {
+        for (; t + 2 < nk; ++t)
+            tn8_ktile<false, V, false>(t, nk, L, smem, lds0, wc, false, acc, bacc);
+        for (; t < nk; ++t)
+            tn8_ktile<true, V, false>(t, nk, L, smem, lds0, wc, false, acc, bacc);
+    }
+    if (wr == 0) NT8_BARRIER();
+    if (prof && tid == 0) prof[2] = wall_clock64();
+
+    const int col_in = lane & 31, row_hi = (lane >> 5) * 4;
+    if (bias_tiles > 0 && col_in == 0) {           // every column of bacc holds the sums: column 0 writes them
+        const int nbase = bn0 + (wr * 4 + wc) * 32 + row_hi;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int n = nbase + (e & 3) + 8 * (e >> 2);
+            if (n < p.n_real) atomic_add_f32(p.gbias + n, p.alpha * bacc[e]);
+        }
+    }
+    const int gap = p.split_dst - p.split_src;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int k = bk0 + (wc * 2 + j) * 32 + col_in;
+        int kk = -1;
+        if (k < p.split_src) kk = k;
+        else if (k >= p.split_dst && k - gap < p.k_real) kk = k - gap;
+        if (kk < 0) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int nbase = bn0 + (wr * 4 + i) * 32 + row_hi;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = nbase + (e & 3) + 8 * (e >> 2);
+                if (n < p.n_real) atomic_add_f32(p.G + (int64_t)n * p.k_real + kk, p.alpha * acc[i][j][e]);
+            }
+        }
+    }
+    if (prof) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) prof[3] = wall_clock64();
+    }
+}
+
+template <int V>
+__global__ __launch_bounds__(512) void gemm_tn8_kernel(TNParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nwg = p.tiles_n * p.tiles_k;
+    const int tile = xcd_remap(blockIdx.x, nwg);
+    const int m_begin = blockIdx.z * p.m_chunk;
+    const int m_end = min(p.M, m_begin + p.m_chunk);
+    if (m_begin >= m_end) return;
+    tn8_body<V>(p, smem, (tile / p.tiles_k) * 256, (tile % p.tiles_k) * 256, m_begin, (m_end - m_begin) / 64,
+                p.prof ? p.prof + (blockIdx.z * gridDim.x + blockIdx.x) * 4 : nullptr);
+}
+
+// Grouped launch.  problems: device int64[n][16] = {A, lda, B, ldb, G, gbias, bias_rows, M, N, K, n_real, k_real,
+// split_src, split_dst, alpha (f32 bits), tiles_k}, leading dimensions in ELEMENTS; work: device int32[n_work][4] =
+// {problem, tile, m_begin, nk} (ase_hip_gemm_tn_grouped_plan).
+template <int V>
+__global__ __launch_bounds__(512) void gemm_tn8g_kernel(const int64_t* __restrict__ problems,
+                                                        const int32_t* __restrict__ work, int n_work,
+                                                        unsigned long long* prof) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int item = xcd_remap(blockIdx.x, n_work);             // neighbours in the work list share operand panels
+    const int32_t* w = work + 4 * item;
+    const int pi = __builtin_amdgcn_readfirstlane(w[0]), tile = __builtin_amdgcn_readfirstlane(w[1]);
+    const int m_begin = __builtin_amdgcn_readfirstlane(w[2]), nk = __builtin_amdgcn_readfirstlane(w[3]);
+    const int64_t* d = problems + 16 * pi;
+    TNParams p;
+    p.A = reinterpret_cast<const char*>(d[0]); p.lda = d[1] * 2;
+    p.B = reinterpret_cast<const char*>(d[2]); p.ldb = d[3] * 2;
+    p.G = reinterpret_cast<float*>(d[4]); p.gbias = reinterpret_cast<float*>(d[5]);
+    p.bias_rows = (int)d[6]; p.M = (int)d[7]; p.N = (int)d[8]; p.K = (int)d[9];
+    p.n_real = (int)d[10]; p.k_real = (int)d[11]; p.split_src = (int)d[12]; p.split_dst = (int)d[13];
+    p.alpha = __builtin_bit_cast(float, (int)d[14]);
+    p.tiles_k = (int)d[15];
+    tn8_body<V>(p, smem, (tile / p.tiles_k) * 256, (tile % p.tiles_k) * 256, m_begin, nk,
+                prof ? prof + blockIdx.x * 4 : nullptr);
+}
+
+template <int V> int launch_tn8(TNParams p, hipStream_t stream) {
+    constexpr int lds = 2 * 65536;
+    static bool attr_done = false;
+    auto kern = gemm_tn8_kernel<V>;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            ase_set_error("gemm_tn8: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return ASE_ELAUNCH;
+        }
+        attr_done = true;
+    }
+    p.tiles_n = (p.n_real + 255) / 256;
+    p.tiles_k = (p.K + 255) / 256;
+    const int tiles = p.tiles_n * p.tiles_k;
+    int splits = 256 / tiles;                                   // one 8-wave workgroup per CU
+    const int max_splits = p.M / 256;                           // >= 4 K-tiles per split
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    int chunk = (p.M + splits - 1) / splits;
+    chunk = (chunk + 63) / 64 * 64;
+    splits = (p.M + chunk - 1) / chunk;
+    p.m_chunk = chunk;
+    p.prof = g_nt_prof;
+    hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(512), lds, stream, p);
+    ASE_CHECK_LAUNCH("gemm_tn8");
+    return ASE_OK;
+}
+
+template <int V> int launch_tn8g(const int64_t* problems, const int32_t* work, int n_work, hipStream_t stream) {
+    constexpr int lds = 2 * 65536;
+    static bool attr_done = false;
+    auto kern = gemm_tn8g_kernel<V>;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            ase_set_error("gemm_tn_grouped: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return ASE_ELAUNCH;
+        }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(n_work), dim3(512), lds, stream, problems, work, n_work, g_nt_prof);
+    ASE_CHECK_LAUNCH("gemm_tn_grouped");
+    return ASE_OK;
+}
+
 template <typename T> int launch_tn(TNParams p, hipStream_t stream) {
     using Gm = TNGeom<T>;
     constexpr int lds = 4 * Gm::BKM * Gm::STRIDE;
@@ -721,6 +1318,11 @@ extern "C" int ase_hip_refresh_shadow_multi(const int64_t* desc, int n_layers, i
     return ASE_OK;
 }
 
+extern "C" int ase_hip_debug_nt_profile(void* buf) {
+    g_nt_prof = reinterpret_cast<unsigned long long*>(buf);
+    return ASE_OK;
+}
+
 extern "C" int ase_hip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                                const float* bias, const void* aux, int64_t ldaux, int aux_split, int aux_delta,
                                float* colsum, int colsum_n, int M, int N, int K, int act, int aux_mode, int out_f32, float alpha, int dtype, void* stream) {
@@ -742,6 +1344,7 @@ extern "C" int ase_hip_gemm_nt(const void* A, int64_t lda, const void* B, int64_
     p.bias = bias; p.aux = (const char*)aux; p.ldaux = ldaux * es; p.aux_split = aux_split > 0 ? aux_split : M; p.aux_delta = aux_delta; p.colsum = colsum; p.colsum_n = colsum ? colsum_n : 0;
     p.M = M; p.N = N; p.K = K; p.act = act; p.aux_mode = aux_mode; p.out_f32 = out_f32; p.alpha = alpha;
     p.tiles_m = p.tiles_n = 0;
+    p.prof = nullptr;
     if (dtype == ASE_BF16) return dispatch_nt<bf16_t>(p, (hipStream_t)stream);
     if (dtype == ASE_F32X3) return dispatch_nt<f32s_t>(p, (hipStream_t)stream);
     return dispatch_nt<float>(p, (hipStream_t)stream);
@@ -762,10 +1365,99 @@ extern "C" int ase_hip_gemm_tn(const void* A, int64_t lda, const void* B, int64_
     TNParams p;
     p.A = (const char*)A; p.lda = lda * es; p.B = (const char*)B; p.ldb = ldb * es; p.G = G; p.gbias = gbias; p.bias_rows = bias_rows > 0 ? bias_rows : M;
     p.M = M; p.N = N; p.K = K; p.n_real = n_real; p.k_real = k_real; p.split_src = split_src; p.split_dst = split_dst;
-    p.alpha = alpha; p.tiles_n = p.tiles_k = p.m_chunk = 0;
-    if (dtype == ASE_BF16) return launch_tn<bf16_t>(p, (hipStream_t)stream);
+    p.alpha = alpha; p.tiles_n = p.tiles_k = p.m_chunk = 0; p.prof = nullptr;
+    if (dtype == ASE_BF16) {
+        static int tn8 = -1;
+        if (tn8 < 0) {
+            const char* e = getenv("ASE_TN8");
+            tn8 = e ? atoi(e) : 1;
+        }
+        // Single-problem launches take the phased 256 x 256 kernel only when few M-splits fill the chip (its split
+        // reduction costs 256 KB of memory-side atomics per workgroup; see the grouped launch): whole 64-row K-tiles,
+        // whole bias tiles, >= 32 K-tiles per split.
+        const int t256 = ((n_real + 255) / 256) * ((K + 255) / 256);
+        if (tn8 && M % 64 == 0 && p.bias_rows % 64 == 0 && n_real >= 128 && K >= 128 && (int64_t)M * t256 >= 256 * 2048)
+            return launch_tn8<0>(p, (hipStream_t)stream);
+        return launch_tn<bf16_t>(p, (hipStream_t)stream);
+    }
     if (dtype == ASE_F32X3) return launch_tn<f32s_t>(p, (hipStream_t)stream);
     return launch_tn<float>(p, (hipStream_t)stream);
+}
+
+
+// ---- grouped weight gradients (bf16) -----------------------------------------------------------------------------
+static int tn_problem_check(const int64_t* d, int i) {
+    const int64_t lda = d[1], ldb = d[3], bias_rows = d[6], M = d[7], N = d[8], K = d[9], n_real = d[10], k_real = d[11];
+    ASE_CHECK_ARG(d[0] && d[2] && d[4] && M > 0 && N > 0 && K > 0, "gemm_tn_grouped: problem %d: null/empty operand", i);
+    ASE_CHECK_ARG(M % 64 == 0 && (bias_rows <= 0 || bias_rows % 64 == 0),
+                  "gemm_tn_grouped: problem %d: M=%lld / bias_rows=%lld must be whole 64-row K-tiles", i, (long long)M, (long long)bias_rows);
+    ASE_CHECK_ARG(N % 8 == 0 && K % 8 == 0 && lda >= N && ldb >= K && lda % 8 == 0 && ldb % 8 == 0 &&
+                      ((uintptr_t)d[0] % 16) == 0 && ((uintptr_t)d[2] % 16) == 0,
+                  "gemm_tn_grouped: problem %d: operands must be 16-byte aligned with whole 16-byte chunks per row", i);
+    ASE_CHECK_ARG(n_real > 0 && n_real <= N && k_real > 0 && d[12] <= d[13] && d[12] <= k_real,
+                  "gemm_tn_grouped: problem %d: bad real dims / split", i);
+    return ASE_OK;
+}
+
+extern "C" int ase_hip_gemm_tn_grouped_plan(int64_t* problems, int n_problems, int target_wg, int32_t* work, int max_work,
+                                            int* n_work) {
+    ASE_CHECK_ARG(problems && work && n_work && n_problems > 0 && max_work > 0, "gemm_tn_grouped_plan: null/empty argument");
+    if (target_wg <= 0) {
+        const char* e = getenv("ASE_TN_GROUP_WG");
+        target_wg = e ? atoi(e) : 256;                       // one 8-wave workgroup per CU
+    }
+    int64_t max_kt = 1;
+    for (int i = 0; i < n_problems; ++i) {
+        int64_t* d = problems + 16 * i;
+        const int rc = tn_problem_check(d, i);
+        if (rc != ASE_OK) return rc;
+        if (d[6] <= 0) d[6] = d[7];                          // bias_rows: all rows
+        d[15] = (d[9] + 255) / 256;                          // tiles_k
+        if (d[7] / 64 > max_kt) max_kt = d[7] / 64;
+    }
+    // Contraction length c (K-tiles per work item): all tiles of a problem are cut at the same rows (workgroups on the
+    // same rows of neighbouring tiles share operand panels in L2), one workgroup per CU is resident, and the grid runs
+    // in ceil(items / target) rounds of ~c K-tiles each; every item also pays a prologue and 256 KB of atomics
+    // (~8 K-tiles of main loop).  Pick the c with the shortest makespan.
+    auto count = [&](int64_t c) {
+        int64_t tot = 0;
+        for (int i = 0; i < n_problems; ++i) {
+            const int64_t* d = problems + 16 * i;
+            const int64_t tiles = ((d[10] + 255) / 256) * d[15], kt = d[7] / 64;
+            tot += tiles * ((kt + c - 1) / c);
+        }
+        return tot;
+    };
+    int64_t c = max_kt, best = -1;
+    for (int64_t cc = (max_kt < 8 ? max_kt : 8); cc <= max_kt; ++cc) {
+        const int64_t items = count(cc), rounds = (items + target_wg - 1) / target_wg;
+        if (items > max_work) continue;
+        const int64_t cost = rounds * (cc + 8);
+        if (best < 0 || cost < best) { best = cost; c = cc; }
+    }
+    int nw = 0;
+    for (int i = 0; i < n_problems; ++i) {
+        const int64_t* d = problems + 16 * i;
+        const int tiles = (int)(((d[10] + 255) / 256) * d[15]);
+        const int64_t kt = d[7] / 64, splits = (kt + c - 1) / c, chunk = (kt + splits - 1) / splits;
+        for (int64_t s = 0; s < splits; ++s) {
+            const int64_t k0 = s * chunk, nk = (k0 + chunk <= kt) ? chunk : kt - k0;
+            if (nk <= 0) continue;
+            for (int t = 0; t < tiles; ++t) {
+                ASE_CHECK_ARG(nw < max_work, "gemm_tn_grouped_plan: more than %d work items", max_work);
+                work[4 * nw + 0] = i; work[4 * nw + 1] = t; work[4 * nw + 2] = (int)(k0 * 64); work[4 * nw + 3] = (int)nk;
+                ++nw;
+            }
+        }
+    }
+    *n_work = nw;
+    return ASE_OK;
+}
+
+extern "C" int ase_hip_gemm_tn_grouped(const int64_t* problems, const int32_t* work, int n_work, int dtype, void* stream) {
+    ASE_CHECK_ARG(problems && work && n_work > 0, "gemm_tn_grouped: null/empty argument");
+    ASE_CHECK_ARG(dtype == ASE_BF16, "gemm_tn_grouped: bf16 only (dtype %d)", dtype);
+    return launch_tn8g<0>(problems, work, n_work, (hipStream_t)stream);
 }
 
 extern "C" int ase_hip_refresh_shadow(const float* W, int n_real, int k_real, void* Ws, int64_t ldws, void* Wts,

@@ -21,6 +21,7 @@ Data layout in HBM
     kernels, so neither swap_and_flatten01 nor the dataset gather materialise anything.
 """
 import math
+import os
 
 import torch
 
@@ -81,6 +82,8 @@ class UpdateEngine:
         self._scratch = {}
         self.multi_stream = bool(cfg.get('multi_stream', True)) and getattr(backend, 'name', '') == 'hip'
         self._side_streams = None
+        self._tn_defer = bool(getattr(backend, 'grouped_tn_ok', None)) and os.environ.get('ASE_TN_GROUPED', '1') != '0'
+        self._tn_queue, self._tn_plans = [], {}
         self.force_dist = bool(cfg.get('force_dist', False))   # exercise the collectives with a 1-rank group
         self._refresh_desc = None
         self._mb_desc = None
@@ -287,8 +290,30 @@ class UpdateEngine:
         gradients in the loss-head kernels already."""
         heads = len(d.parts) > 1 or d in (self.mu_head, self.value_head, self.disc_head, self.enc_head)
         for (name, nr, off), gW, gb in zip(d.parts, d.gW, d.gb):
-            self.be.gemm_tn(dY[:, off:], X, gW, rows, P(nr), d.k_pad, nr, d.K, d.split_src, d.split_dst, alpha=alpha,
-                            gbias=gb if (bias and not heads) else None)
+            self._tn(dY[:, off:], X, gW, rows, P(nr), d.k_pad, nr, d.K, d.split_src, d.split_dst, alpha=alpha,
+                     gbias=gb if (bias and not heads) else None)
+
+    def _tn(self, A, B, G, M, N, K, n_real, k_real, split_src, split_dst, alpha=1.0, gbias=None, bias_rows=0):
+        """Weight (+ bias) gradient G += A^T B.  Layers the grouped kernel takes are only QUEUED here: they read buffers
+        the data-gradient chain never overwrites, so phase_main launches all of them as ONE grid at its end
+        (ase_hip_gemm_tn_grouped: the split-M reduction is paid once per step instead of once per layer)."""
+        br = bias_rows if bias_rows > 0 else M
+        if self._tn_defer and self.be.grouped_tn_ok(A.dtype, M, n_real, K, br):
+            self._tn_queue.append((A, B, G, gbias, br, M, N, K, n_real, k_real, split_src, split_dst, alpha))
+        else:
+            self.be.gemm_tn(A, B, G, M, N, K, n_real, k_real, split_src, split_dst, alpha=alpha, gbias=gbias,
+                            bias_rows=bias_rows)
+
+    def _flush_tn(self):
+        q, self._tn_queue = self._tn_queue, []
+        if not q:
+            return
+        key = tuple((a.data_ptr(), b.data_ptr(), g.data_ptr(), 0 if gb is None else gb.data_ptr(), br, M, N, K, al)
+                    for (a, b, g, gb, br, M, N, K, nr, kr, ss, sd, al) in q)
+        plan = self._tn_plans.get(key)
+        if plan is None:
+            plan = self._tn_plans[key] = self.be.make_tn_plan(q)
+        self.be.gemm_tn_grouped(plan)
 
     def _bwd_chain(self, chain, X0, H, dZ, rows):
         """dZ[-1] holds d loss / d Z of the last chain layer (its bias grad already accumulated)."""
@@ -479,6 +504,7 @@ class UpdateEngine:
         self._join(0)
         if self.has_disc:
             self._join(1)
+        self._flush_tn()
 
     # ---- phase C: weight-only loss terms, optimizer, shadows, reported scalars --------------------
     def phase_apply(self, apply=True):
@@ -549,8 +575,8 @@ class UpdateEngine:
         for l in range(nl):
             d = self.disc[l]
             X = self.Xd4 if l == 0 else self.Hd4[l - 1]
-            be.gemm_tn(self.dZd4[l], X, d.gW[0], 4 * AMB, d.n_pad, d.k_pad, d.N, d.K, d.split_src, d.split_dst,
-                       gbias=d.gb[0], bias_rows=Rd)
+            self._tn(self.dZd4[l], X, d.gW[0], 4 * AMB, d.n_pad, d.k_pad, d.N, d.K, d.split_src, d.split_dst,
+                     gbias=d.gb[0], bias_rows=Rd)
 
     # ------------------------------------------------------------------ collectives (single rank: no-ops)
     def _ar(self, t):

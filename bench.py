@@ -78,6 +78,11 @@ class TimedBackend:
         self._timed('tn', 2.0 * M * n_real * k_real, self._be.gemm_tn, A, B, G, M, N, K, n_real, k_real, split_src,
                     split_dst, **kw)
 
+    def gemm_tn_grouped(self, plan):
+        flops = sum(2.0 * M * nr * kr for (A, B, G, gb, br, M, N, K, nr, kr, ss, sd, al) in plan['keep'])
+        self._shape = (0, len(plan['keep']), plan['n_work'])       # grouped: N = problems, K = work items
+        self._timed('tn', flops, self._be.gemm_tn_grouped, plan)
+
     def summary(self):
         torch.cuda.synchronize()
         out = {}

@@ -41,6 +41,10 @@ enum { ASE_OK = 0, ASE_EINVAL = -1, ASE_ELAUNCH = -2, ASE_EUNSUPPORTED = -3 };
 int ase_hip_abi_version(void);
 const char* ase_hip_last_error(void);
 
+/* Kernel-tuning aid (scripts/lab): when buf is a device uint64[4 * workgroups] array, the phased NT kernel stamps
+ * {entry, first tile landed, main loop done, stores retired} per workgroup (100 MHz clock); NULL switches it off. */
+int ase_hip_debug_nt_profile(void* buf);
+
 /* ---------------------------------------------------------------------------------------------
  * Dense layers (matrix cores).
  * ------------------------------------------------------------------------------------------- */
@@ -74,6 +78,21 @@ int ase_hip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void
 int ase_hip_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* G, float* gbias,
                     int bias_rows, int M, int N, int K, int n_real, int k_real, int split_src, int split_dst,
                     float alpha, int dtype, void* stream);
+
+/* All weight gradients of one optimisation step in ONE launch (bf16).  They only depend on buffers the data-gradient
+ * chain has already written, and one grid of ~256 long contractions pays the split-M reduction (f32 atomics, memory-side
+ * on this chip) once per step instead of once per layer.
+ *   problems: int64[n][16] = {A, lda, B, ldb, G, gbias (or 0), bias_rows (0 = all), M, N, K, n_real, k_real, split_src,
+ *             split_dst, alpha (f32 bit pattern), 0}, fields as in ase_hip_gemm_tn, leading dimensions in elements;
+ *             M and bias_rows multiples of 64.
+ *   ase_hip_gemm_tn_grouped_plan (host only, no GPU needed): validates the HOST copy of the table, fills field 15 and
+ *             writes the work list int32[n_work][4] = {problem, 256 x 256 output tile, first row, 64-row K-tiles};
+ *             target_wg <= 0: one workgroup per CU.
+ *   ase_hip_gemm_tn_grouped: launch with DEVICE copies of the planned table and work list.
+ * Replaces: loss.backward()'s weight / bias gradients of every nn.Linear (learning/ase_agent.py:271). */
+int ase_hip_gemm_tn_grouped_plan(int64_t* problems, int n_problems, int target_wg, int32_t* work, int max_work,
+                                 int* n_work);
+int ase_hip_gemm_tn_grouped(const int64_t* problems, const int32_t* work, int n_work, int dtype, void* stream);
 
 /* Shadow copies of one weight matrix for the matrix cores: W_s [n_pad,k_pad] and its transpose
  * Wt_s [k_pad,n_pad] (both dtype, zero padded, concat columns moved to split_dst).  Run after

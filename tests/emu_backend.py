@@ -26,8 +26,10 @@ def _rows(idx, remap, M):
 class EmuBackend:
     name = "emu"
 
-    def __init__(self):
+    def __init__(self, group_all=False):
         self.rng = torch.Generator().manual_seed(99)
+        self.group_all = group_all        # queue EVERY weight gradient for the grouped launch (tiny test shapes)
+        self.grouped_launches = 0
 
     def zero_(self, t):
         t.zero_()
@@ -66,6 +68,19 @@ class EmuBackend:
         gap = split_dst - split_src
         cols = list(range(split_src)) + [k for k in range(split_dst, K) if k - gap < k_real]
         G[:n_real, :] += full[:n_real][:, cols]
+
+    def grouped_tn_ok(self, dtype, M, n_real, K, bias_rows):
+        if self.group_all:
+            return True
+        return M % 64 == 0 and bias_rows % 64 == 0 and n_real >= 128 and K >= 128      # any dtype: exercises the deferral on CPU
+
+    def make_tn_plan(self, problems):
+        return {'keep': problems}
+
+    def gemm_tn_grouped(self, plan):
+        self.grouped_launches += 1
+        for (A, B, G, gb, br, M, N, K, nr, kr, ss, sd, alpha) in plan['keep']:
+            self.gemm_tn(A, B, G, M, N, K, nr, kr, ss, sd, alpha=alpha, gbias=gb, bias_rows=br)
 
     def refresh_shadow(self, W, Ws, Wts, split_src, split_dst):
         n, k = W.shape
