@@ -55,13 +55,18 @@ class HipBackend:
 
     # ------------------------------------------------------------------ GEMMs
     def gemm_nt(self, A, B, Cm, M, N, K, bias=None, aux=None, aux_mode=L.AUX_NONE, colsum=None, colsum_n=0,
-                act=L.ACT_NONE, alpha=1.0, aux_split=0, aux_delta=0):
+                act=L.ACT_NONE, alpha=1.0, aux_split=0, aux_delta=0, mask_out=None):
         dt = self._gemm_code(A.dtype)
-        assert B.dtype == A.dtype and (aux is None or aux.dtype == A.dtype)
+        assert B.dtype == A.dtype
+        if aux_mode == L.AUX_RELU_BITS:
+            assert aux.dtype == torch.int32
+        else:
+            assert aux is None or aux.dtype == A.dtype
+        assert mask_out is None or mask_out.dtype == torch.int32
         out_f32 = int(Cm.dtype == torch.float32 and A.dtype != torch.float32)
         L.check(self.lib.ase_hip_gemm_nt(_ptr(A), _ld(A), _ptr(B), _ld(B), _ptr(Cm), _ld(Cm), _ptr(bias), _ptr(aux),
-                                         _ld(aux), int(aux_split), int(aux_delta), _ptr(colsum), int(colsum_n), M, N, K, act,
-                                         aux_mode, out_f32,
+                                         _ld(aux), int(aux_split), int(aux_delta), _ptr(colsum), int(colsum_n),
+                                         _ptr(mask_out), _ld(mask_out), M, N, K, act, aux_mode, out_f32,
                                          float(alpha), dt, self._stream()), "gemm_nt")
 
     def gemm_tn(self, A, B, G, M, N, K, n_real, k_real, split_src, split_dst, alpha=1.0, gbias=None, bias_rows=0):

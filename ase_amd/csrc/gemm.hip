@@ -148,6 +148,7 @@ struct NTParams {
     const char* aux; int64_t ldaux; // bytes
     int aux_split, aux_delta;       // rows m >= aux_split read aux row m - aux_delta (stacked row blocks sharing a mask)
     float* colsum; int colsum_n;
+    uint32_t* mask_out; int64_t ldmask;   // nullable: bit (m, n) = stored value > 0, 32 columns per word, ldmask in words
     int M, N, K;                    // K in elements (multiple of 128/sizeof(T))
     int act, aux_mode, out_f32;
     float alpha;
@@ -199,7 +200,14 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x16 (&acc)[FM]
                     const int m = mrow0 + ic * 32 + row;
                     if (m >= p.M) continue;
                     f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * WCOLS + c4 * 4);
-                    if (p.aux_mode != ASE_AUX_NONE) {
+                    if (p.aux_mode == ASE_AUX_RELU_BITS) {
+                        // 32 columns per word: the 8 lanes of a word load the same 4 bytes
+                        const int ma = (m >= p.aux_split) ? m - p.aux_delta : m;
+                        const uint32_t w = *reinterpret_cast<const uint32_t*>(p.aux + (int64_t)ma * p.ldaux + (n0 >> 5) * 4);
+                        const uint32_t nib = w >> (n0 & 31);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = ((nib >> q) & 1u) ? v[q] : 0.f;
+                    } else if (p.aux_mode != ASE_AUX_NONE) {
                         float a[4];
                         const int ma = (m >= p.aux_split) ? m - p.aux_delta : m;
                         const char* ap = p.aux + (int64_t)ma * p.ldaux + (int64_t)n0 * sizeof(T);
@@ -229,6 +237,17 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x16 (&acc)[FM]
                     }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) cs[q] += v[q];
+                    if (p.mask_out) {
+                        // nibble of this lane's 4 columns -> OR over the 8 lanes of a 32-column word -> one 4-byte store
+                        uint32_t bits = 0;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) bits |= (v[q] > 0.f ? 1u : 0u) << q;
+                        bits <<= (n0 & 31);
+                        bits |= __shfl_xor(bits, 1, 64);
+                        bits |= __shfl_xor(bits, 2, 64);
+                        bits |= __shfl_xor(bits, 4, 64);
+                        if ((c4 & 7) == 0) p.mask_out[(int64_t)m * p.ldmask + (n0 >> 5)] = bits;
+                    }
                 }
             }
         }
@@ -1325,7 +1344,8 @@ extern "C" int ase_hip_debug_nt_profile(void* buf) {
 
 extern "C" int ase_hip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                                const float* bias, const void* aux, int64_t ldaux, int aux_split, int aux_delta,
-                               float* colsum, int colsum_n, int M, int N, int K, int act, int aux_mode, int out_f32, float alpha, int dtype, void* stream) {
+                               float* colsum, int colsum_n, void* mask_out, int64_t ldmask, int M, int N, int K, int act,
+                               int aux_mode, int out_f32, float alpha, int dtype, void* stream) {
     const int es = (dtype == ASE_BF16) ? 2 : 4;
     ASE_CHECK_ARG(dtype == ASE_F32 || dtype == ASE_BF16 || dtype == ASE_F32X3, "gemm_nt: bad dtype %d", dtype);
     ASE_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0, "gemm_nt: null/empty operand (M=%d N=%d K=%d)", M, N, K);
@@ -1334,14 +1354,19 @@ extern "C" int ase_hip_gemm_nt(const void* A, int64_t lda, const void* B, int64_
     ASE_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && (lda * es) % 16 == 0 && (ldb * es) % 16 == 0,
                   "gemm_nt: A/B must be 16-byte aligned with 16-byte row pitch");
     ASE_CHECK_ARG(aux_mode == ASE_AUX_NONE || aux != nullptr, "gemm_nt: aux_mode %d without aux", aux_mode);
+    const bool bits = aux_mode == ASE_AUX_RELU_BITS;
     ASE_CHECK_ARG(N % 4 == 0 && ((uintptr_t)C % 16) == 0 && (ldc * (out_f32 ? 4 : es)) % 8 == 0 &&
-                      (aux == nullptr || (((uintptr_t)aux % 8) == 0 && (ldaux * es) % 8 == 0)),
+                      (aux == nullptr || bits || (((uintptr_t)aux % 8) == 0 && (ldaux * es) % 8 == 0)),
                   "gemm_nt: C / aux must allow 8/16-byte row-vector access (N %% 4 == 0, aligned pitches)");
+    ASE_CHECK_ARG(!bits || (((uintptr_t)aux % 4) == 0 && ldaux * 32 >= N), "gemm_nt: bit mask needs ldaux >= N / 32 words");
+    ASE_CHECK_ARG(mask_out == nullptr || (N % 32 == 0 && ((uintptr_t)mask_out % 4) == 0 && ldmask * 32 >= N),
+                  "gemm_nt: mask_out needs N %% 32 == 0 and ldmask >= N / 32 words");
     NTParams p;
     p.A = (const char*)A; p.lda = lda * es;
     p.B = (const char*)B; p.ldb = ldb * es;
     p.C = (char*)C; p.ldc = ldc * (out_f32 ? 4 : es);
-    p.bias = bias; p.aux = (const char*)aux; p.ldaux = ldaux * es; p.aux_split = aux_split > 0 ? aux_split : M; p.aux_delta = aux_delta; p.colsum = colsum; p.colsum_n = colsum ? colsum_n : 0;
+    p.mask_out = (uint32_t*)mask_out; p.ldmask = ldmask;
+    p.bias = bias; p.aux = (const char*)aux; p.ldaux = bits ? ldaux * 4 : ldaux * es; p.aux_split = aux_split > 0 ? aux_split : M; p.aux_delta = aux_delta; p.colsum = colsum; p.colsum_n = colsum ? colsum_n : 0;
     p.M = M; p.N = N; p.K = K; p.act = act; p.aux_mode = aux_mode; p.out_f32 = out_f32; p.alpha = alpha;
     p.tiles_m = p.tiles_n = 0;
     p.prof = nullptr;

@@ -84,6 +84,7 @@ class UpdateEngine:
         self._side_streams = None
         self._tn_defer = bool(getattr(backend, 'grouped_tn_ok', None)) and os.environ.get('ASE_TN_GROUPED', '1') != '0'
         self._tn_queue, self._tn_plans = [], {}
+        self._use_bits = os.environ.get('ASE_RELU_BITS', '1') != '0'
         self.force_dist = bool(cfg.get('force_dist', False))   # exercise the collectives with a 1-rank group
         self._refresh_desc = None
         self._mb_desc = None
@@ -191,8 +192,18 @@ class UpdateEngine:
         def zt(r, c, dt=T):
             return torch.zeros(r, c, dtype=dt, device=dev)
 
+        self._bits = {}      # activation buffer (storage pointer) -> (buffer, bit-mask twin [rows, n_pad / 32] int32)
+
+        def with_bits(h, d):
+            """ReLU activations get a bit-mask twin: the forward epilogue writes it (mask_out), the data-gradient
+            epilogue reads 1 bit instead of 2-4 bytes per element (ASE_AUX_RELU_BITS)."""
+            if d.act == L.ACT_RELU and self._use_bits:
+                self._bits[h.untyped_storage().data_ptr()] = (h, torch.zeros(h.shape[0], h.shape[1] // 32, dtype=torch.int32,
+                                                                                device=dev))
+            return h
+
         def chain_bufs(chain, rows):
-            return [zt(rows, d.n_pad) for d in chain], [zt(rows, d.n_pad) for d in chain]
+            return [with_bits(zt(rows, d.n_pad), d) for d in chain], [zt(rows, d.n_pad) for d in chain]
 
         f32 = torch.float32
         self.Xa = zt(Ra, self.actor[0].k_pad)
@@ -217,7 +228,7 @@ class UpdateEngine:
             self.Xd4 = zt(4 * AMB, self.disc[0].k_pad)                   # [Xd ; s*g_0]
             self.Xd = self.Xd4[:Rd]
             self.G0 = self.Xd4[Rd:]
-            self.Hd4 = [zt(4 * AMB, d.n_pad) for d in self.disc]         # [H_l ; dJ/dU_l (masked)]
+            self.Hd4 = [with_bits(zt(4 * AMB, d.n_pad), d) for d in self.disc]   # [H_l ; dJ/dU_l (masked)]
             self.dZd4 = [zt(4 * AMB, d.n_pad) for d in self.disc]        # [dZ_l ; s*g_l]
             self.Hd = [h[:Rd] for h in self.Hd4]
             self.dGp = [h[Rd:] for h in self.Hd4]
@@ -270,7 +281,29 @@ class UpdateEngine:
 
     # ------------------------------------------------------------------ primitive layer ops
     def _fwd(self, d, X, Y, rows, act=None):
-        self.be.gemm_nt(X, d.Ws, Y, rows, d.n_pad, d.k_pad, bias=d.bs, act=d.act if act is None else act)
+        act = d.act if act is None else act
+        self.be.gemm_nt(X, d.Ws, Y, rows, d.n_pad, d.k_pad, bias=d.bs, act=act,
+                        mask_out=self._mask_of(Y) if act == L.ACT_RELU else None)
+
+    def _aux(self, aux, mode):
+        """(aux tensor, aux mode) of a data-gradient launch: the bit-mask twin replaces a ReLU activation."""
+        if mode == L.AUX_RELU_MASK:
+            bits = self._mask_of(aux)
+            if bits is not None:
+                return bits, L.AUX_RELU_BITS
+        return (aux if mode else None), mode
+
+    def _mask_of(self, h):
+        """Bit-mask twin of (a row range of) an activation buffer, or None."""
+        e = self._bits.get(h.untyped_storage().data_ptr()) if h is not None else None
+        if e is None:
+            return None
+        base, bits = e
+        off = (h.data_ptr() - base.data_ptr()) // base.element_size()
+        r0, c0 = divmod(off, base.stride(0))
+        if c0 != 0 or h.shape[1] != base.shape[1]:
+            return None
+        return bits[r0:r0 + h.shape[0]]
 
     def _fwd_chain(self, chain, X, H, rows):
         for d, h in zip(chain, H):
@@ -282,8 +315,8 @@ class UpdateEngine:
         """dX = (dY @ W) * act'(aux): gradient w.r.t. the pre-activation of the layer that produced aux."""
         wts = d.Wts if wts is None else wts
         n_out = d.k_pad if n_out is None else n_out
-        self.be.gemm_nt(dY, wts, dX, rows, n_out, d.n_pad, aux=aux if _AUX[aux_act] else None, aux_mode=_AUX[aux_act],
-                        alpha=alpha)
+        aux, mode = self._aux(aux, _AUX[aux_act])
+        self.be.gemm_nt(dY, wts, dX, rows, n_out, d.n_pad, aux=aux, aux_mode=mode, alpha=alpha)
 
     def _wgrad(self, d, dY, X, rows, alpha=1.0, bias=True):
         """gW += dY^T X and (bias) gb += colsum(dY) from the same staged tiles.  Head groups computed their bias
@@ -558,18 +591,21 @@ class UpdateEngine:
         # data-gradient chain on 4 AMB rows: [dZ_l ; s g_l] -> [dZ_{l-1} ; s g_{l-1}]
         for l in range(nl - 1, 0, -1):
             d, pl = self.disc[l], self.disc[l - 1]
-            be.gemm_nt(self.dZd4[l], d.Wts, self.dZd4[l - 1], 4 * AMB, d.k_pad, d.n_pad, aux=self.Hd4[l - 1],
-                       aux_mode=_AUX[pl.act], aux_split=Rd, aux_delta=AMB)
+            aux, mode = self._aux(self.Hd4[l - 1], _AUX[pl.act])
+            be.gemm_nt(self.dZd4[l], d.Wts, self.dZd4[l - 1], 4 * AMB, d.k_pad, d.n_pad, aux=aux, aux_mode=mode,
+                       aux_split=Rd, aux_delta=AMB)
         d0 = self.disc[0]
         be.gemm_nt(self.Gp[0], d0.Wts, self.G0, AMB, d0.k_pad, d0.n_pad)                 # s * g_0
         be.sqnorm(self.G0, AMB, d0.k_pad, self.acc, L.ACC_GP, scale=1.0 / cg)
         # backward of the chain (values scaled by s; see the docstring): dJ/dU_l, masked by the demo rows' ReLU masks
-        be.gemm_nt(self.G0, d0.Ws, self.dGp[0], AMB, d0.n_pad, d0.k_pad, aux=self.Hd[0][2 * AMB:], aux_mode=L.AUX_RELU_MASK)
+        aux, mode = self._aux(self.Hd[0][2 * AMB:], L.AUX_RELU_MASK)
+        be.gemm_nt(self.G0, d0.Ws, self.dGp[0], AMB, d0.n_pad, d0.k_pad, aux=aux, aux_mode=mode)
         for l in range(1, nl):
             d = self.disc[l]
             last = l == nl - 1
-            be.gemm_nt(self.dGp[l - 1], d.Ws, self.dGp[l], AMB, d.n_pad, d.k_pad, aux=self.Hd[l][2 * AMB:],
-                       aux_mode=L.AUX_RELU_MASK, alpha=s if last else 1.0,
+            aux, mode = self._aux(self.Hd[l][2 * AMB:], L.AUX_RELU_MASK)
+            be.gemm_nt(self.dGp[l - 1], d.Ws, self.dGp[l], AMB, d.n_pad, d.k_pad, aux=aux,
+                       aux_mode=mode, alpha=s if last else 1.0,
                        colsum=self.disc_head.gW[0].view(-1) if last else None, colsum_n=d.N if last else 0)
         # weight (+ bias) gradients: one launch per layer over the stacked rows
         for l in range(nl):

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libase_hip.so")
 
 F32, BF16, F32X3 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
-AUX_NONE, AUX_RELU_MASK, AUX_TANH_GRAD = 0, 1, 2
+AUX_NONE, AUX_RELU_MASK, AUX_TANH_GRAD, AUX_RELU_BITS = 0, 1, 2, 3
 
 # accumulator slots (ASE_ACC_*)
 (ACC_MASK_SUM, ACC_A_LOSS, ACC_B_LOSS, ACC_ENTROPY, ACC_CLIPPED, ACC_C_LOSS, ACC_KL, ACC_DIV, ACC_BCE_AGENT,
@@ -28,7 +28,7 @@ _p, _i, _i64, _f, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 # name -> argtypes; every function returns int.  Keep in lock-step with include/ase_hip.h
 # (tests/test_abi.py parses the header and checks names + arity against this table).
 SIGNATURES = {
-    "ase_hip_gemm_nt": [_p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
+    "ase_hip_gemm_nt": [_p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _i, _i, _p, _i, _p, _i64, _i, _i, _i, _i, _i, _i, _f, _i, _p],
     "ase_hip_gemm_tn": [_p, _i64, _p, _i64, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
     "ase_hip_refresh_shadow": [_p, _i, _i, _p, _i64, _p, _i64, _i, _i, _i, _p],
     "ase_hip_refresh_shadow_multi": [_p, _i, _i, _p],

@@ -35,7 +35,7 @@ extern "C" {
 
 enum { ASE_F32 = 0, ASE_BF16 = 1, ASE_F32X3 = 2 /* f32 storage, products as 3 bf16 MFMAs on a hi/lo split (GEMMs only) */ };
 enum { ASE_ACT_NONE = 0, ASE_ACT_RELU = 1, ASE_ACT_TANH = 2 };
-enum { ASE_AUX_NONE = 0, ASE_AUX_RELU_MASK = 1, ASE_AUX_TANH_GRAD = 2 };
+enum { ASE_AUX_NONE = 0, ASE_AUX_RELU_MASK = 1, ASE_AUX_TANH_GRAD = 2, ASE_AUX_RELU_BITS = 3 /* aux = bit matrix written by mask_out */ };
 enum { ASE_OK = 0, ASE_EINVAL = -1, ASE_ELAUNCH = -2, ASE_EUNSUPPORTED = -3 };
 
 int ase_hip_abi_version(void);
@@ -56,14 +56,17 @@ int ase_hip_debug_nt_profile(void* buf);
  *   the gradient-penalty chain rides on the discriminator's data-gradient launches).
  *   colsum (nullable, f32[colsum_n]) += column sums of the stored values for n < colsum_n (atomic):
  *   the bias gradient of the producing layer.
+ *   mask_out (nullable, uint32 [M, ldmask], N % 32 == 0): bit n % 32 of word [m, n / 32] = (stored C[m,n] > 0).  A forward
+ *   ReLU layer writes it; the data-gradient launch of the same activation reads it as aux with ASE_AUX_RELU_BITS
+ *   (ldaux in words) - 1/16 of the bytes of re-reading the bf16 activation in the store-bound epilogue.
  * Replaces: nn.Linear + activation forward  (learning/ase_network_builder.py:255-259,305-324,
  *   learning/amp_network_builder.py:81-84), and autograd's data-gradient of the same layers
  *   (B = the transposed weight shadow; mask = derivative of the previous activation), and the
  *   transposed-MLP chain of the gradient penalty (learning/amp_agent.py:453-459). */
 int ase_hip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                     const float* bias, const void* aux, int64_t ldaux, int aux_split, int aux_delta,
-                    float* colsum, int colsum_n, int M, int N, int K, int act, int aux_mode, int out_f32, float alpha,
-                    int dtype, void* stream);
+                    float* colsum, int colsum_n, void* mask_out, int64_t ldmask, int M, int N, int K, int act,
+                    int aux_mode, int out_f32, float alpha, int dtype, void* stream);
 
 /* G[n, kmap(k)] += alpha * sum_m A[m,n] * B[m,k]   for n < n_real, kmap(k) valid     "TN" GEMM
  *   A [M,N] dtype (output gradients), B [M,K] dtype (layer inputs), G f32 [n_real, k_real]

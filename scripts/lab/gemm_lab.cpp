@@ -37,6 +37,16 @@ __global__ void fillf_kernel(float* x, int64_t n, uint64_t seed, float scale) {
     x[i] = ((float)(z >> 40) * (1.0f / 16777216.0f) * 2.f - 1.f) * scale;
 }
 
+__global__ void pack_bits_kernel(const bf16_t* aux, uint32_t* bits, int M, int N) {
+    const int64_t words = (int64_t)M * ((N + 31) / 32);
+    for (int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; w < words; w += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = w / ((N + 31) / 32); const int j = (int)(w % ((N + 31) / 32));
+        uint32_t v = 0;
+        for (int b = 0; b < 32 && j * 32 + b < N; ++b) v |= ((float)aux[m * N + j * 32 + b] > 0.f ? 1u : 0u) << b;
+        bits[w] = v;
+    }
+}
+
 // NT reference on sampled rows: out[s, n] = mask(act(sum_k A[row_s, k] B[n, k] + bias[n]))
 __global__ void ref_nt_kernel(const bf16_t* A, const bf16_t* B, const float* bias, const bf16_t* aux, const int* rows,
                               float* out, int N, int K, int relu) {
@@ -191,16 +201,20 @@ int main(int argc, char** argv) {
         fill_kernel<<<1024, 256, 0, st>>>(A, (int64_t)M * K, 1, 1.0f);
         fill_kernel<<<1024, 256, 0, st>>>(B, (int64_t)N * K, 2, 0.05f);
         fillf_kernel<<<(N + 255) / 256, 256, 0, st>>>(bias, N, 3, 0.5f);
+        uint32_t* bitsbuf = nullptr;     // use_aux: 1 = bf16 mask, 2 = bit mask (consumer), 3 = produce mask_out
+        CK(hipMalloc(&bitsbuf, (int64_t)M * ((N + 31) / 32) * 4));
         if (use_aux) { CK(hipMalloc(&aux, (int64_t)M * N * 2)); fill_kernel<<<1024, 256, 0, st>>>(aux, (int64_t)M * N, 4, 1.0f); }
+        if (use_aux == 2) pack_bits_kernel<<<4096, 256, 0, st>>>(aux, bitsbuf, M, N);
         CK(hipMemsetAsync(C, 0xff, (int64_t)M * N * 2, st));
         auto run = [&]() {
-            int rc = ase_hip_gemm_nt(A, K, B, K, C, N, bias, aux, N, 0, 0, nullptr, 0, M, N, K, relu ? ASE_ACT_RELU : ASE_ACT_NONE,
-                                     use_aux ? ASE_AUX_RELU_MASK : ASE_AUX_NONE, 0, 1.0f, ASE_BF16, st);
+            int rc = ase_hip_gemm_nt(A, K, B, K, C, N, bias, use_aux == 2 ? (void*)bitsbuf : (void*)aux, use_aux == 2 ? (N + 31) / 32 : N, 0, 0, nullptr, 0,
+                                     use_aux == 3 ? bitsbuf : nullptr, (N + 31) / 32, M, N, K, relu ? ASE_ACT_RELU : ASE_ACT_NONE,
+                                     use_aux == 2 ? ASE_AUX_RELU_BITS : (use_aux == 1 ? ASE_AUX_RELU_MASK : ASE_AUX_NONE), 0, 1.0f, ASE_BF16, st);
             if (rc) { printf("gemm_nt failed: %s\n", ase_hip_last_error()); exit(3); }
         };
         run();
         dim3 g((N + 127) / 128, S);
-        ref_nt_kernel<<<g, 128, 0, st>>>(A, B, bias, aux, drows, ref, N, K, relu);
+        ref_nt_kernel<<<g, 128, 0, st>>>(A, B, bias, (use_aux == 1 || use_aux == 2) ? aux : nullptr, drows, ref, N, K, relu);
         CK(hipStreamSynchronize(st));
         std::vector<float> href((size_t)S * N); std::vector<uint16_t> hc(N);
         CK(hipMemcpy(href.data(), ref, (size_t)S * N * 4, hipMemcpyDeviceToHost));
@@ -213,6 +227,15 @@ int main(int argc, char** argv) {
                 if (err > maxerr) maxerr = err;
                 if (fabs(r) > maxref) maxref = fabs(r);
                 if (!(err <= 0.02 + 0.01 * fabs(r))) { if (bad < 5) printf("  mismatch row %d col %d: ref %g got %g\n", rows[s], n, r, c); ++bad; }
+            }
+        }
+        if (use_aux == 3) {     // the produced bit mask must equal (stored C > 0) on the sampled rows
+            std::vector<uint32_t> hb((N + 31) / 32);
+            for (int s = 0; s < S; ++s) {
+                CK(hipMemcpy(hc.data(), C + (int64_t)rows[s] * N, N * 2, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(hb.data(), bitsbuf + (int64_t)rows[s] * ((N + 31) / 32), hb.size() * 4, hipMemcpyDeviceToHost));
+                for (int n = 0; n < N; ++n)
+                    if (((hb[n >> 5] >> (n & 31)) & 1u) != (bf2f(hc[n]) > 0.f ? 1u : 0u)) { if (bad < 5) printf("  mask bit mismatch row %d col %d\n", rows[s], n); ++bad; }
             }
         }
         for (int i = 0; i < 3; ++i) run();

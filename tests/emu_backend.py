@@ -36,7 +36,7 @@ class EmuBackend:
 
     # ------------------------------------------------------------------ GEMMs
     def gemm_nt(self, A, B, Cm, M, N, K, bias=None, aux=None, aux_mode=L.AUX_NONE, colsum=None, colsum_n=0,
-                act=L.ACT_NONE, alpha=1.0, aux_split=0, aux_delta=0):
+                act=L.ACT_NONE, alpha=1.0, aux_split=0, aux_delta=0, mask_out=None):
         if aux is not None and aux_split > 0:
             rows = torch.arange(M)
             rows = torch.where(rows >= aux_split, rows - aux_delta, rows)
@@ -52,11 +52,21 @@ class EmuBackend:
             v = torch.tanh(v)
         if aux_mode == L.AUX_RELU_MASK:
             v = v * (aux[:M, :N].float() > 0)
+        elif aux_mode == L.AUX_RELU_BITS:         # uint32 words, 32 columns each (stored as int32)
+            w = aux[:M, :(N + 31) // 32].to(torch.int64) & 0xFFFFFFFF
+            bits = (w.unsqueeze(-1) >> torch.arange(32)) & 1
+            v = v * bits.reshape(M, -1)[:, :N].to(v.dtype)
         elif aux_mode == L.AUX_TANH_GRAD:
             x = aux[:M, :N].float()
             v = v * (1 - x * x)
         out = v.to(Cm.dtype)
         Cm[:M, :N] = out
+        if mask_out is not None:
+            assert N % 32 == 0
+            b = (out.float() > 0).to(torch.int64).reshape(M, N // 32, 32)
+            w = (b << torch.arange(32)).sum(-1)
+            w = torch.where(w >= 2 ** 31, w - 2 ** 32, w)
+            mask_out[:M, :N // 32] = w.to(torch.int32)
         if colsum is not None and colsum_n > 0:
             colsum[:colsum_n] += out.float().sum(0)[:colsum_n]
 

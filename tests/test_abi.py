@@ -46,7 +46,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 def test_argument_validation_fails_loudly_without_gpu():
     """Null operands are rejected by the host-side checks before any launch (works without a GPU)."""
     lib = L.load()
-    rc = lib.ase_hip_gemm_nt(None, 0, None, 0, None, 0, None, None, 0, 0, 0, None, 0, 0, 0, 0, 0, 0, 0, 1.0, L.BF16, None)
+    rc = lib.ase_hip_gemm_nt(None, 0, None, 0, None, 0, None, None, 0, 0, 0, None, 0, None, 0, 0, 0, 0, 0, 0, 0, 1.0, L.BF16, None)
     assert rc == -1 and b'gemm_nt' in lib.ase_hip_last_error()
     with pytest.raises(L.AseHipError):
         L.check(rc, 'gemm_nt')

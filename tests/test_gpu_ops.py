@@ -441,3 +441,73 @@ def test_gemm_x3_split_mode(M, N, K):
     gref = Cg.cpu().double().t() @ X.double()
     gscale = float((Cg.cpu().abs().double().t() @ X.abs().double()).max())
     assert float((G.cpu().double() - gref).abs().max()) <= 3e-5 * gscale
+
+
+@pytest.mark.parametrize('dt', DT)
+@pytest.mark.parametrize('M,N,K', [(300, 192, 256), (777, 64, 128), (1024, 1024, 1024), (4096, 512, 320)])
+def test_gemm_nt_relu_bit_mask(be, dt, M, N, K):
+    """mask_out of a forward ReLU layer = (stored activation > 0), bit-exact against the emulation; the data-gradient
+    launch that reads the bits (ASE_AUX_RELU_BITS, with a stacked row block wrapping onto earlier rows) equals the one
+    that reads the activation itself (ASE_AUX_RELU_MASK), bit for bit."""
+    g = torch.Generator().manual_seed(M + N)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(dt)
+    B = (torch.randn(N, K, generator=g) * 0.1).to(dt)
+    bias = torch.randn(N, generator=g)
+    Hg, Hc = torch.zeros(M, N, dtype=dt).cuda(), torch.zeros(M, N, dtype=dt)
+    Wg = torch.full((M, N // 32 + 2), -1, dtype=torch.int32).cuda()        # ldmask > N / 32
+    Wc = torch.full((M, N // 32 + 2), -1, dtype=torch.int32)
+    be.gemm_nt(A.cuda(), B.cuda(), Hg, M, N, K, bias=bias.cuda(), act=L.ACT_RELU, mask_out=Wg)
+    EmuBackend().gemm_nt(A, B, Hc, M, N, K, bias=bias, act=L.ACT_RELU, mask_out=Wc)
+    w = Wg.cpu().to(torch.int64) & 0xFFFFFFFF
+    bits = ((w[:, :N // 32].unsqueeze(-1) >> torch.arange(32)) & 1).reshape(M, N).bool()
+    assert torch.equal(bits, Hg.float().cpu() > 0)
+    assert torch.equal(Wg.cpu()[:, N // 32:], Wc[:, N // 32:])             # pad words untouched
+    # data gradient with 1.5 M rows: the extra half block re-uses the masks of rows M/2 .. M
+    K2, R = 128, M + M // 2
+    dY = (torch.randn(R, K2, generator=g) * 0.3).to(dt).cuda()
+    Wt = (torch.randn(N, K2, generator=g) * 0.1).to(dt).cuda()
+    d1, d2 = torch.zeros(R, N, dtype=dt).cuda(), torch.zeros(R, N, dtype=dt).cuda()
+    be.gemm_nt(dY, Wt, d1, R, N, K2, aux=Hg, aux_mode=L.AUX_RELU_MASK, aux_split=M, aux_delta=M // 2)
+    be.gemm_nt(dY, Wt, d2, R, N, K2, aux=Wg, aux_mode=L.AUX_RELU_BITS, aux_split=M, aux_delta=M // 2)
+    assert torch.equal(d1, d2)
+    assert float(d1.float().abs().max()) > 0
+
+
+def test_gemm_tn_grouped_matches_per_layer(be):
+    """One grouped launch over several layers (different row counts, widths, concat column maps, bias row limits)
+    against the per-layer kernel and the emulation."""
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(21)
+    shapes = [(2048, 512, 1024, 512, 1024, 1024, 1024, 0), (4096, 1024, 320, 1024, 317, 253, 256, 0),
+              (1024, 256, 1408, 200, 1400, 1400, 1400, 768), (2048, 1024, 1024, 1024, 1024, 1024, 1024, 1536)]
+    probs, ref = [], []
+    for (M, N, K, nr, kr, ss, sd, br) in shapes:
+        A = (torch.randn(M, N, generator=g) * 0.2).to(dt)
+        B = (torch.randn(M, K, generator=g) * 0.2).to(dt)
+        G0, b0 = torch.randn(nr, kr, generator=g), torch.randn(nr, generator=g)
+        Gc, bc = G0.clone(), b0.clone()
+        EmuBackend().gemm_tn(A, B, Gc, M, N, K, nr, kr, ss, sd, alpha=0.5, gbias=bc, bias_rows=br)
+        ref.append((Gc, bc, M))
+        probs.append((A.cuda(), B.cuda(), G0.cuda(), b0.cuda(), br if br else M, M, N, K, nr, kr, ss, sd, 0.5))
+        assert be.grouped_tn_ok(dt, M, nr, K, br if br else M)
+    plan = be.make_tn_plan(probs)
+    assert plan['n_work'] >= len(shapes)
+    be.gemm_tn_grouped(plan)
+    for (A, B, G, gb, *_), (Gc, bc, M) in zip(probs, ref):
+        close(G, Gc, 3e-5, 3e-5 * math.sqrt(M), 'grouped tn G')
+        close(gb, bc, 3e-5, 3e-5 * math.sqrt(M), 'grouped tn bias')
+
+
+@pytest.mark.parametrize('M,N,K', [(16384, 1024, 1024), (8192, 512, 1408), (16000, 1000, 192), (32768, 256, 64)])
+def test_gemm_nt_phased_tile(be, M, N, K):
+    """Shapes that take the phased 256 x 256 kernel (whole rounds of tiles) incl. ragged edges and 1-3 K-tiles."""
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(K)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(dt)
+    B = (torch.randn(N, K, generator=g) * 0.1).to(dt)
+    bias = torch.randn(N, generator=g)
+    Cg, Cc = torch.zeros(M, N, dtype=dt).cuda(), torch.zeros(M, N, dtype=dt)
+    be.gemm_nt(A.cuda(), B.cuda(), Cg, M, N, K, bias=bias.cuda(), act=L.ACT_RELU)
+    EmuBackend().gemm_nt(A, B, Cc, M, N, K, bias=bias, act=L.ACT_RELU)
+    rt, at = _tol(dt)
+    close(Cg.float(), Cc.float(), rt, at * math.sqrt(K / 64), f'nt phased {M}x{N}x{K}')
