@@ -160,97 +160,129 @@ struct NTParams {
 // i.e. a lane owns ONE column: storing from registers would be 2-byte scattered stores.  Phase 1 applies bias +
 // activation (per-column bias = per-lane scalar) and transposes FMC x FNC fragments of the wave's sub-tile through a
 // wave-private f32 LDS slab [FMC*32][FNC*32] (row pitch 64 dwords: ds_write_b32 and ds_read_b128 are both
-// conflict-free); phase 2 lets every lane pick up 4 consecutive columns of a row, applies the derivative mask from
-// 8/16-byte aux loads, issues 8/16-byte row-contiguous stores (full 128-byte lines per row) and keeps per-column
-// partial sums for the bias gradient.  The caller guarantees that nobody still reads the staging ring (barrier).
-template <typename T, int FM, int FN, int FMC, int FNC>
-__device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x16 (&acc)[FM][FN], float* slab, int lane, int mrow0,
-                                            int ncol0) {
+// conflict-free); phase 2 lets every lane pick up 4 consecutive columns of a row, applies the derivative mask,
+// issues 8/16-byte row-contiguous stores (full 128-byte lines per row) and keeps per-column partial sums for the bias
+// gradient.  The caller guarantees that nobody still reads the staging ring (barrier).
+//   The mask operand (AUXK = 1: the activation itself, 8/16 bytes per lane and row; AUXK = 2: its bit matrix, one word)
+// is loaded a whole chunk AHEAD of its use - all rows of a chunk at once, the next chunk's before the current chunk's
+// LDS transposition: left inside the row loop the loads cost one exposed HBM round trip per 4 rows (+10 us on a
+// 256 x 256 tile, measured, whatever their width).
+template <typename T, int AUXK> struct AuxReg;
+template <typename T> struct AuxReg<T, 0> { char v; };
+template <> struct AuxReg<bf16_t, 1> { bf16x4 v; };
+template <> struct AuxReg<float, 1> { f32x4 v; };
+template <> struct AuxReg<f32s_t, 1> { f32x4 v; };
+template <typename T> struct AuxReg<T, 2> { uint32_t v; };
+
+// OR over aligned groups of 8 lanes with DPP only (no LDS round trip): xor 1, xor 2, then the half-row mirror
+__device__ __forceinline__ uint32_t or8_dpp(uint32_t x) {
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+    x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, true);   // row_half_mirror
+    return x;
+}
+
+template <typename T, int FM, int FN, int FMC, int FNC, int AUXK>
+__device__ __forceinline__ void nt_epilogue_impl(const NTParams& p, f32x16 (&acc)[FM][FN], float* slab, int lane,
+                                                 int mrow0, int ncol0) {
     constexpr int WCOLS = FNC * 32, WROWS = FMC * 32;
     const int col_in = lane & 31, row_hi = (lane >> 5) * 4;
     constexpr int ELPR = WCOLS / 4;                // lanes per row (4 columns each)
     constexpr int RPI = 64 / ELPR;                 // rows per iteration
+    constexpr int NIT = WROWS / RPI;               // row iterations per chunk
+    constexpr int NCH = (FN / FNC) * (FM / FMC);   // chunks, jc-major
+    constexpr bool AHEAD = AUXK != 0 && sizeof(AuxReg<T, AUXK>) <= 8;   // 16-byte f32 masks: current chunk only
     const int c4 = lane % ELPR, rsub = lane / ELPR;
+    AuxReg<T, AUXK> areg[AHEAD ? 2 : 1][NIT];
+
+    auto load_aux = [&](int ch, AuxReg<T, AUXK> (&dst)[NIT]) {
+        if constexpr (AUXK != 0) {
+            const int jc = (ch / (FM / FMC)) * FNC, ic = (ch % (FM / FMC)) * FMC;
+            const int n0 = ncol0 + jc * 32 + c4 * 4;
 #pragma unroll
-    for (int jc = 0; jc < FN; jc += FNC) {
-        const int n0 = ncol0 + jc * 32 + c4 * 4;
-        float cs[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ic = 0; ic < FM; ic += FMC) {
-#pragma unroll
-            for (int jj = 0; jj < FNC; ++jj) {
-                const int j = jc + jj;
-                const int n = ncol0 + j * 32 + col_in;
-                const float bias = (p.bias && n < p.N) ? p.bias[n] : 0.f;
-#pragma unroll
-                for (int ii = 0; ii < FMC; ++ii) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        float v = p.alpha * acc[ic + ii][j][e] + bias;
-                        if (p.act == ASE_ACT_RELU) v = fmaxf(v, 0.f);
-                        else if (p.act == ASE_ACT_TANH) v = tanhf(v);
-                        slab[(ii * 32 + row_hi + (e & 3) + 8 * (e >> 2)) * WCOLS + jj * 32 + col_in] = v;
-                    }
-                }
-            }
-            if (n0 < p.N) {                                // N is a multiple of 4 (checked on the host)
-#pragma unroll 4
-                for (int it = 0; it < WROWS / RPI; ++it) {
-                    const int row = it * RPI + rsub;
-                    const int m = mrow0 + ic * 32 + row;
-                    if (m >= p.M) continue;
-                    f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * WCOLS + c4 * 4);
-                    if (p.aux_mode == ASE_AUX_RELU_BITS) {
-                        // 32 columns per word: the 8 lanes of a word load the same 4 bytes
-                        const int ma = (m >= p.aux_split) ? m - p.aux_delta : m;
-                        const uint32_t w = *reinterpret_cast<const uint32_t*>(p.aux + (int64_t)ma * p.ldaux + (n0 >> 5) * 4);
-                        const uint32_t nib = w >> (n0 & 31);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] = ((nib >> q) & 1u) ? v[q] : 0.f;
-                    } else if (p.aux_mode != ASE_AUX_NONE) {
-                        float a[4];
-                        const int ma = (m >= p.aux_split) ? m - p.aux_delta : m;
-                        const char* ap = p.aux + (int64_t)ma * p.ldaux + (int64_t)n0 * sizeof(T);
-                        if constexpr (sizeof(T) == 2) {
-                            const bf16x4 av = *reinterpret_cast<const bf16x4*>(ap);
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) a[q] = (float)av[q];
-                        } else {
-                            const f32x4 av = *reinterpret_cast<const f32x4*>(ap);
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) a[q] = av[q];
-                        }
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            v[q] = (p.aux_mode == ASE_AUX_RELU_MASK) ? (a[q] > 0.f ? v[q] : 0.f) : v[q] * (1.f - a[q] * a[q]);
-                    }
-                    if (p.out_f32 || sizeof(T) == 4) {
-                        *reinterpret_cast<f32x4*>(p.C + (int64_t)m * p.ldc + (int64_t)n0 * 4) = v;
-                    } else {
-                        bf16x4 o;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            o[q] = (bf16_t)v[q];
-                            v[q] = (float)o[q];
-                        }
-                        *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + (int64_t)n0 * 2) = o;
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) cs[q] += v[q];
-                    if (p.mask_out) {
-                        // nibble of this lane's 4 columns -> OR over the 8 lanes of a 32-column word -> one 4-byte store
-                        uint32_t bits = 0;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) bits |= (v[q] > 0.f ? 1u : 0u) << q;
-                        bits <<= (n0 & 31);
-                        bits |= __shfl_xor(bits, 1, 64);
-                        bits |= __shfl_xor(bits, 2, 64);
-                        bits |= __shfl_xor(bits, 4, 64);
-                        if ((c4 & 7) == 0) p.mask_out[(int64_t)m * p.ldmask + (n0 >> 5)] = bits;
-                    }
+            for (int it = 0; it < NIT; ++it) {
+                const int m = mrow0 + ic * 32 + it * RPI + rsub;
+                if (n0 < p.N && m < p.M) {
+                    const int ma = (m >= p.aux_split) ? m - p.aux_delta : m;
+                    if constexpr (AUXK == 2)
+                        dst[it].v = *reinterpret_cast<const uint32_t*>(p.aux + (int64_t)ma * p.ldaux + (n0 >> 5) * 4);
+                    else
+                        dst[it].v = *reinterpret_cast<const decltype(dst[it].v)*>(p.aux + (int64_t)ma * p.ldaux + (int64_t)n0 * sizeof(T));
                 }
             }
         }
+    };
+
+    if constexpr (AUXK != 0) load_aux(0, areg[0]);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int jc = (ch / (FM / FMC)) * FNC, ic = (ch % (FM / FMC)) * FMC;
+        const int n0 = ncol0 + jc * 32 + c4 * 4;
+        if constexpr (AHEAD) {
+            if (ch + 1 < NCH) load_aux(ch + 1, areg[(ch + 1) & 1]);
+        } else if constexpr (AUXK != 0) {
+            if (ch > 0) load_aux(ch, areg[0]);
+        }
+        AuxReg<T, AUXK> (&cur)[NIT] = areg[AHEAD ? (ch & 1) : 0];
+#pragma unroll
+        for (int jj = 0; jj < FNC; ++jj) {
+            const int j = jc + jj;
+            const int n = ncol0 + j * 32 + col_in;
+            const float bias = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int ii = 0; ii < FMC; ++ii) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float v = p.alpha * acc[ic + ii][j][e] + bias;
+                    if (p.act == ASE_ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (p.act == ASE_ACT_TANH) v = tanhf(v);
+                    slab[(ii * 32 + row_hi + (e & 3) + 8 * (e >> 2)) * WCOLS + jj * 32 + col_in] = v;
+                }
+            }
+        }
+        float cs[4] = {0.f, 0.f, 0.f, 0.f};
+        if (n0 < p.N) {                                // N is a multiple of 4 (checked on the host)
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int row = it * RPI + rsub;
+                const int m = mrow0 + ic * 32 + row;
+                if (m >= p.M) continue;
+                f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * WCOLS + c4 * 4);
+                if constexpr (AUXK == 2) {
+                    const uint32_t nib = cur[it].v >> (n0 & 31);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = ((nib >> q) & 1u) ? v[q] : 0.f;
+                } else if constexpr (AUXK == 1) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float a = (float)cur[it].v[q];
+                        v[q] = (p.aux_mode == ASE_AUX_RELU_MASK) ? (a > 0.f ? v[q] : 0.f) : v[q] * (1.f - a * a);
+                    }
+                }
+                if (p.out_f32 || sizeof(T) == 4) {
+                    *reinterpret_cast<f32x4*>(p.C + (int64_t)m * p.ldc + (int64_t)n0 * 4) = v;
+                } else {
+                    bf16x4 o;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        o[q] = (bf16_t)v[q];
+                        v[q] = (float)o[q];
+                    }
+                    *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + (int64_t)n0 * 2) = o;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cs[q] += v[q];
+                if (p.mask_out) {
+                    // nibble of this lane's 4 columns -> OR over the 8 lanes of a 32-column word -> one 4-byte store
+                    uint32_t bits = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bits |= (v[q] > 0.f ? 1u : 0u) << q;
+                    bits = or8_dpp(bits << (n0 & 31));
+                    if ((c4 & 7) == 0) p.mask_out[(int64_t)m * p.ldmask + (n0 >> 5)] = bits;
+                }
+            }
+        }
+        // bias gradient: the chunks of one column group (same jc) follow each other; flush after the last of them
         if (p.colsum) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -264,6 +296,14 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x16 (&acc)[FM]
             }
         }
     }
+}
+
+template <typename T, int FM, int FN, int FMC, int FNC>
+__device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x16 (&acc)[FM][FN], float* slab, int lane, int mrow0,
+                                            int ncol0) {
+    if (p.aux_mode == ASE_AUX_NONE) nt_epilogue_impl<T, FM, FN, FMC, FNC, 0>(p, acc, slab, lane, mrow0, ncol0);
+    else if (p.aux_mode == ASE_AUX_RELU_BITS) nt_epilogue_impl<T, FM, FN, FMC, FNC, 2>(p, acc, slab, lane, mrow0, ncol0);
+    else nt_epilogue_impl<T, FM, FN, FMC, FNC, 1>(p, acc, slab, lane, mrow0, ncol0);
 }
 
 template <typename T, int WGM, int WGN, int FM, int FN, int RB, int S>
@@ -625,14 +665,7 @@ template <typename T> int dispatch_nt(const NTParams& p, hipStream_t s) {
     if (big && force != 128) {
         if constexpr (sizeof(T) == 2) {
             if (variant != 3 && k128) {                                  // phased kernel (ASE_NT_VARIANT=3: the lock-step one)
-                static int sched = -1;
-                if (sched < 0) { const char* e = getenv("ASE_NT8_SCHED"); sched = e ? atoi(e) : 0; }
-                switch (sched) {
-                    case 1: return launch_nt8<T, 1>(p, s);
-                    case 2: return launch_nt8<T, 2>(p, s);
-                    case 3: return launch_nt8<T, 3>(p, s);
-                    default: return launch_nt8<T, 0>(p, s);
-                }
+                return launch_nt8<T, 0>(p, s);
             }
         }
         if ((variant == 1 || variant == 3) && k128) return launch_nt<T, 4, 2, 2, 4, 128, 2>(p, s);
