@@ -116,6 +116,11 @@ class HipBackend:
         L.check(self.lib.ase_hip_refresh_shadow_multi(_ptr(desc), desc.shape[0], _code(dtype), self._stream()),
                 "refresh_shadow_multi")
 
+    def apply_multi(self, desc, items, dtype, opt_state, acc):
+        """Fused optimizer step + shadow refresh of every layer (desc: device int64 [n, 24], see ase_hip.h)."""
+        L.check(self.lib.ase_hip_apply_multi(_ptr(desc), desc.shape[0], _ptr(opt_state), _ptr(acc), _code(dtype),
+                                             self._stream()), "apply_multi")
+
     def gather_multi(self, desc, items, idx, remap, M):
         L.check(self.lib.ase_hip_gather_multi(_ptr(desc), desc.shape[0], _ptr(idx), remap[0], remap[1], M,
                                               self._stream()), "gather_multi")

@@ -661,7 +661,7 @@ template <typename T> int dispatch_nt(const NTParams& p, hipStream_t s) {
     // 256 x 256 tile, 8 waves of 64 x 128: half the L2->LDS bytes per flop of the 128 x 128 tile, one workgroup per
     // CU.  Used when the grid still fills the 256 CUs in whole rounds.
     const int t256 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-    const bool big = (force == 256) || (force == 0 && p.N % 256 == 0 && t256 >= 240 && (t256 % 256 == 0 || t256 >= 1024));
+    const bool big = (force == 256) || (force == 0 && p.N % 256 == 0 && t256 >= 192 && (t256 <= 256 || t256 % 256 == 0 || t256 >= 1024));
     if (big && force != 128) {
         if constexpr (sizeof(T) == 2) {
             if (variant != 3 && k128) {                                  // phased kernel (ASE_NT_VARIANT=3: the lock-step one)

@@ -296,16 +296,32 @@ __global__ __launch_bounds__(256) void gp_seed_kernel(const T* __restrict__ h, i
     }
 }
 
-template <typename T>
+// 16-byte row chunks (8 bf16 / 4 f32), f32 partial per chunk, f64 across chunks; cols % VEC == 0 and 16-byte aligned rows
+// (the host falls back to VEC = 1 otherwise)
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void sqnorm_kernel(const T* __restrict__ x, int64_t ld, int rows, int cols,
                                                      double* __restrict__ acc, double scale) {
     __shared__ double sm[16];
-    const int64_t n = (int64_t)rows * cols;
+    const int cpr = cols / VEC;                            // chunks per row
+    const int64_t n = (int64_t)rows * cpr;
     double v[1] = {0.0};
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int r = (int)(i / cols), j = (int)(i - (int64_t)r * cols);
-        const double t = (double)to_f32(x[(int64_t)r * ld + j]);
-        v[0] += t * t;
+        const int r = (int)(i / cpr), j = (int)(i - (int64_t)r * cpr) * VEC;
+        const T* p = x + (int64_t)r * ld + j;
+        float s = 0.f;
+        if constexpr (VEC == 8) {
+            const bf16x8 q = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float t = (float)q[e]; s += t * t; }
+        } else if constexpr (VEC == 4) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += q[e] * q[e];
+        } else {
+            const float t = to_f32(p[0]);
+            s = t * t;
+        }
+        v[0] += (double)s;
     }
     block_sum<1>(v, sm);
     if (threadIdx.x == 0) atomic_add_f64(acc, v[0] * scale);
@@ -456,14 +472,16 @@ extern "C" int ase_hip_gp_seed(const void* h, int64_t ld_h, const float* w, void
 extern "C" int ase_hip_sqnorm(const void* x, int64_t ld, int rows, int cols, double* acc, int slot, double scale,
                               int dtype, void* stream) {
     ASE_CHECK_ARG(x && acc && rows > 0 && cols > 0 && slot >= 0, "sqnorm: null/empty operand");
-    const dim3 grid(grid_for((int64_t)rows * cols, 2048, 256));
-    if (dtype == ASE_BF16)
-        hipLaunchKernelGGL(sqnorm_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, rows,
-                           cols, acc + slot, scale);
-    else if (dtype == ASE_F32)
-        hipLaunchKernelGGL(sqnorm_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ld, rows,
-                           cols, acc + slot, scale);
-    else ASE_CHECK_ARG(false, "sqnorm: bad dtype %d", dtype);
+    const int es = dtype == ASE_BF16 ? 2 : 4, vec = 16 / es;
+    const bool wide = cols % vec == 0 && (ld * es) % 16 == 0 && ((uintptr_t)x % 16) == 0;
+    const dim3 grid(grid_for((int64_t)rows * cols / (wide ? vec : 1), 2048, 256));
+    if (dtype == ASE_BF16) {
+        if (wide) hipLaunchKernelGGL((sqnorm_kernel<bf16_t, 8>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, rows, cols, acc + slot, scale);
+        else hipLaunchKernelGGL((sqnorm_kernel<bf16_t, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, rows, cols, acc + slot, scale);
+    } else if (dtype == ASE_F32) {
+        if (wide) hipLaunchKernelGGL((sqnorm_kernel<float, 4>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ld, rows, cols, acc + slot, scale);
+        else hipLaunchKernelGGL((sqnorm_kernel<float, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ld, rows, cols, acc + slot, scale);
+    } else ASE_CHECK_ARG(false, "sqnorm: bad dtype %d", dtype);
     ASE_CHECK_LAUNCH("sqnorm");
     return ASE_OK;
 }

@@ -41,6 +41,109 @@ __global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ g, const 
         g[i] = g[i] + c * w[i];
 }
 
+// ---- fused optimizer step over every dense layer (one launch) -------------------------------------------------------
+// desc[l] (int64 x 24), one entry per weight matrix:
+//   0 W  1 n_real  2 k_real  3 Ws  4 ldws  5 Wts  6 ldwts  7 split_src  8 gap  9 bias  10 bias_shadow  11 tiles_k
+//   12 gW  13 mW  14 vW  15 gb  16 mb  17 vb  18 wd coefficient (f32 bits)  19 acc slot A (or -1)  20 acc slot B (or -1)
+// Per 32 x 32 tile of W (rows coalesced): g += wd * w (weight-only loss terms), sum of w^2 of the PRE-update weights
+// into acc[slot A / B] (reported regularisers), Adam, then the fresh weight goes straight into the compute-dtype
+// shadows W_s (row-major) and W_s^T (through an LDS transpose).  The first workgroup of a layer also steps the bias.
+__device__ __forceinline__ float adam_elem(float w, float gi, float& mi, float& vi, float one_m_b1, float b2,
+                                           float one_m_b2, float eps, float step_size, float bc2_sqrt) {
+    mi = mi + one_m_b1 * (gi - mi);                 // exp_avg.lerp_(grad, 1 - beta1)
+    vi = vi * b2;                                   // exp_avg_sq.mul_(beta2)
+    vi = vi + one_m_b2 * (gi * gi);                 //            .addcmul_(grad, grad, value=1 - beta2)
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    return w - step_size * (mi / denom);            // param.addcdiv_(exp_avg, denom, value=-step_size)
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void apply_multi_kernel(const int64_t* __restrict__ desc, const double* __restrict__ st,
+                                                          double* __restrict__ acc) {
+    __shared__ float tile[32][33];
+    __shared__ double red[16];
+    const int64_t* d = desc + 24 * blockIdx.y;
+    float* W = reinterpret_cast<float*>(d[0]);
+    const int n_real = (int)d[1], k_real = (int)d[2];
+    T* Ws = reinterpret_cast<T*>(d[3]);
+    const int64_t ldws = d[4];
+    T* Wts = reinterpret_cast<T*>(d[5]);
+    const int64_t ldwts = d[6];
+    const int split_src = (int)d[7], gap = (int)d[8];
+    const int tiles_k = (int)d[11];
+    float* gW = reinterpret_cast<float*>(d[12]);
+    float* mW = reinterpret_cast<float*>(d[13]);
+    float* vW = reinterpret_cast<float*>(d[14]);
+    const float wd = __builtin_bit_cast(float, (int)d[18]);
+    const int slot_a = (int)d[19], slot_b = (int)d[20];
+    const bool adam = st != nullptr;
+    float one_m_b1 = 0.f, b2 = 0.f, one_m_b2 = 0.f, eps = 0.f, step_size = 0.f, bc2_sqrt = 1.f;
+    if (adam) {      // scalars are formed in double (as torch does in Python) and applied in f32
+        one_m_b1 = (float)(1.0 - st[2]); b2 = (float)st[3]; one_m_b2 = (float)(1.0 - st[3]);
+        eps = (float)st[4]; step_size = (float)(st[1] / st[5]); bc2_sqrt = (float)sqrt(st[6]);
+    }
+    const int tiles = tiles_k * ((n_real + 31) / 32);
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    if (blockIdx.x == 0 && d[9]) {
+        float* b = reinterpret_cast<float*>(d[9]);
+        float* bs = reinterpret_cast<float*>(d[10]);
+        float* gb = reinterpret_cast<float*>(d[15]);
+        float* mb = reinterpret_cast<float*>(d[16]);
+        float* vb = reinterpret_cast<float*>(d[17]);
+        for (int i = threadIdx.x; i < n_real; i += 256) {
+            float w = b[i];
+            if (adam) {
+                float mi = mb[i], vi = vb[i];
+                w = adam_elem(w, gb[i], mi, vi, one_m_b1, b2, one_m_b2, eps, step_size, bc2_sqrt);
+                b[i] = w; mb[i] = mi; vb[i] = vi;
+            }
+            bs[i] = w;
+        }
+    }
+    double w2[1] = {0.0};
+    for (int t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const int k0 = (t % tiles_k) * 32, n0 = (t / tiles_k) * 32;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + ty + 8 * i, k = k0 + tx;
+            float w = 0.f;
+            if (n < n_real && k < k_real) {
+                const int64_t o = (int64_t)n * k_real + k;
+                w = W[o];
+                if (adam) {
+                    if (slot_a >= 0) w2[0] += (double)w * (double)w;
+                    float gi = gW[o];
+                    if (wd != 0.f) {
+                        gi = gi + wd * w;
+                        gW[o] = gi;                       // the exported gradient includes the weight-only terms
+                    }
+                    float mi = mW[o], vi = vW[o];
+                    w = adam_elem(w, gi, mi, vi, one_m_b1, b2, one_m_b2, eps, step_size, bc2_sqrt);
+                    W[o] = w; mW[o] = mi; vW[o] = vi;
+                }
+                Ws[(int64_t)n * ldws + ((k < split_src) ? k : k + gap)] = from_f32<T>(w);
+            }
+            tile[ty + 8 * i][tx] = w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + ty + 8 * i, n = n0 + tx;
+            if (k < k_real && n < n_real)
+                Wts[(int64_t)((k < split_src) ? k : k + gap) * ldwts + n] = from_f32<T>(tile[tx][ty + 8 * i]);
+        }
+    }
+    if (adam && slot_a >= 0) {
+        __syncthreads();
+        block_sum<1>(w2, red);
+        if (threadIdx.x == 0 && w2[0] != 0.0) {
+            atomic_add_f64(acc + slot_a, w2[0]);
+            if (slot_b >= 0) atomic_add_f64(acc + slot_b, w2[0]);
+        }
+    }
+}
+
 inline int grid_for(int64_t n) {
     int64_t g = (n + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -67,5 +170,20 @@ extern "C" int ase_hip_axpy(float* g, const float* w, int64_t n, float c, void* 
     ASE_CHECK_ARG(g && w && n > 0, "axpy: null/empty operand");
     hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, w, n, c);
     ASE_CHECK_LAUNCH("axpy");
+    return ASE_OK;
+}
+
+extern "C" int ase_hip_apply_multi(const int64_t* desc, int n_layers, const double* opt_state, double* acc, int dtype,
+                                   void* stream) {
+    ASE_CHECK_ARG(desc && n_layers > 0, "apply_multi: null/empty operand");
+    ASE_CHECK_ARG(opt_state == nullptr || acc != nullptr, "apply_multi: optimizer step without the accumulator array");
+    const dim3 grid(256, n_layers);
+    if (dtype == ASE_BF16)
+        hipLaunchKernelGGL(apply_multi_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, desc, opt_state, acc);
+    else if (dtype == ASE_F32)
+        hipLaunchKernelGGL(apply_multi_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, desc, opt_state, acc);
+    else
+        ASE_CHECK_ARG(false, "apply_multi: bad dtype %d", dtype);
+    ASE_CHECK_LAUNCH("apply_multi");
     return ASE_OK;
 }

@@ -85,6 +85,8 @@ class UpdateEngine:
         self._tn_defer = bool(getattr(backend, 'grouped_tn_ok', None)) and os.environ.get('ASE_TN_GROUPED', '1') != '0'
         self._tn_queue, self._tn_plans = [], {}
         self._use_bits = os.environ.get('ASE_RELU_BITS', '1') != '0'
+        self._fused_apply = hasattr(backend, 'apply_multi') and os.environ.get('ASE_FUSED_APPLY', '1') != '0'
+        self._apply_desc = self._apply_items = None
         self.force_dist = bool(cfg.get('force_dist', False))   # exercise the collectives with a 1-rank group
         self._refresh_desc = None
         self._mb_desc = None
@@ -278,6 +280,47 @@ class UpdateEngine:
             self._refresh_desc = torch.tensor(rows, dtype=torch.int64, device=self.dev)
             self._refresh_items = items
         self.be.refresh_shadow_multi(self._refresh_desc, self._refresh_items, self.dtype)
+
+    def _build_apply_desc(self):
+        """Pointer table of ase_hip_apply_multi: per weight matrix its parameter / gradient / Adam-moment slices, the
+        summed coefficient of its weight-only loss terms and the accumulator slots of the reported norms."""
+        if self._apply_desc is not None:
+            return
+        import struct
+        c = self.cfg
+        terms = {}
+        for W, gW, coef, slot in self.l2_terms:
+            t = terms.setdefault(W.data_ptr(), [0.0, []])
+            t[0] += coef
+            if slot is not None and slot not in t[1]:
+                t[1].append(slot)
+        if self.has_disc:
+            t = terms.setdefault(self.disc_head.W[0].data_ptr(), [0.0, []])
+            t[1].insert(0, L.ACC_LOGIT_W2)
+            if c['disc_weight_decay'] != 0 and L.ACC_DISC_W2 not in t[1]:
+                t[1].append(L.ACC_DISC_W2)
+        base = self.params.data_ptr()
+        rows, items = [], []
+        for d in self.layers:
+            for (name, nr, off), W, b, gW, gb in zip(d.parts, d.W, d.b, d.gW, d.gb):
+                ws, wts, bs = d.Ws[off:], d.Wts[:, off:], d.bs[off:off + nr]
+                ow, ob = (W.data_ptr() - base) // 4, (b.data_ptr() - base) // 4
+                mW, vW = self.adam_m[ow:ow + W.numel()], self.adam_v[ow:ow + W.numel()]
+                mb, vb = self.adam_m[ob:ob + nr], self.adam_v[ob:ob + nr]
+                coef, slots = terms.get(W.data_ptr(), [0.0, []])
+                assert len(slots) <= 2, slots
+                sa = slots[0] if len(slots) > 0 else -1
+                sb = slots[1] if len(slots) > 1 else -1
+                rows.append([W.data_ptr(), nr, d.K, ws.data_ptr(), ws.stride(0), wts.data_ptr(), wts.stride(0), d.split_src,
+                             d.split_dst - d.split_src, b.data_ptr(), bs.data_ptr(), (d.K + 31) // 32, gW.data_ptr(),
+                             mW.data_ptr(), vW.data_ptr(), gb.data_ptr(), mb.data_ptr(), vb.data_ptr(),
+                             struct.unpack('<i', struct.pack('<f', float(coef)))[0], sa, sb, 0, 0, 0])
+                items.append((W, ws, wts, d.split_src, d.split_dst, b, bs, gW.view(-1).view_as(W), mW.view_as(W), vW.view_as(W),
+                              gb, mb, vb, float(coef), sa, sb))
+        n_cov = sum(it[0].numel() + it[5].numel() for it in items)
+        assert n_cov == self.n_train, (n_cov, self.n_train)     # every trainable scalar belongs to exactly one layer part
+        self._apply_desc = torch.tensor(rows, dtype=torch.int64, device=self.dev)
+        self._apply_items = items
 
     # ------------------------------------------------------------------ primitive layer ops
     def _fwd(self, d, X, Y, rows, act=None):
@@ -542,25 +585,30 @@ class UpdateEngine:
     # ---- phase C: weight-only loss terms, optimizer, shadows, reported scalars --------------------
     def phase_apply(self, apply=True):
         be, c = self.be, self.cfg
-        if self.has_disc:
-            # weight-only loss terms, added once after the gradient reduction
-            for W, gW, coef, slot in self.l2_terms:
-                if coef != 0:
-                    be.axpy(gW.view(-1), W.view(-1), coef)
-            wl = self.disc_head.W[0]
-            be.reduce_sum(wl.view(-1), wl.numel(), True, self.acc, L.ACC_LOGIT_W2)
-            if c['disc_weight_decay'] != 0:
-                for d in self.disc:
-                    be.reduce_sum(d.W[0].view(-1), d.W[0].numel(), True, self.acc, L.ACC_DISC_W2)
-                be.reduce_sum(wl.view(-1), wl.numel(), True, self.acc, L.ACC_DISC_W2)
-            if self.has_enc and c.get('enc_weight_decay', 0) != 0:
+        if apply and self._fused_apply:
+            # weight-only loss terms + their reported norms + Adam + shadow refresh of every layer: ONE launch
+            self._build_apply_desc()
+            be.apply_multi(self._apply_desc, self._apply_items, self.dtype, self.opt_state, self.acc)
+        else:
+            if self.has_disc:
+                # weight-only loss terms, added once after the gradient reduction
                 for W, gW, coef, slot in self.l2_terms:
-                    if slot == L.ACC_ENC_W2:
-                        be.reduce_sum(W.view(-1), W.numel(), True, self.acc, L.ACC_ENC_W2)
-        if apply:
-            be.adam(self.params[:self.n_train], self.grads[:self.n_train], self.adam_m[:self.n_train],
-                    self.adam_v[:self.n_train], self.opt_state)
-            self.refresh_shadows()
+                    if coef != 0:
+                        be.axpy(gW.view(-1), W.view(-1), coef)
+                wl = self.disc_head.W[0]
+                be.reduce_sum(wl.view(-1), wl.numel(), True, self.acc, L.ACC_LOGIT_W2)
+                if c['disc_weight_decay'] != 0:
+                    for d in self.disc:
+                        be.reduce_sum(d.W[0].view(-1), d.W[0].numel(), True, self.acc, L.ACC_DISC_W2)
+                    be.reduce_sum(wl.view(-1), wl.numel(), True, self.acc, L.ACC_DISC_W2)
+                if self.has_enc and c.get('enc_weight_decay', 0) != 0:
+                    for W, gW, coef, slot in self.l2_terms:
+                        if slot == L.ACC_ENC_W2:
+                            be.reduce_sum(W.view(-1), W.numel(), True, self.acc, L.ACC_ENC_W2)
+            if apply:
+                be.adam(self.params[:self.n_train], self.grads[:self.n_train], self.adam_m[:self.n_train],
+                        self.adam_v[:self.n_train], self.opt_state)
+                self.refresh_shadows()
         be.finalize_scalars(self.acc, self.res, self.Mg, self.AMBg, self.masked, self.has_disc, self.has_enc,
                             self.div_on, c)
 
@@ -648,17 +696,20 @@ class UpdateEngine:
         std.fill_(1.0)
 
     # ------------------------------------------------------------------ results
-    def results(self):
-        """train_result with the reference's keys (learning/ase_agent.py:296-306) as device scalars."""
-        r = self.res
+    def results(self, snapshot=False):
+        """train_result with the reference's keys (learning/ase_agent.py:296-306) as device scalars.  snapshot=True:
+        views of ONE copy of the scalar vector (+ one of the logit column), instead of live views the next step
+        overwrites: two small device copies per optimisation step."""
+        r = self.res.clone() if snapshot else self.res
         out = {'entropy': r[L.RES_ENTROPY], 'kl': r[L.RES_KL], 'b_loss': r[L.RES_B_LOSS], 'actor_loss': r[L.RES_A_LOSS],
                'actor_clip_frac': r[L.RES_CLIP_FRAC], 'critic_loss': r[L.RES_C_LOSS], 'loss': r[L.RES_LOSS]}
         if self.has_disc:
             AMB = self.AMB
+            logit = self.HD[:, 0:1].clone() if snapshot else self.HD[:, 0:1]
             out.update({'disc_loss': r[L.RES_DISC_LOSS], 'disc_grad_penalty': r[L.RES_DISC_GP],
                         'disc_logit_loss': r[L.RES_DISC_LOGIT_LOSS], 'disc_agent_acc': r[L.RES_DISC_AGENT_ACC],
-                        'disc_demo_acc': r[L.RES_DISC_DEMO_ACC], 'disc_agent_logit': self.HD[:2 * AMB, 0:1],
-                        'disc_demo_logit': self.HD[2 * AMB:, 0:1]})
+                        'disc_demo_acc': r[L.RES_DISC_DEMO_ACC], 'disc_agent_logit': logit[:2 * AMB],
+                        'disc_demo_logit': logit[2 * AMB:]})
         if self.has_enc:
             out['enc_loss'] = r[L.RES_ENC_LOSS]
         if self.div_on:

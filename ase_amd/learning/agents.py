@@ -350,7 +350,7 @@ class CommonAgent:
         return self.train_result
 
     def _collect_result(self):
-        r = {k: v.clone() for k, v in self.engine.results().items()}
+        r = dict(self.engine.results(snapshot=True))
         r['last_lr'] = self.last_lr
         r['lr_mul'] = 1.0
         return r

@@ -272,6 +272,16 @@ int ase_hip_ring_store(const float* src, int64_t ld_src, int D, const int32_t* i
  * stream position read from and advanced in rng_state (u64[2] = {seed, offset}). */
 int ase_hip_sample_latents(float* z, int rows, int dim, uint64_t* rng_state, void* stream);
 
+/* The whole optimizer step of every dense layer in ONE launch: weight-only gradient terms (g += c * w: discriminator
+ * weight decay / logit regulariser / encoder weight decay), their reported sums of squares (pre-update weights, into
+ * acc[slot]), torch.optim.Adam, and the refreshed compute-dtype shadows W_s / W_s^T / bias (ase_hip_refresh_shadow_multi's
+ * job).  desc: DEVICE int64[n_layers][24] = {W, n_real, k_real, Ws, ldws, Wts, ldwts, split_src, split_dst - split_src,
+ * bias, bias_shadow, ceil(k_real/32), gW, mW, vW, gb, mb, vb, coefficient c (f32 bit pattern), acc slot A or -1,
+ * acc slot B or -1, 0, 0, 0}.  opt_state NULL: shadows only.
+ * Replaces: the weight terms of learning/amp_agent.py:449-466 + optimizer.step() (learning/ase_agent.py:287). */
+int ase_hip_apply_multi(const int64_t* desc, int n_layers, const double* opt_state, double* acc, int dtype,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

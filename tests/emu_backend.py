@@ -106,6 +106,21 @@ class EmuBackend:
             self.refresh_shadow(W, ws, wts, ss, sd)
             bs[:b.numel()] = b
 
+    def apply_multi(self, desc, items, dtype, opt_state, acc):
+        for (W, ws, wts, ss, sd, b, bs, gW, mW, vW, gb, mb, vb, coef, slot_a, slot_b) in items:
+            if opt_state is not None:
+                if slot_a >= 0:
+                    s2 = (W.double() ** 2).sum()
+                    acc[slot_a] += s2
+                    if slot_b >= 0:
+                        acc[slot_b] += s2
+                if coef != 0:
+                    self.axpy(gW, W, coef)
+                self.adam(W, gW, mW, vW, opt_state)
+                self.adam(b, gb, mb, vb, opt_state)
+            self.refresh_shadow(W, ws, wts, ss, sd)
+            bs[:b.numel()] = b
+
     def gather_multi(self, desc, items, idx, remap, M):
         for src, D, dst in items:
             self.gather_rows(src, D, idx, remap, M, dst)

@@ -511,3 +511,42 @@ def test_gemm_nt_phased_tile(be, M, N, K):
     EmuBackend().gemm_nt(A, B, Cc, M, N, K, bias=bias, act=L.ACT_RELU)
     rt, at = _tol(dt)
     close(Cg.float(), Cc.float(), rt, at * math.sqrt(K / 64), f'nt phased {M}x{N}x{K}')
+
+
+@pytest.mark.parametrize('dt', DT)
+def test_apply_multi_fused_optimizer_step(be, dt):
+    """ase_hip_apply_multi = weight-only gradient terms + their norms + Adam + shadow refresh, against the separate ops
+    of the emulation (axpy / reduce_sum / adam / refresh_shadow) on two layers with concat column maps."""
+    import struct
+    g = torch.Generator().manual_seed(7)
+    specs = [(48, 53, 37, 64, 0.02, 3, 5), (130, 200, 200, 200, 0.0, -1, -1), (1, 70, 70, 70, 0.5, 4, -1)]
+    outs = []
+    for dev in ('cuda', 'cpu'):
+        b = be if dev == 'cuda' else EmuBackend()
+        gg = torch.Generator().manual_seed(7)
+        rows, items, keep = [], [], []
+        acc = torch.zeros(8, dtype=torch.float64, device=dev)
+        st = torch.tensor([3.0, 1e-3, 0.9, 0.999, 1e-8, 1 - 0.9 ** 3, 1 - 0.999 ** 3, 0.0], dtype=torch.float64, device=dev)
+        for (n, k, ss, sd, coef, sa, sb) in specs:
+            W, b_ = torch.randn(n, k, generator=gg).to(dev), torch.randn(n, generator=gg).to(dev)
+            gW, gb = torch.randn(n, k, generator=gg).to(dev), torch.randn(n, generator=gg).to(dev)
+            mW, vW = torch.randn(n, k, generator=gg).to(dev) * 0.1, torch.rand(n, k, generator=gg).to(dev) * 0.01
+            mb, vb = torch.randn(n, generator=gg).to(dev) * 0.1, torch.rand(n, generator=gg).to(dev) * 0.01
+            npad, kpad = (n + 63) // 64 * 64, (k + (sd - ss) + 63) // 64 * 64
+            Ws, Wts = torch.zeros(npad, kpad, dtype=dt, device=dev), torch.zeros(kpad, npad, dtype=dt, device=dev)
+            bs = torch.zeros(npad, device=dev)
+            rows.append([W.data_ptr(), n, k, Ws.data_ptr(), Ws.stride(0), Wts.data_ptr(), Wts.stride(0), ss, sd - ss,
+                         b_.data_ptr(), bs.data_ptr(), (k + 31) // 32, gW.data_ptr(), mW.data_ptr(), vW.data_ptr(),
+                         gb.data_ptr(), mb.data_ptr(), vb.data_ptr(), struct.unpack('<i', struct.pack('<f', coef))[0], sa, sb, 0, 0, 0])
+            items.append((W, Ws, Wts, ss, sd, b_, bs[:n], gW, mW, vW, gb, mb, vb, coef, sa, sb))
+            keep.append((W, b_, gW, mW, vW, mb, vb, Ws, Wts, bs))
+        desc = torch.tensor(rows, dtype=torch.int64, device=dev)
+        b.apply_multi(desc, items, dt, st, acc)
+        outs.append(([tuple(t.float().cpu() for t in kk) for kk in keep], acc.cpu()))
+    for kg, kc in zip(outs[0][0], outs[1][0]):
+        for i, (a, c) in enumerate(zip(kg, kc)):
+            if i >= 7:
+                assert torch.equal(a, c), f'shadow {i}'          # shadows: same rounding of the same f32 weights
+            else:
+                close(a, c, 1e-6, 1e-7, f'apply_multi tensor {i}')
+    close(outs[0][1], outs[1][1], 1e-9, 1e-12, 'norm accumulators')
