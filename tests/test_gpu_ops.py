@@ -284,7 +284,10 @@ def test_gp_seed_sqnorm_reduce(be, dt):
         b.reduce_sum(v.to(dev), v.numel(), True, acc, 1)
         outs.append((g.float().cpu(), acc.cpu()))
     assert torch.equal(outs[0][0], outs[1][0])
-    close(outs[0][1], outs[1][1], 1e-10, 1e-9, 'acc')
+    a_g, a_c = outs[0][1].clone(), outs[1][1].clone()
+    close(a_g[L.ACC_GP], a_c[L.ACC_GP], 1e-6, 0, 'sqnorm')      # 16-byte chunks are summed in f32 before the f64 accumulation
+    a_g[L.ACC_GP] = a_c[L.ACC_GP] = 0
+    close(a_g, a_c, 1e-10, 1e-9, 'acc')
 
 
 def test_finalize_begin_adam_axpy(be):
@@ -545,8 +548,8 @@ def test_apply_multi_fused_optimizer_step(be, dt):
         outs.append(([tuple(t.float().cpu() for t in kk) for kk in keep], acc.cpu()))
     for kg, kc in zip(outs[0][0], outs[1][0]):
         for i, (a, c) in enumerate(zip(kg, kc)):
-            if i >= 7:
-                assert torch.equal(a, c), f'shadow {i}'          # shadows: same rounding of the same f32 weights
+            if i >= 7:      # shadows / bias copy: the updated weights differ by f32 rounding noise between the two Adam codes
+                close(a, c, 1e-6 if dt == torch.float32 else 8e-3, 1e-7, f'shadow {i}')
             else:
                 close(a, c, 1e-6, 1e-7, f'apply_multi tensor {i}')
     close(outs[0][1], outs[1][1], 1e-9, 1e-12, 'norm accumulators')
