@@ -648,32 +648,40 @@ template <typename T, int V> int launch_nt8(const NTParams& p0, hipStream_t stre
     return ASE_OK;
 }
 
-template <typename T> int dispatch_nt(const NTParams& p, hipStream_t s) {
-    static int force = -1, variant = 0;
+// Kernel choice of an NT launch (also reported by ase_hip_gemm_nt_kernel_id):
+//   0:  64 x  64 tile, 4 waves   narrow heads (N <= 64): more workgroups
+//   1: 128 x 128 tile, 4 waves   grids that would leave a 256 x 256 tiling with a ragged round
+//   2: 256 x 256 tile, 8 waves, PHASED (bf16, K in whole 128-byte steps)   192+ tiles in whole rounds
+//   3: 256 x 256 tile, 8 waves, lock-step (the f32 / bf16x3 storage types, or ASE_NT_PHASED=0)
+int nt_choice(int M, int N, int K, int es, bool bf16) {
+    static int force = -1, phased = 1;
     if (force < 0) {
         const char* e = getenv("ASE_NT_TILE");
         force = e ? atoi(e) : 0;
-        const char* v = getenv("ASE_NT_VARIANT");
-        variant = v ? atoi(v) : 1;   // 1: 128-byte rows, 2-stage ring (measured best); 0: 64-byte rows, 4-stage ring; 2: 3-stage
+        const char* v = getenv("ASE_NT_PHASED");
+        phased = v ? atoi(v) : 1;
     }
+    if (N <= 64) return 0;
+    const int t256 = ((M + 255) / 256) * ((N + 255) / 256);
+    const bool big = (force == 256) || (force == 0 && N % 256 == 0 && t256 >= 192 && (t256 <= 256 || t256 % 256 == 0 || t256 >= 1024));
+    if (!big || force == 128) return 1;
+    return (bf16 && phased && (K * es) % 128 == 0) ? 2 : 3;
+}
+
+template <typename T> int dispatch_nt(const NTParams& p, hipStream_t s) {
     const bool k128 = (p.K * (int)sizeof(T)) % 128 == 0;       // 128-byte staged rows need K in whole 128-byte steps
-    if (p.N <= 64) return launch_nt<T, 2, 2, 1, 1, 64, 4>(p, s);          //  64 x  64 tile (narrow heads: more workgroups)
-    // 256 x 256 tile, 8 waves of 64 x 128: half the L2->LDS bytes per flop of the 128 x 128 tile, one workgroup per
-    // CU.  Used when the grid still fills the 256 CUs in whole rounds.
-    const int t256 = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-    const bool big = (force == 256) || (force == 0 && p.N % 256 == 0 && t256 >= 192 && (t256 <= 256 || t256 % 256 == 0 || t256 >= 1024));
-    if (big && force != 128) {
-        if constexpr (sizeof(T) == 2) {
-            if (variant != 3 && k128) {                                  // phased kernel (ASE_NT_VARIANT=3: the lock-step one)
-                return launch_nt8<T, 0>(p, s);
-            }
-        }
-        if ((variant == 1 || variant == 3) && k128) return launch_nt<T, 4, 2, 2, 4, 128, 2>(p, s);
-        return launch_nt<T, 4, 2, 2, 4, 64, 4>(p, s);                     // 64-byte rows, 4-stage ring (128 KB)
+    switch (nt_choice(p.M, p.N, p.K, (int)sizeof(T), std::is_same<T, bf16_t>::value)) {
+        case 0: return launch_nt<T, 2, 2, 1, 1, 64, 4>(p, s);
+        case 2:
+            if constexpr (sizeof(T) == 2) return launch_nt8<T, 0>(p, s);
+            [[fallthrough]];
+        case 3:
+            if (k128) return launch_nt<T, 4, 2, 2, 4, 128, 2>(p, s);
+            return launch_nt<T, 4, 2, 2, 4, 64, 4>(p, s);                 // 64-byte rows, 4-stage ring (128 KB)
+        default:
+            if (k128) return launch_nt<T, 2, 2, 2, 2, 128, 2>(p, s);
+            return launch_nt<T, 2, 2, 2, 2, 64, 4>(p, s);                 // 64-byte rows, 4-stage ring (64 KB)
     }
-    if (variant == 1 && k128) return launch_nt<T, 2, 2, 2, 2, 128, 2>(p, s);
-    if (variant == 2 && k128) return launch_nt<T, 2, 2, 2, 2, 128, 3>(p, s);
-    return launch_nt<T, 2, 2, 2, 2, 64, 4>(p, s);                         // 128 x 128 tile, 4-stage ring (64 KB)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1373,6 +1381,10 @@ extern "C" int ase_hip_refresh_shadow_multi(const int64_t* desc, int n_layers, i
 extern "C" int ase_hip_debug_nt_profile(void* buf) {
     g_nt_prof = reinterpret_cast<unsigned long long*>(buf);
     return ASE_OK;
+}
+
+extern "C" int ase_hip_gemm_nt_kernel_id(int M, int N, int K, int dtype) {
+    return nt_choice(M, N, K, dtype == ASE_BF16 ? 2 : 4, dtype == ASE_BF16);
 }
 
 extern "C" int ase_hip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,

@@ -55,7 +55,7 @@ class TimedBackend:
     def __init__(self, be):
         self._be = be
         self.records = []          # (kind, flops, start_event, end_event)
-        self.nt_bytes = 0.0        # algorithmic operand bytes of the NT launches (A + B + C [+ aux])
+        self.bytes = {}            # algorithmic operand bytes per NT kernel class (A + B + C [+ mask operand / mask output])
 
     def __getattr__(self, k):
         return getattr(self._be, k)
@@ -68,10 +68,17 @@ class TimedBackend:
         self.records.append((kind, flops, s, e, self._shape))
 
     def gemm_nt(self, A, B, Cm, M, N, K, **kw):
+        from ase_amd import lib as L
         self._shape = (M, N, K)
         es = A.element_size()
-        self.nt_bytes += (M * K + N * K) * es + M * N * Cm.element_size() + (M * N * es if kw.get('aux') is not None else 0)
-        self._timed('nt', 2.0 * M * N * K, self._be.gemm_nt, A, B, Cm, M, N, K, **kw)
+        aux = kw.get('aux')
+        nbytes = (M * K + N * K) * es + M * N * Cm.element_size() + (aux.shape[1] * aux.element_size() * M if aux is not None else 0) \
+            + (M * N // 8 if kw.get('mask_out') is not None else 0)
+        # 2 = the phased 256 x 256 kernel (the dominant kernel of the update): timed as its own class
+        kid = self._be.lib.ase_hip_gemm_nt_kernel_id(M, N, K, self._be._gemm_code(A.dtype))
+        kind = 'nt8' if kid == 2 else 'nt'
+        self.bytes[kind] = self.bytes.get(kind, 0.0) + nbytes
+        self._timed(kind, 2.0 * M * N * K, self._be.gemm_nt, A, B, Cm, M, N, K, **kw)
 
     def gemm_tn(self, A, B, G, M, N, K, n_real, k_real, split_src, split_dst, **kw):
         self._shape = (M, N, K)
@@ -86,7 +93,7 @@ class TimedBackend:
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for kind in ('nt', 'tn'):
+        for kind in ('nt8', 'nt', 'tn'):
             rs = [r for r in self.records if r[0] == kind]
             if rs:
                 ms = sum(r[2].elapsed_time(r[3]) for r in rs)
@@ -128,7 +135,7 @@ def algorithmic_flops_per_step(eng):
     return f
 
 
-def make_agent(device, precision, use_graph, world, rank, seed=0, force_dist=False):
+def make_agent(device, precision, use_graph, world, rank, seed=0, force_dist=False, multi_stream=True):
     from ase_amd.learning import agents, models
     from ase_amd.learning.network_builder import ASEBuilder
     from ase_amd.synthetic import EnvSpec, SyntheticSource
@@ -145,6 +152,7 @@ def make_agent(device, precision, use_graph, world, rank, seed=0, force_dist=Fal
     cfg = dict(cfg)
     cfg.update(network=models.ModelASEContinuous(b), num_actors=spec.num_envs, device=device, precision=precision,
                graph_capture=use_graph, world_size=world, rank=rank, vec_env=src, force_dist=force_dist,
+               multi_stream=multi_stream,
                env_info={'observation_space': sp(253), 'action_space': sp(31), 'amp_observation_space': sp(1400)})
     return agents.ASEAgent('bench', cfg), cfg, spec
 
@@ -203,6 +211,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'f32', 'bf16x3'])
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-multi-stream', action='store_true', help='launch the three network branches on ONE stream')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=2)
     ap.add_argument('--force-dist', action='store_true', help='run the collectives even with one rank (RCCL smoke)')
@@ -231,7 +240,8 @@ def main():
     use_graph = not args.no_graph
     t_setup = time.time()
     _dbg('init done')
-    agent, cfg, spec = make_agent(device, args.precision, use_graph, world, rank, force_dist=args.force_dist)
+    agent, cfg, spec = make_agent(device, args.precision, use_graph, world, rank, force_dist=args.force_dist,
+                                   multi_stream=not args.no_multi_stream)
     B = agent.batch_size
     _dbg('agent built')
 
@@ -303,22 +313,32 @@ def main():
             + 2.0 * B * (1 + eng.z) * eng.disc_head.K
         gemm_ms = sum(v['ms'] for v in summ.values())
         launches = sum(v['launches'] for v in summ.values())
-        achieved = alg / (gemm_ms * 1e-3) / 1e12
         peak = MFMA_PEAK_TFLOPS[args.precision]
-        # HBM traffic of the dominant kernel per launch: PMC measurement committed under profiles/ (rocprofv3 --pmc
-        # FETCH_SIZE / WRITE_SIZE in separate passes, FETCH doubled per the gfx950 note); bench cannot profile itself
+        # the dominant kernel = the GEMM kernel class with the most time (bf16: the phased 256 x 256 NT kernel)
+        dom = max(summ, key=lambda k: summ[k]['ms'])
+        dname = {'nt8': 'gemm_nt8_kernel (phased 256x256 NT, bf16: forward + data-gradient of the wide layers)',
+                 'nt': 'gemm_nt_kernel (NT tiles 64/128/256)', 'tn': 'gemm_tn kernels (weight gradients)'}[dom]
+        dv = summ[dom]
+        achieved = dv['flops'] / (dv['ms'] * 1e-3) / 1e12
+        # HBM traffic of that kernel per launch: PMC measurement committed under profiles/ (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE in separate passes, FETCH doubled per the gfx950 note); bench cannot profile itself
         traffic, traffic_src = None, None
         pmc = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_pmc.json')) \
             if os.path.isdir(os.path.join(ROOT, 'profiles')) else []
         if pmc and args.precision == 'bf16':
             j = json.load(open(os.path.join(ROOT, 'profiles', pmc[-1])))
-            traffic, traffic_src = j['hbm_bytes_per_launch'], 'profiles/' + pmc[-1]
-        roof = {'bound': 'mfma', 'kernel': 'gemm_nt + gemm_tn (all dense layers of one update)',
+            if j.get('kernel_class') == dom:
+                traffic, traffic_src = j['hbm_bytes_per_launch'], 'profiles/' + pmc[-1]
+        roof = {'bound': 'mfma', 'kernel': dname,
                 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
-                'traffic': traffic, 'traffic_unit': 'HBM bytes per gemm_nt launch (PMC)', 'traffic_source': traffic_src,
-                'algorithmic_bytes_per_nt_launch': round(tb.nt_bytes / max(1, summ['nt']['launches'])),
-                'launches_per_update': launches, 'avg_launch_us': round(gemm_ms * 1e3 / launches, 2),
-                'gemm_ms_per_update': round(gemm_ms, 3), 'algorithmic_tflop_per_update': round(alg / 1e12, 3),
+                'traffic': traffic, 'traffic_unit': 'HBM bytes per launch of that kernel (PMC)', 'traffic_source': traffic_src,
+                'launches': dv['launches'], 'avg_launch_us': round(dv['ms'] * 1e3 / dv['launches'], 2),
+                'algorithmic_flop_per_launch': round(dv['flops'] / dv['launches']),
+                'algorithmic_bytes_per_launch': round(tb.bytes.get(dom, 0.0) / dv['launches']) if dom in tb.bytes else None,
+                'share_of_gemm_time': round(dv['ms'] / gemm_ms, 3),
+                'all_gemm': {'achieved': round(alg / (gemm_ms * 1e-3) / 1e12, 2), 'frac': round(alg / (gemm_ms * 1e-3) / 1e12 / peak, 4),
+                             'launches_per_update': launches, 'gemm_ms_per_update': round(gemm_ms, 3),
+                             'algorithmic_tflop_per_update': round(alg / 1e12, 3)},
                 'per_kind': {k: {'launches': v['launches'], 'ms': round(v['ms'], 3),
                                  'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1)} for k, v in summ.items()}}
 

@@ -41,6 +41,10 @@ enum { ASE_OK = 0, ASE_EINVAL = -1, ASE_ELAUNCH = -2, ASE_EUNSUPPORTED = -3 };
 int ase_hip_abi_version(void);
 const char* ase_hip_last_error(void);
 
+/* Which kernel ase_hip_gemm_nt launches for a shape (host only): 0 = 64 x 64 tile, 1 = 128 x 128, 2 = phased 256 x 256
+ * (bf16), 3 = lock-step 256 x 256.  bench.py uses it to attribute launch times to the dominant kernel. */
+int ase_hip_gemm_nt_kernel_id(int M, int N, int K, int dtype);
+
 /* Kernel-tuning aid (scripts/lab): when buf is a device uint64[4 * workgroups] array, the phased NT kernel stamps
  * {entry, first tile landed, main loop done, stores retired} per workgroup (100 MHz clock); NULL switches it off. */
 int ase_hip_debug_nt_profile(void* buf);

@@ -2,8 +2,8 @@
 # A/B of the phased 256x256 NT kernel against the lock-step one (ASE_NT_VARIANT=3) + edge shapes
 L=scripts/lab/gemm_lab
 for shape in "16384 1024 1024" "32768 1024 1024" "12288 1024 1408" "32768 512 1024" "16384 1024 512" "4096 4096 4096" "8192 8192 8192"; do
-  for v in 1 3; do
-    echo -n "variant $v: "; ASE_NT_TILE=256 ASE_NT_VARIANT=$v timeout 60 $L nt $shape 20 0 1 || echo "rc=$?"
+  for v in 1 0; do
+    echo -n "variant $v: "; ASE_NT_TILE=256 ASE_NT_PHASED=$v timeout 60 $L nt $shape 20 0 1 || echo "rc=$?"
   done
 done
 echo "--- edge shapes (forced 256 tile, phased kernel)"
