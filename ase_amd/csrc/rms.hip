@@ -47,6 +47,63 @@ __global__ __launch_bounds__(256) void rms_moments_kernel(const float* __restric
     }
 }
 
+// 16-byte variant (D % 4 == 0, 16-byte aligned rows): a thread owns 4 columns; same row partition (rows = ty mod 4, ascending)
+// and the same f64 arithmetic per element as the scalar kernel, so the sums are identical
+__global__ __launch_bounds__(256) void rms_moments4_kernel(const float* __restrict__ src, int64_t ld_src, int D,
+                                                           const int32_t* __restrict__ idx, int remap_h, int remap_n,
+                                                           int M, const double* __restrict__ state,
+                                                           double* __restrict__ sums) {
+    __shared__ double red[3][8][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int j = (blockIdx.x * 64 + tx) * 4;
+    const int r0 = blockIdx.y * kRowsPerBlock;
+    const int r1 = min(M, r0 + kRowsPerBlock);
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    if (j < D) {
+        float shift[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) shift[c] = (float)state[j + c];
+        for (int r = r0 + ty; r < r1; r += 16) {
+            f32x4 x[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rr = r + 4 * q;
+                if (rr < r1) x[q] = *reinterpret_cast<const f32x4*>(src + map_row(rr, idx, remap_h, remap_n) * ld_src + j);
+                else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) x[q][c] = shift[c];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const double d = (double)(x[q][c] - shift[c]);
+                    s1[c] += d;
+                    s2[c] += d * d;
+                }
+        }
+    }
+    if (ty > 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            red[ty - 1][c][tx] = s1[c];
+            red[ty - 1][4 + c][tx] = s2[c];
+        }
+    }
+    __syncthreads();
+    if (ty == 0 && j < D) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            // same association as the scalar kernel: ((t0 + t1) + t2) + t3
+            const double a = ((s1[c] + red[0][c][tx]) + red[1][c][tx]) + red[2][c][tx];
+            const double b = ((s2[c] + red[0][4 + c][tx]) + red[1][4 + c][tx]) + red[2][4 + c][tx];
+            atomic_add_f64(sums + j + c, a);
+            atomic_add_f64(sums + D + j + c, b);
+        }
+    }
+}
+
 // ---- merge into the running state; single block so `count` is read before it is rewritten ------
 __global__ __launch_bounds__(256) void rms_finalize_kernel(double* __restrict__ state, int D,
                                                            const double* __restrict__ sums, int count,
@@ -108,6 +165,39 @@ __global__ __launch_bounds__(256) void rms_normalize_kernel(const float* __restr
     }
 }
 
+// 16-byte variant: one f32x4 per thread, 8/16-byte stores
+template <typename T>
+__global__ __launch_bounds__(256) void rms_normalize4_kernel(const float* __restrict__ src, int64_t ld_src, int D,
+                                                             const int32_t* __restrict__ idx, int remap_h, int remap_n,
+                                                             int M, const float* __restrict__ mean,
+                                                             const float* __restrict__ stdv, void* out0, int64_t ld0,
+                                                             void* out1, int64_t ld1, void* out2, int64_t ld2) {
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int r = blockIdx.y * 4 + ty;
+    const int j = (blockIdx.x * 64 + tx) * 4;
+    if (r >= M || j >= D) return;
+    const int64_t p = map_row(r, idx, remap_h, remap_n);
+    const f32x4 x = *reinterpret_cast<const f32x4*>(src + p * ld_src + j);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + j), sd = *reinterpret_cast<const f32x4*>(stdv + j);
+    f32x4 y;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) y[c] = fminf(fmaxf((x[c] - mu[c]) / sd[c], -5.f), 5.f);
+    void* outs[3] = {out0, out1, out2};
+    const int64_t lds[3] = {ld0, ld1, ld2};
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        if (!outs[o]) continue;
+        if constexpr (sizeof(T) == 2) {
+            bf16x4 v;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = (bf16_t)y[c];
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(outs[o]) + (int64_t)r * lds[o] + j) = v;
+        } else {
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(outs[o]) + (int64_t)r * lds[o] + j) = y;
+        }
+    }
+}
+
 __global__ void rms_unnormalize_kernel(const double* __restrict__ state, const float* __restrict__ x,
                                        float* __restrict__ y, int64_t n) {
     const float mean = (float)state[0], sd = sqrtf((float)state[1] + 1e-5f);
@@ -163,9 +253,15 @@ extern "C" int ase_hip_gather_multi(const int64_t* desc, int n_fields, const int
 extern "C" int ase_hip_rms_moments(const float* src, int64_t ld_src, int D, const int32_t* idx, int remap_h,
                                    int remap_n, int M, const double* state, double* sums, void* stream) {
     ASE_CHECK_ARG(src && state && sums && D > 0 && M > 0, "rms_moments: null/empty operand");
-    const dim3 grid((D + 63) / 64, (M + kRowsPerBlock - 1) / kRowsPerBlock);
-    hipLaunchKernelGGL(rms_moments_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, D, idx, remap_h,
-                       remap_n, M, state, sums);
+    if (D % 4 == 0 && ld_src % 4 == 0 && ((uintptr_t)src % 16) == 0) {
+        const dim3 grid((D / 4 + 63) / 64, (M + kRowsPerBlock - 1) / kRowsPerBlock);
+        hipLaunchKernelGGL(rms_moments4_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, D, idx, remap_h,
+                           remap_n, M, state, sums);
+    } else {
+        const dim3 grid((D + 63) / 64, (M + kRowsPerBlock - 1) / kRowsPerBlock);
+        hipLaunchKernelGGL(rms_moments_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, D, idx, remap_h,
+                           remap_n, M, state, sums);
+    }
     ASE_CHECK_LAUNCH("rms_moments");
     return ASE_OK;
 }
@@ -193,6 +289,21 @@ extern "C" int ase_hip_rms_normalize(const float* src, int64_t ld_src, int D, co
                                      int64_t ld0, void* out1, int64_t ld1, void* out2, int64_t ld2, int dtype,
                                      void* stream) {
     ASE_CHECK_ARG(src && mean && stdv && out0 && D > 0 && M > 0, "rms_normalize: null/empty operand");
+    const int es = dtype == ASE_BF16 ? 2 : 4;
+    auto ok = [&](void* o, int64_t ld) { return o == nullptr || (ld % 4 == 0 && ((uintptr_t)o % (4 * es)) == 0); };
+    const bool wide = D % 4 == 0 && ld_src % 4 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)mean % 16) == 0 &&
+                      ((uintptr_t)stdv % 16) == 0 && ok(out0, ld0) && ok(out1, ld1) && ok(out2, ld2);
+    if (wide && (dtype == ASE_BF16 || dtype == ASE_F32)) {
+        const dim3 g4((D / 4 + 63) / 64, (M + 3) / 4);
+        if (dtype == ASE_BF16)
+            hipLaunchKernelGGL(rms_normalize4_kernel<bf16_t>, g4, dim3(256), 0, (hipStream_t)stream, src, ld_src, D, idx,
+                               remap_h, remap_n, M, mean, stdv, out0, ld0, out1, ld1, out2, ld2);
+        else
+            hipLaunchKernelGGL(rms_normalize4_kernel<float>, g4, dim3(256), 0, (hipStream_t)stream, src, ld_src, D, idx,
+                               remap_h, remap_n, M, mean, stdv, out0, ld0, out1, ld1, out2, ld2);
+        ASE_CHECK_LAUNCH("rms_normalize");
+        return ASE_OK;
+    }
     const dim3 grid((D + 255) / 256, (M + 3) / 4);
     if (dtype == ASE_BF16)
         hipLaunchKernelGGL(rms_normalize_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, D, idx,

@@ -439,11 +439,20 @@ class UpdateEngine:
             be.reduce_sum(self.mb['rand_action_mask'], M, False, self.acc, L.ACC_MASK_SUM)
         if c.get('normalize_input', True):
             be.rms_moments(ds['obs'], self.obs, idx, remap, M, self.obs_state, self.obs_sums)
-        if self.has_disc:
-            be.zero_(self.amp_sums)
-            if c.get('normalize_amp_input', True):
-                for s, (src, sidx, srm) in enumerate(amp_streams):
-                    be.rms_moments(src, self.amp, sidx, srm, AMB, self.amp_state, self.amp_sums[s])
+        if self.has_disc and not self._amp_stats_in_branch():
+            self._amp_moments(amp_streams)
+
+    def _amp_stats_in_branch(self):
+        """Single GPU: nothing is exchanged between the phases, so the amp-observation moments run at the head of the
+        discriminator branch (its own stream) next to the actor / critic kernels instead of in the serial prologue."""
+        return self.multi_stream and not self._dist_on()
+
+    def _amp_moments(self, amp_streams):
+        be, c = self.be, self.cfg
+        be.zero_(self.amp_sums)
+        if c.get('normalize_amp_input', True):
+            for s, (src, sidx, srm) in enumerate(amp_streams):
+                be.rms_moments(src, self.amp, sidx, srm, self.AMB, self.amp_state, self.amp_sums[s])
 
     # ---- fork / join of the independent actor / critic / discriminator branches -------------------
     def _side(self, k):
@@ -504,6 +513,8 @@ class UpdateEngine:
         # -- discriminator (+ encoder) branch: normalise, forward, heads, backward, gradient penalty
         with self._Branch(self._side(1) if self.has_disc else None):
             if self.has_disc:
+                if self._amp_stats_in_branch():
+                    self._amp_moments(amp_streams)
                 if norm_amp:
                     be.rms_finalize(self.amp_state, self.amp, self.amp_sums, self.AMBg, 3, self.amp_mean, self.amp_std)
                 else:

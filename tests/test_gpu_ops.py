@@ -121,8 +121,9 @@ def test_refresh_shadow(be, dt):
 
 
 @pytest.mark.parametrize('dt', DT)
-def test_rms_pipeline(be, dt):
-    H, N, D, M = 8, 50, 253, 300
+@pytest.mark.parametrize('D,W', [(253, 320), (1400, 1408)])      # scalar path / 16-byte path (D % 4 == 0)
+def test_rms_pipeline(be, dt, D, W):
+    H, N, M = 8, 50, 300
     g = torch.Generator().manual_seed(3)
     src = torch.randn(H * N, D, generator=g) * 2 + 0.5
     idx = torch.randperm(H * N, generator=g)[:M].to(torch.int32)
@@ -134,8 +135,8 @@ def test_rms_pipeline(be, dt):
         state[:D] = 0.1
         sums = torch.zeros(3, 2 * D, dtype=torch.float64, device=dev)
         mean, std = torch.zeros(3, D, device=dev), torch.zeros(3, D, device=dev)
-        o0 = torch.zeros(M, 320, dtype=dt, device=dev)
-        o1 = torch.zeros(M, 320, dtype=dt, device=dev)
+        o0 = torch.zeros(M, W, dtype=dt, device=dev)
+        o1 = torch.zeros(M, W, dtype=dt, device=dev)
         for s in range(3):
             b.rms_moments(src.to(dev), D, idx.to(dev), (H, N), M, state, sums[s])
         b.rms_finalize(state, D, sums, M, 3, mean, std)
