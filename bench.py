@@ -217,6 +217,7 @@ def main():
     ap.add_argument('--force-dist', action='store_true', help='run the collectives even with one rank (RCCL smoke)')
     ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'])
     ap.add_argument('--breakdown', action='store_true', help='per-shape GEMM time table on stderr')
+    ap.add_argument('--verbose', action='store_true', help='per-update times on stderr')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -278,11 +279,17 @@ def main():
     for _ in range(args.warmup):
         one_update()
     sync()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         info = one_update()
+        marks[i + 1].record()
     sync()
     dt = time.perf_counter() - t0
+    if args.verbose and rank == 0:
+        print('[bench] per-update ms: ' + ' '.join(f'{marks[i].elapsed_time(marks[i + 1]):.1f}' for i in range(args.steps)),
+              file=sys.stderr)
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device=device)
