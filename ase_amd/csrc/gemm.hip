@@ -1273,7 +1273,9 @@ template <typename T> int launch_tn(TNParams p, hipStream_t stream) {
         const char* e = getenv("ASE_TN_TARGET_WG");
         target_wg = e ? atoi(e) : 512;
     }
-    int splits = target_wg / tiles;
+    // narrow outputs (<= 8 tiles): the partial-sum atomics outweigh the second resident workgroup per CU (measured:
+    // 256 workgroups beat 512 by 20-30 % on the head / style-MLP gradients)
+    int splits = ((tiles <= 8 && !getenv("ASE_TN_TARGET_WG")) ? 256 : target_wg) / tiles;
     const int max_splits = (p.M + 4 * Gm::BKM - 1) / (4 * Gm::BKM); // >= 4 staged tiles per split
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
