@@ -370,6 +370,11 @@ def main():
                           if world > 1 else 'single GPU'},
                'roofline': roof, 'cpu_baseline': cpu, 'last_train_result': {k: round(v, 6) for k, v in last.items()}}
         sys.stdout.flush()
+        try:        # RCCL's version banner sits in the C stdio buffer until exit: push it out BEFORE the JSON line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
         print(json.dumps(out), flush=True)      # the ONE JSON line, last thing on stdout
 
 

@@ -59,3 +59,61 @@ def test_product_has_no_cpu_fallback():
     from ase_amd.backend import HipBackend
     with pytest.raises(L.AseHipError):
         HipBackend()
+
+
+def _plan(problems, target=256):
+    """problems: [(M, N, K, n_real, k_real, bias_rows)] -> (rc, work items) through the host-only planner."""
+    lib = L.load()
+    n = len(problems)
+    tab = (ctypes.c_int64 * (16 * n))()
+    for i, (M, N, K, nr, kr, br) in enumerate(problems):
+        row = [0x1000, N, 0x2000, K, 0x3000, 0, br, M, N, K, nr, kr, kr, kr, 0x3F800000, 0]
+        for j, v in enumerate(row):
+            tab[16 * i + j] = v
+    work = (ctypes.c_int32 * (4 * 8192))()
+    nw = ctypes.c_int(0)
+    rc = lib.ase_hip_gemm_tn_grouped_plan(tab, n, target, work, 8192, ctypes.byref(nw))
+    items = [tuple(work[4 * i:4 * i + 4]) for i in range(nw.value)]
+    return rc, items, tab
+
+
+def test_grouped_weight_gradient_plan_covers_every_tile_once():
+    """Host-side planner of ase_hip_gemm_tn_grouped (no GPU): every 256 x 256 tile of every layer gets disjoint row
+    ranges that add up to M, in whole 64-row K-tiles, and the config-2 layer set lands on one workgroup per CU."""
+    probs = [(32768, 1024, 320, 1024, 317, 0), (32768, 1024, 1024, 1024, 1024, 0), (32768, 512, 1024, 512, 1024, 0),
+             (16384, 1024, 320, 1024, 317, 0), (16384, 1024, 1024, 1024, 1024, 0), (16384, 512, 1024, 512, 1024, 0),
+             (16384, 1024, 1408, 1024, 1400, 12288), (16384, 1024, 1024, 1024, 1024, 12288), (16384, 512, 1024, 512, 1024, 12288)]
+    rc, items, tab = _plan(probs)
+    assert rc == 0
+    assert len(items) == 256
+    cover = {}
+    for p, t, m0, nk in items:
+        M, N, K, nr, kr, br = probs[p]
+        tiles = ((nr + 255) // 256) * ((K + 255) // 256)
+        assert 0 <= t < tiles and m0 % 64 == 0 and nk >= 1 and m0 + 64 * nk <= M
+        cover.setdefault((p, t), []).append((m0, m0 + 64 * nk))
+    for p, (M, N, K, nr, kr, br) in enumerate(probs):
+        tiles = ((nr + 255) // 256) * ((K + 255) // 256)
+        assert tab[16 * p + 15] == (K + 255) // 256 and tab[16 * p + 6] == (br or M)
+        for t in range(tiles):
+            segs = sorted(cover[(p, t)])
+            assert segs[0][0] == 0 and segs[-1][1] == M
+            assert all(a[1] == b[0] for a, b in zip(segs, segs[1:]))
+    # fewer tiles than workgroups per layer set, longer contraction: still a full cover with no split below 4 K-tiles
+    rc, items, _ = _plan([(1024, 256, 256, 200, 250, 0)])
+    assert rc == 0 and sum(nk for _, _, _, nk in items) == 16 and all(nk >= 4 for *_, nk in items)
+
+
+def test_grouped_plan_rejects_ragged_rows():
+    rc, _, _ = _plan([(1000, 256, 256, 256, 256, 0)])
+    assert rc == -1 and b'64-row' in L.load().ase_hip_last_error()
+    rc, _, _ = _plan([(1024, 256, 256, 256, 256, 100)])
+    assert rc == -1
+
+
+def test_nt_kernel_choice_is_reported():
+    lib = L.load()
+    assert lib.ase_hip_gemm_nt_kernel_id(16384, 1024, 1024, L.BF16) == 2      # phased 256 x 256
+    assert lib.ase_hip_gemm_nt_kernel_id(16384, 1024, 1024, L.F32) == 3       # lock-step 256 x 256 (exact f32)
+    assert lib.ase_hip_gemm_nt_kernel_id(4096, 512, 1024, L.BF16) == 1        # 128 x 128
+    assert lib.ase_hip_gemm_nt_kernel_id(16384, 64, 512, L.BF16) == 0         # narrow head
