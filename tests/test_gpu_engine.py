@@ -58,7 +58,9 @@ def _ase_full_cfg():
 
 @pytest.mark.parametrize('dt,M,AMB,x3', [(torch.float32, 2048, 512, False), (torch.bfloat16, 2048, 512, False),
                                          (torch.float32, 2048, 512, True),
-                                         (torch.float32, 16384, 4096, False)])     # BASELINE config 2 minibatch
+                                         (torch.float32, 16384, 4096, False),      # BASELINE config 2 minibatch
+                                         (torch.bfloat16, 16384, 4096, False)])    # ... in the bench's mode: phased NT kernel,
+                                                                                   # grouped weight gradients, bit masks
 def test_full_width_step_vs_oracle(be, dt, M, AMB, x3):
     """Real ASE net (7,039,905 parameters), real feature sizes; minibatch reduced so the CPU oracle
     finishes in seconds.  Same seeded inputs on both sides; oracle = oracle/restated.py (pinned to the

@@ -448,7 +448,7 @@ def test_gemm_x3_split_mode(M, N, K):
 
 
 @pytest.mark.parametrize('dt', DT)
-@pytest.mark.parametrize('M,N,K', [(300, 192, 256), (777, 64, 128), (1024, 1024, 1024), (4096, 512, 320)])
+@pytest.mark.parametrize('M,N,K', [(300, 192, 256), (777, 64, 128), (1024, 1024, 1024), (4096, 512, 320), (16384, 1024, 256)])
 def test_gemm_nt_relu_bit_mask(be, dt, M, N, K):
     """mask_out of a forward ReLU layer = (stored activation > 0), bit-exact against the emulation; the data-gradient
     launch that reads the bits (ASE_AUX_RELU_BITS, with a stacked row block wrapping onto earlier rows) equals the one
@@ -467,12 +467,14 @@ def test_gemm_nt_relu_bit_mask(be, dt, M, N, K):
     assert torch.equal(bits, Hg.float().cpu() > 0)
     assert torch.equal(Wg.cpu()[:, N // 32:], Wc[:, N // 32:])             # pad words untouched
     # data gradient with 1.5 M rows: the extra half block re-uses the masks of rows M/2 .. M
-    K2, R = 128, M + M // 2
+    # (the last shape is a whole number of rounds of 256 x 256 tiles in both launches: the phased bf16 kernel)
+    K2, R = 128, (2 * M if M >= 16384 else M + M // 2)
     dY = (torch.randn(R, K2, generator=g) * 0.3).to(dt).cuda()
     Wt = (torch.randn(N, K2, generator=g) * 0.1).to(dt).cuda()
     d1, d2 = torch.zeros(R, N, dtype=dt).cuda(), torch.zeros(R, N, dtype=dt).cuda()
-    be.gemm_nt(dY, Wt, d1, R, N, K2, aux=Hg, aux_mode=L.AUX_RELU_MASK, aux_split=M, aux_delta=M // 2)
-    be.gemm_nt(dY, Wt, d2, R, N, K2, aux=Wg, aux_mode=L.AUX_RELU_BITS, aux_split=M, aux_delta=M // 2)
+    delta = R - M
+    be.gemm_nt(dY, Wt, d1, R, N, K2, aux=Hg, aux_mode=L.AUX_RELU_MASK, aux_split=M, aux_delta=delta)
+    be.gemm_nt(dY, Wt, d2, R, N, K2, aux=Wg, aux_mode=L.AUX_RELU_BITS, aux_split=M, aux_delta=delta)
     assert torch.equal(d1, d2)
     assert float(d1.float().abs().max()) > 0
 
