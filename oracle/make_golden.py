@@ -25,7 +25,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 from ase_amd.synthetic import EnvSpec, SyntheticSource  # noqa: E402
 from oracle import ref_runner  # noqa: E402
 
-OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+OUT = os.environ.get("ASE_GOLDEN_OUT", os.path.join(os.path.dirname(HERE), "tests", "golden"))
 
 NET_ASE = {
     'name': 'ase', 'separate': True,
@@ -229,6 +229,11 @@ def make_case(name, kind, seed, num_envs=16, obs_size=37, act_size=7, amp_size=4
             E['replay_head_after'] = A._amp_replay_buffer._head
         E['sd_after'] = {k.replace('a2c_network.', '', 1): v.detach().clone() for k, v in A.model.state_dict().items()}
         G['epochs'].append(E)
+
+    # the reference's checkpoint dictionary after the two epochs (rl_games A2CBase.get_full_state_weights through
+    # learning/amp_agent.py:47-52 get_stats_weights): what save() writes and restore() reads
+    import copy
+    G['ckpt_after'] = copy.deepcopy(A.get_full_state_weights())
 
     os.makedirs(OUT, exist_ok=True)
     path = os.path.join(OUT, name + '.pt')

@@ -57,6 +57,7 @@ def replay_epochs(G, ag, rtol, wtol, check=True):
         ag._amp_replay_buffer._sample_idx = G['replay_sample_perm0'].to(dev)
     all_info = []
     for E in G['epochs']:
+        ag.update_epoch()               # the train loop's epoch counter (rl_games A2CBase.train / make_golden.py)
         for k, v in E['exp'].items():
             if k in ag.experience:
                 ag.experience[k].copy_(v)
@@ -130,3 +131,89 @@ def test_checkpoint_keys_match_reference(golden_dir):
     ag2.set_full_state_weights(w)
     for k, v in ag2.model.state_dict().items():
         assert torch.equal(v, w['model'][k])
+
+
+def check_rollout_inference(G, ag, rtol, atol):
+    """Rollout-time inference: eval-mode obs normalisation -> actor / critic -> (mu, sigma, un-normalised
+    value) for every step of the reference's recorded rollout, and the reference's neglogp for its recorded actions
+    (learning/ase_agent.py:117-148, common_agent.py get_action_values)."""
+    import math
+    from tests.helpers import set_rms
+    E = G['epochs'][0]
+    dev = ag.ppo_device
+    set_rms(ag.engine.obs_state, E['rms_before']['obs'])
+    set_rms(ag.engine.val_state, E['rms_before']['value'])
+    exp = E['exp']
+    H, N = exp['obses'].shape[:2]
+    obs = exp['obses'].reshape(H * N, -1).to(dev)
+    extra = ()
+    if G['kind'] in ('ase',):
+        extra = (exp['ase_latents'].reshape(H * N, -1).to(dev),)
+    ag.set_eval()
+    res = ag.get_action_values({'obs': obs}, *extra)
+    close(res['mus'], exp['mus'].reshape(H * N, -1), rtol, atol, 'rollout mus')
+    close(res['sigmas'], exp['sigmas'].reshape(H * N, -1), rtol, atol * 0.1, 'rollout sigmas')
+    close(res['values'], exp['values'].reshape(H * N, -1), rtol * 5, atol * 5, 'rollout values')
+    a, mu, sg = exp['actions'].reshape(H * N, -1).to(dev), res['mus'], res['sigmas']
+    nlp = 0.5 * (((a - mu) / sg) ** 2).sum(-1) + 0.5 * math.log(2 * math.pi) * mu.shape[-1] + torch.log(sg).sum(-1)
+    if 'rand_action_mask' in exp:       # deterministic (mask 0) steps store mu as the action but keep the sample's neglogp
+        keep = exp['rand_action_mask'].reshape(-1) > 0
+    else:
+        keep = torch.ones(H * N, dtype=torch.bool)
+    close(nlp[keep.to(dev)], exp['neglogpacs'].reshape(-1)[keep], rtol * 20, atol * 200, 'rollout neglogp of the recorded actions')
+    nv = ag._eval_critic({'obs': exp['next_obses'].reshape(H * N, -1).to(dev)}, *extra)
+    live = (exp['next_values'].reshape(-1) != 0)                  # terminated steps were zeroed by the reference
+    close(nv.reshape(-1)[live.to(dev)], exp['next_values'].reshape(-1)[live], rtol * 5, atol * 5, 'next values')
+
+
+@pytest.mark.parametrize('name', ['ase_tiny', 'amp_tiny', 'ppo_tiny'])
+def test_rollout_inference_emulated(name, golden_dir):
+    G = torch.load(os.path.join(golden_dir, name + '.pt'), weights_only=False)
+    check_rollout_inference(G, make_agent(G, EmuBackend()), rtol=2e-5, atol=2e-6)
+
+
+def check_checkpoint_interop(G, ag_after, make_fresh, wtol):
+    """N3: after the same two epochs our checkpoint dictionary equals the one the REFERENCE wrote (weights, running
+    statistics, torch.optim.Adam state in its layout), and a fresh agent restored from the reference's dictionary
+    carries exactly its weights / moments / statistics."""
+    ref = G['ckpt_after']
+    ours = ag_after.get_full_state_weights()
+    assert set(ours) == set(ref)
+    assert ours['epoch'] == ref['epoch']
+    for k, v in ref['model'].items():
+        close(ours['model'][k], v, 1e-5, wtol, 'ckpt model ' + k)
+    for key in ('running_mean_std', 'reward_mean_std', 'amp_input_mean_std'):
+        if key in ref:
+            close(ours[key]['running_mean'], ref[key]['running_mean'].view(-1), 1e-5, 1e-6, key + ' mean')
+            close(ours[key]['running_var'], ref[key]['running_var'].view(-1), 1e-4, 1e-6, key + ' var')
+            close(ours[key]['count'], ref[key]['count'], 0, 0, key + ' count')
+    ro, oo = ref['optimizer'], ours['optimizer']
+    assert len(oo['state']) == len(ro['state']) and oo['param_groups'][0]['params'] == ro['param_groups'][0]['params']
+    for k in ('lr', 'betas', 'eps', 'weight_decay'):
+        assert oo['param_groups'][0][k] == ro['param_groups'][0][k], k
+    for i, st in ro['state'].items():
+        assert float(oo['state'][i]['step']) == float(st['step'])
+        close(oo['state'][i]['exp_avg'], st['exp_avg'], 1e-3, 1e-7, f'exp_avg[{i}]')
+        close(oo['state'][i]['exp_avg_sq'], st['exp_avg_sq'], 2e-3, 1e-10, f'exp_avg_sq[{i}]')
+    fresh = make_fresh()
+    fresh.set_full_state_weights(ref)
+    back = fresh.get_full_state_weights()
+    for k, v in ref['model'].items():
+        assert torch.equal(back['model'][k].cpu(), v), k
+    for i, st in ro['state'].items():
+        assert torch.equal(back['optimizer']['state'][i]['exp_avg'].cpu(), st['exp_avg'])
+        assert torch.equal(back['optimizer']['state'][i]['exp_avg_sq'].cpu(), st['exp_avg_sq'])
+        assert float(back['optimizer']['state'][i]['step']) == float(st['step'])
+    for key in ('running_mean_std', 'reward_mean_std', 'amp_input_mean_std'):
+        if key in ref:
+            assert torch.equal(back[key]['running_mean'].cpu().view(-1), ref[key]['running_mean'].view(-1))
+            assert torch.equal(back[key]['running_var'].cpu().view(-1), ref[key]['running_var'].view(-1))
+    assert back['epoch'] == ref['epoch']
+
+
+@pytest.mark.parametrize('name', ['ase_tiny', 'amp_tiny', 'ppo_tiny', 'ase_sep_tiny'])
+def test_checkpoint_interop_with_reference(name, golden_dir):
+    G = torch.load(os.path.join(golden_dir, name + '.pt'), weights_only=False)
+    ag = make_agent(G, EmuBackend())
+    replay_epochs(G, ag, rtol=2e-4, wtol=G['cfg']['learning_rate'] * 0.05, check=False)
+    check_checkpoint_interop(G, ag, lambda: make_agent(G, EmuBackend()), wtol=G['cfg']['learning_rate'] * 0.05)

@@ -96,3 +96,27 @@ def test_two_ranks_sharded_update_matches_reference(name, graph):
     port = s.getsockname()[1]
     s.close()
     mp.spawn(_dp_worker, args=(2, port, name, 'f32', graph), nprocs=2, join=True)
+
+
+@pytest.mark.parametrize('name', ['ase_tiny', 'amp_tiny', 'ppo_tiny'])
+@pytest.mark.parametrize('precision', ['f32', 'bf16'])
+def test_rollout_inference_matches_reference(be, name, precision, golden_dir):
+    """N1: get_action_values / _eval_critic on the HIP inference path against the reference's recorded rollout."""
+    from tests.test_agent_emu import check_rollout_inference
+    G = torch.load(os.path.join(golden_dir, name + '.pt'), weights_only=False)
+    ag = make_agent(G, be, device='cuda', precision=precision)
+    if precision == 'f32':
+        check_rollout_inference(G, ag, rtol=2e-5, atol=2e-6)
+    else:
+        check_rollout_inference(G, ag, rtol=3e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize('name', ['ase_tiny', 'ppo_tiny'])
+def test_checkpoint_interop_with_reference_gpu(be, name, golden_dir):
+    """N3 on the HIP path: our checkpoint after the two epochs == the reference's; restore() of the reference's."""
+    from tests.test_agent_emu import check_checkpoint_interop
+    G = torch.load(os.path.join(golden_dir, name + '.pt'), weights_only=False)
+    ag = make_agent(G, be, device='cuda', precision='f32')
+    replay_epochs(G, ag, rtol=3e-4, wtol=G['cfg']['learning_rate'] * 0.25, check=False)
+    check_checkpoint_interop(G, ag, lambda: make_agent(G, be, device='cuda', precision='f32'),
+                             wtol=G['cfg']['learning_rate'] * 0.25)
