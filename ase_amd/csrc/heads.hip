@@ -31,18 +31,20 @@ struct PpoArgs {
     float e_clip, critic_coef, bounds_coef, div_coef, div_tar;
 };
 
-// 32 lanes per row (act_dim <= 32), 8 rows per 256-thread block.
-template <typename T>
+// LPR lanes per row (act_dim <= LPR: 32 for the humanoid's 28 / 31 actions, 64 for the HRL high-level policy whose action
+// is the 64-d latent), 256 / LPR rows per 256-thread block.
+template <typename T, int LPR>
 __global__ __launch_bounds__(256) void ppo_head_kernel(PpoArgs p) {
+    constexpr int ROWS = 256 / LPR;
     __shared__ double sm[7 * 16];
-    __shared__ float sdb[8][33];
-    const int lane = threadIdx.x & 31;
+    __shared__ float sdb[ROWS][LPR + 1];
+    const int lane = threadIdx.x & (LPR - 1), rib = threadIdx.x / LPR;
     float gm_out = 0.f, gm2_out = 0.f, dv_out = 0.f;
     const int D = p.act_dim;
     double part[7] = {0, 0, 0, 0, 0, 0, 0};  // a_loss, b_loss, entropy, clipped, c_loss, kl, div
 
     // grid-stride over rows: few workgroups => few contended f64 atomics on the 7 accumulators
-    for (int i = blockIdx.x * 8 + (threadIdx.x >> 5); i < p.M; i += gridDim.x * 8) {
+    for (int i = blockIdx.x * ROWS + rib; i < p.M; i += gridDim.x * ROWS) {
         const bool act_ok = lane < p.act_dim;
         const float S = p.masked ? (float)p.acc[ASE_ACC_MASK_SUM] : (float)p.m_global;
         const float mk = p.masked ? p.mask[i] : 1.f;
@@ -60,8 +62,8 @@ __global__ __launch_bounds__(256) void ppo_head_kernel(PpoArgs p) {
             osg = p.old_sigma[(int64_t)i * D + lane];
             if (p.mu_out) p.mu_out[(int64_t)i * D + lane] = m;
         }
-        const float sum_d2 = group_sum<32>(act_ok ? d * d : 0.f);
-        const float sum_ls = group_sum<32>(act_ok ? ls : 0.f);
+        const float sum_d2 = group_sum<LPR>(act_ok ? d * d : 0.f);
+        const float sum_ls = group_sum<LPR>(act_ok ? ls : 0.f);
         const float nlp = 0.5f * sum_d2 + kHalfLog2Pi * (float)D + sum_ls;
         const float ratio = expf(p.old_logp[i] - nlp);
         const float adv = p.adv[i];
@@ -74,15 +76,15 @@ __global__ __launch_bounds__(256) void ppo_head_kernel(PpoArgs p) {
 
         // bound loss, entropy, KL (rl_games policy_kl(p0 = new, p1 = old))
         const float bh = fmaxf(m - 1.f, 0.f), bl = fminf(m + 1.f, 0.f);
-        const float b_row = group_sum<32>(act_ok ? bh * bh + bl * bl : 0.f);
-        const float ent_row = group_sum<32>(act_ok ? 0.5f + kHalfLog2Pi + ls : 0.f);
+        const float b_row = group_sum<LPR>(act_ok ? bh * bh + bl * bl : 0.f);
+        const float ent_row = group_sum<LPR>(act_ok ? 0.5f + kHalfLog2Pi + ls : 0.f);
         float klj = 0.f;
         if (act_ok) {
             const float c1 = logf(osg / sg + 1e-5f);
             const float c2 = (sg * sg + (omu - m) * (omu - m)) / (2.f * (osg * osg + 1e-5f));
             klj = c1 + c2 - 0.5f;
         }
-        const float kl_row = group_sum<32>(klj);
+        const float kl_row = group_sum<LPR>(klj);
 
         float gm = w * g * ratio * d / sg + p.bounds_coef * w * 2.f * (bh + bl);
 
@@ -97,10 +99,10 @@ __global__ __launch_bounds__(256) void ppo_head_kernel(PpoArgs p) {
                 cm2 = fminf(fmaxf(m2, -1.f), 1.f);
             }
             const float diff = cm - cm2;
-            const float a_diff = group_sum<32>(act_ok ? diff * diff : 0.f) / (float)D;
+            const float a_diff = group_sum<LPR>(act_ok ? diff * diff : 0.f) / (float)D;
             float zz = 0.f;
-            for (int k = lane; k < p.z_dim; k += 32) zz += p.new_z[(int64_t)i * p.z_dim + k] * p.z[(int64_t)i * p.z_dim + k];
-            zz = group_sum<32>(zz);
+            for (int k = lane; k < p.z_dim; k += LPR) zz += p.new_z[(int64_t)i * p.z_dim + k] * p.z[(int64_t)i * p.z_dim + k];
+            zz = group_sum<LPR>(zz);
             const float z_diff = 0.5f - 0.5f * zz;
             const float inv = 1.f / (z_diff + 1e-5f);
             const float bonus = a_diff * inv;
@@ -156,15 +158,15 @@ __global__ __launch_bounds__(256) void ppo_head_kernel(PpoArgs p) {
         }
     }
     if (p.db_mu) {  // head bias gradients: column sums over this block's 8 rows, one atomic per column
-        sdb[threadIdx.x >> 5][lane] = gm_out + gm2_out;
-        if (lane == 0) sdb[threadIdx.x >> 5][32] = dv_out;
+        sdb[rib][lane] = gm_out + gm2_out;
+        if (lane == 0) sdb[rib][LPR] = dv_out;
         __syncthreads();
-        if (threadIdx.x < 33) {
+        if (threadIdx.x < LPR + 1) {
             float t = 0.f;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) t += sdb[q][threadIdx.x];
+            for (int q = 0; q < ROWS; ++q) t += sdb[q][threadIdx.x];
             if (threadIdx.x < p.act_dim) atomic_add_f32(p.db_mu + threadIdx.x, t);
-            else if (threadIdx.x == 32 && p.db_value) atomic_add_f32(p.db_value, t);
+            else if (threadIdx.x == LPR && p.db_value) atomic_add_f32(p.db_value, t);
         }
     }
     block_sum<7>(part, sm);
@@ -401,7 +403,7 @@ extern "C" int ase_hip_ppo_head(const float* mu, int64_t ld_mu, const float* val
     ASE_CHECK_ARG(mu && value && mb_actions && mb_old_mu && mb_old_sigma && mb_old_logp && mb_adv && mb_return &&
                       logstd && d_mu && d_value && acc && scratch && M > 0 && m_global >= M,
                   "ppo_head: null/empty operand");
-    ASE_CHECK_ARG(act_dim >= 1 && act_dim <= 32, "ppo_head: act_dim %d not in [1,32]", act_dim);
+    ASE_CHECK_ARG(act_dim >= 1 && act_dim <= 64, "ppo_head: act_dim %d not in [1,64]", act_dim);
     ASE_CHECK_ARG(!masked || mb_mask, "ppo_head: masked reduction without a mask");
     ASE_CHECK_ARG(!div_on || (mb_z && new_z && z_dim > 0), "ppo_head: diversity loss without latents");
     ASE_CHECK_ARG(!clip_value || mb_old_value, "ppo_head: clip_value without old values");
@@ -413,10 +415,16 @@ extern "C" int ase_hip_ppo_head(const float* mu, int64_t ld_mu, const float* val
     p.acc = acc; p.scratch = scratch; p.M = M; p.m_global = m_global; p.act_dim = act_dim; p.z_dim = z_dim; p.masked = masked;
     p.div_on = div_on; p.mu_tanh = mu_tanh; p.clip_value = clip_value; p.e_clip = e_clip; p.critic_coef = critic_coef;
     p.bounds_coef = bounds_coef; p.div_coef = div_coef; p.div_tar = div_tar;
-    const dim3 grid(min((M + 7) / 8, 1024));       // scratch holds 1024 x 8 doubles
-    if (dtype == ASE_BF16) hipLaunchKernelGGL(ppo_head_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    else if (dtype == ASE_F32) hipLaunchKernelGGL(ppo_head_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    else ASE_CHECK_ARG(false, "ppo_head: bad dtype %d", dtype);
+    const int rows = act_dim <= 32 ? 8 : 4;         // rows per workgroup (32 / 64 lanes per row)
+    const dim3 grid(min((M + rows - 1) / rows, 1024));       // scratch holds 1024 x 8 doubles
+    ASE_CHECK_ARG(dtype == ASE_BF16 || dtype == ASE_F32, "ppo_head: bad dtype %d", dtype);
+    if (act_dim <= 32) {
+        if (dtype == ASE_BF16) hipLaunchKernelGGL((ppo_head_kernel<bf16_t, 32>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((ppo_head_kernel<float, 32>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+        if (dtype == ASE_BF16) hipLaunchKernelGGL((ppo_head_kernel<bf16_t, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((ppo_head_kernel<float, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    }
     hipLaunchKernelGGL(ppo_head_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, (int)grid.x, acc, div_on);
     ASE_CHECK_LAUNCH("ppo_head");
     return ASE_OK;

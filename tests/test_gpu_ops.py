@@ -191,8 +191,9 @@ def _mb(M, D, Z, g, masked=True):
 
 @pytest.mark.parametrize('dt', DT)
 @pytest.mark.parametrize('masked,div_on,mu_tanh,clip_value', [(1, 1, 0, 0), (1, 0, 0, 1), (0, 0, 1, 0)])
-def test_ppo_head(be, dt, masked, div_on, mu_tanh, clip_value):
-    M, D, Z = 1003, 31, 64
+@pytest.mark.parametrize('D', [31, 64])        # humanoid actions / the HRL high-level action (= the 64-d latent)
+def test_ppo_head(be, dt, masked, div_on, mu_tanh, clip_value, D):
+    M, Z = 1003, 64
     g = torch.Generator().manual_seed(17 + masked + 2 * div_on)
     mb = _mb(M, D, Z if div_on else 0, g, masked)
     rows = 2 * M if div_on else M
