@@ -1268,14 +1268,15 @@ template <typename T> int launch_tn(TNParams p, hipStream_t stream) {
     const int tiles = p.tiles_n * p.tiles_k;
     // Split M so that the grid is ONE resident wave of workgroups: 80 KB of LDS => 2 workgroups per CU => 512 slots
     // on 256 CUs.  More splits only add f32 atomics (splits x N x K of them) and a partial second wave.
-    static int target_wg = 0;
+    static int target_wg = 0, target_forced = 0;
     if (target_wg == 0) {
         const char* e = getenv("ASE_TN_TARGET_WG");
+        target_forced = e != nullptr;
         target_wg = e ? atoi(e) : 512;
     }
     // narrow outputs (<= 8 tiles): the partial-sum atomics outweigh the second resident workgroup per CU (measured:
     // 256 workgroups beat 512 by 20-30 % on the head / style-MLP gradients)
-    int splits = ((tiles <= 8 && !getenv("ASE_TN_TARGET_WG")) ? 256 : target_wg) / tiles;
+    int splits = ((tiles <= 8 && !target_forced) ? 256 : target_wg) / tiles;
     const int max_splits = (p.M + 4 * Gm::BKM - 1) / (4 * Gm::BKM); // >= 4 staged tiles per split
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
