@@ -121,12 +121,13 @@ def test_refresh_shadow(be, dt):
 
 
 @pytest.mark.parametrize('dt', DT)
-@pytest.mark.parametrize('D,W', [(253, 320), (1400, 1408)])      # scalar path / 16-byte path (D % 4 == 0)
-def test_rms_pipeline(be, dt, D, W):
+@pytest.mark.parametrize('D,W,gathered', [(253, 320, True), (1400, 1408, True), (1400, 1408, False)])   # scalar / 16-byte paths
+def test_rms_pipeline(be, dt, D, W, gathered):
     H, N, M = 8, 50, 300
     g = torch.Generator().manual_seed(3)
     src = torch.randn(H * N, D, generator=g) * 2 + 0.5
-    idx = torch.randperm(H * N, generator=g)[:M].to(torch.int32)
+    idx = torch.randperm(H * N, generator=g)[:M].to(torch.int32) if gathered else None
+    remap = (H, N) if gathered else (0, 0)
     outs = []
     for dev in ('cuda', 'cpu'):
         b = be if dev == 'cuda' else EmuBackend()
@@ -138,9 +139,9 @@ def test_rms_pipeline(be, dt, D, W):
         o0 = torch.zeros(M, W, dtype=dt, device=dev)
         o1 = torch.zeros(M, W, dtype=dt, device=dev)
         for s in range(3):
-            b.rms_moments(src.to(dev), D, idx.to(dev), (H, N), M, state, sums[s])
+            b.rms_moments(src.to(dev), D, None if idx is None else idx.to(dev), remap, M, state, sums[s])
         b.rms_finalize(state, D, sums, M, 3, mean, std)
-        b.rms_normalize(src.to(dev), D, idx.to(dev), (H, N), M, mean[2], std[2], [o0, o1[:, 0:]])
+        b.rms_normalize(src.to(dev), D, None if idx is None else idx.to(dev), remap, M, mean[2], std[2], [o0, o1[:, 0:]])
         outs.append((state.cpu(), mean.cpu(), std.cpu(), o0.float().cpu(), o1.float().cpu()))
     close(outs[0][0], outs[1][0], 1e-9, 1e-12, 'state')
     close(outs[0][1], outs[1][1], 1e-6, 1e-7, 'mean')
