@@ -182,9 +182,34 @@ __device__ __forceinline__ uint32_t or8_dpp(uint32_t x) {
     return x;
 }
 
+// mask operand of chunk ch (jc-major) of a wave's sub-tile: one AuxReg per row iteration
 template <typename T, int FM, int FN, int FMC, int FNC, int AUXK>
+__device__ __forceinline__ void nt_aux_load(const NTParams& p, int ch, int lane, int mrow0, int ncol0,
+                                            AuxReg<T, AUXK> (&dst)[(FMC * 32) / (64 / (FNC * 8))]) {
+    constexpr int ELPR = FNC * 8, RPI = 64 / ELPR, NIT = (FMC * 32) / RPI;
+    if constexpr (AUXK != 0) {
+        const int c4 = lane % ELPR, rsub = lane / ELPR;
+        const int jc = (ch / (FM / FMC)) * FNC, ic = (ch % (FM / FMC)) * FMC;
+        const int n0 = ncol0 + jc * 32 + c4 * 4;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int m = mrow0 + ic * 32 + it * RPI + rsub;
+            if (n0 < p.N && m < p.M) {
+                const int ma = (m >= p.aux_split) ? m - p.aux_delta : m;
+                if constexpr (AUXK == 2)
+                    dst[it].v = *reinterpret_cast<const uint32_t*>(p.aux + (int64_t)ma * p.ldaux + (n0 >> 5) * 4);
+                else
+                    dst[it].v = *reinterpret_cast<const decltype(dst[it].v)*>(p.aux + (int64_t)ma * p.ldaux + (int64_t)n0 * sizeof(T));
+            }
+        }
+    }
+}
+
+// PRE: chunk 0 of the mask operand was loaded by the caller (before its main loop) into pre[]
+template <typename T, int FM, int FN, int FMC, int FNC, int AUXK, bool PRE = false>
 __device__ __forceinline__ void nt_epilogue_impl(const NTParams& p, f32x16 (&acc)[FM][FN], float* slab, int lane,
-                                                 int mrow0, int ncol0) {
+                                                 int mrow0, int ncol0,
+                                                 AuxReg<T, AUXK> (*pre)[(FMC * 32) / (64 / (FNC * 8))] = nullptr) {
     constexpr int WCOLS = FNC * 32, WROWS = FMC * 32;
     const int col_in = lane & 31, row_hi = (lane >> 5) * 4;
     constexpr int ELPR = WCOLS / 4;                // lanes per row (4 columns each)
@@ -196,24 +221,15 @@ __device__ __forceinline__ void nt_epilogue_impl(const NTParams& p, f32x16 (&acc
     AuxReg<T, AUXK> areg[AHEAD ? 2 : 1][NIT];
 
     auto load_aux = [&](int ch, AuxReg<T, AUXK> (&dst)[NIT]) {
-        if constexpr (AUXK != 0) {
-            const int jc = (ch / (FM / FMC)) * FNC, ic = (ch % (FM / FMC)) * FMC;
-            const int n0 = ncol0 + jc * 32 + c4 * 4;
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int m = mrow0 + ic * 32 + it * RPI + rsub;
-                if (n0 < p.N && m < p.M) {
-                    const int ma = (m >= p.aux_split) ? m - p.aux_delta : m;
-                    if constexpr (AUXK == 2)
-                        dst[it].v = *reinterpret_cast<const uint32_t*>(p.aux + (int64_t)ma * p.ldaux + (n0 >> 5) * 4);
-                    else
-                        dst[it].v = *reinterpret_cast<const decltype(dst[it].v)*>(p.aux + (int64_t)ma * p.ldaux + (int64_t)n0 * sizeof(T));
-                }
-            }
-        }
+        nt_aux_load<T, FM, FN, FMC, FNC, AUXK>(p, ch, lane, mrow0, ncol0, dst);
     };
 
-    if constexpr (AUXK != 0) load_aux(0, areg[0]);
+    if constexpr (PRE) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) areg[0][it] = (*pre)[it];
+    } else if constexpr (AUXK != 0) {
+        load_aux(0, areg[0]);
+    }
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         const int jc = (ch / (FM / FMC)) * FNC, ic = (ch % (FM / FMC)) * FMC;
@@ -585,6 +601,11 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(NTParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    // the first chunk's mask words (16 registers) are fetched before anything else: older than every DMA, they retire
+    // first and the epilogue finds them in registers instead of waiting an HBM round trip after the last K-tile
+    AuxReg<T, 2> pre_bits[16];
+    if (p.aux_mode == ASE_AUX_RELU_BITS) nt_aux_load<T, 4, 2, 2, 2, 2>(p, 0, lane, bm0 + wr * 128, bn0 + wc * 64, pre_bits);
+
     const int nk = p.K / BK;
     // prologue: units 0..5 (K-tile 0 and A0, B0 of K-tile 1); A0 / B0 of K-tile 0 must have landed for phase 0
     nt8_issue<0>(L, smem, 0);
@@ -618,7 +639,10 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(NTParams p) {
     if (p.prof && tid == 0) p.prof[blockIdx.x * 4 + 2] = wall_clock64();
 
     float* slab = reinterpret_cast<float*>(smem) + wid * (64 * 64);
-    nt_epilogue<T, 4, 2, 2, 2>(p, acc, slab, lane, bm0 + wr * 128, bn0 + wc * 64);
+    if (p.aux_mode == ASE_AUX_RELU_BITS)
+        nt_epilogue_impl<T, 4, 2, 2, 2, 2, true>(p, acc, slab, lane, bm0 + wr * 128, bn0 + wc * 64, &pre_bits);
+    else
+        nt_epilogue<T, 4, 2, 2, 2>(p, acc, slab, lane, bm0 + wr * 128, bn0 + wc * 64);
     if (p.prof) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
