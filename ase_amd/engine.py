@@ -461,8 +461,9 @@ class UpdateEngine:
         if not self.multi_stream:
             return None
         if self._side_streams is None:
-            self._side_streams = [torch.cuda.Stream(device=self.dev) for _ in range(2)]
-        return self._side_streams[k]
+            n = int(os.environ.get('ASE_SIDE_STREAMS', '2'))        # 1: critic and discriminator share one side stream
+            self._side_streams = [torch.cuda.Stream(device=self.dev) for _ in range(max(1, min(n, 2)))]
+        return self._side_streams[k % len(self._side_streams)]
 
     class _Branch:
         def __init__(self, stream):
