@@ -1,16 +1,19 @@
 // Matrix-core kernels for the dense layers of the ASE/AMP update (gfx950 / CDNA4).
 //
 //   gemm_nt : C = mask(act(alpha * A·Bᵀ + bias))      forward, data-gradient, gradient-penalty chain
-//   gemm_tn : G += alpha * Aᵀ·B                        weight gradient (split over M, f32 atomics)
+//   gemm_tn : G += alpha * Aᵀ·B                        weight (+ bias) gradient, split over M, f32 atomics
 //
-// Both come in two storage types: bf16 (v_mfma_f32_32x32x16_bf16, f32 accumulate) and exact f32
-// (v_mfma_f32_32x32x2_f32).  Wave64, 256-thread workgroups (4 waves), XCD-aware tile order (8 XCDs, private L2s).
-//   NT: tiles go HBM -> LDS directly with global_load_lds_dwordx4 (no staging VGPRs, no ds_write pass); LDS rows
+// Storage types: bf16 (v_mfma_f32_32x32x16_bf16, f32 accumulate), exact f32 (v_mfma_f32_32x32x2_f32) and f32 multiplied
+// as three bf16 MFMAs on a hi/lo split.  Wave64, XCD-aware tile order (8 XCDs, private L2s).
+//   Staging: tiles go HBM -> LDS directly with global_load_lds_dwordx4 (no staging VGPRs, no ds_write pass); LDS rows
 //       are 128 bytes, unpadded (the DMA writes lane-linear), with the 16-byte chunks of row r stored at slot
-//       chunk ^ ((r >> 1) & 7): the permutation is applied to the per-lane SOURCE address and again on the
-//       fragment read, which makes every ds_read_b128 lane group hit 16 distinct bank slots.  Two LDS buffers,
-//       one barrier per K-tile (the next tile's DMA runs under the current tile's MFMAs).
-//   TN: register-staged double buffering, 16-byte-padded rows.
+//       chunk ^ ((r >> 1) & 7): the permutation is applied to the per-lane SOURCE address and again on the fragment
+//       read, which makes every ds_read_b128 lane group hit 16 distinct bank slots.
+//   NT kernels: gemm_nt_kernel (64 / 128 / 256 tiles, S-stage ring, one barrier per K-tile, every wave in lock-step) and
+//       gemm_nt8_kernel (bf16, 256 x 256: four phases per K-tile, two wave groups one barrier apart, counted vmcnt) -
+//       see the comment blocks in front of each; nt_choice() picks per shape.  One epilogue (nt_epilogue) for all.
+//   TN kernels: gemm_tn_kernel (128 x 128, register-staged, transposed LDS reads) and the phased gemm_tn8 kernels
+//       (256 x 256, DMA-staged), single problem or grouped (all weight gradients of a step in one grid).
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>

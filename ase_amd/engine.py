@@ -10,12 +10,13 @@ in ``ASEAgent.calc_gradients`` (learning/ase_agent.py:159-308 under /root/refere
 
 Data layout in HBM
   * master parameters, gradients, Adam moments: four flat f32 buffers in checkpoint layout
-    (one Adam launch, one RCCL all-reduce over the flat gradient buffer);
+    (one fused optimizer launch, one RCCL all-reduce over the flat gradient buffer);
   * per layer "shadow" copies in the compute dtype (bf16 or f32): W_s [P(N), Kpad] and its
-    transpose Wt_s [Kpad, P(N)], zero padded (P(x) = x rounded up to 64), refreshed after the
-    optimizer step; the concat inputs [obs | z] of the first actor/critic layer are laid out as
+    transpose Wt_s [Kpad, P(N)], zero padded (P(x) = x rounded up to 64), rewritten by the
+    optimizer launch; the concat inputs [obs | z] of the first actor/critic layer are laid out as
     [obs, pad to P(obs) | z], so the latent block starts on a 128-byte boundary;
-  * activations [rows, P(features)] in the compute dtype; head outputs and all loss math in f32;
+  * activations [rows, P(features)] in the compute dtype, ReLU activations with a bit-mask twin
+    [rows, P(features) / 32] that the data-gradient epilogues read; head outputs and all loss math in f32;
   * the experience buffer stays time-major [H, N, ...]; minibatch rows are addressed through
     the epoch permutation (env-major flat index -> physical row) inside the gather/normalise
     kernels, so neither swap_and_flatten01 nor the dataset gather materialise anything.
