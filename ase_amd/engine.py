@@ -245,12 +245,17 @@ class UpdateEngine:
                 self.dE = zt(AMB, self.enc_head.n_pad)
             if self.has_enc:
                 self.enc_z = zt(AMB, self.z, f32)     # latents of the amp rows (first amp_minibatch rows of the GLOBAL minibatch)
-            self.amp_sums = torch.zeros(3, 2 * self.amp, dtype=torch.float64, device=dev)
             self.amp_mean = zt(3, self.amp, f32)
             self.amp_std = zt(3, self.amp, f32)
             self.amp_state = torch.zeros(2 * self.amp + 1, dtype=torch.float64, device=dev)
             self.amp_state[self.amp:] = 1.0
-        self.obs_sums = torch.zeros(2 * self.obs, dtype=torch.float64, device=dev)
+        # every per-step partial statistic that the data-parallel ranks exchange lives in ONE f64 buffer
+        # [obs sums | amp sums x3 | mask sum]: one small all-reduce per step
+        n_amp = 3 * 2 * self.amp if self.has_disc else 0
+        self.stats_flat = torch.zeros(2 * self.obs + n_amp + 1, dtype=torch.float64, device=dev)
+        self.obs_sums = self.stats_flat[:2 * self.obs]
+        if self.has_disc:
+            self.amp_sums = self.stats_flat[2 * self.obs:2 * self.obs + n_amp].view(3, 2 * self.amp)
         self.obs_mean = zt(1, self.obs, f32)
         self.obs_std = zt(1, self.obs, f32)
         self.obs_state = torch.zeros(2 * self.obs + 1, dtype=torch.float64, device=dev)
@@ -693,11 +698,11 @@ class UpdateEngine:
 
     def _allreduce_stats(self):
         if self._dist_on():
-            self._ar(self.obs_sums)
-            if self.has_disc:
-                self._ar(self.amp_sums)
             if self.masked:
-                self._ar(self.acc[L.ACC_MASK_SUM:L.ACC_MASK_SUM + 1])
+                self.stats_flat[-1:].copy_(self.acc[L.ACC_MASK_SUM:L.ACC_MASK_SUM + 1])
+            self._ar(self.stats_flat)
+            if self.masked:
+                self.acc[L.ACC_MASK_SUM:L.ACC_MASK_SUM + 1].copy_(self.stats_flat[-1:])
 
     def _allreduce_grads(self):
         if self._dist_on():
