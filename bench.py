@@ -23,6 +23,12 @@ import os
 import sys
 import time
 
+# The captured step runs its three network branches on three streams.  How many of their kernels the runtime lets run
+# side by side is set by its hardware-queue count, read when libamdhip64 loads: measured on MI355X 85.4 ms per update
+# with 3 queues (= what an unset variable gave on most boxes), 94 ms with 4, 136 ms with 8 (every launch fills the chip;
+# more co-running launches only thrash L2), and a crash inside hipGraphLaunch with fewer queues than branches.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '3')
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
