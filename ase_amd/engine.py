@@ -484,7 +484,13 @@ class UpdateEngine:
 
         def __exit__(self, *a):
             if self.stream is not None:
+                self.done = torch.cuda.Event()
+                self.done.record(self.stream)          # what the main stream waits for when only THIS branch is needed
                 self.ctx.__exit__(*a)
+
+    def _join_branch(self, br):
+        if br.stream is not None:
+            torch.cuda.current_stream().wait_event(br.done)
 
     def _join(self, k):
         st = self._side(k)
@@ -518,56 +524,63 @@ class UpdateEngine:
                 be.gather_rows(self.new_z, self.z, None, (0, 0), M, self.Zs[M:])
 
         # -- discriminator (+ encoder) branch: normalise, forward, heads, backward, gradient penalty
-        with self._Branch(self._side(1) if self.has_disc else None):
-            if self.has_disc:
-                if self._amp_stats_in_branch():
-                    self._amp_moments(amp_streams)
-                if norm_amp:
-                    be.rms_finalize(self.amp_state, self.amp, self.amp_sums, self.AMBg, 3, self.amp_mean, self.amp_std)
-                else:
-                    self._identity_stats(self.amp_mean, self.amp_std)
-                for s, (src, sidx, srm) in enumerate(amp_streams):
-                    be.rms_normalize(src, self.amp, sidx, srm, AMB, self.amp_mean[s], self.amp_std[s],
-                                     [self.Xd[s * AMB:(s + 1) * AMB]])
-                Rd = 3 * AMB
-                hd = self._fwd_chain(self.disc, self.Xd, self.Hd, Rd)
-                self._fwd(self.disc_head, hd, self.HD, Rd)
-                if self.enc_chain:
-                    he = self._fwd_chain(self.enc_chain, self.Xd[:AMB], self.He, AMB)
-                    self._fwd(self.enc_head, he, self.E, AMB)
-                be.disc_head(self.HD, self.dHD, self.disc_head.gb[0], self.acc, AMB, self.AMBg, c['disc_coef'])
-                if self.has_enc:
-                    src, sidx, srm = amp_streams[0]   # enc_latents = ase_latents[0:amp_minibatch] (learning/ase_agent.py:247)
-                    zsrc = ds['ase_latents'].view(ds['ase_latents'].shape[0], -1)
-                    be.gather_rows(zsrc, self.z, sidx, srm, AMB, self.enc_z)
-                    if self.enc_sep:
-                        be.enc_head(self.E, self.enc_z, self.dE, self.enc_head.gb[0], None, self.acc, AMB, self.AMBg,
-                                    self.z, c['enc_coef'])
+        def disc_branch():
+            with self._Branch(self._side(1) if self.has_disc else None):
+                if self.has_disc:
+                    if self._amp_stats_in_branch():
+                        self._amp_moments(amp_streams)
+                    if norm_amp:
+                        be.rms_finalize(self.amp_state, self.amp, self.amp_sums, self.AMBg, 3, self.amp_mean, self.amp_std)
                     else:
-                        off = self.disc_head.parts[1][2]
-                        be.enc_head(self.HD[:AMB, off:], self.enc_z, self.dHD[:AMB, off:], self.disc_head.gb[1], None,
-                                    self.acc, AMB, self.AMBg, self.z, c['enc_coef'])
-                self._wgrad(self.disc_head, self.dHD, hd, Rd)
-                last = self.disc[-1]
-                self._dgrad(self.disc_head, self.dHD, self.dZd[-1], Rd, self.Hd[-1], last.act)
-                self._disc_backward()
-                if self.enc_chain:
-                    self._wgrad(self.enc_head, self.dE, he, AMB)
-                    last = self.enc_chain[-1]
-                    self._dgrad(self.enc_head, self.dE, self.dZe[-1], AMB, self.He[-1], last.act)
-                    self._bwd_chain(self.enc_chain, self.Xd[:AMB], self.He, self.dZe, AMB)
+                        self._identity_stats(self.amp_mean, self.amp_std)
+                    for s, (src, sidx, srm) in enumerate(amp_streams):
+                        be.rms_normalize(src, self.amp, sidx, srm, AMB, self.amp_mean[s], self.amp_std[s],
+                                         [self.Xd[s * AMB:(s + 1) * AMB]])
+                    Rd = 3 * AMB
+                    hd = self._fwd_chain(self.disc, self.Xd, self.Hd, Rd)
+                    self._fwd(self.disc_head, hd, self.HD, Rd)
+                    if self.enc_chain:
+                        he = self._fwd_chain(self.enc_chain, self.Xd[:AMB], self.He, AMB)
+                        self._fwd(self.enc_head, he, self.E, AMB)
+                    be.disc_head(self.HD, self.dHD, self.disc_head.gb[0], self.acc, AMB, self.AMBg, c['disc_coef'])
+                    if self.has_enc:
+                        src, sidx, srm = amp_streams[0]   # enc_latents = ase_latents[0:amp_minibatch] (learning/ase_agent.py:247)
+                        zsrc = ds['ase_latents'].view(ds['ase_latents'].shape[0], -1)
+                        be.gather_rows(zsrc, self.z, sidx, srm, AMB, self.enc_z)
+                        if self.enc_sep:
+                            be.enc_head(self.E, self.enc_z, self.dE, self.enc_head.gb[0], None, self.acc, AMB, self.AMBg,
+                                        self.z, c['enc_coef'])
+                        else:
+                            off = self.disc_head.parts[1][2]
+                            be.enc_head(self.HD[:AMB, off:], self.enc_z, self.dHD[:AMB, off:], self.disc_head.gb[1], None,
+                                        self.acc, AMB, self.AMBg, self.z, c['enc_coef'])
+                    self._wgrad(self.disc_head, self.dHD, hd, Rd)
+                    last = self.disc[-1]
+                    self._dgrad(self.disc_head, self.dHD, self.dZd[-1], Rd, self.Hd[-1], last.act)
+                    self._disc_backward()
+                    if self.enc_chain:
+                        self._wgrad(self.enc_head, self.dE, he, AMB)
+                        last = self.enc_chain[-1]
+                        self._dgrad(self.enc_head, self.dE, self.dZe[-1], AMB, self.He[-1], last.act)
+                        self._bwd_chain(self.enc_chain, self.Xd[:AMB], self.He, self.dZe, AMB)
 
-        # -- critic forward (side stream 0) next to the actor forward (main stream)
-        with self._Branch(self._side(0)):
+        # -- critic forward (side stream 0) next to the actor forward (main stream).  With ONE side stream
+        # (ASE_SIDE_STREAMS=1) its order is critic forward -> discriminator branch -> critic backward: two balanced lanes.
+        one_lane = self.multi_stream and self._side(0) is self._side(1)
+        if not one_lane:
+            disc_branch()
+        with self._Branch(self._side(0)) as br_critic:
             hc = self._fwd_chain(self.critic, self.Xc, self.Hc, M)
             self._fwd(self.value_head, hc, self.V, M)
+        if one_lane:
+            disc_branch()
         if self.style:
             sd = self.actor[0].split_dst
             h = self._fwd_chain(self.style[:-1], self.Zs, self.Hs, Ra)
             self._fwd(self.style[-1], h, self.Xa[:, sd:], Ra)
         ha = self._fwd_chain(self.actor, self.Xa, self.Ha, Ra)
         self._fwd(self.mu_head, ha, self.MU, Ra)
-        self._join(0)
+        self._join_branch(br_critic)
 
         # -- PPO loss head (value + gradient w.r.t. mu / value + head bias gradients)
         be.ppo_head(self.MU, self.V, self.mb, self.new_z if self.div_on else None, self.logstd, self.dMU, self.dV,
