@@ -265,8 +265,14 @@ def main():
     if rank == 0:
         print(f'[bench] setup + synthetic rollout: {time.time() - t_setup:.1f} s', file=sys.stderr)
 
+    tail_marks = []            # (event before the tail, event after it) per update: SURVEY §8d also wants the 48-step-only figure
+
     def one_update():
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
         batch = agent._play_steps_tail()
+        b.record()
+        tail_marks.append((a, b))
         return agent.update(batch)
 
     def sync():
@@ -293,6 +299,7 @@ def main():
         marks[i + 1].record()
     sync()
     dt = time.perf_counter() - t0
+    ms_tail = sum(a.elapsed_time(b) for a, b in tail_marks[-args.steps:]) / args.steps
     if args.verbose and rank == 0:
         print('[bench] per-update ms: ' + ' '.join(f'{marks[i].elapsed_time(marks[i + 1]):.1f}' for i in range(args.steps)),
               file=sys.stderr)
@@ -372,6 +379,7 @@ def main():
                                       '1400 / latent 64, [1024,1024,512] MLPs + disc + shared-trunk encoder, minibatch 16384 '
                                       '(amp 4096) x 6 mini-epochs = 48 optimisation steps per update; random-init weights',
                           'samples_per_step': B, 'optimisation_steps_per_step': cfg['mini_epochs'] * (B // cfg['minibatch_size']),
+                          'ms_epoch_tail': round(ms_tail, 3), 'ms_optimisation_steps_only': round(ms_per_step - ms_tail, 3),
                           'hipgraph': use_graph, 'parallelism': f'dp{world} (minibatch rows sharded, RCCL grad all-reduce)'
                           if world > 1 else 'single GPU'},
                'roofline': roof, 'cpu_baseline': cpu, 'last_train_result': {k: round(v, 6) for k, v in last.items()}}
