@@ -125,6 +125,19 @@ class HipBackend:
         L.check(self.lib.ase_hip_gather_multi(_ptr(desc), desc.shape[0], _ptr(idx), remap[0], remap[1], M,
                                               self._stream()), "gather_multi")
 
+    # ------------------------------------------------------------------ observation side (N2)
+    def build_amp_obs(self, root_pos, root_rot, root_vel, root_ang_vel, dof_pos, dof_vel, key_body_pos, dof_offsets,
+                      local_root_obs, root_height_obs, hist, shift=True):
+        """One AMP-observation frame per env pushed into hist [N, S, F] (env/tasks/humanoid_amp.py:248-316)."""
+        n, S, F = hist.shape
+        offs = (C.c_int32 * len(dof_offsets))(*[int(x) for x in dof_offsets])
+        for t in (root_pos, root_rot, root_vel, root_ang_vel, dof_pos, dof_vel, key_body_pos, hist):
+            assert t.dtype == torch.float32 and t.is_contiguous()
+        L.check(self.lib.ase_hip_build_amp_obs(_ptr(root_pos), _ptr(root_rot), _ptr(root_vel), _ptr(root_ang_vel), _ptr(dof_pos),
+                                               _ptr(dof_vel), _ptr(key_body_pos), n, dof_pos.shape[1], key_body_pos.shape[1], offs,
+                                               len(dof_offsets) - 1, int(local_root_obs), int(root_height_obs), _ptr(hist), S,
+                                               int(shift), self._stream()), "build_amp_obs")
+
     # ------------------------------------------------------------------ normaliser / gather
     def rms_moments(self, src, D, idx, remap, M, state, sums):
         L.check(self.lib.ase_hip_rms_moments(_ptr(src), _ld(src), D, _ptr(idx), remap[0], remap[1], M, _ptr(state),

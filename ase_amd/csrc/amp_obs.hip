@@ -1,0 +1,135 @@
+// AMP observation production: one frame of the 140-float (per character: 1 + 6 + 3 + 3 + 6 J + D + 3 K)
+// discriminator observation from the simulator state, pushed into the per-env history [N, S, F] whose flattened rows
+// are the amp_obs the update path consumes.  HBM-light quaternion arithmetic: one lane per environment, the frame is
+// staged through LDS so that both the history shift and the new slot are row-contiguous accesses.
+// Follows env/tasks/humanoid_amp.py:248-266,280-316 and env/tasks/humanoid.py:523-552 (reference, /root/reference/ase).
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxJoints = 32;
+constexpr int kEnvPerBlock = 64;
+
+struct AmpObsArgs {
+    const float *root_pos, *root_rot, *root_vel, *root_ang_vel, *dof_pos, *dof_vel, *key_pos;
+    float* hist;            // [N, S, F]
+    int N, D, K, J, S, F;
+    int local_root, root_height, shift;
+    int dof_off[kMaxJoints + 1];
+};
+
+struct V3 { float x, y, z; };
+struct Q4 { float x, y, z, w; };
+
+// v rotated by the unit quaternion q (xyzw):  v (2 w^2 - 1) + 2 w (u x v) + 2 u (u . v)
+__device__ __forceinline__ V3 rot(const Q4& q, const V3& v) {
+    const float a = 2.f * q.w * q.w - 1.f, d = 2.f * (q.x * v.x + q.y * v.y + q.z * v.z), w2 = 2.f * q.w;
+    return V3{v.x * a + (q.y * v.z - q.z * v.y) * w2 + q.x * d,
+              v.y * a + (q.z * v.x - q.x * v.z) * w2 + q.y * d,
+              v.z * a + (q.x * v.y - q.y * v.x) * w2 + q.z * d};
+}
+__device__ __forceinline__ Q4 mul(const Q4& a, const Q4& b) {
+    return Q4{a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x,
+              a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
+}
+__device__ __forceinline__ Q4 from_angle_axis(float angle, V3 ax) {
+    const float n = fmaxf(sqrtf(ax.x * ax.x + ax.y * ax.y + ax.z * ax.z), 1e-9f);
+    const float s = sinf(0.5f * angle) / n, c = cosf(0.5f * angle);
+    Q4 q{ax.x * s, ax.y * s, ax.z * s, c};
+    const float m = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-9f);
+    return Q4{q.x / m, q.y / m, q.z / m, q.w / m};
+}
+// tangent (rotated x axis) and normal (rotated z axis)
+__device__ __forceinline__ void tan_norm(const Q4& q, float* o) {
+    const V3 t = rot(q, V3{1.f, 0.f, 0.f}), n = rot(q, V3{0.f, 0.f, 1.f});
+    o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = n.x; o[4] = n.y; o[5] = n.z;
+}
+
+__global__ __launch_bounds__(kEnvPerBlock) void amp_obs_kernel(AmpObsArgs a) {
+    extern __shared__ float tile[];                       // [kEnvPerBlock][F + 1]
+    const int F = a.F, pitch = F + 1;
+    const int e0 = blockIdx.x * kEnvPerBlock, n = e0 + threadIdx.x;
+    const int live = min(kEnvPerBlock, a.N - e0);
+    if (n < a.N) {
+        float* o = tile + threadIdx.x * pitch;
+        const float* rp = a.root_pos + 3 * (int64_t)n;
+        const float* rq = a.root_rot + 4 * (int64_t)n;
+        const Q4 q{rq[0], rq[1], rq[2], rq[3]};
+        const V3 d = rot(q, V3{1.f, 0.f, 0.f});
+        const Q4 hq = from_angle_axis(-atan2f(d.y, d.x), V3{0.f, 0.f, 1.f});      // inverse heading rotation
+        o[0] = a.root_height ? rp[2] : 0.f;
+        tan_norm(a.local_root ? mul(hq, q) : q, o + 1);
+        const float* v = a.root_vel + 3 * (int64_t)n;
+        const float* w = a.root_ang_vel + 3 * (int64_t)n;
+        const V3 lv = rot(hq, V3{v[0], v[1], v[2]}), lw = rot(hq, V3{w[0], w[1], w[2]});
+        o[7] = lv.x; o[8] = lv.y; o[9] = lv.z; o[10] = lw.x; o[11] = lw.y; o[12] = lw.z;
+        const float* dp = a.dof_pos + (int64_t)a.D * n;
+        for (int j = 0; j < a.J; ++j) {
+            const int b = a.dof_off[j], sz = a.dof_off[j + 1] - b;
+            Q4 jq;
+            if (sz == 3) {                               // exponential map -> quaternion
+                const V3 e{dp[b], dp[b + 1], dp[b + 2]};
+                const float len = sqrtf(e.x * e.x + e.y * e.y + e.z * e.z);
+                float ang = atan2f(sinf(len), cosf(len));
+                V3 ax{e.x / len, e.y / len, e.z / len};
+                if (!(fabsf(ang) > 1e-5f)) { ang = 0.f; ax = V3{0.f, 0.f, 1.f}; }
+                jq = from_angle_axis(ang, ax);
+            } else {                                     // hinge about y
+                jq = from_angle_axis(dp[b], V3{0.f, 1.f, 0.f});
+            }
+            tan_norm(jq, o + 13 + 6 * j);
+        }
+        const int od = 13 + 6 * a.J;
+        const float* dv = a.dof_vel + (int64_t)a.D * n;
+        for (int i = 0; i < a.D; ++i) o[od + i] = dv[i];
+        const float* kp = a.key_pos + (int64_t)a.K * 3 * n;
+        for (int k = 0; k < a.K; ++k) {
+            const V3 l = rot(hq, V3{kp[3 * k] - rp[0], kp[3 * k + 1] - rp[1], kp[3 * k + 2] - rp[2]});
+            o[od + a.D + 3 * k] = l.x; o[od + a.D + 3 * k + 1] = l.y; o[od + a.D + 3 * k + 2] = l.z;
+        }
+    }
+    __syncthreads();
+    // history: slots move one step into the past (oldest dropped), then the new frame takes slot 0; every thread walks
+    // feature columns of all the block's environments, so the accesses are row-contiguous
+    for (int e = 0; e < live; ++e) {
+        float* h = a.hist + (int64_t)(e0 + e) * a.S * F;
+        for (int f = threadIdx.x; f < F; f += kEnvPerBlock) {
+            if (a.shift)
+                for (int s = a.S - 2; s >= 0; --s) h[(int64_t)(s + 1) * F + f] = h[(int64_t)s * F + f];
+            h[f] = tile[e * pitch + f];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int ase_hip_build_amp_obs(const float* root_pos, const float* root_rot, const float* root_vel,
+                                     const float* root_ang_vel, const float* dof_pos, const float* dof_vel,
+                                     const float* key_body_pos, int n_envs, int n_dof, int n_key,
+                                     const int32_t* dof_offsets, int n_joints, int local_root_obs, int root_height_obs,
+                                     float* hist, int n_steps, int shift, void* stream) {
+    ASE_CHECK_ARG(root_pos && root_rot && root_vel && root_ang_vel && dof_pos && dof_vel && key_body_pos && hist && dof_offsets,
+                  "build_amp_obs: null operand");
+    ASE_CHECK_ARG(n_envs > 0 && n_dof > 0 && n_key >= 0 && n_steps >= 1 && n_joints >= 1 && n_joints <= kMaxJoints,
+                  "build_amp_obs: bad sizes (envs %d, dofs %d, joints %d)", n_envs, n_dof, n_joints);
+    AmpObsArgs a;
+    a.root_pos = root_pos; a.root_rot = root_rot; a.root_vel = root_vel; a.root_ang_vel = root_ang_vel;
+    a.dof_pos = dof_pos; a.dof_vel = dof_vel; a.key_pos = key_body_pos; a.hist = hist;
+    a.N = n_envs; a.D = n_dof; a.K = n_key; a.J = n_joints; a.S = n_steps;
+    a.local_root = local_root_obs; a.root_height = root_height_obs; a.shift = shift;
+    for (int j = 0; j <= n_joints; ++j) {
+        a.dof_off[j] = dof_offsets[j];
+        if (j > 0) {
+            const int sz = dof_offsets[j] - dof_offsets[j - 1];
+            ASE_CHECK_ARG(sz == 1 || sz == 3, "build_amp_obs: joint %d has %d dofs (1 or 3 supported)", j - 1, sz);
+        }
+    }
+    ASE_CHECK_ARG(dof_offsets[0] == 0 && dof_offsets[n_joints] == n_dof, "build_amp_obs: dof_offsets do not cover the dofs");
+    a.F = 13 + 6 * n_joints + n_dof + 3 * n_key;
+    const int lds = kEnvPerBlock * (a.F + 1) * (int)sizeof(float);
+    ASE_CHECK_ARG(lds <= 64 * 1024, "build_amp_obs: frame of %d floats does not fit the staging tile", a.F);
+    hipLaunchKernelGGL(amp_obs_kernel, dim3((n_envs + kEnvPerBlock - 1) / kEnvPerBlock), dim3(kEnvPerBlock), lds,
+                       (hipStream_t)stream, a);
+    ASE_CHECK_LAUNCH("build_amp_obs");
+    return ASE_OK;
+}

@@ -286,6 +286,24 @@ int ase_hip_sample_latents(float* z, int rows, int dim, uint64_t* rng_state, voi
 int ase_hip_apply_multi(const int64_t* desc, int n_layers, const double* opt_state, double* acc, int dtype,
                         void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Observation side.
+ * ------------------------------------------------------------------------------------------- */
+
+/* One frame of the AMP (discriminator) observation per environment from the simulator state, pushed into the history
+ * hist [n_envs, n_steps, F], F = 13 + 6 n_joints + n_dof + 3 n_key: {root height, root rotation as tangent + normal
+ * (heading-local when local_root_obs), heading-local root velocity and angular velocity, per joint tangent + normal of
+ * its rotation (3-dof joints: exponential map; 1-dof: hinge about y), dof velocities, heading-local key body
+ * positions}.  shift != 0: slots move one step into the past first; the new frame takes slot 0.  Quaternions xyzw.
+ * dof_offsets: HOST int32[n_joints + 1].
+ * Replaces: build_amp_observations + _update_hist_amp_obs (env/tasks/humanoid_amp.py:248-266,280-316),
+ *   dof_to_obs (env/tasks/humanoid.py:523-552). */
+int ase_hip_build_amp_obs(const float* root_pos, const float* root_rot, const float* root_vel,
+                          const float* root_ang_vel, const float* dof_pos, const float* dof_vel,
+                          const float* key_body_pos, int n_envs, int n_dof, int n_key, const int32_t* dof_offsets,
+                          int n_joints, int local_root_obs, int root_height_obs, float* hist, int n_steps, int shift,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

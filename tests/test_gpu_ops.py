@@ -558,3 +558,29 @@ def test_apply_multi_fused_optimizer_step(be, dt):
             else:
                 close(a, c, 1e-6, 1e-7, f'apply_multi tensor {i}')
     close(outs[0][1], outs[1][1], 1e-9, 1e-12, 'norm accumulators')
+
+
+@pytest.mark.parametrize('local_root,root_h', [(True, True), (True, False), (False, True), (False, False)])
+def test_build_amp_obs_matches_reference(be, local_root, root_h, golden_dir):
+    """N2: ase_hip_build_amp_obs against the reference's build_amp_observations (golden) and its history update."""
+    import os
+    from oracle import amp_obs as A
+    G = torch.load(os.path.join(golden_dir, 'amp_obs.pt'), weights_only=False)
+    i = {k: v.contiguous().cuda() for k, v in G['inputs'].items()}
+    ref = G['outputs'][(local_root, root_h)]
+    N, F, S = ref.shape[0], ref.shape[1], 10
+    g = torch.Generator().manual_seed(9)
+    hist0 = torch.randn(N, S, F, generator=g)
+    hist = hist0.clone().cuda()
+    be.build_amp_obs(i['root_pos'], i['root_rot'], i['root_vel'], i['root_ang_vel'], i['dof_pos'], i['dof_vel'],
+                     i['key_body_pos'], G['dof_offsets'], local_root, root_h, hist, shift=True)
+    want = A.push_history(hist0.clone(), ref)
+    close(hist[:, 0].cpu(), ref, 1e-5, 3e-6, 'amp obs frame')
+    assert torch.equal(hist[:, 1:].cpu(), want[:, 1:])                  # the shifted past is a pure copy
+    # without the shift only slot 0 changes; a ragged environment count exercises the partial workgroup
+    M = 70
+    hist = hist0[:M].clone().cuda()
+    be.build_amp_obs(*[i[k][:M].contiguous() for k in ('root_pos', 'root_rot', 'root_vel', 'root_ang_vel', 'dof_pos', 'dof_vel',
+                                                      'key_body_pos')], G['dof_offsets'], local_root, root_h, hist, shift=False)
+    close(hist[:, 0].cpu(), ref[:M], 1e-5, 3e-6, 'amp obs frame (no shift)')
+    assert torch.equal(hist[:, 1:].cpu(), hist0[:M, 1:])

@@ -121,3 +121,19 @@ def test_first_step_gradients(name, golden_dir):
     for k, g in E['first_grads'].items():
         scale = float(g.abs().max()) + 1e-12
         _close(sd[k].grad, g, rtol=1e-4, atol=1e-5 * scale, what=f'grad.{k}')
+
+
+def test_amp_obs_restatement_matches_reference(golden_dir):
+    """N2 oracle (oracle/amp_obs.py) against the reference's own build_amp_observations (golden: oracle/make_golden_amp_obs.py),
+    all four (local_root_obs, root_height_obs) settings, incl. the zero / tiny / wrapped exponential-map branches."""
+    from oracle import amp_obs as A
+    G = torch.load(os.path.join(golden_dir, 'amp_obs.pt'), weights_only=False)
+    i = G['inputs']
+    for (local_root, root_h), ref in G['outputs'].items():
+        out = A.build_amp_observations(i['root_pos'], i['root_rot'], i['root_vel'], i['root_ang_vel'], i['dof_pos'], i['dof_vel'],
+                                       i['key_body_pos'], local_root, root_h, G['dof_offsets'])
+        assert out.shape == ref.shape == (96, 140)
+        assert float((out - ref).abs().max()) <= 2e-6
+    h = torch.arange(2 * 3 * 4, dtype=torch.float32).view(2, 3, 4)
+    h2 = A.push_history(h.clone(), torch.full((2, 4), -1.0))
+    assert torch.equal(h2[:, 1:], h[:, :2]) and torch.equal(h2[:, 0], torch.full((2, 4), -1.0))
