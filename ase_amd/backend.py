@@ -138,6 +138,23 @@ class HipBackend:
                                                len(dof_offsets) - 1, int(local_root_obs), int(root_height_obs), _ptr(hist), S,
                                                int(shift), self._stream()), "build_amp_obs")
 
+    def motion_state(self, clips, motion_ids, times):
+        """MotionLib.get_motion_state (utils/motion_lib.py:122-172) on device clip tensors.  clips: dict with gts, grs, lrs,
+        grvs, gravs, dvs (f32), lengths, dt (f32), num_frames, length_starts (int32) on this device and the python lists
+        dof_body_ids, dof_offsets, key_body_ids.  Returns (root_pos, root_rot, dof_pos, root_vel, root_ang_vel, dof_vel, key_pos)."""
+        n, B = motion_ids.shape[0], clips['gts'].shape[1]
+        D, J, K = clips['dof_offsets'][-1], len(clips['dof_body_ids']), len(clips['key_body_ids'])
+        ia = lambda xs: (C.c_int32 * len(xs))(*[int(x) for x in xs])
+        f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=self.device)
+        out = (f(n, 3), f(n, 4), f(n, D), f(n, 3), f(n, 3), f(n, D), f(n, K, 3))
+        assert motion_ids.dtype == torch.int32 and times.dtype == torch.float32
+        L.check(self.lib.ase_hip_motion_state(_ptr(clips['gts']), _ptr(clips['grs']), _ptr(clips['lrs']), _ptr(clips['grvs']),
+                                              _ptr(clips['gravs']), _ptr(clips['dvs']), B, _ptr(clips['lengths']),
+                                              _ptr(clips['num_frames']), _ptr(clips['dt']), _ptr(clips['length_starts']),
+                                              _ptr(motion_ids), _ptr(times), n, ia(clips['dof_body_ids']), ia(clips['dof_offsets']), J,
+                                              ia(clips['key_body_ids']), K, *[_ptr(o) for o in out], self._stream()), "motion_state")
+        return out
+
     # ------------------------------------------------------------------ normaliser / gather
     def rms_moments(self, src, D, idx, remap, M, state, sums):
         L.check(self.lib.ase_hip_rms_moments(_ptr(src), _ld(src), D, _ptr(idx), remap[0], remap[1], M, _ptr(state),

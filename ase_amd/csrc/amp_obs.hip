@@ -101,6 +101,80 @@ __global__ __launch_bounds__(kEnvPerBlock) void amp_obs_kernel(AmpObsArgs a) {
     }
 }
 
+// ---- motion clip sampler (utils/motion_lib.py:122-172,263-272,296-325; utils/torch_utils.py:7-28,94-118) -------------
+struct MotionArgs {
+    const float *gts, *grs, *lrs, *grvs, *gravs, *dvs;       // [frames, B, 3] [frames, B, 4] x2 [frames, 3] x2 [frames, D]
+    const float *lengths, *dt;                               // per motion
+    const int32_t *num_frames, *length_starts, *motion_ids;
+    const float* times;
+    float *root_pos, *root_rot, *dof_pos, *root_vel, *root_ang_vel, *dof_vel, *key_pos;
+    int n, B, D, J, K;
+    int dof_off[kMaxJoints + 1], dof_body[kMaxJoints], key_body[kMaxJoints];
+};
+
+__device__ __forceinline__ Q4 load_q(const float* p) { return Q4{p[0], p[1], p[2], p[3]}; }
+
+__device__ __forceinline__ Q4 slerp(const Q4& a, Q4 b, float t) {
+    float c = a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    if (c < 0.f) b = Q4{-b.x, -b.y, -b.z, -b.w};
+    c = fabsf(c);
+    if (c >= 1.f) return a;
+    const float ht = acosf(c), s = sqrtf(1.f - c * c);
+    if (fabsf(s) < 0.001f) return Q4{0.5f * a.x + 0.5f * b.x, 0.5f * a.y + 0.5f * b.y, 0.5f * a.z + 0.5f * b.z, 0.5f * a.w + 0.5f * b.w};
+    const float ra = sinf((1.f - t) * ht) / s, rb = sinf(t * ht) / s;
+    return Q4{ra * a.x + rb * b.x, ra * a.y + rb * b.y, ra * a.z + rb * b.z, ra * a.w + rb * b.w};
+}
+
+__global__ __launch_bounds__(64) void motion_state_kernel(MotionArgs a) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= a.n) return;
+    const int mid = a.motion_ids[i];
+    const float t = a.times[i], len = a.lengths[mid], dt = a.dt[mid];
+    const int nf = a.num_frames[mid];
+    const float phase = fminf(fmaxf(t / len, 0.f), 1.f);
+    const int i0 = (int)(phase * (float)(nf - 1));
+    const int i1 = min(i0 + 1, nf - 1);
+    const float blend = (t - (float)i0 * dt) / dt;
+    const int64_t f0 = i0 + a.length_starts[mid], f1 = i1 + a.length_starts[mid];
+    const int B = a.B;
+    const float* p0 = a.gts + f0 * B * 3;
+    const float* p1 = a.gts + f1 * B * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a.root_pos[3 * (int64_t)i + c] = (1.f - blend) * p0[c] + blend * p1[c];
+    const Q4 rr = slerp(load_q(a.grs + f0 * B * 4), load_q(a.grs + f1 * B * 4), blend);
+    float* ro = a.root_rot + 4 * (int64_t)i;
+    ro[0] = rr.x; ro[1] = rr.y; ro[2] = rr.z; ro[3] = rr.w;
+    for (int k = 0; k < a.K; ++k) {
+        const int b = a.key_body[k];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            a.key_pos[((int64_t)i * a.K + k) * 3 + c] = (1.f - blend) * p0[b * 3 + c] + blend * p1[b * 3 + c];
+    }
+    float* dp = a.dof_pos + (int64_t)a.D * i;
+    for (int j = 0; j < a.J; ++j) {
+        const int b = a.dof_body[j], o = a.dof_off[j], sz = a.dof_off[j + 1] - o;
+        const Q4 q = slerp(load_q(a.lrs + (f0 * B + b) * 4), load_q(a.lrs + (f1 * B + b) * 4), blend);
+        // quaternion -> (angle, axis): below sin(theta/2) = 1e-5 (or NaN from w > 1) the rotation counts as none about z
+        const float sn = sqrtf(1.f - q.w * q.w);
+        float ang = 2.f * acosf(q.w);
+        ang = atan2f(sinf(ang), cosf(ang));
+        V3 ax{q.x / sn, q.y / sn, q.z / sn};
+        if (!(fabsf(sn) > 1e-5f)) { ang = 0.f; ax = V3{0.f, 0.f, 1.f}; }
+        if (sz == 3) {
+            dp[o] = ang * ax.x; dp[o + 1] = ang * ax.y; dp[o + 2] = ang * ax.z;
+        } else {
+            const float th = ang * ax.y;                       // hinge joints turn about y
+            dp[o] = atan2f(sinf(th), cosf(th));
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        a.root_vel[3 * (int64_t)i + c] = a.grvs[f0 * 3 + c];
+        a.root_ang_vel[3 * (int64_t)i + c] = a.gravs[f0 * 3 + c];
+    }
+    for (int d = 0; d < a.D; ++d) a.dof_vel[(int64_t)a.D * i + d] = a.dvs[f0 * a.D + d];
+}
+
 }  // namespace
 
 extern "C" int ase_hip_build_amp_obs(const float* root_pos, const float* root_rot, const float* root_vel,
@@ -131,5 +205,41 @@ extern "C" int ase_hip_build_amp_obs(const float* root_pos, const float* root_ro
     hipLaunchKernelGGL(amp_obs_kernel, dim3((n_envs + kEnvPerBlock - 1) / kEnvPerBlock), dim3(kEnvPerBlock), lds,
                        (hipStream_t)stream, a);
     ASE_CHECK_LAUNCH("build_amp_obs");
+    return ASE_OK;
+}
+
+extern "C" int ase_hip_motion_state(const float* gts, const float* grs, const float* lrs, const float* grvs,
+                                    const float* gravs, const float* dvs, int n_bodies, const float* lengths,
+                                    const int32_t* num_frames, const float* dt, const int32_t* length_starts,
+                                    const int32_t* motion_ids, const float* times, int n, const int32_t* dof_body_ids,
+                                    const int32_t* dof_offsets, int n_joints, const int32_t* key_body_ids, int n_key,
+                                    float* root_pos, float* root_rot, float* dof_pos, float* root_vel,
+                                    float* root_ang_vel, float* dof_vel, float* key_pos, void* stream) {
+    ASE_CHECK_ARG(gts && grs && lrs && grvs && gravs && dvs && lengths && num_frames && dt && length_starts && motion_ids &&
+                      times && dof_body_ids && dof_offsets && root_pos && root_rot && dof_pos && root_vel && root_ang_vel &&
+                      dof_vel && (key_pos || n_key == 0) && (key_body_ids || n_key == 0),
+                  "motion_state: null operand");
+    ASE_CHECK_ARG(n > 0 && n_bodies > 0 && n_joints >= 1 && n_joints <= kMaxJoints && n_key >= 0 && n_key <= kMaxJoints,
+                  "motion_state: bad sizes (n %d, bodies %d, joints %d, key bodies %d)", n, n_bodies, n_joints, n_key);
+    MotionArgs a;
+    a.gts = gts; a.grs = grs; a.lrs = lrs; a.grvs = grvs; a.gravs = gravs; a.dvs = dvs;
+    a.lengths = lengths; a.dt = dt; a.num_frames = num_frames; a.length_starts = length_starts;
+    a.motion_ids = motion_ids; a.times = times;
+    a.root_pos = root_pos; a.root_rot = root_rot; a.dof_pos = dof_pos; a.root_vel = root_vel;
+    a.root_ang_vel = root_ang_vel; a.dof_vel = dof_vel; a.key_pos = key_pos;
+    a.n = n; a.B = n_bodies; a.J = n_joints; a.K = n_key; a.D = dof_offsets[n_joints];
+    for (int j = 0; j <= n_joints; ++j) a.dof_off[j] = dof_offsets[j];
+    for (int j = 0; j < n_joints; ++j) {
+        const int sz = dof_offsets[j + 1] - dof_offsets[j];
+        ASE_CHECK_ARG((sz == 1 || sz == 3) && dof_body_ids[j] >= 0 && dof_body_ids[j] < n_bodies,
+                      "motion_state: joint %d: %d dofs on body %d", j, sz, dof_body_ids[j]);
+        a.dof_body[j] = dof_body_ids[j];
+    }
+    for (int k = 0; k < n_key; ++k) {
+        ASE_CHECK_ARG(key_body_ids[k] >= 0 && key_body_ids[k] < n_bodies, "motion_state: key body %d out of range", key_body_ids[k]);
+        a.key_body[k] = key_body_ids[k];
+    }
+    hipLaunchKernelGGL(motion_state_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, a);
+    ASE_CHECK_LAUNCH("motion_state");
     return ASE_OK;
 }

@@ -304,6 +304,20 @@ int ase_hip_build_amp_obs(const float* root_pos, const float* root_rot, const fl
                           int n_joints, int local_root_obs, int root_height_obs, float* hist, int n_steps, int shift,
                           void* stream);
 
+/* Motion-clip sampler: the reference pose at (motion id, time) for n samples from the concatenated clip tensors
+ * (global translations gts [frames, B, 3], global / local rotations grs / lrs [frames, B, 4] xyzw, root velocities
+ * grvs / gravs [frames, 3], dof velocities dvs [frames, D]; per motion: lengths [s], num_frames, dt, length_starts):
+ * frame pair + blend, linear interpolation of positions, spherical interpolation of rotations, local rotations ->
+ * dof positions (3-dof: exponential map, 1-dof: angle about y).  Outputs feed ase_hip_build_amp_obs (demo stream).
+ * dof_body_ids / dof_offsets / key_body_ids: HOST int32 arrays; everything else device memory.
+ * Replaces: MotionLib.get_motion_state (utils/motion_lib.py:122-172,263-272,296-325). */
+int ase_hip_motion_state(const float* gts, const float* grs, const float* lrs, const float* grvs, const float* gravs,
+                         const float* dvs, int n_bodies, const float* lengths, const int32_t* num_frames, const float* dt,
+                         const int32_t* length_starts, const int32_t* motion_ids, const float* times, int n,
+                         const int32_t* dof_body_ids, const int32_t* dof_offsets, int n_joints,
+                         const int32_t* key_body_ids, int n_key, float* root_pos, float* root_rot, float* dof_pos,
+                         float* root_vel, float* root_ang_vel, float* dof_vel, float* key_pos, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,3 +96,57 @@ def push_history(hist, frame):
     hist[:, 1:] = hist[:, :-1].clone()
     hist[:, 0] = frame
     return hist
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Motion clip sampler (utils/motion_lib.py:122-172 get_motion_state, :263-272 _calc_frame_blend, :296-325
+# _local_rotation_to_dof; utils/torch_utils.py:7-28 quat_to_angle_axis, :94-118 slerp)
+# ---------------------------------------------------------------------------------------------------------------------
+def slerp(q0, q1, t):
+    c = (q0 * q1).sum(-1)
+    q1 = torch.where((c < 0).unsqueeze(-1), -q1, q1)
+    c = c.abs().unsqueeze(-1)
+    ht = torch.acos(c)
+    s = torch.sqrt(1.0 - c * c)
+    out = torch.sin((1 - t) * ht) / s * q0 + torch.sin(t * ht) / s * q1
+    out = torch.where(s.abs() < 0.001, 0.5 * q0 + 0.5 * q1, out)
+    return torch.where(c.abs() >= 1, q0, out)
+
+
+def quat_to_angle_axis(q):
+    w = q[..., 3]
+    s = torch.sqrt(1 - w * w)
+    angle = 2 * torch.acos(w)
+    angle = torch.atan2(torch.sin(angle), torch.cos(angle))
+    axis = q[..., :3] / s.unsqueeze(-1)
+    ok = s.abs() > 1e-5
+    ez = torch.zeros_like(axis); ez[..., 2] = 1
+    return torch.where(ok, angle, torch.zeros_like(angle)), torch.where(ok.unsqueeze(-1), axis, ez)
+
+
+def motion_state(clips, motion_ids, times):
+    """clips: dict of the MotionLib tensors (gts [F, B, 3], grs / lrs [F, B, 4], grvs / gravs [F, 3], dvs [F, D],
+    lengths / num_frames / dt / length_starts [n_motions], dof_body_ids, dof_offsets, key_body_ids)."""
+    ln, nf, dt = clips['lengths'][motion_ids], clips['num_frames'][motion_ids], clips['dt'][motion_ids]
+    phase = torch.clip(times / ln, 0.0, 1.0)
+    i0 = (phase * (nf - 1)).long()
+    i1 = torch.min(i0 + 1, nf - 1)
+    blend = ((times - i0 * dt) / dt).unsqueeze(-1)
+    f0, f1 = i0 + clips['length_starts'][motion_ids], i1 + clips['length_starts'][motion_ids]
+    gts, grs, lrs = clips['gts'], clips['grs'], clips['lrs']
+    root_pos = (1.0 - blend) * gts[f0, 0] + blend * gts[f1, 0]
+    root_rot = slerp(grs[f0, 0], grs[f1, 0], blend)
+    kb = torch.as_tensor(clips['key_body_ids'])
+    key_pos = (1.0 - blend.unsqueeze(-1)) * gts[f0][:, kb] + blend.unsqueeze(-1) * gts[f1][:, kb]
+    local_rot = slerp(lrs[f0], lrs[f1], blend.unsqueeze(-1))
+    offs = clips['dof_offsets']
+    dof_pos = torch.zeros(len(motion_ids), offs[-1])
+    for j, body in enumerate(clips['dof_body_ids']):
+        a, b = offs[j], offs[j + 1]
+        angle, axis = quat_to_angle_axis(local_rot[:, body])
+        if b - a == 3:
+            dof_pos[:, a:b] = angle.unsqueeze(-1) * axis
+        else:
+            th = angle * axis[..., 1]
+            dof_pos[:, a] = torch.atan2(torch.sin(th), torch.cos(th))
+    return root_pos, root_rot, dof_pos, clips['grvs'][f0], clips['gravs'][f0], clips['dvs'][f0], key_pos

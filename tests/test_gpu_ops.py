@@ -584,3 +584,32 @@ def test_build_amp_obs_matches_reference(be, local_root, root_h, golden_dir):
                                                       'key_body_pos')], G['dof_offsets'], local_root, root_h, hist, shift=False)
     close(hist[:, 0].cpu(), ref[:M], 1e-5, 3e-6, 'amp obs frame (no shift)')
     assert torch.equal(hist[:, 1:].cpu(), hist0[:M, 1:])
+
+
+def test_motion_state_matches_reference(be, golden_dir):
+    """N2: ase_hip_motion_state against the reference's MotionLib.get_motion_state (golden, two shipped clips), then the
+    demo-side chain motion state -> build_amp_obs against the oracle chain."""
+    import os
+    from oracle import amp_obs as A
+    G = torch.load(os.path.join(golden_dir, 'motion_state.pt'), weights_only=False)
+    c = G['clips']
+    dev = {k: c[k].float().contiguous().cuda() for k in ('gts', 'grs', 'lrs', 'grvs', 'gravs', 'dvs', 'lengths', 'dt')}
+    dev.update({k: c[k].to(torch.int32).cuda() for k in ('num_frames', 'length_starts')})
+    dev.update({k: c[k] for k in ('dof_body_ids', 'dof_offsets', 'key_body_ids')})
+    ids, t = G['motion_ids'].to(torch.int32).cuda(), G['times'].float().cuda()
+    out = be.motion_state(dev, ids, t)
+    names = list(G['outputs'])
+    for k, o in zip(names, out):
+        ref = G['outputs'][k]
+        # interpolated rotations go through acos / sin on both sides (device vs host libm): 1e-5; copies are exact
+        if k in ('root_vel', 'root_ang_vel', 'dof_vel'):
+            assert torch.equal(o.cpu(), ref), k
+        else:
+            close(o.cpu(), ref, 2e-5, 2e-5, 'motion ' + k)
+    n = ids.shape[0]
+    hist = torch.zeros(n, 1, 13 + 6 * 13 + 31 + 18, device='cuda')
+    be.build_amp_obs(*out[:2], out[3], out[4], out[2], out[5], out[6], c['dof_offsets'], True, True, hist, shift=False)
+    o = G['outputs']
+    want = A.build_amp_observations(o['root_pos'], o['root_rot'], o['root_vel'], o['root_ang_vel'], o['dof_pos'], o['dof_vel'],
+                                    o['key_pos'], True, True, c['dof_offsets'])
+    close(hist[:, 0].cpu(), want, 1e-4, 1e-4, 'demo amp obs')

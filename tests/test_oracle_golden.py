@@ -137,3 +137,14 @@ def test_amp_obs_restatement_matches_reference(golden_dir):
     h = torch.arange(2 * 3 * 4, dtype=torch.float32).view(2, 3, 4)
     h2 = A.push_history(h.clone(), torch.full((2, 4), -1.0))
     assert torch.equal(h2[:, 1:], h[:, :2]) and torch.equal(h2[:, 0], torch.full((2, 4), -1.0))
+
+
+def test_motion_state_restatement_matches_reference(golden_dir):
+    """N2 oracle of the motion-clip sampler against the reference's own MotionLib.get_motion_state on two shipped clips
+    (golden: oracle/make_golden_motion.py), incl. clip start / exact end / past the end."""
+    from oracle import amp_obs as A
+    G = torch.load(os.path.join(golden_dir, 'motion_state.pt'), weights_only=False)
+    out = A.motion_state(G['clips'], G['motion_ids'], G['times'])
+    for k, o in zip(G['outputs'], out):
+        assert o.shape == G['outputs'][k].shape
+        assert float((o - G['outputs'][k]).abs().max()) <= 1e-6, k
