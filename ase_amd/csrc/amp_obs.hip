@@ -89,16 +89,23 @@ __global__ __launch_bounds__(kEnvPerBlock) void amp_obs_kernel(AmpObsArgs a) {
         }
     }
     __syncthreads();
-    // history: slots move one step into the past (oldest dropped), then the new frame takes slot 0; every thread walks
-    // feature columns of all the block's environments, so the accesses are row-contiguous
+    // the new frame takes slot 0 (the shift kernel has already moved the past): threads walk feature columns of the
+    // block's environments, so the stores are row-contiguous
     for (int e = 0; e < live; ++e) {
         float* h = a.hist + (int64_t)(e0 + e) * a.S * F;
-        for (int f = threadIdx.x; f < F; f += kEnvPerBlock) {
-            if (a.shift)
-                for (int s = a.S - 2; s >= 0; --s) h[(int64_t)(s + 1) * F + f] = h[(int64_t)s * F + f];
-            h[f] = tile[e * pitch + f];
-        }
+        for (int f = threadIdx.x; f < F; f += kEnvPerBlock) h[f] = tile[e * pitch + f];
     }
+}
+
+// history slots move one step into the past (oldest dropped): one thread per (env, feature) walks its column from the
+// oldest slot down, lanes cover consecutive features -> every access is a contiguous row segment
+__global__ __launch_bounds__(256) void amp_hist_shift_kernel(float* __restrict__ hist, int64_t n_cols, int S, int F) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n_cols) return;
+    const int64_t e = i / F;
+    const int f = (int)(i - e * F);
+    float* h = hist + e * S * F + f;
+    for (int s = S - 2; s >= 0; --s) h[(int64_t)(s + 1) * F] = h[(int64_t)s * F];
 }
 
 // ---- motion clip sampler (utils/motion_lib.py:122-172,263-272,296-325; utils/torch_utils.py:7-28,94-118) -------------
@@ -202,6 +209,11 @@ extern "C" int ase_hip_build_amp_obs(const float* root_pos, const float* root_ro
     a.F = 13 + 6 * n_joints + n_dof + 3 * n_key;
     const int lds = kEnvPerBlock * (a.F + 1) * (int)sizeof(float);
     ASE_CHECK_ARG(lds <= 64 * 1024, "build_amp_obs: frame of %d floats does not fit the staging tile", a.F);
+    if (shift && n_steps > 1) {
+        const int64_t cols = (int64_t)n_envs * a.F;
+        hipLaunchKernelGGL(amp_hist_shift_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, (hipStream_t)stream, hist,
+                           cols, n_steps, a.F);
+    }
     hipLaunchKernelGGL(amp_obs_kernel, dim3((n_envs + kEnvPerBlock - 1) / kEnvPerBlock), dim3(kEnvPerBlock), lds,
                        (hipStream_t)stream, a);
     ASE_CHECK_LAUNCH("build_amp_obs");

@@ -108,6 +108,48 @@ def main():
         print(json.dumps({'measurement': 'infer', 'metric': 'rollout inference (get_action_values) env-steps/sec',
                           'value': round(4096 / dt, 1), 'unit': 'env-steps/s', 'us_per_call': round(dt * 1e6, 1), 'envs': 4096,
                           'precision': 'bf16', 'hipgraph': False}), flush=True)
+    if not args.only or 'ampobs' in args.only.split(','):
+        # N2: observation production for 4096 envs (one frame + history push) and 5120 demo samples (512 x 10 steps)
+        from ase_amd.backend import HipBackend
+        be = HipBackend('cuda:0')
+        g = torch.Generator().manual_seed(0)
+        offs = [0, 3, 6, 9, 10, 13, 16, 17, 20, 21, 24, 27, 28, 31]
+        N, D, K, S = 4096, 31, 6, 10
+        q = torch.randn(N, 4, generator=g)
+        q = (q / q.norm(dim=-1, keepdim=True)).cuda()
+        st = [torch.randn(N, 3, generator=g).cuda(), q, torch.randn(N, 3, generator=g).cuda(), torch.randn(N, 3, generator=g).cuda(),
+              (torch.randn(N, D, generator=g) * 0.5).cuda(), torch.randn(N, D, generator=g).cuda(), torch.randn(N, K, 3, generator=g).cuda()]
+        hist = torch.zeros(N, S, 140, device='cuda')
+
+        def timeit(fn, n=200):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(n):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            return a.elapsed_time(b) / n * 1e3
+        us = timeit(lambda: be.build_amp_obs(*st, offs, True, True, hist, shift=True))
+        byt = N * (S * 140 * 4 * 2 + (13 + 2 * D + 3 * K) * 4)
+        print(json.dumps({'measurement': 'amp-obs frame + history push', 'envs': N, 'us_per_call': round(us, 1),
+                          'GB_per_s': round(byt / us / 1e3, 1), 'bytes': byt}), flush=True)
+        F_, B = 4000, 17
+        lr = torch.randn(F_, B, 4, generator=g)
+        clips = {'gts': torch.randn(F_, B, 3, generator=g).cuda(), 'grs': (lr / lr.norm(dim=-1, keepdim=True)).cuda(),
+                 'lrs': (lr / lr.norm(dim=-1, keepdim=True)).cuda(), 'grvs': torch.randn(F_, 3, generator=g).cuda(),
+                 'gravs': torch.randn(F_, 3, generator=g).cuda(), 'dvs': torch.randn(F_, D, generator=g).cuda(),
+                 'lengths': torch.full((40,), 3.3).cuda(), 'dt': torch.full((40,), 1 / 30).cuda(),
+                 'num_frames': torch.full((40,), 100, dtype=torch.int32).cuda(),
+                 'length_starts': (torch.arange(40, dtype=torch.int32) * 100).cuda(),
+                 'dof_body_ids': [1, 2, 3, 4, 5, 7, 8, 11, 12, 13, 14, 15, 16], 'dof_offsets': offs, 'key_body_ids': [5, 10, 13, 16, 6, 9]}
+        n = 5120
+        ids = torch.randint(0, 40, (n,), generator=g).to(torch.int32).cuda()
+        tt = (torch.rand(n, generator=g) * 3.3).cuda()
+        us = timeit(lambda: be.motion_state(clips, ids, tt))
+        print(json.dumps({'measurement': 'motion-clip sampler', 'samples': n, 'us_per_call': round(us, 1)}), flush=True)
 
 
 if __name__ == '__main__':
