@@ -117,3 +117,31 @@ def test_nt_kernel_choice_is_reported():
     assert lib.ase_hip_gemm_nt_kernel_id(16384, 1024, 1024, L.F32) == 3       # lock-step 256 x 256 (exact f32)
     assert lib.ase_hip_gemm_nt_kernel_id(4096, 512, 1024, L.BF16) == 1        # 128 x 128
     assert lib.ase_hip_gemm_nt_kernel_id(16384, 64, 512, L.BF16) == 0         # narrow head
+
+
+def test_grouped_plan_random_layer_sets():
+    """Property check of the host-side planner over random layer sets: disjoint 64-row-aligned ranges that tile [0, M) for
+    every output tile, never more work items than the table holds, deterministic."""
+    import random
+    rnd = random.Random(5)
+    for trial in range(40):
+        probs = []
+        for _ in range(rnd.randint(1, 12)):
+            M = 64 * rnd.randint(1, 600)
+            nr, kr = rnd.choice([64, 128, 200, 512, 1000, 1024]), rnd.choice([128, 317, 512, 1024, 1400])
+            N, K = (nr + 63) // 64 * 64, (kr + 63) // 64 * 64
+            probs.append((M, N, K, nr, kr, rnd.choice([0, 0, 64 * rnd.randint(1, M // 64)])))
+        target = rnd.choice([64, 256, 512])
+        rc, items, _ = _plan(probs, target)
+        rc2, items2, _ = _plan(probs, target)
+        assert rc == 0 and items == items2
+        cover = {}
+        for p, t, m0, nk in items:
+            M, N, K, nr, kr, br = probs[p]
+            assert 0 <= t < ((nr + 255) // 256) * ((K + 255) // 256)
+            assert m0 % 64 == 0 and nk >= 1 and m0 + 64 * nk <= M
+            cover.setdefault((p, t), []).append((m0, m0 + 64 * nk))
+        for p, (M, N, K, nr, kr, br) in enumerate(probs):
+            for t in range(((nr + 255) // 256) * ((K + 255) // 256)):
+                segs = sorted(cover[(p, t)])
+                assert segs[0][0] == 0 and segs[-1][1] == M and all(a[1] == b[0] for a, b in zip(segs, segs[1:])), (trial, p, t)
