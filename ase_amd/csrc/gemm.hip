@@ -325,8 +325,9 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x16 (&acc)[FM]
     else nt_epilogue_impl<T, FM, FN, FMC, FNC, 1>(p, acc, slab, lane, mrow0, ncol0);
 }
 
-template <typename T, int WGM, int WGN, int FM, int FN, int RB, int S>
-__global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(NTParams p) {
+// WPE = minimum waves per SIMD the register allocation must leave room for (k workgroups of T threads per CU <=> k T / 256)
+template <typename T, int WGM, int WGN, int FM, int FN, int RB, int S, int WPE = 1>
+__global__ __launch_bounds__(WGM * WGN * 64, WPE) void gemm_nt_kernel(NTParams p) {
     constexpr int BM = WGM * FM * 32, BN = WGN * FN * 32;
     constexpr int BK = RB / (int)sizeof(T);
     constexpr int LPR = RB / 16;                             // lanes (16-byte chunks) per staged row
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_nt_kernel(NTParams p) {
     nt_epilogue<T, FM, FN, FM, FNC>(p, acc, slab, lane, bm0 + wm * FM * 32, bn0 + wn * FN * 32);
 }
 
-template <typename T, int WGM, int WGN, int FM, int FN, int RB, int S>
+template <typename T, int WGM, int WGN, int FM, int FN, int RB, int S, int WPE = 1>
 int launch_nt(const NTParams& p0, hipStream_t stream) {
     constexpr int BM = WGM * FM * 32, BN = WGN * FN * 32;
     constexpr int ring = S * (BM + BN) * RB;
@@ -413,7 +414,7 @@ int launch_nt(const NTParams& p0, hipStream_t stream) {
     constexpr int lds = ring > slab ? ring : slab;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
-    auto kern = gemm_nt_kernel<T, WGM, WGN, FM, FN, RB, S>;
+    auto kern = gemm_nt_kernel<T, WGM, WGN, FM, FN, RB, S, WPE>;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -464,8 +465,9 @@ struct NT8Lane {
     int roff[4];               // per-lane fragment read offsets (row * 128 + swizzled chunk) for the 4 k-steps
 };
 
-template <int KIND>
+template <int KIND, bool LIVE = true>
 __device__ __forceinline__ void nt8_issue(const NT8Lane& L, char* smem, int tile) {
+    if constexpr (!LIVE) return;
     constexpr int kBuf = 512 * 128;
     char* buf = smem + (tile & 1) * kBuf;
     const int64_t koff = (int64_t)tile * 128;
@@ -475,18 +477,60 @@ __device__ __forceinline__ void nt8_issue(const NT8Lane& L, char* smem, int tile
 }
 
 // fragment registers of one 32-row operand block: 4 k-steps x 16 bytes
+template <bool LIVE = true>
 __device__ __forceinline__ void nt8_read(i32x4 (&f)[4], const char* base, const NT8Lane& L) {
+    if constexpr (!LIVE) { asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3])); return; }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) f[ks] = *reinterpret_cast<const i32x4*>(base + L.roff[ks]);
 }
 
+// SW: operands swapped in the MFMA (D = B-fragment x A-fragment): the accumulator then holds the TRANSPOSED 32 x 32
+// block - a lane owns one output ROW and 4 x 4 consecutive columns - which nt8_epilogue_rows stores straight from
+// registers (no LDS transposition).
+template <bool SW>
+__device__ __forceinline__ f32x16 nt8_mfma(const i32x4& a, const bf16x8& bv, const f32x16& c) {
+    if constexpr (SW) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv, __builtin_bit_cast(bf16x8, a), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), bv, c, 0, 0, 0);
+}
+
+template <bool LIVE = true, bool SW = false>
 __device__ __forceinline__ void nt8_mma(f32x16& c0, f32x16& c1, const i32x4 (&a0)[4], const i32x4 (&a1)[4],
                                         const i32x4 (&b)[4]) {
+    if constexpr (!LIVE) { asm volatile("" : "+v"(c0), "+v"(c1) : "v"(a0[0]), "v"(a1[3]), "v"(b[2])); return; }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         const bf16x8 bv = __builtin_bit_cast(bf16x8, b[ks]);
-        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0[ks]), bv, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1[ks]), bv, c1, 0, 0, 0);
+        c0 = nt8_mfma<SW>(a0[ks], bv, c0);
+        c1 = nt8_mfma<SW>(a1[ks], bv, c1);
+    }
+}
+
+// the same 8 MFMAs with the two DMA pieces of unit KIND (K-tile `tile`) issued among them: an LDS-DMA instruction costs
+// ~60 issue cycles beside MFMAs (the matrix pipe stays fed by the 32-cycle MFMA issue cadence) but 100-185 cycles in the
+// read half of a phase, where it sat on the critical path of the OTHER wave group's MFMA block (measured by ablation:
+// DMA and fragment reads were additive on top of the MFMA time)
+template <int KIND, bool DM, bool MM, bool SW>
+__device__ __forceinline__ void nt8_mma_issue(f32x16& c0, f32x16& c1, const i32x4 (&a0)[4], const i32x4 (&a1)[4],
+                                              const i32x4 (&b)[4], const NT8Lane& L, char* smem, int tile, bool live) {
+    if constexpr (!MM) {
+        asm volatile("" : "+v"(c0), "+v"(c1) : "v"(a0[0]), "v"(a1[3]), "v"(b[2]));
+        if (DM && live) nt8_issue<KIND>(L, smem, tile);
+        return;
+    }
+    constexpr int kBuf = 512 * 128;
+    char* buf = smem + (tile & 1) * kBuf;
+    const int64_t koff = (int64_t)tile * 128;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 bv = __builtin_bit_cast(bf16x8, b[ks]);
+        c0 = nt8_mfma<SW>(a0[ks], bv, c0);
+        c1 = nt8_mfma<SW>(a1[ks], bv, c1);
+        if (DM && (ks == 0 || ks == 2)) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (live)
+                __builtin_amdgcn_global_load_lds((gptr_t*)(L.src[KIND][ks >> 1] + koff), (lptr_t*)(buf + L.dst[KIND][ks >> 1]), 16, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 
@@ -515,51 +559,163 @@ template <int V> __device__ __forceinline__ void nt8_sync_out() {     // end of 
 }
 
 // one K-tile = 4 phases.  TAIL = false: every issued unit exists (t + 2 < nk) and the waits are compile-time counts.
-template <bool TAIL, int V>
+// V & 64: the DMA of a phase is issued INSIDE its MFMA block (nt8_mma_issue).  Unit 4 t + p + 6 still belongs to phase
+// (t, p), but at the counted wait of a phase (in front of its first barrier) the newest issued unit is now the one of the
+// previous phase: three units may stay in flight instead of four.  RAW (read one phase after wait + barrier) is unchanged,
+// the WAR distance grows by half a phase.
+template <bool TAIL, int V, bool SW>
+__device__ __forceinline__ void nt8_ktile_m(int t, int nk, const NT8Lane& L, char* smem, const char* aP, const char* bP,
+                                            f32x16 (&acc)[4][2], i32x4 (&a0)[4], i32x4 (&a1)[4], i32x4 (&b0)[4],
+                                            i32x4 (&b1)[4]) {
+    constexpr int RB = 128;
+    constexpr bool DM = !(V & 4), RD = !(V & 8), MM = !(V & 16);
+    const int U = 4 * nk;
+    const bool l1 = !TAIL || t + 1 < nk, l2 = !TAIL || t + 2 < nk;
+    // ---- phase 0
+    nt8_read<RD>(b0, bP, L);
+    nt8_read<RD>(a0, aP, L);
+    nt8_read<RD>(a1, aP + 32 * RB, L);
+    if (!TAIL) wait_dma_units<3>();
+    else wait_dma_units_rt(min(U, 4 * t + 6) - (4 * t + 3));
+    nt8_sync_in<V>();
+    nt8_mma_issue<2, DM, MM, SW>(acc[0][0], acc[1][0], a0, a1, b0, L, smem, t + 1, l1);
+    nt8_sync_out<V>();
+    // ---- phase 1
+    nt8_read<RD>(b1, bP + 32 * RB, L);
+    if (!TAIL) wait_dma_units<3>();
+    else wait_dma_units_rt(min(U, 4 * t + 7) - (4 * t + 4));
+    nt8_sync_in<V>();
+    nt8_mma_issue<3, DM, MM, SW>(acc[0][1], acc[1][1], a0, a1, b1, L, smem, t + 1, l1);
+    nt8_sync_out<V>();
+    // ---- phase 2
+    nt8_read<RD>(a0, aP + 64 * RB, L);
+    nt8_read<RD>(a1, aP + 96 * RB, L);
+    nt8_sync_in<V>();
+    nt8_mma_issue<0, DM, MM, SW>(acc[2][1], acc[3][1], a0, a1, b1, L, smem, t + 2, l2);
+    nt8_sync_out<V>();
+    // ---- phase 3
+    if (!TAIL) wait_dma_units<3>();
+    else if (t + 1 < nk) wait_dma_units_rt(min(U, 4 * t + 9) - (4 * t + 6));
+    nt8_sync_in<V>();
+    nt8_mma_issue<1, DM, MM, SW>(acc[2][0], acc[3][0], a0, a1, b0, L, smem, t + 2, l2);
+    nt8_sync_out<V>();
+}
+
+template <bool TAIL, int V, bool SW>
 __device__ __forceinline__ void nt8_ktile(int t, int nk, const NT8Lane& L, char* smem, const char* aP, const char* bP,
                                           f32x16 (&acc)[4][2], i32x4 (&a0)[4], i32x4 (&a1)[4], i32x4 (&b0)[4],
                                           i32x4 (&b1)[4]) {
     constexpr int RB = 128;
     constexpr bool IF = false;
+    constexpr bool DM = !(V & 4), RD = !(V & 8), MM = !(V & 16);     // ablations (timing only): no DMA / reads / MFMAs in the loop
     const int U = 4 * nk;
     // ---- phase 0: A sub-tile 0, B fragment 0 -> quadrant (0, 0)
-    if (IF && (!TAIL || t + 1 < nk)) nt8_issue<2>(L, smem, t + 1);
-    nt8_read(b0, bP, L);
-    nt8_read(a0, aP, L);
-    nt8_read(a1, aP + 32 * RB, L);
-    if (!IF && (!TAIL || t + 1 < nk)) nt8_issue<2>(L, smem, t + 1);
+    if (IF && (!TAIL || t + 1 < nk)) nt8_issue<2, DM>(L, smem, t + 1);
+    nt8_read<RD>(b0, bP, L);
+    nt8_read<RD>(a0, aP, L);
+    nt8_read<RD>(a1, aP + 32 * RB, L);
+    if (!IF && (!TAIL || t + 1 < nk)) nt8_issue<2, DM>(L, smem, t + 1);
     if (!TAIL) wait_dma_units<4>();
     else wait_dma_units_rt(min(U, 4 * t + 7) - (4 * t + 3));
     nt8_sync_in<V>();
-    nt8_mma(acc[0][0], acc[1][0], a0, a1, b0);
+    nt8_mma<MM, SW>(acc[0][0], acc[1][0], a0, a1, b0);
     nt8_sync_out<V>();
     // ---- phase 1: B fragment 1 -> quadrant (0, 1)
-    if (IF && (!TAIL || t + 1 < nk)) nt8_issue<3>(L, smem, t + 1);
-    nt8_read(b1, bP + 32 * RB, L);
-    if (!IF && (!TAIL || t + 1 < nk)) nt8_issue<3>(L, smem, t + 1);
+    if (IF && (!TAIL || t + 1 < nk)) nt8_issue<3, DM>(L, smem, t + 1);
+    nt8_read<RD>(b1, bP + 32 * RB, L);
+    if (!IF && (!TAIL || t + 1 < nk)) nt8_issue<3, DM>(L, smem, t + 1);
     if (!TAIL) wait_dma_units<4>();
     else wait_dma_units_rt(min(U, 4 * t + 8) - (4 * t + 4));
     nt8_sync_in<V>();
-    nt8_mma(acc[0][1], acc[1][1], a0, a1, b1);
+    nt8_mma<MM, SW>(acc[0][1], acc[1][1], a0, a1, b1);
     nt8_sync_out<V>();
     // ---- phase 2: A sub-tile 1 -> quadrant (1, 1)
-    if (IF && (!TAIL || t + 2 < nk)) nt8_issue<0>(L, smem, t + 2);
-    nt8_read(a0, aP + 64 * RB, L);
-    nt8_read(a1, aP + 96 * RB, L);
-    if (!IF && (!TAIL || t + 2 < nk)) nt8_issue<0>(L, smem, t + 2);
+    if (IF && (!TAIL || t + 2 < nk)) nt8_issue<0, DM>(L, smem, t + 2);
+    nt8_read<RD>(a0, aP + 64 * RB, L);
+    nt8_read<RD>(a1, aP + 96 * RB, L);
+    if (!IF && (!TAIL || t + 2 < nk)) nt8_issue<0, DM>(L, smem, t + 2);
     nt8_sync_in<V>();
-    nt8_mma(acc[2][1], acc[3][1], a0, a1, b1);
+    nt8_mma<MM, SW>(acc[2][1], acc[3][1], a0, a1, b1);
     nt8_sync_out<V>();
     // ---- phase 3: quadrant (1, 0); the wait retires A0 / B0 of K-tile t + 1 for the next phase 0
-    if (!TAIL || t + 2 < nk) nt8_issue<1>(L, smem, t + 2);
+    if (!TAIL || t + 2 < nk) nt8_issue<1, DM>(L, smem, t + 2);
     if (!TAIL) wait_dma_units<4>();
     else if (t + 1 < nk) wait_dma_units_rt(min(U, 4 * t + 10) - (4 * t + 6));
     nt8_sync_in<V>();
-    nt8_mma(acc[2][0], acc[3][0], a0, a1, b0);
+    nt8_mma<MM, SW>(acc[2][0], acc[3][0], a0, a1, b0);
     nt8_sync_out<V>();
 }
 
-template <typename T, int V>
+
+// ---- epilogue of the phased kernel with swapped MFMA operands.  acc[i][j] holds the transposed 32 x 32 block: lane
+// (r = lane & 31, h = lane >> 5) owns output row i*32 + r and the columns j*32 + 8 g + 4 h + q (g = e >> 2, q = e & 3):
+// four runs of 4 consecutive columns.  bias + activation + mask in registers, bf16 packing, then v_permlane32_swap
+// between the column groups (g, g + 1) of the two half-waves gives every lane 8 consecutive columns = ONE 16-byte store
+// (lanes 0-31: columns 8 g .., lanes 32-63: columns 8 (g + 1) ..): 16 global_store_dwordx4 per wave for its 128 x 64
+// outputs instead of 256 ds_write_b32 + 64 ds_read_b128 + 64 global_store_dwordx2 through an LDS slab (the epilogue was
+// bound by store ISSUE, not by bandwidth).  Mask words: one 32-bit word per (row, 32-column fragment) per lane - all 8 of
+// a wave tile are fetched before the main loop (bits[]); the forward's mask_out word is assembled from the two
+// half-waves' 16 bits each with one more swap.  Needs whole 64-column wave tiles (N % 64 == 0) and a bf16 output.
+template <int AUXK>
+__device__ __forceinline__ void nt8_epilogue_rows(const NTParams& p, f32x16 (&acc)[4][2], int lane, int mrow0, int ncol0,
+                                                  const uint32_t (&bits)[4][2]) {
+    if (ncol0 >= p.N) return;                                   // wave-uniform: N is a multiple of 64
+    const int r = lane & 31, h = lane >> 5;
+    f32x4 bias[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (p.bias) bias[j][g] = *reinterpret_cast<const f32x4*>(p.bias + ncol0 + j * 32 + 8 * g + 4 * h);
+            else bias[j][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = mrow0 + i * 32 + r;
+        const bool row_ok = m < p.M;
+        char* crow = p.C + (int64_t)m * p.ldc + (int64_t)ncol0 * 2 + h * 16;
+        uint32_t mword[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            uint32_t pk[4][2];
+            uint32_t mb = 0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16_t o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v = p.alpha * acc[i][j][g * 4 + q] + bias[j][g][q];
+                    if (p.act == ASE_ACT_RELU) v = fmaxf(v, 0.f);
+                    if constexpr (AUXK == 2) v = ((bits[i][j] >> (8 * g + 4 * h + q)) & 1u) ? v : 0.f;
+                    o[q] = (bf16_t)v;
+                    mb |= ((float)o[q] > 0.f ? 1u : 0u) << (8 * g + 4 * h + q);
+                }
+                pk[g][0] = (uint32_t)__builtin_bit_cast(uint16_t, o[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, o[1]) << 16);
+                pk[g][1] = (uint32_t)__builtin_bit_cast(uint16_t, o[2]) | ((uint32_t)__builtin_bit_cast(uint16_t, o[3]) << 16);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                const auto s0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
+                // lanes 0-31: [own g | upper's g] = columns 8 g .. 8 g + 7; lanes 32-63: [lower's g + 1 | own g + 1]
+                if (row_ok) {
+                    const uint4 out = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                    *reinterpret_cast<uint4*>(crow + (j * 32 + 8 * g) * 2) = out;
+                }
+            }
+            mword[j] = mb;
+        }
+        if (p.mask_out) {
+            // word j of this row = own 16 bits | the other half-wave's 16 bits
+            const auto w = __builtin_amdgcn_permlane32_swap(mword[0], mword[1], false, false);
+            // after the swap: lanes 0-31 hold (own word 0 bits, upper's word 0 bits); lanes 32-63 (lower's word 1, own word 1)
+            const uint32_t full = w[0] | w[1];
+            if (row_ok) p.mask_out[(int64_t)m * p.ldmask + (ncol0 >> 5) + h] = full;
+        }
+    }
+}
+
+template <typename T, int V, bool SW>
 __global__ __launch_bounds__(512) void gemm_nt8_kernel(NTParams p) {
     static_assert(sizeof(T) == 2, "the phased kernel is bf16 only");
     constexpr int RB = 128, BM = 256, BN = 256, BK = 64;
@@ -607,7 +763,10 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(NTParams p) {
     // the first chunk's mask words (16 registers) are fetched before anything else: older than every DMA, they retire
     // first and the epilogue finds them in registers instead of waiting an HBM round trip after the last K-tile
     AuxReg<T, 2> pre_bits[16];
-    if (p.aux_mode == ASE_AUX_RELU_BITS) nt_aux_load<T, 4, 2, 2, 2, 2>(p, 0, lane, bm0 + wr * 128, bn0 + wc * 64, pre_bits);
+    uint32_t row_bits[4][2];
+    if constexpr (!SW) {
+        if (p.aux_mode == ASE_AUX_RELU_BITS) nt_aux_load<T, 4, 2, 2, 2, 2>(p, 0, lane, bm0 + wr * 128, bn0 + wc * 64, pre_bits);
+    }
 
     const int nk = p.K / BK;
     // prologue: units 0..5 (K-tile 0 and A0, B0 of K-tile 1); A0 / B0 of K-tile 0 must have landed for phase 0
@@ -618,9 +777,32 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(NTParams p) {
     if (nk > 1) {
         nt8_issue<0>(L, smem, 1);
         nt8_issue<1>(L, smem, 1);
-        wait_dma_units<4>();
+    }
+    bool mask_dma = false;
+    if constexpr (SW) {
+        // row-per-lane epilogue: the mask words of the wave tile (128 rows x 2 words) travel as four 4-byte DMA pieces
+        // BEHIND the prologue's units into 1 KiB of LDS per wave past the ring (as ordinary loads in front of the DMA
+        // queue they add an exposed HBM round trip to the prologue, 3.1 vs 1.4 us; as ordinary loads behind it their
+        // position in the vmcnt queue would be the compiler's choice).  Lane (r, h) fetches word h of row 32 i + r;
+        // the first counted wait of the main loop retires them.
+        mask_dma = p.aux_mode == ASE_AUX_RELU_BITS && bn0 + wc * 64 < p.N;
+        if (mask_dma) {
+            char* mlds = smem + 2 * kBuf + wid * 1024;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = bm0 + wr * 128 + i * 32 + (lane & 31);
+                const int ma = (m >= p.aux_split) ? m - p.aux_delta : m;
+                const uint32_t* w = reinterpret_cast<const uint32_t*>(p.aux + (int64_t)min(ma, p.M - 1) * p.ldaux) +
+                                    ((bn0 + wc * 64) >> 5) + (lane >> 5);
+                __builtin_amdgcn_global_load_lds((gptr_t*)w, (lptr_t*)(mlds + i * 256), 4, 0, 0);
+            }
+        }
+    }
+    // units 0, 1 (A0 / B0 of K-tile 0) must have landed; the mask pieces (if any) are the 4 youngest entries of the queue
+    if (nk > 1) {
+        if (mask_dma) wait_vmcnt<8 + 4>(); else wait_dma_units<4>();
     } else {
-        wait_dma_units<2>();
+        if (mask_dma) wait_vmcnt<4 + 4>(); else wait_dma_units<2>();
     }
     NT8_BARRIER();
     if (p.prof && tid == 0) p.prof[blockIdx.x * 4 + 1] = wall_clock64();
@@ -631,18 +813,31 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(NTParams p) {
     int t = 0;
     for (; t + 2 < nk; ++t) {
         const char* buf = smem + (t & 1) * kBuf;
-        nt8_ktile<false, V>(t, nk, L, smem, buf + aoff, buf + boff, acc, a0, a1, b0, b1);
+        if constexpr (V & 64) nt8_ktile_m<false, V, SW>(t, nk, L, smem, buf + aoff, buf + boff, acc, a0, a1, b0, b1);
+        else nt8_ktile<false, V, SW>(t, nk, L, smem, buf + aoff, buf + boff, acc, a0, a1, b0, b1);
     }
     for (; t < nk; ++t) {
         const char* buf = smem + (t & 1) * kBuf;
-        nt8_ktile<true, V>(t, nk, L, smem, buf + aoff, buf + boff, acc, a0, a1, b0, b1);
+        if constexpr (V & 64) nt8_ktile_m<true, V, SW>(t, nk, L, smem, buf + aoff, buf + boff, acc, a0, a1, b0, b1);
+        else nt8_ktile<true, V, SW>(t, nk, L, smem, buf + aoff, buf + boff, acc, a0, a1, b0, b1);
     }
     if (wr == 0) NT8_BARRIER();
     __syncthreads();                             // the ring becomes the epilogue slab
     if (p.prof && tid == 0) p.prof[blockIdx.x * 4 + 2] = wall_clock64();
 
     float* slab = reinterpret_cast<float*>(smem) + wid * (64 * 64);
-    if (p.aux_mode == ASE_AUX_RELU_BITS)
+    if ((V & 32) && p.alpha != 12345.f) return;      // ablation: no epilogue (the guard keeps the accumulators live)
+    if constexpr (SW) {
+        if (p.aux_mode == ASE_AUX_RELU_BITS) {
+            const uint32_t* mw = reinterpret_cast<const uint32_t*>(smem + 2 * kBuf + wid * 1024);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                row_bits[i][0] = mw[i * 64 + (lane & 31)];
+                row_bits[i][1] = mw[i * 64 + 32 + (lane & 31)];
+            }
+            nt8_epilogue_rows<2>(p, acc, lane, bm0 + wr * 128, bn0 + wc * 64, row_bits);
+        } else nt8_epilogue_rows<0>(p, acc, lane, bm0 + wr * 128, bn0 + wc * 64, row_bits);
+    } else if (p.aux_mode == ASE_AUX_RELU_BITS)
         nt_epilogue_impl<T, 4, 2, 2, 2, 2, true>(p, acc, slab, lane, bm0 + wr * 128, bn0 + wc * 64, &pre_bits);
     else
         nt_epilogue<T, 4, 2, 2, 2>(p, acc, slab, lane, bm0 + wr * 128, bn0 + wc * 64);
@@ -653,10 +848,10 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(NTParams p) {
     }
 }
 
-template <typename T, int V> int launch_nt8(const NTParams& p0, hipStream_t stream) {
-    constexpr int lds = 2 * 512 * 128;
+template <typename T, int V, bool SW = false> int launch_nt8(const NTParams& p0, hipStream_t stream) {
+    constexpr int lds = 2 * 512 * 128 + (SW ? 8 * 1024 : 0);     // ring + (row-per-lane epilogue) 1 KiB of mask words per wave
     static bool attr_done = false;
-    auto kern = gemm_nt8_kernel<T, V>;
+    auto kern = gemm_nt8_kernel<T, V, SW>;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -697,10 +892,57 @@ int nt_choice(int M, int N, int K, int es, bool bf16) {
 
 template <typename T> int dispatch_nt(const NTParams& p, hipStream_t s) {
     const bool k128 = (p.K * (int)sizeof(T)) % 128 == 0;       // 128-byte staged rows need K in whole 128-byte steps
+    if constexpr (sizeof(T) == 2) {
+        // tuning aid (scripts/lab): force one of the co-resident tilings (<= 80 KB of LDS => two workgroups per CU)
+        static int variant = -1;
+        if (variant < 0) {
+            const char* e = getenv("ASE_NT_VARIANT");
+            variant = e ? atoi(e) : 0;
+        }
+        switch (variant) {
+            case 10: return launch_nt<T, 2, 2, 2, 4, 64, 3, 2>(p, s);    // 128 x 256, 4 waves (64 x 128 each), 72 KB
+            case 11: return launch_nt<T, 2, 2, 4, 2, 64, 3, 2>(p, s);    // 256 x 128, 4 waves (128 x 64 each), 72 KB
+            case 12: return launch_nt<T, 4, 2, 2, 2, 64, 3, 4>(p, s);    // 256 x 128, 8 waves (64 x 64 each), 72 KB
+            case 13: return launch_nt<T, 2, 4, 2, 2, 64, 3, 4>(p, s);    // 128 x 256, 8 waves
+            case 14: if (k128) return launch_nt<T, 2, 2, 2, 2, 128, 2, 2>(p, s); break;   // 128 x 128, 4 waves, 64 KB
+            case 15: return launch_nt<T, 2, 2, 2, 2, 64, 4, 2>(p, s);    // 128 x 128, 64-byte rows, 4 stages, 64 KB
+            case 16: return launch_nt<T, 2, 2, 2, 2, 64, 3, 3>(p, s);    // 128 x 128, 48 KB => three workgroups per CU
+            case 17: return launch_nt<T, 2, 2, 2, 4, 64, 2, 2>(p, s);    // 128 x 256, 4 waves, 2 stages (48 KB => 3 per CU by LDS)
+            default: break;
+        }
+    }
     switch (nt_choice(p.M, p.N, p.K, (int)sizeof(T), std::is_same<T, bf16_t>::value)) {
         case 0: return launch_nt<T, 2, 2, 1, 1, 64, 4>(p, s);
         case 2:
-            if constexpr (sizeof(T) == 2) return launch_nt8<T, 0>(p, s);
+            if constexpr (sizeof(T) == 2) {
+                static int v8 = -1;                      // tuning aid: ablation builds of the phased kernel (timing only)
+                if (v8 == -1) {
+                    const char* e = getenv("ASE_NT8_V");
+                    v8 = e ? atoi(e) : -2;               // default: DMA inside the MFMA block + (where eligible) row-per-lane epilogue
+                }
+                // row-per-lane epilogue (swapped MFMA operands): bf16 output in whole 64-column wave tiles, no column sums,
+                // mask operand absent or a bit matrix
+                const bool rows_ok = !p.out_f32 && p.N % 64 == 0 && p.colsum == nullptr && p.act != ASE_ACT_TANH &&
+                                     (p.aux_mode == ASE_AUX_NONE || p.aux_mode == ASE_AUX_RELU_BITS);
+                if (rows_ok && v8 == 128) return launch_nt8<T, 0, true>(p, s);
+                if (rows_ok && (v8 == 192 || v8 == -2)) return launch_nt8<T, 64, true>(p, s);
+                if (v8 == -2) return launch_nt8<T, 64>(p, s);
+                switch (v8) {
+                    case 4: return launch_nt8<T, 4>(p, s);
+                    case 8: return launch_nt8<T, 8>(p, s);
+                    case 12: return launch_nt8<T, 12>(p, s);
+                    case 16: return launch_nt8<T, 16>(p, s);
+                    case 28: return launch_nt8<T, 28>(p, s);
+                    case 32: return launch_nt8<T, 32>(p, s);
+                    case 2: return launch_nt8<T, 2>(p, s);
+                    case 1: return launch_nt8<T, 1>(p, s);
+                    case 64: return launch_nt8<T, 64>(p, s);
+                    case 66: return launch_nt8<T, 66>(p, s);
+                    case 72: return launch_nt8<T, 72>(p, s);
+                    case 80: return launch_nt8<T, 80>(p, s);
+                    default: return launch_nt8<T, 0>(p, s);
+                }
+            }
             [[fallthrough]];
         case 3:
             if (k128) return launch_nt<T, 4, 2, 2, 4, 128, 2>(p, s);
