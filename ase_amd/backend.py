@@ -219,7 +219,7 @@ class HipBackend:
     def finalize_scalars(self, acc, out, m_global, amb_global, masked, has_disc, has_enc, has_div, c):
         L.check(self.lib.ase_hip_finalize_scalars(
             _ptr(acc), _ptr(out), m_global, amb_global, int(masked), int(has_disc), int(has_enc), int(has_div),
-            float(c['critic_coef']), float(c['entropy_coef']), float(c['bounds_loss_coef']), float(c.get('disc_coef', 0)),
+            float(c['critic_coef']), float(c['entropy_coef']), float(c.get('bounds_loss_coef') or 0.0), float(c.get('disc_coef', 0)),
             float(c.get('disc_logit_reg', 0)), float(c.get('disc_grad_penalty', 0)), float(c.get('disc_weight_decay', 0)),
             float(c.get('enc_coef', 0)), float(c.get('enc_weight_decay', 0)), float(c.get('amp_diversity_bonus', 0)),
             self._stream()), "finalize_scalars")
@@ -259,5 +259,15 @@ class HipBackend:
         L.check(self.lib.ase_hip_ring_store(_ptr(src), _ld(src), D, _ptr(idx), remap[0], remap[1], n, _ptr(dst), size,
                                             head, self._stream()), "ring_store")
 
-    def sample_latents(self, z, rows, dim, rng_state):
-        L.check(self.lib.ase_hip_sample_latents(_ptr(z), rows, dim, _ptr(rng_state), self._stream()), "sample_latents")
+    def normalize_rows(self, x, y, n, dim):
+        L.check(self.lib.ase_hip_normalize_rows(_ptr(x), _ld(x), _ptr(y), _ld(y), n, dim, self._stream()), "normalize_rows")
+
+    def sample_actions(self, mu, logstd, rand_probs, rng_state, mu_out, sigma_out, actions, neglogp, rand_mask, n, act_dim,
+                       mu_tanh=False):
+        L.check(self.lib.ase_hip_sample_actions(_ptr(mu), _ld(mu), _ptr(logstd), _ptr(rand_probs), _ptr(rng_state), _ptr(mu_out),
+                                                _ptr(sigma_out), _ptr(actions), _ptr(neglogp), _ptr(rand_mask), n, act_dim,
+                                                int(mu_tanh), self._stream()), "sample_actions")
+
+    def sample_latents(self, z, rows, dim, rng_state, row_offset=0):
+        L.check(self.lib.ase_hip_sample_latents(_ptr(z), rows, dim, _ptr(rng_state), int(row_offset), self._stream()),
+                "sample_latents")

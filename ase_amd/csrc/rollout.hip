@@ -127,9 +127,75 @@ __device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t offset, u
     return sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
 }
 
+__device__ __forceinline__ float philox_uniform(uint64_t seed, uint64_t offset, uint64_t elem) {
+    uint32_t c[4] = {(uint32_t)elem, (uint32_t)(elem >> 32), (uint32_t)offset, (uint32_t)(offset >> 32)};
+    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+    for (int i = 0; i < 10; ++i) philox_round(c, k);
+    return (float)c[2] * 2.3283064365386963e-10f;                    // [0, 1)
+}
+
+// Rollout-time action head (learning/amp_models.py:29-36 eval branch + learning/amp_agent.py:160-166): one wave per row,
+//   mu (optionally tanh, learning/hrl_network_builder.py:26-29) -> a = mu + sigma * N(0, 1) -> neglogp(a) -> eps-greedy:
+//   rows whose Bernoulli(p_row) draw is 0 take the deterministic action mu (the stored neglogp stays the sampled one).
+__global__ __launch_bounds__(256) void sample_actions_kernel(const float* __restrict__ mu, int64_t ld_mu,
+                                                             const float* __restrict__ logstd,
+                                                             const float* __restrict__ rand_probs,
+                                                             const uint64_t* __restrict__ rng, float* __restrict__ mu_out,
+                                                             float* __restrict__ sigma_out, float* __restrict__ actions,
+                                                             float* __restrict__ neglogp, float* __restrict__ rand_mask,
+                                                             int n, int A, int mu_tanh) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const uint64_t seed = rng[0], off = rng[1];
+    float m = 0.f, s = 1.f, a = 0.f, q = 0.f, ls = 0.f;
+    if (lane < A) {
+        m = mu[(int64_t)r * ld_mu + lane];
+        if (mu_tanh) m = tanhf(m);
+        ls = logstd[lane];
+        s = expf(ls);
+        a = m + s * philox_normal(seed, off, (uint64_t)r * A + lane);
+        const float d = (a - m) / s;
+        q = d * d;
+    }
+    const float nlp = 0.5f * wave_sum(q) + 0.5f * 1.8378770664093453f * (float)A + wave_sum(ls);
+    float keep = 1.f;
+    if (rand_probs) keep = philox_uniform(seed, off, (uint64_t)n * A + r) < rand_probs[r] ? 1.f : 0.f;
+    if (lane < A) {
+        mu_out[(int64_t)r * A + lane] = m;
+        sigma_out[(int64_t)r * A + lane] = s;
+        actions[(int64_t)r * A + lane] = keep != 0.f ? a : m;
+    }
+    if (lane == 0) {
+        neglogp[r] = nlp;
+        if (rand_mask) rand_mask[r] = keep;
+    }
+}
+
+// y[r, :] = x[r, :] / max(|x[r, :]|, 1e-12)   (torch.nn.functional.normalize, dim <= 128): one wave per row
+__global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ x, int64_t ld_x, float* __restrict__ y,
+                                                             int64_t ld_y, int n, int dim) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    float v[2] = {0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int j = lane + 64 * q;
+        if (j < dim) v[q] = x[(int64_t)r * ld_x + j];
+    }
+    const float nrm = fmaxf(sqrtf(wave_sum(v[0] * v[0] + v[1] * v[1])), 1e-12f);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int j = lane + 64 * q;
+        if (j < dim) y[(int64_t)r * ld_y + j] = v[q] / nrm;
+    }
+}
+
 // one wave per row, dim <= 128
 __global__ __launch_bounds__(256) void sample_latents_kernel(float* __restrict__ z, int rows, int dim,
-                                                             const uint64_t* __restrict__ rng) {
+                                                             const uint64_t* __restrict__ rng, int64_t row_offset) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
@@ -138,7 +204,7 @@ __global__ __launch_bounds__(256) void sample_latents_kernel(float* __restrict__
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int j = lane + 64 * q;
-        if (j < dim) v[q] = philox_normal(seed, off, (uint64_t)r * dim + j);
+        if (j < dim) v[q] = philox_normal(seed, off, (uint64_t)(row_offset + r) * dim + j);
     }
     const float nrm = fmaxf(sqrtf(wave_sum(v[0] * v[0] + v[1] * v[1])), 1e-12f);
 #pragma unroll
@@ -209,10 +275,29 @@ extern "C" int ase_hip_ring_store(const float* src, int64_t ld_src, int D, const
     return ASE_OK;
 }
 
-extern "C" int ase_hip_sample_latents(float* z, int rows, int dim, uint64_t* rng_state, void* stream) {
-    ASE_CHECK_ARG(z && rng_state && rows > 0 && dim >= 1 && dim <= 128, "sample_latents: bad operand");
+extern "C" int ase_hip_normalize_rows(const float* x, int64_t ld_x, float* y, int64_t ld_y, int n, int dim, void* stream) {
+    ASE_CHECK_ARG(x && y && n > 0 && dim >= 1 && dim <= 128 && ld_x >= dim && ld_y >= dim, "normalize_rows: bad operand");
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ld_x, y, ld_y, n, dim);
+    ASE_CHECK_LAUNCH("normalize_rows");
+    return ASE_OK;
+}
+
+extern "C" int ase_hip_sample_actions(const float* mu, int64_t ld_mu, const float* logstd, const float* rand_probs,
+                                      uint64_t* rng_state, float* mu_out, float* sigma_out, float* actions,
+                                      float* neglogp, float* rand_mask, int n, int act_dim, int mu_tanh, void* stream) {
+    ASE_CHECK_ARG(mu && logstd && rng_state && mu_out && sigma_out && actions && neglogp && n > 0 && act_dim >= 1 &&
+                      act_dim <= 64 && ld_mu >= act_dim, "sample_actions: bad operand");
+    hipLaunchKernelGGL(sample_actions_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, mu, ld_mu, logstd,
+                       rand_probs, rng_state, mu_out, sigma_out, actions, neglogp, rand_mask, n, act_dim, mu_tanh);
+    hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng_state);
+    ASE_CHECK_LAUNCH("sample_actions");
+    return ASE_OK;
+}
+
+extern "C" int ase_hip_sample_latents(float* z, int rows, int dim, uint64_t* rng_state, int64_t row_offset, void* stream) {
+    ASE_CHECK_ARG(z && rng_state && rows > 0 && dim >= 1 && dim <= 128 && row_offset >= 0, "sample_latents: bad operand");
     hipLaunchKernelGGL(sample_latents_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, z, rows, dim,
-                       rng_state);
+                       rng_state, row_offset);
     hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng_state);
     ASE_CHECK_LAUNCH("sample_latents");
     return ASE_OK;

@@ -62,14 +62,26 @@ class UpdateEngine:
     """kind: 'ase' | 'amp' | 'ppo'.  sizes: rows handled by THIS rank (M, AMB) and global counts."""
 
     def __init__(self, kind, net, cfg, backend, *, minibatch, amp_minibatch=0, dtype=torch.bfloat16,
-                 world_size=1, rank=0, infer_rows=0):
+                 world_size=1, rank=0, infer_rows=0, dp_mode='shard'):
+        """dp_mode (world_size > 1):
+          'shard'    every minibatch is row-sharded over the ranks; global denominators, normaliser moments summed over
+                     the ranks, gradients SUM-reduced: the R-rank update equals the 1-rank update (BASELINE config 3);
+          'horovod'  the reference's multi-GPU semantics (rl_games HorovodWrapper, learning/common_agent.py:94-107): every
+                     rank owns its environments and minibatches, local statistics, gradients AVERAGED over the ranks,
+                     running statistics averaged once per epoch (CommonAgent.sync_stats)."""
         self.kind, self.net, self.cfg, self.be = kind, net, cfg, backend
         self.dtype = dtype
         self.dev = net.flat_params.device
         self.R, self.rank = world_size, rank
-        assert minibatch % world_size == 0 and amp_minibatch % world_size == 0
+        assert dp_mode in ('shard', 'horovod')
+        self.shard = dp_mode == 'shard'
+        div = world_size if self.shard else 1
+        assert minibatch % div == 0 and amp_minibatch % div == 0
         self.Mg, self.AMBg = minibatch, amp_minibatch
-        self.M, self.AMB = minibatch // world_size, amp_minibatch // world_size
+        self.M, self.AMB = minibatch // div, amp_minibatch // div
+        # flags resolved once (rl_games defaults: normalize_value False, bounds_loss_coef None = no bound loss)
+        self.norm_value = bool(cfg.get('normalize_value', False))
+        self.bounds_coef = float(cfg.get('bounds_loss_coef') or 0.0)
         self.obs, self.act = net.obs_size, net.actions_num
         self.z = net.latent_dim if kind == 'ase' else 0
         self.amp = net.amp_obs_size if kind in ('amp', 'ase') else 0
@@ -147,6 +159,7 @@ class UpdateEngine:
     def _bind_params(self):
         net, dev, T = self.net, self.dev, self.dtype
         self.params = net.flat_params
+        net._engine_bound = True          # A2CNetwork._apply refuses to re-allocate the flat buffer from now on
         n = self.params.numel()
         self.grads = torch.zeros(n, dtype=torch.float32, device=dev)
         self.adam_m = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -222,7 +235,9 @@ class UpdateEngine:
             self.Hs, self.dZs = chain_bufs(self.style[:-1], Ra)
             self.dStyle = zt(Ra, P(self.z))
             self.new_z = zt(M, self.z, f32)
-            self.rng_state = torch.tensor([0x5EED, 0], dtype=torch.int64, device=dev)
+            # Philox stream of the latent draws {seed, offset}: seeded by the run, advanced on device, part of the
+            # checkpoint (CommonAgent.get_full_state_weights)
+            self.rng_state = torch.tensor([int(self.cfg.get('seed', 0)) ^ 0x5EED, 0], dtype=torch.int64, device=dev)
         if self.has_disc:
             Rd = 3 * AMB
             # Rows [0, 3 AMB) = agent | replay | demo.  A 4th block of AMB rows carries the gradient-penalty chain of
@@ -421,13 +436,33 @@ class UpdateEngine:
             self._mb_desc_key = key
         self.be.gather_multi(self._mb_desc, self._mb_items, idx, remap, self.M)
 
+    def sync_from_rank0(self):
+        """Start-up / restore: every rank takes rank 0's parameters, optimizer state, running statistics and latent
+        stream position (rl_games HorovodWrapper.setup_algo: broadcast_parameters + broadcast_optimizer_state)."""
+        if self.R <= 1 and not self.force_dist:
+            return
+        import torch.distributed as dist
+        bufs = [self.params, self.adam_m, self.adam_v, self.opt_state, self.obs_state, self.val_state]
+        if self.has_disc:
+            bufs.append(self.amp_state)
+        if self.style:
+            bufs.append(self.rng_state)
+        for t in bufs:
+            if t.is_cuda and dist.get_backend() == 'gloo':
+                h = t.cpu()
+                dist.broadcast(h, 0)
+                t.copy_(h)
+            else:
+                dist.broadcast(t, 0)
+        self.refresh_shadows()
+
     def step(self, ds, idx, remap, amp_streams=None, new_z=None, apply=True):
         """ds: dataset dict of physical-order device tensors; idx int32 [M] (this rank's rows);
         amp_streams: [(src, idx, remap)] x3 for agent / replay / demo (AMB rows each);
         new_z: optional injected diversity latents f32 [M, z] (else drawn on device).
         Three phases separated by the only two exchange points of the data-parallel update
         (normaliser moments + mask sum; gradients) — each phase is hipGraph-capturable on its own."""
-        self.phase_stats(ds, idx, remap, amp_streams)
+        self.phase_stats(ds, idx, remap, amp_streams, advance=apply)
         self._allreduce_stats()
         self.phase_main(ds, idx, remap, amp_streams, new_z)
         self._allreduce_grads()
@@ -435,9 +470,10 @@ class UpdateEngine:
         return self.res
 
     # ---- phase A: local partial statistics -------------------------------------------------------
-    def phase_stats(self, ds, idx, remap, amp_streams=None):
+    def phase_stats(self, ds, idx, remap, amp_streams=None, advance=True):
         be, c, M, AMB = self.be, self.cfg, self.M, self.AMB
-        be.begin_step(self.opt_state, self.acc)
+        # advance=False (calc_gradients-style calls, apply=False): the Adam step counter / bias corrections stay put
+        be.begin_step(self.opt_state if advance else None, self.acc)
         be.zero_(self.grads[:self.n_train])
         be.zero_(self.obs_sums)
         self.gather_minibatch(ds, idx, remap)
@@ -520,7 +556,9 @@ class UpdateEngine:
                 if new_z is not None:
                     self.new_z.copy_(new_z)
                 else:
-                    be.sample_latents(self.new_z, M, self.z, self.rng_state)
+                    # element index = GLOBAL minibatch row: rank r of a sharded step draws rows [r M, (r + 1) M)
+                    be.sample_latents(self.new_z, M, self.z, self.rng_state,
+                                      row_offset=self.rank * M if (self.shard and self.R > 1) else 0)
                 be.gather_rows(self.new_z, self.z, None, (0, 0), M, self.Zs[M:])
 
         # -- discriminator (+ encoder) branch: normalise, forward, heads, backward, gradient penalty
@@ -586,7 +624,7 @@ class UpdateEngine:
         be.ppo_head(self.MU, self.V, self.mb, self.new_z if self.div_on else None, self.logstd, self.dMU, self.dV,
                     self.mu_head.gb[0], self.value_head.gb[0], self.acc, M, self.Mg, self.act, self.z, self.masked,
                     self.div_on, self.mu_tanh, c['clip_value'], c['e_clip'], c['critic_coef'],
-                    c['bounds_loss_coef'], c.get('amp_diversity_bonus', 0.0), c.get('amp_diversity_tar', 0.0))
+                    self.bounds_coef, c.get('amp_diversity_bonus', 0.0), c.get('amp_diversity_tar', 0.0))
 
         # -- critic backward (side stream 0) next to the actor (+ style) backward
         with self._Branch(self._side(0)):
@@ -710,7 +748,7 @@ class UpdateEngine:
         return self.R > 1 or self.force_dist
 
     def _allreduce_stats(self):
-        if self._dist_on():
+        if self._dist_on() and self.shard:
             if self.masked:
                 self.stats_flat[-1:].copy_(self.acc[L.ACC_MASK_SUM:L.ACC_MASK_SUM + 1])
             self._ar(self.stats_flat)
@@ -720,7 +758,11 @@ class UpdateEngine:
     def _allreduce_grads(self):
         if self._dist_on():
             self._ar(self.grads[:self.n_train])     # SUM of per-rank partials (global denominators inside)
-            self._ar(self.acc[1:])                  # slot 0 (mask sum) is already global
+            if self.shard:
+                self._ar(self.acc[1:])              # slot 0 (mask sum) is already global
+            else:
+                # Horovod semantics: every rank's loss is complete on its own minibatch; the optimizer sees the AVERAGE
+                self.grads[:self.n_train].mul_(1.0 / self.R)
 
     def _identity_stats(self, mean, std):
         mean.zero_()
@@ -762,9 +804,9 @@ class UpdateEngine:
         self.be.rms_finalize(state, D, None, 0, 0, mean, std)
         return mean[0], std[0]
 
-    def policy_forward(self, obs, z=None, normalize=True, unnorm_value=True, want=('mu', 'value')):
-        """Eval-mode actor / critic on raw observations [n, obs] (learning/ase_agent.py:117-148,385-393):
-        eval-mode obs normalisation -> nets -> (mu [n, act], value [n, 1] un-normalised)."""
+    def _policy_nets(self, obs, z, normalize, want_mu, want_value):
+        """Eval-mode observation normalisation + actor / critic forward on raw observations [n, obs].  Returns the padded
+        head outputs (MU f32 [n, P(act)] before any tanh, V f32 [n, 64]); every buffer is persistent scratch."""
         be, n = self.be, obs.shape[0]
         f32 = torch.float32
         a0 = self.actor[0]
@@ -774,11 +816,11 @@ class UpdateEngine:
         else:
             mean, std = self._scr('one_m', 1, self.obs, f32)[0].zero_(), self._scr('one_s', 1, self.obs, f32)[0].fill_(1.0)
         be.rms_normalize(obs, self.obs, None, (0, 0), n, mean, std, [Xa, Xc])
-        out = {}
+        MU = V = None
         if self.z:
             sd = a0.split_dst
             be.gather_rows(z, self.z, None, (0, 0), n, Xc[:, sd:])
-        if 'mu' in want:
+        if want_mu:
             if self.style:
                 Zs = self._scr('Zs', n, P(self.z))
                 be.gather_rows(z, self.z, None, (0, 0), n, Zs)
@@ -795,9 +837,7 @@ class UpdateEngine:
                 h = y
             MU = self._scr('MU', n, self.mu_head.n_pad, f32)
             self._fwd(self.mu_head, h, MU, n)
-            mu = MU[:, :self.act]
-            out['mu'] = torch.tanh(mu) if self.mu_tanh else mu.clone()
-        if 'value' in want:
+        if want_value:
             h = Xc
             for i, d in enumerate(self.critic):
                 y = self._scr(f'Hc{i}', n, d.n_pad)
@@ -805,13 +845,47 @@ class UpdateEngine:
                 h = y
             V = self._scr('V', n, self.value_head.n_pad, f32)
             self._fwd(self.value_head, h, V, n)
-            v = V[:, 0:1].contiguous()
-            if unnorm_value and self.cfg.get('normalize_value', True):
-                vu = torch.empty_like(v)
-                be.rms_unnormalize(self.val_state, v, vu)
-                v = vu
-            out['value'] = v
+        return MU, V
+
+    def _value_out(self, V, n, unnorm_value, key='value_out'):
+        """Column 0 of the padded value head -> dense [n, 1] (un-normalised like RunningMeanStd(unnorm=True))."""
+        v = self._scr(key, n, 1, torch.float32)
+        self.be.gather_rows(V, 1, None, (0, 0), n, v)
+        if unnorm_value and self.norm_value:
+            self.be.rms_unnormalize(self.val_state, v, v)
+        return v
+
+    def policy_forward(self, obs, z=None, normalize=True, unnorm_value=True, want=('mu', 'value')):
+        """Eval-mode actor / critic on raw observations [n, obs] (learning/ase_agent.py:117-148,385-393):
+        eval-mode obs normalisation -> nets -> (mu [n, act], value [n, 1] un-normalised).  The returned tensors are
+        persistent scratch, overwritten by the next call with the same n."""
+        n = obs.shape[0]
+        MU, V = self._policy_nets(obs, z, normalize, 'mu' in want, 'value' in want)
+        out = {}
+        if 'mu' in want:
+            mu = self._scr('mu_out', n, self.act, torch.float32)
+            self.be.gather_rows(MU, self.act, None, (0, 0), n, mu)
+            out['mu'] = torch.tanh_(mu) if self.mu_tanh else mu
+        if 'value' in want:
+            out['value'] = self._value_out(V, n, unnorm_value)
         return out
+
+    def policy_act(self, obs, z, rand_probs, rng_state):
+        """One rollout step of get_action_values (learning/amp_agent.py:139-169, learning/ase_agent.py:117-148) as an
+        explicit launch sequence: normalise -> actor + critic -> ase_hip_sample_actions (tanh / Normal sample / neglogp /
+        eps-greedy on device) -> value un-normalisation.  rand_probs None: every row stochastic (plain PPO)."""
+        n, f32 = obs.shape[0], torch.float32
+        MU, V = self._policy_nets(obs, z, True, True, True)
+        o = {k: self._scr('act_' + k, n, c, f32) for k, c in (('mus', self.act), ('sigmas', self.act), ('actions', self.act),
+                                                             ('neglogpacs', 1), ('rand_action_mask', 1))}
+        self.be.sample_actions(MU, self.logstd, rand_probs, rng_state, o['mus'], o['sigmas'], o['actions'],
+                               o['neglogpacs'], o['rand_action_mask'] if rand_probs is not None else None, n, self.act,
+                               self.mu_tanh)
+        res = {'neglogpacs': o['neglogpacs'].view(-1), 'values': self._value_out(V, n, True, 'act_values'),
+               'actions': o['actions'], 'mus': o['mus'], 'sigmas': o['sigmas'], 'rnn_states': None}
+        if rand_probs is not None:
+            res['rand_action_mask'] = o['rand_action_mask'].view(-1)
+        return res
 
     def amp_heads(self, amp_obs, normalize=True):
         """Eval-mode discriminator logits [n,1] (+ un-normalised encoder output [n,z]) on raw amp obs
@@ -861,17 +935,35 @@ class UpdateEngine:
         info = {}
         if self.has_disc:
             amp = exp['amp_obs'].view(B, self.amp)
-            HD, enc = self.amp_heads(amp)
-            r_disc = self._scr('r_disc', B, 1, f32)
-            be.disc_reward(HD, r_disc, B, c['disc_reward_scale'])
+            # Sharded data parallel: the experience buffer is replicated, so the 0.8 TFLOP of discriminator / encoder
+            # inference is split by rows and the two reward vectors are assembled by ONE sum all-reduce of a buffer that
+            # is zero outside the rank's rows (exact: x + 0).  Everything after it (GAE, moments) is cheap and replicated.
+            split = self.shard and self._dist_on() and B % self.R == 0
+            lo, n = (self.rank * (B // self.R), B // self.R) if split else (0, B)
+            rw = self._scr('r_amp', 2 * B, 1, f32)
+            if split:
+                be.zero_(rw)
+            r_disc = rw[:B]
+            HD, enc = self.amp_heads(amp[lo:lo + n])
+            be.disc_reward(HD, r_disc[lo:lo + n], n, c['disc_reward_scale'])
             info['disc_rewards'] = r_disc
             if self.has_enc:
-                r_enc = self._scr('r_enc', B, 1, f32)
-                be.enc_reward(enc, exp['ase_latents'].view(B, self.z), r_enc, B, self.z, c['enc_reward_scale'])
+                r_enc = rw[B:]
+                be.enc_reward(enc, exp['ase_latents'].view(B, self.z)[lo:lo + n], r_enc[lo:lo + n], n, self.z,
+                              c['enc_reward_scale'])
                 info['enc_rewards'] = r_enc
+            if split:
+                self._ar(rw)
+        w_task = c.get('task_reward_w', 1.0) if self.has_disc else 1.0
+        if not self.has_disc and 'disc_rewards' in exp:
+            # HRL high-level update: the rollout recorded the frozen low-level controller's discriminator reward
+            # (learning/hrl_agent.py:145-147,251-256): r = task_reward_w * r_task + disc_reward_w * r_disc
+            r_disc = exp['disc_rewards'].view(B, 1)
+            info['disc_rewards'] = r_disc
+            w_task = c.get('task_reward_w', 1.0)
         advs, rets = self._scr('advs', B, 1, f32), self._scr('rets', B, 1, f32)
         be.gae(exp['dones'], exp['values'], exp['next_values'], exp['rewards'], r_disc, r_enc,
-               c.get('task_reward_w', 1.0) if self.has_disc else 1.0, c.get('disc_reward_w', 0.0),
+               w_task, c.get('disc_reward_w', 0.0) if r_disc is not None else 0.0,
                c.get('enc_reward_w', 0.0), c['gamma'], c['tau'], advs, rets, H, N)
         info['mb_advs'], info['mb_returns'] = advs, rets
         values = exp['values'].view(B, 1)
@@ -881,16 +973,15 @@ class UpdateEngine:
         be.zero_(acc3)
         be.adv_norm(rets, values, mask, adv, acc3, B, c['normalize_advantage'], 0)
         be.adv_norm(rets, values, mask, adv, acc3, B, c['normalize_advantage'], 1)
-        if c.get('normalize_value', True):
+        if self.norm_value:
             nv, nr = self._scr('val_n', B, 1, f32), self._scr('ret_n', B, 1, f32)
             sums = self._scr('val_sums', 1, 2, torch.float64)[0]
             m, s = self._scr('val_m', 1, 1, f32), self._scr('val_s', 1, 1, f32)
             for src, dst in ((values, nv), (rets, nr)):
                 be.zero_(sums)
                 be.rms_moments(src, 1, None, (0, 0), B, self.val_state, sums)
-                if self.R > 1:
-                    import torch.distributed as dist
-                    pass  # the experience buffer is replicated across ranks in strong-scaling mode: no reduction
+                # (sharded mode: the experience buffer is replicated, every rank computes the same moments; Horovod
+                #  mode: local moments, the running statistics are averaged once per epoch by CommonAgent.sync_stats)
                 be.rms_finalize(self.val_state, 1, sums, B, 1, m, s)
                 be.rms_normalize(src, 1, None, (0, 0), B, m[0], s[0], [dst])
         else:

@@ -21,6 +21,7 @@ for its IdentityScheduler and is dropped).
 Isaac Gym is out of scope (BASELINE.json): ``config['vec_env']`` is any object with
 ``experience(policy) -> dict`` and ``fetch_amp_obs_demo(n)`` (ase_amd.synthetic.SyntheticSource).
 """
+import os
 import time
 
 import numpy as np
@@ -30,6 +31,70 @@ from .. import lib as L
 from ..engine import UpdateEngine
 from ..inference import InferenceEngine
 from .replay_buffer import ReplayBuffer
+
+
+class AverageMeter:
+    """rl_games torch_ext.AverageMeter: mean of the last `max_size` values pushed (episode rewards / lengths)."""
+
+    def __init__(self, in_shape, max_size, device='cpu'):
+        self.max_size = max_size
+        self.current_size = 0
+        self.mean = torch.zeros(in_shape, dtype=torch.float32, device=device)
+
+    def update(self, values):
+        size = values.size()[0]
+        if size == 0:
+            return
+        new_mean = torch.mean(values.float(), dim=0)
+        size = int(np.clip(size, 0, self.max_size))
+        old_size = min(self.max_size - size, self.current_size)
+        size_sum = old_size + size
+        self.current_size = size_sum
+        self.mean = (self.mean * old_size + new_mean.to(self.mean.device) * size) / size_sum
+
+    def clear(self):
+        self.current_size = 0
+        self.mean.fill_(0)
+
+    def get_mean(self):
+        return self.mean.squeeze(0).cpu().numpy()
+
+
+class _NullObserver:
+    """rl_games AlgoObserver interface (config['features']['observer']); the default does nothing."""
+
+    def after_init(self, algo):
+        pass
+
+    def process_infos(self, infos, done_indices):
+        pass
+
+    def after_steps(self):
+        pass
+
+    def after_print_stats(self, frame, epoch_num, total_time):
+        pass
+
+
+class ScalarLog:
+    """Stand-in for tensorboardX.SummaryWriter (logging back ends are out of scope): keeps the last value per tag."""
+
+    def __init__(self):
+        self.scalars = {}
+
+    def add_scalar(self, tag, value, step=None):
+        self.scalars[tag] = (float(value), step)
+
+
+def rescale_actions(low, high, action):
+    """rl_games players.rescale_actions"""
+    d = (high - low) / 2.0
+    m = (high + low) / 2.0
+    return action * d + m
+
+
+def _mean_list(vals):
+    return torch.stack([torch.as_tensor(v, dtype=torch.float32).reshape(-1).mean() for v in vals]).mean()
 
 
 class CommonAgent:
@@ -61,6 +126,11 @@ class CommonAgent:
         assert config.get('lr_schedule', 'constant') in ('constant', None)
         self.multi_gpu = config.get('multi_gpu', False)
         self.world_size, self.rank = config.get('world_size', 1), config.get('rank', 0)
+        # 'shard' (strong scaling: the R-rank update equals the 1-rank update) | 'horovod' (the reference's semantics:
+        # every rank owns its environments, gradients averaged, statistics averaged per epoch)
+        self.dp_mode = config.get('dp_mode', 'shard')
+        self.multi_gpu = self.multi_gpu or self.world_size > 1
+        self.seed = int(config.get('seed', 0) or 0)
         self.last_lr = float(config['learning_rate'])
         self.epoch_num = 0
         self.frame = 0
@@ -70,7 +140,21 @@ class CommonAgent:
         self.actions_num = self.env_info['action_space'].shape[0]
         self.value_size = self.env_info.get('value_size', 1)
         self.vec_env = config.get('vec_env', None)
+        self.name = config.get('name', base_name)
+        self.max_epochs = config.get('max_epochs', 1e6)
+        self.save_freq = config.get('save_frequency', 0)
+        self.print_stats = config.get('print_stats', True) and self.rank == 0
+        self.games_to_track = config.get('games_to_track', 100)
+        self.clip_actions = config.get('clip_actions', True)
+        self._save_intermediate = config.get('save_intermediate', False)
+        self.nn_dir = config.get('train_dir', os.path.join('runs', self.name, 'nn'))
+        rs = config.get('reward_shaper', {}) or {}
+        self._reward_scale, self._reward_shift = float(rs.get('scale_value', 1.0)), float(rs.get('shift_value', 0.0))
+        self.algo_observer = (config.get('features', {}) or {}).get('observer', None) or _NullObserver()
+        self.writer = config.get('writer', None) or ScalarLog()
+        self.is_tensor_obses = True
         self._load_config_params(config)
+        self._setup_action_space()
 
         self.network = config['network']
         self.model = self.network.build(self._build_net_config())
@@ -86,14 +170,57 @@ class CommonAgent:
         self.backend = backend
         self.engine = UpdateEngine(self.kind, self.model.a2c_network, config, backend, minibatch=self.minibatch_size,
                                    amp_minibatch=getattr(self, '_amp_minibatch_size', 0), dtype=dtype,
-                                   world_size=self.world_size, rank=self.rank)
+                                   world_size=self.world_size, rank=self.rank, dp_mode=self.dp_mode)
         self.model.a2c_network.infer = InferenceEngine(self.model.a2c_network, self.engine)
         self.use_graph = bool(config.get('graph_capture', False))
         self._graphs = {}
         self._train_mode = True
         self.train_result = None
-        self.dataset_perm = torch.randperm(self.batch_size, device=self.ppo_device).to(torch.int32)
+        # Every random draw of the update (dataset permutations, ring sample permutations, replay keep masks) comes from
+        # ONE generator.  Sharded data parallel: all ranks seed it identically and make the same draws in the same order,
+        # so minibatch r of rank k is the k-th shard of the same global minibatch; Horovod mode: rank-distinct streams.
+        self._gen = torch.Generator(device=self.ppo_device)
+        self._gen.manual_seed(self.seed * 1000003 + 12345 + (0 if self.dp_mode == 'shard' else 7919 * self.rank))
+        self.dataset_perm = self._randperm(self.batch_size)
+        self.action_rng = torch.tensor([(self.seed ^ 0xAC7105) + (0 if self.dp_mode == 'shard' else self.rank), 0],
+                                       dtype=torch.int64, device=self.ppo_device)       # Philox stream of the rollout's actions
+        self.game_rewards = AverageMeter(self.value_size, self.games_to_track)
+        self.game_lengths = AverageMeter(1, self.games_to_track)
+        self.obs = None
         self.init_tensors()
+        self.algo_observer.after_init(self)
+        if self.world_size > 1:
+            self._sync_initial_state()
+
+    def _randperm(self, n):
+        return torch.randperm(n, device=self.ppo_device, generator=self._gen).to(torch.int32)
+
+    def _sync_initial_state(self):
+        """rl_games HorovodWrapper.setup_algo: rank 0's parameters / optimizer state / statistics everywhere."""
+        self.engine.sync_from_rank0()
+
+    def sync_stats(self):
+        """rl_games HorovodWrapper.sync_stats (learning/common_agent.py:106-107): average every running-statistics buffer
+        over the ranks, sum the frame counters.  Sharded mode keeps the statistics identical by construction."""
+        if self.world_size <= 1 or self.dp_mode == 'shard':
+            return
+        e = self.engine
+        bufs = [e.obs_state, e.val_state] + ([e.amp_state] if e.has_disc else [])
+        for t in bufs:
+            e._ar(t)
+            t.mul_(1.0 / self.world_size)
+        cf = torch.tensor([float(self.curr_frames)], dtype=torch.float64, device=self.ppo_device)
+        e._ar(cf)
+        self.curr_frames = int(cf.item())
+
+    def _setup_action_space(self):
+        sp = self.env_info['action_space']
+        low, high = getattr(sp, 'low', None), getattr(sp, 'high', None)
+        n = sp.shape[0]
+        self.actions_low = torch.as_tensor(np.full(n, -1.0) if low is None else np.asarray(low), dtype=torch.float32,
+                                           device=self.ppo_device)
+        self.actions_high = torch.as_tensor(np.full(n, 1.0) if high is None else np.asarray(high), dtype=torch.float32,
+                                            device=self.ppo_device)
 
     # ------------------------------------------------------------------ config
     def _load_config_params(self, config):
@@ -116,6 +243,9 @@ class CommonAgent:
             'mus': torch.zeros(H, N, A, **f32), 'sigmas': torch.zeros(H, N, A, **f32),
             'next_obses': torch.zeros(H, N, *self.obs_shape, **f32), 'next_values': torch.zeros(H, N, 1, **f32)}
         self.tensor_list = ['actions', 'neglogpacs', 'values', 'mus', 'sigmas', 'obses', 'states', 'dones', 'next_obses']
+        self.current_rewards = torch.zeros(N, self.value_size, dtype=torch.float32, device=dev)   # rl_games A2CBase.init_tensors
+        self.current_lengths = torch.zeros(N, dtype=torch.float32, device=dev)
+        self.dones = torch.ones(N, dtype=torch.uint8, device=dev)
 
     # ------------------------------------------------------------------ mode switches / stats
     def set_eval(self):
@@ -199,6 +329,9 @@ class CommonAgent:
         state['frame'] = self.frame
         state['last_mean_rewards'] = self.last_mean_rewards
         state['env_state'] = None
+        # extra key (ignored by the reference's loader): position of the device-side latent / action streams
+        state['hip_rng_state'] = {'latents': self.engine.rng_state.cpu().clone() if self.engine.style else None,
+                                  'actions': self.action_rng.cpu().clone()}
         return state
 
     def set_full_state_weights(self, weights):
@@ -207,6 +340,13 @@ class CommonAgent:
         self._load_optimizer_state_dict(weights['optimizer'])
         self.frame = weights.get('frame', 0)
         self.last_mean_rewards = weights.get('last_mean_rewards', -100500)
+        rs = weights.get('hip_rng_state')
+        if rs is not None:
+            if rs.get('latents') is not None and self.engine.style:
+                self.engine.rng_state.copy_(rs['latents'])
+            self.action_rng.copy_(rs['actions'])
+        if self.world_size > 1:
+            self._sync_initial_state()
 
     def save(self, fn):
         torch.save(self.get_full_state_weights(), fn + '.pth')       # rl_games torch_ext.save_checkpoint
@@ -229,23 +369,114 @@ class CommonAgent:
         sigma = torch.exp(mu * 0.0 + self.engine.logstd)
         return mu, sigma, out['value']
 
+    def _preproc_obs(self, obs_batch):
+        """rl_games A2CBase._preproc_obs: uint8 -> /255, then the eval-mode observation normaliser.  The agents' own
+        rollout path fuses this into the first layer's input buffers (UpdateEngine._policy_nets); this stand-alone form
+        serves callers that feed the network-level API (model.a2c_network.eval_actor, learning/hrl_agent.py:231-236)."""
+        if obs_batch.dtype == torch.uint8:
+            obs_batch = obs_batch.float() / 255.0
+        if not self.normalize_input:
+            return obs_batch
+        e = self.engine
+        x = obs_batch.reshape(-1, obs_batch.shape[-1]).contiguous()
+        out = torch.empty_like(x, dtype=torch.float32)
+        mean, std = e._eval_stats(e.obs_state, e.obs, 'obs')
+        self.backend.rms_normalize(x, e.obs, None, (0, 0), x.shape[0], mean, std, [out])
+        return out.view(obs_batch.shape)
+
     def get_action_values(self, obs_dict, *extra):
-        mu, sigma, value = self._policy(obs_dict['obs'], *extra[:1] if self.kind == 'ase' else ())
-        action = mu + sigma * torch.randn_like(mu)
-        logstd = torch.log(sigma)
-        nlp = 0.5 * (((action - mu) / sigma) ** 2).sum(-1) + 0.5 * np.log(2 * np.pi) * mu.shape[-1] + logstd.sum(-1)
-        return {'neglogpacs': nlp, 'values': value, 'actions': action, 'mus': mu, 'sigmas': sigma, 'rnn_states': None}
+        """rl_games A2CBase.get_action_values(obs) / AMPAgent(obs, rand_action_probs) / ASEAgent(obs, ase_latents,
+        rand_action_probs) (learning/amp_agent.py:139-169, learning/ase_agent.py:117-148): eval-mode model forward, sampled
+        action, its neglogp, un-normalised value and - AMP / ASE - the eps-greedy substitution of mu for the rows whose
+        Bernoulli(rand_action_probs) draw is 0.  All of it on the device (UpdateEngine.policy_act)."""
+        z = probs = None
+        if self.kind == 'ase':
+            z = extra[0] if len(extra) > 0 else None
+            probs = extra[1] if len(extra) > 1 else None
+        elif self.kind == 'amp':
+            probs = extra[0] if len(extra) > 0 else None
+        return self.engine.policy_act(obs_dict['obs'], z, probs, self.action_rng)
 
     def _eval_critic(self, obs_dict, *extra):
         return self.engine.policy_forward(obs_dict['obs'], *extra[:1], want=('value',))['value']
 
+    # ---- environment plumbing (rl_games A2CBase / ContinuousA2CBase)
+    def obs_to_tensors(self, obs):
+        if isinstance(obs, dict):
+            return {k: (v.to(self.ppo_device) if torch.is_tensor(v) else torch.as_tensor(v, device=self.ppo_device))
+                    for k, v in obs.items()}
+        return {'obs': obs.to(self.ppo_device) if torch.is_tensor(obs) else torch.as_tensor(obs, device=self.ppo_device)}
+
+    def env_reset(self, env_ids=None):
+        return self.obs_to_tensors(self.vec_env.reset(env_ids))
+
+    def preprocess_actions(self, actions):
+        if self.clip_actions:
+            return rescale_actions(self.actions_low, self.actions_high, torch.clamp(actions, -1.0, 1.0))
+        return actions
+
+    def env_step(self, actions):
+        obs, rewards, dones, infos = self.vec_env.step(self.preprocess_actions(actions))
+        if self.value_size == 1:
+            rewards = rewards.unsqueeze(1)
+        return self.obs_to_tensors(obs), rewards.to(self.ppo_device), dones.to(self.ppo_device), infos
+
+    def rewards_shaper(self, rewards):
+        return (rewards + self._reward_shift) * self._reward_scale
+
+    def _rollout_extras(self, n, res_dict, infos):
+        """Per-step experience fields beyond CommonAgent's (AMP: amp_obs, rand_action_mask; ASE: + ase_latents)."""
+
+    def _act(self):
+        return self.get_action_values(self.obs)
+
+    def _next_values(self):
+        return self._eval_critic(self.obs)
+
+    def _before_act(self):
+        pass
+
     def play_steps(self):
-        """Fill the experience buffer from the (synthetic) environment, then run the reference's tail."""
+        """learning/common_agent.py:241-307 (amp_agent.py:61-137, ase_agent.py:36-115, hrl_agent.py:95-163): roll the
+        vectorised environment for `horizon_length` steps with the HIP inference path, then the tail (rewards, GAE,
+        dataset) in UpdateEngine.prepare_epoch.  A source that hands over a whole rollout at once
+        (SyntheticSource.experience, the benchmark's generator) is copied in directly."""
         self.set_eval()
-        exp = self.vec_env.experience(self._cpu_policy(), **self._experience_kwargs())
-        for k, v in exp.items():
-            if k in self.experience:
-                self.experience[k].copy_(v.to(self.ppo_device))
+        if not hasattr(self.vec_env, 'step'):
+            exp = self.vec_env.experience(self._cpu_policy(), **self._experience_kwargs())
+            for k, v in exp.items():
+                if k in self.experience:
+                    self.experience[k].copy_(v.to(self.ppo_device))
+            return self._play_steps_tail()
+        E = self.experience
+        done_indices = []
+        if self.obs is None:
+            self.obs = self.env_reset()
+        for n in range(self.horizon_length):
+            self.obs = self.env_reset(done_indices)
+            E['obses'][n].copy_(self.obs['obs'])
+            self._before_act()
+            res = self._act()
+            for k in ('actions', 'neglogpacs', 'values', 'mus', 'sigmas'):
+                E[k][n].copy_(res[k].view(E[k][n].shape))
+            self.obs, rewards, self.dones, infos = self.env_step(res['actions'])
+            E['rewards'][n].copy_(self.rewards_shaper(rewards))
+            E['next_obses'][n].copy_(self.obs['obs'])
+            E['dones'][n].copy_(self.dones)
+            self._rollout_extras(n, res, infos)
+            terminated = infos['terminate'].float().unsqueeze(-1).to(self.ppo_device)
+            E['next_values'][n].copy_(self._next_values() * (1.0 - terminated))
+            self.current_rewards += rewards
+            self.current_lengths += 1
+            all_done_indices = self.dones.nonzero(as_tuple=False)
+            done_indices = all_done_indices[::self.num_agents]
+            self.game_rewards.update(self.current_rewards[done_indices])
+            self.game_lengths.update(self.current_lengths[done_indices])
+            self.algo_observer.process_infos(infos, done_indices)
+            not_dones = 1.0 - self.dones.float()
+            self.current_rewards = self.current_rewards * not_dones.unsqueeze(1)
+            self.current_lengths = self.current_lengths * not_dones
+            done_indices = done_indices[:, 0]
         return self._play_steps_tail()
 
     def _experience_kwargs(self):
@@ -372,7 +603,85 @@ class CommonAgent:
         train_info['play_time'] = play_time_end - play_time_start
         train_info['update_time'] = update_time_end - update_time_start
         train_info['total_time'] = update_time_end - play_time_start
+        self._record_train_batch_info(batch_dict, train_info)
         return train_info
+
+    # ------------------------------------------------------------------ the training loop (learning/common_agent.py:82-155)
+    def _init_train(self):
+        pass
+
+    def train(self):
+        """What rl_games' Runner.run calls: rollout + update until max_epochs, with the reference's bookkeeping (frame
+        counters, reward / length meters, periodic checkpoints, per-epoch statistics sync under data parallel)."""
+        self.init_tensors()
+        self.last_mean_rewards = -100500
+        total_time = 0
+        self.frame = 0
+        self.obs = self.env_reset() if hasattr(self.vec_env, 'reset') else None
+        self.curr_frames = self.batch_size
+        model_output_file = os.path.join(self.nn_dir, self.name)
+        if self.multi_gpu:
+            self._sync_initial_state()
+        self._init_train()
+        while True:
+            epoch_num = self.update_epoch()
+            train_info = self.train_epoch()
+            sum_time = train_info['total_time']
+            total_time += sum_time
+            frame = self.frame
+            if self.multi_gpu:
+                self.sync_stats()
+            if self.rank == 0:
+                curr_frames = self.curr_frames
+                self.frame += curr_frames
+                if self.print_stats:
+                    print(f"fps step: {curr_frames / max(train_info['play_time'], 1e-9):.1f} "
+                          f"fps total: {curr_frames / max(sum_time, 1e-9):.1f}")
+                self.writer.add_scalar('performance/total_fps', curr_frames / max(sum_time, 1e-9), frame)
+                self.writer.add_scalar('performance/step_fps', curr_frames / max(train_info['play_time'], 1e-9), frame)
+                self.writer.add_scalar('info/epochs', epoch_num, frame)
+                self._log_train_info(train_info, frame)
+                self.algo_observer.after_print_stats(frame, epoch_num, total_time)
+                if self.game_rewards.current_size > 0:
+                    mean_rewards = np.atleast_1d(self._get_mean_rewards())
+                    mean_lengths = self.game_lengths.get_mean()
+                    for i in range(self.value_size):
+                        self.writer.add_scalar(f'rewards{i}/frame', mean_rewards[i], frame)
+                        self.writer.add_scalar(f'rewards{i}/iter', mean_rewards[i], epoch_num)
+                        self.writer.add_scalar(f'rewards{i}/time', mean_rewards[i], total_time)
+                    self.writer.add_scalar('episode_lengths/frame', mean_lengths, frame)
+                    self.writer.add_scalar('episode_lengths/iter', mean_lengths, epoch_num)
+                if self.save_freq > 0 and epoch_num % self.save_freq == 0:
+                    os.makedirs(self.nn_dir, exist_ok=True)
+                    self.save(model_output_file)
+                    if self._save_intermediate:
+                        self.save(model_output_file + '_' + str(epoch_num).zfill(8))
+            if epoch_num > self.max_epochs:
+                if self.rank == 0:
+                    os.makedirs(self.nn_dir, exist_ok=True)
+                    self.save(model_output_file)
+                    print('MAX EPOCHS NUM!')
+                return self.last_mean_rewards, epoch_num
+
+    def _get_mean_rewards(self):
+        return self.game_rewards.get_mean()
+
+    def _record_train_batch_info(self, batch_dict, train_info):
+        pass
+
+    def _log_train_info(self, train_info, frame):
+        w = self.writer
+        w.add_scalar('performance/update_time', train_info['update_time'], frame)
+        w.add_scalar('performance/play_time', train_info['play_time'], frame)
+        w.add_scalar('losses/a_loss', _mean_list(train_info['actor_loss']).item(), frame)
+        w.add_scalar('losses/c_loss', _mean_list(train_info['critic_loss']).item(), frame)
+        w.add_scalar('losses/bounds_loss', _mean_list(train_info['b_loss']).item(), frame)
+        w.add_scalar('losses/entropy', _mean_list(train_info['entropy']).item(), frame)
+        w.add_scalar('info/last_lr', train_info['last_lr'][-1] * train_info['lr_mul'][-1], frame)
+        w.add_scalar('info/lr_mul', train_info['lr_mul'][-1], frame)
+        w.add_scalar('info/e_clip', self.e_clip * train_info['lr_mul'][-1], frame)
+        w.add_scalar('info/clip_frac', _mean_list(train_info['actor_clip_frac']).item(), frame)
+        w.add_scalar('info/kl', _mean_list(train_info['kl']).item(), frame)
 
     def update(self, batch_dict, perms=None, new_zs=None, max_steps=None):
         """Everything train_epoch does after the rollout (learning/amp_agent.py:194-262): the timed region of
@@ -406,7 +715,7 @@ class CommonAgent:
                         train_info[k].append(v)
                 step += 1
             if perms is None:          # AMPDataset reshuffles after the last minibatch (learning/amp_datasets.py:24-30)
-                self.dataset_perm = torch.randperm(self.batch_size, device=self.ppo_device).to(torch.int32)
+                self.dataset_perm = self._randperm(self.batch_size)
         self._post_update(batch_dict)
         return train_info
 
@@ -442,10 +751,47 @@ class AMPAgent(CommonAgent):
         A = self._amp_observation_space.shape[0]
         self.experience['amp_obs'] = torch.zeros(H, N, A, dtype=torch.float32, device=dev)
         self.experience['rand_action_mask'] = torch.zeros(H, N, dtype=torch.float32, device=dev)
-        self._amp_obs_demo_buffer = ReplayBuffer(int(self.config['amp_obs_demo_buffer_size']), dev, self.backend)
-        self._amp_replay_buffer = ReplayBuffer(int(self.config['amp_replay_buffer_size']), dev, self.backend)
+        self._amp_obs_demo_buffer = ReplayBuffer(int(self.config['amp_obs_demo_buffer_size']), dev, self.backend, self._gen)
+        self._amp_replay_buffer = ReplayBuffer(int(self.config['amp_replay_buffer_size']), dev, self.backend, self._gen)
         self.tensor_list += ['amp_obs', 'rand_action_mask']
         self._demo_ready = False
+        self._build_rand_action_probs()
+
+    def _build_rand_action_probs(self):
+        """learning/amp_agent.py:424-435: env i acts stochastically with probability 1 - exp(10 (i / (N - 1) - 1))."""
+        n = self.num_actors * self.num_agents
+        env_ids = torch.arange(n, dtype=torch.float32, device=self.ppo_device)
+        self._rand_action_probs = 1.0 - torch.exp(10 * (env_ids / (n - 1.0) - 1.0))
+        self._rand_action_probs[0] = 1.0
+        self._rand_action_probs[-1] = 0.0
+        if not self._enable_eps_greedy:
+            self._rand_action_probs[:] = 1.0
+
+    def _init_train(self):
+        super()._init_train()
+        self._init_amp_demo_buf()
+
+    def _act(self):
+        return self.get_action_values(self.obs, self._rand_action_probs)
+
+    def _rollout_extras(self, n, res_dict, infos):
+        self.experience['amp_obs'][n].copy_(infos['amp_obs'])
+        self.experience['rand_action_mask'][n].copy_(res_dict['rand_action_mask'])
+
+    def _record_train_batch_info(self, batch_dict, train_info):
+        super()._record_train_batch_info(batch_dict, train_info)
+        train_info['disc_rewards'] = batch_dict['disc_rewards']
+
+    def _log_train_info(self, train_info, frame):
+        super()._log_train_info(train_info, frame)
+        w = self.writer
+        w.add_scalar('losses/disc_loss', _mean_list(train_info['disc_loss']).item(), frame)
+        for k in ('disc_agent_acc', 'disc_demo_acc', 'disc_agent_logit', 'disc_demo_logit', 'disc_grad_penalty',
+                  'disc_logit_loss'):
+            w.add_scalar('info/' + k, _mean_list(train_info[k]).item(), frame)
+        std, mean = torch.std_mean(train_info['disc_rewards'])
+        w.add_scalar('info/disc_reward_mean', mean.item(), frame)
+        w.add_scalar('info/disc_reward_std', std.item(), frame)
 
     def _experience_kwargs(self):
         return {'with_amp': True, 'with_latents': False}
@@ -463,7 +809,8 @@ class AMPAgent(CommonAgent):
 
     # ---- demo / replay plumbing (learning/amp_agent.py:498-533,579-593)
     def _fetch_amp_obs_demo(self, n):
-        return self.vec_env.fetch_amp_obs_demo(n).to(self.ppo_device)
+        env = getattr(self.vec_env, 'env', self.vec_env)          # the reference reaches through vec_env.env
+        return env.fetch_amp_obs_demo(n).to(self.ppo_device)
 
     def _init_amp_demo_buf(self):
         size = self._amp_obs_demo_buffer.get_buffer_size()
@@ -481,11 +828,12 @@ class AMPAgent(CommonAgent):
         idx = None
         n = B
         if total > size:
-            keep = torch.bernoulli(torch.full((B,), float(self._amp_replay_keep_prob), device=self.ppo_device)) == 1.0
+            keep = torch.bernoulli(torch.full((B,), float(self._amp_replay_keep_prob), device=self.ppo_device),
+                                   generator=self._gen) == 1.0
             idx = keep.nonzero(as_tuple=False).flatten().to(torch.int32)
             n = int(idx.numel())
         if n > size:
-            sel = torch.randperm(n, device=self.ppo_device)[:size]
+            sel = torch.randperm(n, device=self.ppo_device, generator=self._gen)[:size]
             idx = sel.to(torch.int32) if idx is None else idx[sel.long()]
             n = size
         buf.store(amp_obs_exp.view(B, -1), n=n, idx=idx, remap=self._remap)
@@ -568,6 +916,70 @@ class ASEAgent(AMPAgent):
         H, N, dev = self.horizon_length, self.num_actors * self.num_agents, self.ppo_device
         self.experience['ase_latents'] = torch.zeros(H, N, self._latent_dim, dtype=torch.float32, device=dev)
         self.tensor_list += ['ase_latents']
+        self._ase_latents = torch.zeros(N, self._latent_dim, dtype=torch.float32, device=dev)      # learning/ase_agent.py:24-27
+        self._latent_reset_steps = torch.zeros(N, dtype=torch.int32, device=dev)
+
+    # ---- per-environment latents (learning/ase_agent.py:310-379)
+    def _progress_buf(self):
+        env = getattr(self.vec_env, 'env', self.vec_env)
+        return env.task.progress_buf.to(self.ppo_device)
+
+    def env_reset(self, env_ids=None):
+        obs = super().env_reset(env_ids)
+        if env_ids is None:
+            env_ids = torch.arange(self.num_actors * self.num_agents, dtype=torch.long, device=self.ppo_device)
+        if len(env_ids) > 0:
+            env_ids = torch.as_tensor(env_ids, dtype=torch.long, device=self.ppo_device)
+            self._reset_latents(env_ids)
+            self._reset_latent_step_count(env_ids)
+        return obs
+
+    def _rand_steps(self, n):
+        return torch.randint(int(self._latent_steps_min), int(self._latent_steps_max), (n,), device=self.ppo_device,
+                             generator=self._gen, dtype=torch.int32)
+
+    def _reset_latent_step_count(self, env_ids):
+        self._latent_reset_steps[env_ids] = self._rand_steps(len(env_ids))
+
+    def _sample_latents(self, n):
+        return self.model.a2c_network.sample_latents(n)
+
+    def _reset_latents(self, env_ids):
+        self._ase_latents[env_ids] = self._sample_latents(len(env_ids))
+
+    def _update_latents(self):
+        new_latent_envs = self._latent_reset_steps <= self._progress_buf()
+        if bool(torch.any(new_latent_envs)):
+            ids = new_latent_envs.nonzero(as_tuple=False).flatten()
+            self._reset_latents(ids)
+            self._latent_reset_steps[ids] += self._rand_steps(len(ids))
+
+    def _before_act(self):
+        self._update_latents()
+
+    def _act(self):
+        return self.get_action_values(self.obs, self._ase_latents, self._rand_action_probs)
+
+    def _next_values(self):
+        return self._eval_critic(self.obs, self._ase_latents)
+
+    def _rollout_extras(self, n, res_dict, infos):
+        super()._rollout_extras(n, res_dict, infos)
+        self.experience['ase_latents'][n].copy_(self._ase_latents)
+
+    def _record_train_batch_info(self, batch_dict, train_info):
+        super()._record_train_batch_info(batch_dict, train_info)
+        train_info['enc_rewards'] = batch_dict['enc_rewards']
+
+    def _log_train_info(self, train_info, frame):
+        super()._log_train_info(train_info, frame)
+        w = self.writer
+        w.add_scalar('losses/enc_loss', _mean_list(train_info['enc_loss']).item(), frame)
+        if self._amp_diversity_bonus != 0:
+            w.add_scalar('losses/amp_diversity_loss', _mean_list(train_info['amp_diversity_loss']).item(), frame)
+        std, mean = torch.std_mean(train_info['enc_rewards'])
+        w.add_scalar('info/enc_reward_mean', mean.item(), frame)
+        w.add_scalar('info/enc_reward_std', std.item(), frame)
 
     def _experience_kwargs(self):
         return {'with_amp': True, 'with_latents': True}
@@ -584,7 +996,126 @@ class ASEAgent(AMPAgent):
 
 
 class HRLAgent(CommonAgent):
-    """High-level policy update of the HRL agent = CommonAgent's plain PPO step on the tanh-mu A2C net
-    (learning/hrl_agent.py:26, learning/hrl_network_builder.py:26-29).  The frozen low-level controller and
-    its 5-step env_step (hrl_agent.py:45-82) belong to the rollout side."""
+    """learning/hrl_agent.py:26-268: a trainable high-level policy (plain PPO on the tanh-mu A2C net,
+    learning/hrl_network_builder.py:26-29) whose 64-dim action is the latent of a FROZEN ASE low-level controller.
+    One high-level step = `llc_steps` simulator steps: z = normalize(action) -> LLC actor (HIP inference path, deterministic
+    mu) -> env.step, with the LLC discriminator's reward averaged over the inner steps (hrl_agent.py:45-82,231-249).
+
+    config['llc_config']: path of the LLC's yaml or the parsed dict; config['llc_checkpoint']: path of a checkpoint written
+    by ASEAgent.save (or the reference) or the weights dict itself."""
     kind = 'ppo'
+
+    def __init__(self, base_name, config):
+        llc = config['llc_config']
+        if not isinstance(llc, dict):
+            import yaml
+            with open(os.path.join(os.getcwd(), llc), 'r') as f:
+                llc = yaml.load(f, Loader=yaml.SafeLoader)
+        self._llc_params = llc['params']
+        self._latent_dim = self._llc_params['config']['latent_dim']
+        super().__init__(base_name, config)
+        env = getattr(self.vec_env, 'env', self.vec_env)
+        self._task_size = env.task.get_task_obs_size()
+        self._llc_steps = config['llc_steps']
+        llc_checkpoint = config['llc_checkpoint']
+        assert llc_checkpoint != ""                                           # learning/hrl_agent.py:40
+        self._build_llc(self._llc_params, llc_checkpoint)
+
+    def _load_config_params(self, config):
+        super()._load_config_params(config)
+        self._task_reward_w = config['task_reward_w']
+        self._disc_reward_w = config['disc_reward_w']
+
+    def _setup_action_space(self):
+        super()._setup_action_space()             # low / high of the ENVIRONMENT's action space: what the LLC's mu is scaled to
+        self.actions_num = self._latent_dim       # the high-level policy acts in latent space (hrl_agent.py:181-184)
+
+    def init_tensors(self):
+        super().init_tensors()
+        H, N, dev = self.horizon_length, self.num_actors * self.num_agents, self.ppo_device
+        self.experience['disc_rewards'] = torch.zeros(H, N, 1, dtype=torch.float32, device=dev)
+        self.tensor_list += ['disc_rewards']
+
+    # ---- the frozen low-level controller
+    def _build_llc(self, config_params, checkpoint):
+        from . import models
+        from .network_builder import ASEBuilder
+        import copy
+        import types
+        builder = ASEBuilder()
+        builder.load(config_params['network'])
+        obs_size = self.obs_shape[0] - self._task_size
+        env_info = dict(self.env_info)
+        env_info['observation_space'] = types.SimpleNamespace(shape=(obs_size,))
+        env = getattr(self.vec_env, 'env', self.vec_env)
+        if 'amp_observation_space' not in env_info:
+            env_info['amp_observation_space'] = env.amp_observation_space
+        cfg = copy.copy(config_params['config'])
+        cfg.update(network=models.ModelASEContinuous(builder), num_actors=self.num_actors, env_info=env_info,
+                   device=self.ppo_device, vec_env=None, features={'observer': self.algo_observer},
+                   precision=self.config.get('precision', 'bf16'), seed=self.seed)
+        if self.config.get('backend') is not None:
+            cfg['backend'] = self.config['backend']
+        self._llc_agent = ASEAgent('llc', cfg)
+        if isinstance(checkpoint, dict):
+            self._llc_agent.set_full_state_weights(checkpoint)
+        else:
+            self._llc_agent.restore(checkpoint)
+        self._llc_agent.set_eval()
+
+    def _extract_llc_obs(self, obs):
+        return obs[..., :obs.shape[-1] - self._task_size]
+
+    def _compute_llc_action(self, obs, actions):
+        """hrl_agent.py:231-241: normalised LLC observation, z = normalize(high-level action), deterministic LLC mu,
+        scaled to the environment's action range (ASEAgent.preprocess_actions)."""
+        llc_obs = self._extract_llc_obs(obs).contiguous()
+        e = self._llc_agent.engine
+        z = e._scr('hrl_z', actions.shape[0], self._latent_dim, torch.float32)
+        self.backend.normalize_rows(actions, z, actions.shape[0], self._latent_dim)
+        mu = e.policy_forward(llc_obs, z, want=('mu',))['mu']
+        return self._llc_agent.preprocess_actions(mu)
+
+    def _calc_disc_reward(self, amp_obs):
+        return self._llc_agent._calc_disc_rewards(amp_obs)
+
+    def preprocess_actions(self, actions):
+        return torch.clamp(actions, -1.0, 1.0)                                # hrl_agent.py:90-94
+
+    def env_step(self, actions):
+        actions = self.preprocess_actions(actions)
+        obs = self.obs['obs']
+        rewards = disc_rewards = done_count = terminate_count = 0.0
+        for t in range(self._llc_steps):
+            llc_actions = self._compute_llc_action(obs, actions)
+            obs, curr_rewards, curr_dones, infos = self.vec_env.step(llc_actions)
+            obs = obs['obs'] if isinstance(obs, dict) else obs
+            obs = obs.to(self.ppo_device)
+            rewards = rewards + curr_rewards.to(self.ppo_device)
+            done_count = done_count + curr_dones.to(self.ppo_device).float()
+            terminate_count = terminate_count + infos['terminate'].to(self.ppo_device).float()
+            disc_rewards = disc_rewards + self._calc_disc_reward(infos['amp_obs'].to(self.ppo_device))
+        rewards = rewards / self._llc_steps
+        disc_rewards = disc_rewards / self._llc_steps
+        dones = (done_count > 0).to(done_count.dtype)
+        infos['terminate'] = (terminate_count > 0).to(terminate_count.dtype)
+        infos['disc_rewards'] = disc_rewards
+        if self.value_size == 1:
+            rewards = rewards.unsqueeze(1)
+        return self.obs_to_tensors(obs), rewards, dones, infos
+
+    def _rollout_extras(self, n, res_dict, infos):
+        self.experience['disc_rewards'][n].copy_(infos['disc_rewards'].view(-1, 1))
+
+    def _get_mean_rewards(self):
+        return super()._get_mean_rewards() * self._llc_steps
+
+    def _record_train_batch_info(self, batch_dict, train_info):
+        super()._record_train_batch_info(batch_dict, train_info)
+        train_info['disc_rewards'] = batch_dict['disc_rewards']
+
+    def _log_train_info(self, train_info, frame):
+        super()._log_train_info(train_info, frame)
+        std, mean = torch.std_mean(train_info['disc_rewards'])
+        self.writer.add_scalar('info/disc_reward_mean', mean.item(), frame)
+        self.writer.add_scalar('info/disc_reward_std', std.item(), frame)

@@ -141,6 +141,9 @@ class A2CNetwork(nn.Module):
         if flat.dtype != torch.float32:
             raise TypeError("master weights stay f32 (bf16 shadows are derived caches)")
         if flat is not self.flat_params:
+            if getattr(self, '_engine_bound', False):
+                raise RuntimeError("the parameters were moved after an UpdateEngine bound them (its shadows, gradient / "
+                                   "Adam buffers and pointer tables refer to the old storage): move the network first")
             self.flat_params = flat
             for k, p in self.named_parameters():
                 o, shp = self.param_slices[k]

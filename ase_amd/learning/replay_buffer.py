@@ -7,14 +7,15 @@ import torch
 
 
 class ReplayBuffer:
-    def __init__(self, buffer_size, device, backend=None):
+    def __init__(self, buffer_size, device, backend=None, generator=None):
         self._head = 0
         self._total_count = 0
         self._buffer_size = int(buffer_size)
         self._device = device
         self._data = None
         self._be = backend
-        self._sample_idx = torch.randperm(self._buffer_size, device=device)
+        self._gen = generator            # shared by everything an agent draws: data-parallel ranks stay in lock-step
+        self._sample_idx = torch.randperm(self._buffer_size, device=device, generator=generator)
         self._sample_head = 0
 
     def reset(self):
@@ -64,5 +65,5 @@ class ReplayBuffer:
         return {'amp_obs': self._data[self.sample_indices(n).long()]}
 
     def _reset_sample_idx(self):
-        self._sample_idx[:] = torch.randperm(self._buffer_size, device=self._device)
+        self._sample_idx[:] = torch.randperm(self._buffer_size, device=self._device, generator=self._gen)
         self._sample_head = 0

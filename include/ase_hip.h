@@ -272,9 +272,24 @@ int ase_hip_adv_norm(const float* returns, const float* values, const float* mas
 int ase_hip_ring_store(const float* src, int64_t ld_src, int D, const int32_t* idx, int remap_h,
                        int remap_n, int n, float* dst, int64_t size, int64_t head, void* stream);
 
+/* y[r,:] = x[r,:] / max(|x[r,:]|_2, 1e-12): the latent a high-level action selects
+ * (torch.nn.functional.normalize, learning/hrl_agent.py:235; learning/ase_network_builder.py:140-142). */
+int ase_hip_normalize_rows(const float* x, int64_t ld_x, float* y, int64_t ld_y, int n, int dim, void* stream);
+
+/* Rollout-time action head: the eval branch of the model wrapper + the eps-greedy mix
+ * (learning/amp_models.py:29-36; learning/amp_agent.py:139-169; learning/ase_agent.py:117-148): per row
+ * mu' = mu (tanh'ed when mu_tanh, learning/hrl_network_builder.py:26-29), sigma = exp(logstd), a = mu' + sigma N(0,1)
+ * (Philox, rng_state as below), neglogp(a), rand_mask = Bernoulli(rand_probs[row]) and actions = rand_mask ? a : mu'.
+ * rand_probs / rand_mask nullable (plain PPO: every row stochastic).  mu has leading dimension ld_mu, outputs are dense. */
+int ase_hip_sample_actions(const float* mu, int64_t ld_mu, const float* logstd, const float* rand_probs,
+                           uint64_t* rng_state, float* mu_out, float* sigma_out, float* actions, float* neglogp,
+                           float* rand_mask, int n, int act_dim, int mu_tanh, void* stream);
+
 /* z[r,:] = normalize(N(0,I))  (learning/ase_network_builder.py:221-225); counter-based Philox,
- * stream position read from and advanced in rng_state (u64[2] = {seed, offset}). */
-int ase_hip_sample_latents(float* z, int rows, int dim, uint64_t* rng_state, void* stream);
+ * stream position read from and advanced in rng_state (u64[2] = {seed, offset}).  Row r draws the elements
+ * (row_offset + r) * dim .. of the stream: data-parallel ranks pass the global index of their first row, so the R-rank
+ * draw equals the 1-rank draw. */
+int ase_hip_sample_latents(float* z, int rows, int dim, uint64_t* rng_state, int64_t row_offset, void* stream);
 
 /* The whole optimizer step of every dense layer in ONE launch: weight-only gradient terms (g += c * w: discriminator
  * weight decay / logit regulariser / encoder weight decay), their reported sums of squares (pre-update weights, into

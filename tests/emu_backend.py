@@ -296,7 +296,7 @@ class EmuBackend:
         den = S if masked else float(m_global)
         al, bl, ent, cf = a[L.ACC_A_LOSS] / den, a[L.ACC_B_LOSS] / den, a[L.ACC_ENTROPY] / den, a[L.ACC_CLIPPED] / den
         cl, kl = a[L.ACC_C_LOSS] / m_global, a[L.ACC_KL] / m_global
-        loss = al + c['critic_coef'] * cl - c['entropy_coef'] * ent + c['bounds_loss_coef'] * bl
+        loss = al + c['critic_coef'] * cl - c['entropy_coef'] * ent + float(c.get('bounds_loss_coef') or 0.0) * bl
         out.zero_()
         out[L.RES_A_LOSS], out[L.RES_C_LOSS], out[L.RES_B_LOSS] = al, cl, bl
         out[L.RES_ENTROPY], out[L.RES_CLIP_FRAC], out[L.RES_KL], out[L.RES_MASK_SUM] = ent, cf, kl, S
@@ -392,7 +392,33 @@ class EmuBackend:
         q = (head + torch.arange(n)) % size
         dst[q, :D] = src[_rows(idx, remap, n), :D]
 
-    def sample_latents(self, z, rows, dim, rng_state):
-        v = torch.randn(rows, dim, generator=self.rng)
+    def normalize_rows(self, x, y, n, dim):
+        v = x[:n, :dim].float()
+        y[:n, :dim] = v / v.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+
+    def sample_actions(self, mu, logstd, rand_probs, rng_state, mu_out, sigma_out, actions, neglogp, rand_mask, n, act_dim,
+                       mu_tanh=False):
+        g = torch.Generator().manual_seed(int(rng_state[0]) * 1000003 + int(rng_state[1]) + 17)
+        m = mu[:n, :act_dim].float()
+        if mu_tanh:
+            m = torch.tanh(m)
+        s = torch.exp(logstd[:act_dim]).expand_as(m)
+        a = m + s * torch.randn(n, act_dim, generator=g)
+        nlp = 0.5 * (((a - m) / s) ** 2).sum(-1) + 0.5 * math.log(2 * math.pi) * act_dim + logstd[:act_dim].sum()
+        keep = torch.ones(n)
+        if rand_probs is not None:
+            keep = torch.bernoulli(rand_probs[:n].float().cpu(), generator=g)
+        mu_out[:n] = m
+        sigma_out[:n] = s
+        actions[:n] = torch.where(keep.view(-1, 1) != 0, a, m)
+        neglogp.view(-1)[:n] = nlp
+        if rand_mask is not None:
+            rand_mask.view(-1)[:n] = keep
+        rng_state[1] += 1
+
+    def sample_latents(self, z, rows, dim, rng_state, row_offset=0):
+        # counter-based like the kernel: the draw is a function of (seed, offset, global row), not of call history
+        g = torch.Generator().manual_seed(int(rng_state[0]) * 1000003 + int(rng_state[1]))
+        v = torch.randn(row_offset + rows, dim, generator=g)[row_offset:]
         z[:rows, :dim] = v / v.norm(dim=-1, keepdim=True).clamp_min(1e-12)
         rng_state[1] += 1
