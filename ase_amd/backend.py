@@ -80,7 +80,7 @@ class HipBackend:
         return (dtype == torch.bfloat16 and M % 64 == 0 and bias_rows % 64 == 0 and n_real >= 128 and K >= 128
                 and n_real * K >= 512 * 512)
 
-    def make_tn_plan(self, problems):
+    def make_tn_plan(self, problems, target_wg=0):
         """problems: [(A, B, G, gbias|None, bias_rows, M, N, K, n_real, k_real, split_src, split_dst, alpha)] -> plan
         (device tables + the tensors they point to, kept alive)."""
         import struct
@@ -95,7 +95,8 @@ class HipBackend:
         max_work = 8192
         work = (C.c_int32 * (4 * max_work))()
         n_work = C.c_int(0)
-        L.check(self.lib.ase_hip_gemm_tn_grouped_plan(tab, n, 0, work, max_work, C.byref(n_work)), "gemm_tn_grouped_plan")
+        L.check(self.lib.ase_hip_gemm_tn_grouped_plan(tab, n, int(target_wg), work, max_work, C.byref(n_work)),
+                "gemm_tn_grouped_plan")
         nw = n_work.value
         dev_tab = torch.tensor(list(tab), dtype=torch.int64, device=self.device)
         dev_work = torch.tensor(list(work[:4 * nw]), dtype=torch.int32, device=self.device)
@@ -159,6 +160,32 @@ class HipBackend:
     def rms_moments(self, src, D, idx, remap, M, state, sums):
         L.check(self.lib.ase_hip_rms_moments(_ptr(src), _ld(src), D, _ptr(idx), remap[0], remap[1], M, _ptr(state),
                                              _ptr(sums), self._stream()), "rms_moments")
+
+    @staticmethod
+    def _stream_arrays(streams):
+        n = len(streams)
+        srcs = (C.c_void_p * n)(*[s[0].data_ptr() for s in streams])
+        lds = (C.c_int64 * n)(*[int(s[0].stride(0)) for s in streams])
+        idxs = (C.c_void_p * n)(*[None if s[1] is None else s[1].data_ptr() for s in streams])
+        rh = (C.c_int * n)(*[int(s[2][0]) for s in streams])
+        rn = (C.c_int * n)(*[int(s[2][1]) for s in streams])
+        return n, srcs, lds, idxs, rh, rn
+
+    def rms_moments_multi(self, streams, D, M, state, sums_list):
+        """streams: [(src, idx, remap)] (<= 4, same width D and row count M); sums_list: one f64 [2 D] buffer per stream."""
+        n, srcs, lds, idxs, rh, rn = self._stream_arrays(streams)
+        sums = (C.c_void_p * n)(*[t.data_ptr() for t in sums_list])
+        L.check(self.lib.ase_hip_rms_moments_multi(srcs, lds, idxs, rh, rn, sums, n, D, M, _ptr(state), self._stream()),
+                "rms_moments_multi")
+
+    def rms_normalize_multi(self, streams, D, M, means, stds, outs):
+        n, srcs, lds, idxs, rh, rn = self._stream_arrays(streams)
+        mp = (C.c_void_p * n)(*[t.data_ptr() for t in means])
+        sp = (C.c_void_p * n)(*[t.data_ptr() for t in stds])
+        op = (C.c_void_p * n)(*[t.data_ptr() for t in outs])
+        lo = (C.c_int64 * n)(*[int(t.stride(0)) for t in outs])
+        L.check(self.lib.ase_hip_rms_normalize_multi(srcs, lds, idxs, rh, rn, mp, sp, op, lo, n, D, M, _code(outs[0].dtype),
+                                                     self._stream()), "rms_normalize_multi")
 
     def rms_finalize(self, state, D, sums, count, n_streams, mean_out, std_out):
         counts = (C.c_int32 * max(n_streams, 1))(*([int(count)] * max(n_streams, 1)))
@@ -225,9 +252,10 @@ class HipBackend:
             self._stream()), "finalize_scalars")
 
     # ------------------------------------------------------------------ optimizer
-    def begin_step(self, opt_state, acc):
-        L.check(self.lib.ase_hip_begin_step(_ptr(opt_state), _ptr(acc), 0 if acc is None else acc.numel(),
-                                            self._stream()), "begin_step")
+    def begin_step(self, opt_state, acc, zero2=None, rng_bump=None):
+        L.check(self.lib.ase_hip_begin_step(_ptr(opt_state), _ptr(acc), 0 if acc is None else acc.numel(), _ptr(zero2),
+                                            0 if zero2 is None else zero2.numel(), _ptr(rng_bump), self._stream()),
+                "begin_step")
 
     def adam(self, w, g, m, v, opt_state):
         L.check(self.lib.ase_hip_adam(_ptr(w), _ptr(g), _ptr(m), _ptr(v), w.numel(), _ptr(opt_state), self._stream()),
@@ -268,6 +296,6 @@ class HipBackend:
                                                 _ptr(sigma_out), _ptr(actions), _ptr(neglogp), _ptr(rand_mask), n, act_dim,
                                                 int(mu_tanh), self._stream()), "sample_actions")
 
-    def sample_latents(self, z, rows, dim, rng_state, row_offset=0):
-        L.check(self.lib.ase_hip_sample_latents(_ptr(z), rows, dim, _ptr(rng_state), int(row_offset), self._stream()),
-                "sample_latents")
+    def sample_latents(self, z, rows, dim, rng_state, row_offset=0, advance=True):
+        L.check(self.lib.ase_hip_sample_latents(_ptr(z), rows, dim, _ptr(rng_state), int(row_offset), int(advance),
+                                                self._stream()), "sample_latents")

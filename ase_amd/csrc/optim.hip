@@ -4,8 +4,11 @@
 namespace {
 
 // opt_state (f64[8]): {step, lr, beta1, beta2, eps, bias_corr1, bias_corr2, unused}
-__global__ void begin_step_kernel(double* __restrict__ opt_state, double* __restrict__ acc, int n_acc) {
+__global__ void begin_step_kernel(double* __restrict__ opt_state, double* __restrict__ acc, int n_acc,
+                                  double* __restrict__ zero2, int n_zero2, unsigned long long* __restrict__ rng_bump) {
     for (int i = threadIdx.x; i < n_acc; i += blockDim.x) acc[i] = 0.0;
+    for (int i = threadIdx.x; i < n_zero2; i += blockDim.x) zero2[i] = 0.0;
+    if (threadIdx.x == 0 && rng_bump) rng_bump[1] += 1;
     if (threadIdx.x == 0 && opt_state) {
         const double step = opt_state[0] + 1.0;
         opt_state[0] = step;
@@ -151,9 +154,11 @@ inline int grid_for(int64_t n) {
 
 }  // namespace
 
-extern "C" int ase_hip_begin_step(double* opt_state, double* acc, int n_acc, void* stream) {
-    ASE_CHECK_ARG((opt_state || acc) && n_acc >= 0, "begin_step: nothing to do");
-    hipLaunchKernelGGL(begin_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, opt_state, acc, acc ? n_acc : 0);
+extern "C" int ase_hip_begin_step(double* opt_state, double* acc, int n_acc, double* zero2, int n_zero2,
+                                  uint64_t* rng_bump, void* stream) {
+    ASE_CHECK_ARG((opt_state || acc || zero2 || rng_bump) && n_acc >= 0 && n_zero2 >= 0, "begin_step: nothing to do");
+    hipLaunchKernelGGL(begin_step_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, opt_state, acc, acc ? n_acc : 0, zero2,
+                       zero2 ? n_zero2 : 0, (unsigned long long*)rng_bump);
     ASE_CHECK_LAUNCH("begin_step");
     return ASE_OK;
 }

@@ -8,47 +8,8 @@ namespace {
 // ---- batch moments: grid (col tiles of 64, row chunks); block 64 x 4 ---------------------------
 constexpr int kRowsPerBlock = 64;
 
-__global__ __launch_bounds__(256) void rms_moments_kernel(const float* __restrict__ src, int64_t ld_src, int D,
-                                                          const int32_t* __restrict__ idx, int remap_h, int remap_n,
-                                                          int M, const double* __restrict__ state,
-                                                          double* __restrict__ sums) {
-    __shared__ double red[2][4][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + tx;
-    const int r0 = blockIdx.y * kRowsPerBlock;
-    const int r1 = min(M, r0 + kRowsPerBlock);
-    double s1 = 0.0, s2 = 0.0;
-    if (j < D) {
-        const float shift = (float)state[j];
-        // 4 independent row loads in flight per thread (the gather makes every row a dependent index -> data chain)
-        for (int r = r0 + ty; r < r1; r += 16) {
-            float x[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int rr = r + 4 * q;
-                x[q] = (rr < r1) ? src[map_row(rr, idx, remap_h, remap_n) * ld_src + j] : shift;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const double d = (double)(x[q] - shift);
-                s1 += d;
-                s2 += d * d;
-            }
-        }
-    }
-    red[0][ty][tx] = s1;
-    red[1][ty][tx] = s2;
-    __syncthreads();
-    if (ty == 0 && j < D) {
-        s1 = red[0][0][tx] + red[0][1][tx] + red[0][2][tx] + red[0][3][tx];
-        s2 = red[1][0][tx] + red[1][1][tx] + red[1][2][tx] + red[1][3][tx];
-        atomic_add_f64(sums + j, s1);
-        atomic_add_f64(sums + D + j, s2);
-    }
-}
-
 // 16-byte variant (D % 4 == 0, 16-byte aligned rows): a thread owns 4 columns; same row partition (rows = ty mod 4, ascending)
-// and the same f64 arithmetic per element as the scalar kernel, so the sums are identical
+// and the same f64 arithmetic per element as the scalar (multi-stream) kernel below, so the sums are identical
 __global__ __launch_bounds__(256) void rms_moments4_kernel(const float* __restrict__ src, int64_t ld_src, int D,
                                                            const int32_t* __restrict__ idx, int remap_h, int remap_n,
                                                            int M, const double* __restrict__ state,
@@ -104,8 +65,82 @@ __global__ __launch_bounds__(256) void rms_moments4_kernel(const float* __restri
     }
 }
 
+// ---- up to 4 streams of the same width in ONE launch (agent / replay / demo AMP observations): grid z = stream.
+// Same row partition and summation order as rms_moments_kernel (identical sums); the 16 row indices of a thread are
+// fetched first and the 16 row loads are then all in flight at once (the gather makes each row a dependent index -> data
+// chain: with 4 in flight the kernel ran at 1.4 TB/s).
+struct RmsStreams {
+    const float* src[4]; int64_t ld[4]; const int32_t* idx[4]; int rh[4], rn[4];
+    double* sums[4];                       // moments
+    const float* mean[4]; const float* stdv[4]; void* out[4]; int64_t ld_out[4];   // normalize
+};
+
+__global__ __launch_bounds__(256) void rms_moments_multi_kernel(RmsStreams S, int D, int M, const double* __restrict__ state) {
+    __shared__ double red[2][4][64];
+    const int s = blockIdx.z;
+    const float* __restrict__ src = S.src[s];
+    const int32_t* __restrict__ idx = S.idx[s];
+    const int64_t ld_src = S.ld[s];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + tx;
+    const int r0 = blockIdx.y * kRowsPerBlock;
+    const int r1 = min(M, r0 + kRowsPerBlock);
+    double s1 = 0.0, s2 = 0.0;
+    if (j < D) {
+        const float shift = (float)state[j];
+        int64_t p[16];
+        float x[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int rr = r0 + ty + 4 * q;
+            p[q] = (rr < r1) ? map_row(rr, idx, S.rh[s], S.rn[s]) : -1;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) x[q] = (p[q] >= 0) ? src[p[q] * ld_src + j] : shift;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const double d = (double)(x[q] - shift);
+            s1 += d;
+            s2 += d * d;
+        }
+    }
+    red[0][ty][tx] = s1;
+    red[1][ty][tx] = s2;
+    __syncthreads();
+    if (ty == 0 && j < D) {
+        s1 = red[0][0][tx] + red[0][1][tx] + red[0][2][tx] + red[0][3][tx];
+        s2 = red[1][0][tx] + red[1][1][tx] + red[1][2][tx] + red[1][3][tx];
+        atomic_add_f64(S.sums[s] + j, s1);
+        atomic_add_f64(S.sums[s] + D + j, s2);
+    }
+}
+
+// normalise up to 4 streams (one output each) in ONE launch: grid (col tiles, rows / 4, stream); 16-byte accesses
+template <typename T>
+__global__ __launch_bounds__(256) void rms_normalize_multi_kernel(RmsStreams S, int D, int M) {
+    const int s = blockIdx.z;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int r = blockIdx.y * 4 + ty;
+    const int j = (blockIdx.x * 64 + tx) * 4;
+    if (r >= M || j >= D) return;
+    const int64_t p = map_row(r, S.idx[s], S.rh[s], S.rn[s]);
+    const f32x4 x = *reinterpret_cast<const f32x4*>(S.src[s] + p * S.ld[s] + j);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(S.mean[s] + j), sd = *reinterpret_cast<const f32x4*>(S.stdv[s] + j);
+    f32x4 y;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) y[c] = fminf(fmaxf((x[c] - mu[c]) / sd[c], -5.f), 5.f);
+    if constexpr (sizeof(T) == 2) {
+        bf16x4 v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = (bf16_t)y[c];
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(S.out[s]) + (int64_t)r * S.ld_out[s] + j) = v;
+    } else {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(S.out[s]) + (int64_t)r * S.ld_out[s] + j) = y;
+    }
+}
+
 // ---- merge into the running state; single block so `count` is read before it is rewritten ------
-__global__ __launch_bounds__(256) void rms_finalize_kernel(double* __restrict__ state, int D,
+__global__ __launch_bounds__(1024) void rms_finalize_kernel(double* __restrict__ state, int D,
                                                            const double* __restrict__ sums, int count,
                                                            int n_streams, float* __restrict__ mean_out,
                                                            float* __restrict__ std_out) {
@@ -220,22 +255,25 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 }
 
 // fields of one minibatch gathered by ONE launch: desc[f] = {src, ld_src, D, dst, ld_dst, dst_dtype} (int64 each)
-__global__ __launch_bounds__(256) void gather_multi_kernel(const int64_t* __restrict__ desc, const int32_t* __restrict__ idx,
-                                                           int remap_h, int remap_n, int M) {
-    const int64_t* d = desc + 6 * blockIdx.y;
-    const float* src = reinterpret_cast<const float*>(d[0]);
-    const int64_t ld_src = d[1];
-    const int D = (int)d[2];
-    const int64_t ld_dst = d[4];
-    const int dt = (int)d[5];
-    // flat (row, element) index: consecutive threads take consecutive elements of a row, or consecutive rows when D = 1
-    const int64_t total = (int64_t)M * D;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int r = (int)(i / D), j = (int)(i - (int64_t)r * D);
-        const int64_t p = map_row(r, idx, remap_h, remap_n);
-        const float v = src[p * ld_src + j];
-        if (dt == ASE_BF16) reinterpret_cast<bf16_t*>(d[3])[(int64_t)r * ld_dst + j] = (bf16_t)v;
-        else reinterpret_cast<float*>(d[3])[(int64_t)r * ld_dst + j] = v;
+// One wave per minibatch row, ALL fields of that row: the row index is mapped once and the (up to ~12) field loads of a
+// lane are independent, so they are all in flight together (the per-field grid ran at 0.7 TB/s: two dependent
+// index -> element round trips per thread and an integer division per element).
+__global__ __launch_bounds__(256) void gather_multi_kernel(const int64_t* __restrict__ desc, int n_fields,
+                                                           const int32_t* __restrict__ idx, int remap_h, int remap_n, int M) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;
+    const int64_t p = map_row(r, idx, remap_h, remap_n);
+    for (int f = 0; f < n_fields; ++f) {
+        const int64_t* d = desc + 6 * f;
+        const float* src = reinterpret_cast<const float*>(d[0]);
+        const int64_t ld_src = d[1], ld_dst = d[4];
+        const int D = (int)d[2], dt = (int)d[5];
+        for (int j = lane; j < D; j += 64) {
+            const float v = src[p * ld_src + j];
+            if (dt == ASE_BF16) reinterpret_cast<bf16_t*>(d[3])[(int64_t)r * ld_dst + j] = (bf16_t)v;
+            else reinterpret_cast<float*>(d[3])[(int64_t)r * ld_dst + j] = v;
+        }
     }
 }
 
@@ -244,8 +282,8 @@ __global__ __launch_bounds__(256) void gather_multi_kernel(const int64_t* __rest
 extern "C" int ase_hip_gather_multi(const int64_t* desc, int n_fields, const int32_t* idx, int remap_h, int remap_n,
                                     int M, void* stream) {
     ASE_CHECK_ARG(desc && n_fields > 0 && M > 0, "gather_multi: null/empty operand");
-    const dim3 grid(min((M + 7) / 8, 1024), n_fields);       // <= 4 dependent (index -> row) loads per thread at M = 16384
-    hipLaunchKernelGGL(gather_multi_kernel, grid, dim3(256), 0, (hipStream_t)stream, desc, idx, remap_h, remap_n, M);
+    hipLaunchKernelGGL(gather_multi_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, desc, n_fields, idx, remap_h,
+                       remap_n, M);
     ASE_CHECK_LAUNCH("gather_multi");
     return ASE_OK;
 }
@@ -260,11 +298,52 @@ extern "C" int ase_hip_rms_moments(const float* src, int64_t ld_src, int D, cons
         hipLaunchKernelGGL(rms_moments4_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, D, idx, remap_h,
                            remap_n, M, state, sums);
     } else {
-        const dim3 grid((D + 63) / 64, (M + kRowsPerBlock - 1) / kRowsPerBlock);
-        hipLaunchKernelGGL(rms_moments_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, D, idx, remap_h,
-                           remap_n, M, state, sums);
+        RmsStreams S = {};
+        S.src[0] = src; S.ld[0] = ld_src; S.idx[0] = idx; S.rh[0] = remap_h; S.rn[0] = remap_n; S.sums[0] = sums;
+        const dim3 grid((D + 63) / 64, (M + kRowsPerBlock - 1) / kRowsPerBlock, 1);
+        hipLaunchKernelGGL(rms_moments_multi_kernel, grid, dim3(256), 0, (hipStream_t)stream, S, D, M, state);
     }
     ASE_CHECK_LAUNCH("rms_moments");
+    return ASE_OK;
+}
+
+extern "C" int ase_hip_rms_moments_multi(const float* const* srcs, const int64_t* ld_srcs, const int32_t* const* idxs,
+                                         const int* remap_h, const int* remap_n, double* const* sums, int n_streams, int D,
+                                         int M, const double* state, void* stream) {
+    ASE_CHECK_ARG(srcs && ld_srcs && idxs && remap_h && remap_n && sums && state && n_streams >= 1 && n_streams <= 4 && D > 0 && M > 0,
+                  "rms_moments_multi: null/empty operand (1..4 streams)");
+    RmsStreams S = {};
+    for (int s = 0; s < n_streams; ++s) {
+        ASE_CHECK_ARG(srcs[s] && sums[s], "rms_moments_multi: stream %d: null operand", s);
+        S.src[s] = srcs[s]; S.ld[s] = ld_srcs[s]; S.idx[s] = idxs[s]; S.rh[s] = remap_h[s]; S.rn[s] = remap_n[s]; S.sums[s] = sums[s];
+    }
+    const dim3 grid((D + 63) / 64, (M + kRowsPerBlock - 1) / kRowsPerBlock, n_streams);
+    hipLaunchKernelGGL(rms_moments_multi_kernel, grid, dim3(256), 0, (hipStream_t)stream, S, D, M, state);
+    ASE_CHECK_LAUNCH("rms_moments_multi");
+    return ASE_OK;
+}
+
+extern "C" int ase_hip_rms_normalize_multi(const float* const* srcs, const int64_t* ld_srcs, const int32_t* const* idxs,
+                                           const int* remap_h, const int* remap_n, const float* const* means,
+                                           const float* const* stds, void* const* outs, const int64_t* ld_outs, int n_streams,
+                                           int D, int M, int dtype, void* stream) {
+    ASE_CHECK_ARG(srcs && ld_srcs && idxs && remap_h && remap_n && means && stds && outs && ld_outs && n_streams >= 1 &&
+                      n_streams <= 4 && D > 0 && M > 0, "rms_normalize_multi: null/empty operand (1..4 streams)");
+    ASE_CHECK_ARG(dtype == ASE_BF16 || dtype == ASE_F32, "rms_normalize_multi: bad dtype %d", dtype);
+    const int es = dtype == ASE_BF16 ? 2 : 4;
+    RmsStreams S = {};
+    for (int s = 0; s < n_streams; ++s) {
+        ASE_CHECK_ARG(srcs[s] && means[s] && stds[s] && outs[s], "rms_normalize_multi: stream %d: null operand", s);
+        ASE_CHECK_ARG(D % 4 == 0 && ld_srcs[s] % 4 == 0 && ((uintptr_t)srcs[s] % 16) == 0 && ((uintptr_t)means[s] % 16) == 0 &&
+                          ((uintptr_t)stds[s] % 16) == 0 && ld_outs[s] % 4 == 0 && ((uintptr_t)outs[s] % (4 * es)) == 0,
+                      "rms_normalize_multi: stream %d needs 16-byte rows (D %% 4 == 0, aligned pointers / pitches)", s);
+        S.src[s] = srcs[s]; S.ld[s] = ld_srcs[s]; S.idx[s] = idxs[s]; S.rh[s] = remap_h[s]; S.rn[s] = remap_n[s];
+        S.mean[s] = means[s]; S.stdv[s] = stds[s]; S.out[s] = outs[s]; S.ld_out[s] = ld_outs[s];
+    }
+    const dim3 grid((D / 4 + 63) / 64, (M + 3) / 4, n_streams);
+    if (dtype == ASE_BF16) hipLaunchKernelGGL(rms_normalize_multi_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, S, D, M);
+    else hipLaunchKernelGGL(rms_normalize_multi_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, S, D, M);
+    ASE_CHECK_LAUNCH("rms_normalize_multi");
     return ASE_OK;
 }
 
@@ -280,7 +359,8 @@ extern "C" int ase_hip_rms_finalize(double* state, int D, const double* sums, co
             ASE_CHECK_ARG(counts[s] == count, "rms_finalize: all streams of one call must have the same row count");
         ASE_CHECK_ARG(count > 1, "rms_finalize: need at least 2 rows for an unbiased variance");
     }
-    hipLaunchKernelGGL(rms_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, state, D, sums, count,
+    // one workgroup (the count is read before it is rewritten); 1024 threads: the 1400 AMP columns take 2 passes, not 6
+    hipLaunchKernelGGL(rms_finalize_kernel, dim3(1), dim3(D > 256 ? 1024 : 256), 0, (hipStream_t)stream, state, D, sums, count,
                        n_streams, mean_out, std_out);
     ASE_CHECK_LAUNCH("rms_finalize");
     return ASE_OK;

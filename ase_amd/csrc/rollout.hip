@@ -294,11 +294,12 @@ extern "C" int ase_hip_sample_actions(const float* mu, int64_t ld_mu, const floa
     return ASE_OK;
 }
 
-extern "C" int ase_hip_sample_latents(float* z, int rows, int dim, uint64_t* rng_state, int64_t row_offset, void* stream) {
+extern "C" int ase_hip_sample_latents(float* z, int rows, int dim, uint64_t* rng_state, int64_t row_offset, int advance,
+                                      void* stream) {
     ASE_CHECK_ARG(z && rng_state && rows > 0 && dim >= 1 && dim <= 128 && row_offset >= 0, "sample_latents: bad operand");
     hipLaunchKernelGGL(sample_latents_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, z, rows, dim,
                        rng_state, row_offset);
-    hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng_state);
+    if (advance) hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng_state);
     ASE_CHECK_LAUNCH("sample_latents");
     return ASE_OK;
 }

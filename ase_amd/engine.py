@@ -96,7 +96,9 @@ class UpdateEngine:
         self.multi_stream = bool(cfg.get('multi_stream', True)) and getattr(backend, 'name', '') == 'hip'
         self._side_streams = None
         self._tn_defer = bool(getattr(backend, 'grouped_tn_ok', None)) and os.environ.get('ASE_TN_GROUPED', '1') != '0'
-        self._tn_queue, self._tn_plans = [], {}
+        self._tn_queue, self._tn_plans = [], {}          # weight gradients queued by the CURRENT branch (see _flush_tn)
+        self._tn_wg_side = int(os.environ.get('ASE_TN_WG_SIDE', '128'))
+        self._apply_groups = None
         self._use_bits = os.environ.get('ASE_RELU_BITS', '1') != '0'
         self._fused_apply = hasattr(backend, 'apply_multi') and os.environ.get('ASE_FUSED_APPLY', '1') != '0'
         self._apply_desc = self._apply_items = None
@@ -342,6 +344,19 @@ class UpdateEngine:
         assert n_cov == self.n_train, (n_cov, self.n_train)     # every trainable scalar belongs to exactly one layer part
         self._apply_desc = torch.tensor(rows, dtype=torch.int64, device=self.dev)
         self._apply_items = items
+        # parameter buckets of the two branch groups: rows of the table + the range of the flat buffers they cover
+        # (checkpoint order: actor, critic, value, mu | discriminator, logits, encoder - each group is contiguous)
+        n_pol = sum(len(d.parts) for d in self.style + self.actor + [self.mu_head] + self.critic + [self.value_head])
+
+        def span(its):
+            lo = min(min((it[0].data_ptr() - base) // 4, (it[5].data_ptr() - base) // 4) for it in its)
+            hi = max(max((it[0].data_ptr() - base) // 4 + it[0].numel(), (it[5].data_ptr() - base) // 4 + it[5].numel())
+                     for it in its)
+            assert hi - lo == sum(it[0].numel() + it[5].numel() for it in its), "a parameter bucket must be contiguous"
+            return lo, hi
+        self._apply_groups = {'policy': (0, n_pol) + span(items[:n_pol])}
+        if len(items) > n_pol:
+            self._apply_groups['disc'] = (n_pol, len(items)) + span(items[n_pol:])
 
     # ------------------------------------------------------------------ primitive layer ops
     def _fwd(self, d, X, Y, rows, act=None):
@@ -401,15 +416,17 @@ class UpdateEngine:
             self.be.gemm_tn(A, B, G, M, N, K, n_real, k_real, split_src, split_dst, alpha=alpha, gbias=gbias,
                             bias_rows=bias_rows)
 
-    def _flush_tn(self):
+    def _flush_tn(self, target_wg=0):
+        """ONE grouped launch for the weight gradients queued since the last flush (a branch of the step, or the whole step).
+        target_wg: workgroups the planner sizes the work items for (0 = one per CU)."""
         q, self._tn_queue = self._tn_queue, []
         if not q:
             return
-        key = tuple((a.data_ptr(), b.data_ptr(), g.data_ptr(), 0 if gb is None else gb.data_ptr(), br, M, N, K, al)
-                    for (a, b, g, gb, br, M, N, K, nr, kr, ss, sd, al) in q)
+        key = (target_wg,) + tuple((a.data_ptr(), b.data_ptr(), g.data_ptr(), 0 if gb is None else gb.data_ptr(), br, M, N, K, al)
+                                   for (a, b, g, gb, br, M, N, K, nr, kr, ss, sd, al) in q)
         plan = self._tn_plans.get(key)
         if plan is None:
-            plan = self._tn_plans[key] = self.be.make_tn_plan(q)
+            plan = self._tn_plans[key] = self.be.make_tn_plan(q, target_wg)
         self.be.gemm_tn_grouped(plan)
 
     def _bwd_chain(self, chain, X0, H, dZ, rows):
@@ -423,7 +440,8 @@ class UpdateEngine:
 
     # ------------------------------------------------------------------ one optimisation step
     def gather_minibatch(self, ds, idx, remap):
-        """All small per-row fields of the minibatch (learning/amp_datasets.py:21-22) in one launch."""
+        """All small per-row fields of the minibatch (learning/amp_datasets.py:21-22) in one launch - including the two
+        compute-dtype copies of the latents the first actor / critic layers read ([obs | z] without a concat)."""
         key = tuple(ds[k].data_ptr() for k in self.mb)
         if self._mb_desc_key != key:
             rows, items = [], []
@@ -431,6 +449,12 @@ class UpdateEngine:
                 src = ds[k].view(ds[k].shape[0], -1)
                 rows.append([src.data_ptr(), src.stride(0), src.shape[1], dst.data_ptr(), dst.stride(0), L.F32])
                 items.append((src, src.shape[1], dst))
+            if self.z:
+                src = ds['ase_latents'].view(ds['ase_latents'].shape[0], -1)
+                code = L.BF16 if self.dtype == torch.bfloat16 else L.F32
+                for dst in (self.Zs[:self.M], self.Xc[:, self.actor[0].split_dst:]):
+                    rows.append([src.data_ptr(), src.stride(0), self.z, dst.data_ptr(), dst.stride(0), code])
+                    items.append((src, self.z, dst))
             self._mb_desc = torch.tensor(rows, dtype=torch.int64, device=self.dev)
             self._mb_items = items
             self._mb_desc_key = key
@@ -460,22 +484,28 @@ class UpdateEngine:
         """ds: dataset dict of physical-order device tensors; idx int32 [M] (this rank's rows);
         amp_streams: [(src, idx, remap)] x3 for agent / replay / demo (AMB rows each);
         new_z: optional injected diversity latents f32 [M, z] (else drawn on device).
-        Three phases separated by the only two exchange points of the data-parallel update
-        (normaliser moments + mask sum; gradients) — each phase is hipGraph-capturable on its own."""
+        Phases separated by the exchange points of the data-parallel update (normaliser moments + mask sum; gradients).
+        With apply (and the fused optimizer launch) every branch finishes by itself - weight gradients, gradient exchange of
+        its bucket, optimizer step of its parameters - so the discriminator's tail overlaps the policy's backward."""
         self.phase_stats(ds, idx, remap, amp_streams, advance=apply)
         self._allreduce_stats()
-        self.phase_main(ds, idx, remap, amp_streams, new_z)
-        self._allreduce_grads()
-        self.phase_apply(apply)
+        inline = apply and self._fused_apply
+        self.phase_main(ds, idx, remap, amp_streams, new_z, inline_apply=inline)
+        if inline:
+            self.phase_finish()
+        else:
+            self._allreduce_grads()
+            self.phase_apply(apply)
         return self.res
 
     # ---- phase A: local partial statistics -------------------------------------------------------
     def phase_stats(self, ds, idx, remap, amp_streams=None, advance=True):
         be, c, M, AMB = self.be, self.cfg, self.M, self.AMB
-        # advance=False (calc_gradients-style calls, apply=False): the Adam step counter / bias corrections stay put
-        be.begin_step(self.opt_state if advance else None, self.acc)
+        # one launch: Adam step counter / bias corrections (advance=False - calc_gradients-style calls - leaves them),
+        # loss accumulators and per-step partial statistics zeroed, position of the diversity-latent stream advanced
+        be.begin_step(self.opt_state if advance else None, self.acc, zero2=self.stats_flat,
+                      rng_bump=self.rng_state if self.div_on else None)
         be.zero_(self.grads[:self.n_train])
-        be.zero_(self.obs_sums)
         self.gather_minibatch(ds, idx, remap)
         if self.masked:
             be.reduce_sum(self.mb['rand_action_mask'], M, False, self.acc, L.ACC_MASK_SUM)
@@ -490,11 +520,8 @@ class UpdateEngine:
         return self.multi_stream and not self._dist_on()
 
     def _amp_moments(self, amp_streams):
-        be, c = self.be, self.cfg
-        be.zero_(self.amp_sums)
-        if c.get('normalize_amp_input', True):
-            for s, (src, sidx, srm) in enumerate(amp_streams):
-                be.rms_moments(src, self.amp, sidx, srm, self.AMB, self.amp_state, self.amp_sums[s])
+        if self.cfg.get('normalize_amp_input', True):       # (the partial sums were zeroed by begin_step)
+            self.be.rms_moments_multi(amp_streams, self.amp, self.AMB, self.amp_state, [self.amp_sums[s] for s in range(3)])
 
     # ---- fork / join of the independent actor / critic / discriminator branches -------------------
     def _side(self, k):
@@ -508,12 +535,18 @@ class UpdateEngine:
         return self._side_streams[k % len(self._side_streams)]
 
     class _Branch:
-        def __init__(self, stream):
-            self.stream = stream
+        """Run a block of launches on a side stream: it starts after `after` (an event on the main stream; default: everything
+        the main stream holds so far) and leaves `done` for whoever needs its results."""
+
+        def __init__(self, stream, after=None):
+            self.stream, self.after = stream, after
 
         def __enter__(self):
             if self.stream is not None:
-                self.stream.wait_stream(torch.cuda.current_stream())
+                if self.after is not None:
+                    self.stream.wait_event(self.after)
+                else:
+                    self.stream.wait_stream(torch.cuda.current_stream())
                 self.ctx = torch.cuda.stream(self.stream)
                 self.ctx.__enter__()
             return self
@@ -521,117 +554,134 @@ class UpdateEngine:
         def __exit__(self, *a):
             if self.stream is not None:
                 self.done = torch.cuda.Event()
-                self.done.record(self.stream)          # what the main stream waits for when only THIS branch is needed
+                self.done.record(self.stream)
                 self.ctx.__exit__(*a)
 
     def _join_branch(self, br):
         if br.stream is not None:
             torch.cuda.current_stream().wait_event(br.done)
 
-    def _join(self, k):
-        st = self._side(k)
-        if st is not None:
-            torch.cuda.current_stream().wait_stream(st)
+    def _mark(self):
+        """Event at the current position of the main stream (fork point of later branches), None without streams."""
+        if not self.multi_stream:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        return ev
+
+    def _finish_branch(self, group, inline_apply, last=False):
+        """Tail of a branch: its weight gradients as one grouped launch, then (inline_apply) the exchange of its gradient
+        bucket and the optimizer step of its parameters.  Side branches size their grouped launch for part of the chip
+        (they run beside other branches' kernels; every work item pays 256 KB of atomics, so fewer, longer items)."""
+        self._flush_tn(0 if last else self._tn_wg_side)
+        if inline_apply:
+            a, b, lo, hi = self._apply_groups[group]
+            if self._dist_on():
+                self._ar(self.grads[lo:hi])
+                if not self.shard:
+                    self.grads[lo:hi].mul_(1.0 / self.R)
+            self.be.apply_multi(self._apply_desc[a:b], self._apply_items[a:b], self.dtype, self.opt_state, self.acc)
 
     # ---- phase B: normalise, forward, loss heads, backward -----------------------------------------
-    def phase_main(self, ds, idx, remap, amp_streams=None, new_z=None):
+    def phase_main(self, ds, idx, remap, amp_streams=None, new_z=None, inline_apply=False):
         be, c, M, AMB = self.be, self.cfg, self.M, self.AMB
         norm_in = c.get('normalize_input', True)
         norm_amp = self.has_disc and c.get('normalize_amp_input', True)
         Ra = self.Ra
+        if inline_apply:
+            self._build_apply_desc()
+        fork0 = self._mark()                 # the discriminator branch needs nothing of the observation prologue
         if norm_in:
-            be.rms_finalize(self.obs_state, self.obs, self.obs_sums, self.Mg, 1, self.obs_mean, self.obs_std)
+            be.rms_finalize(self.obs_state, self.obs, self.obs_sums, self.Mg if self.shard else self.M, 1, self.obs_mean,
+                            self.obs_std)
         else:
             self._identity_stats(self.obs_mean, self.obs_std)
         outs = [self.Xa[:M], self.Xc]
         if self.div_on:
             outs.append(self.Xa[M:])
         be.rms_normalize(ds['obs'], self.obs, idx, remap, M, self.obs_mean[0], self.obs_std[0], outs)
-        if self.z:
-            zsrc = self.mb['ase_latents']
-            sd = self.actor[0].split_dst
-            be.gather_rows(zsrc, self.z, None, (0, 0), M, self.Zs[:M])
-            be.gather_rows(zsrc, self.z, None, (0, 0), M, self.Xc[:, sd:])
-            if self.div_on:
-                if new_z is not None:
-                    self.new_z.copy_(new_z)
-                else:
-                    # element index = GLOBAL minibatch row: rank r of a sharded step draws rows [r M, (r + 1) M)
-                    be.sample_latents(self.new_z, M, self.z, self.rng_state,
-                                      row_offset=self.rank * M if (self.shard and self.R > 1) else 0)
-                be.gather_rows(self.new_z, self.z, None, (0, 0), M, self.Zs[M:])
+        fork1 = self._mark()                 # critic: observations normalised, latents in place (gather_minibatch)
+        if self.div_on:
+            if new_z is not None:
+                self.new_z.copy_(new_z)
+            else:
+                # element index = GLOBAL minibatch row: rank r of a sharded step draws rows [r M, (r + 1) M)
+                be.sample_latents(self.new_z, M, self.z, self.rng_state,
+                                  row_offset=self.rank * M if (self.shard and self.R > 1) else 0, advance=False)
+            be.gather_rows(self.new_z, self.z, None, (0, 0), M, self.Zs[M:])
 
-        # -- discriminator (+ encoder) branch: normalise, forward, heads, backward, gradient penalty
-        def disc_branch():
-            with self._Branch(self._side(1) if self.has_disc else None):
-                if self.has_disc:
-                    if self._amp_stats_in_branch():
-                        self._amp_moments(amp_streams)
-                    if norm_amp:
-                        be.rms_finalize(self.amp_state, self.amp, self.amp_sums, self.AMBg, 3, self.amp_mean, self.amp_std)
-                    else:
-                        self._identity_stats(self.amp_mean, self.amp_std)
-                    for s, (src, sidx, srm) in enumerate(amp_streams):
-                        be.rms_normalize(src, self.amp, sidx, srm, AMB, self.amp_mean[s], self.amp_std[s],
-                                         [self.Xd[s * AMB:(s + 1) * AMB]])
-                    Rd = 3 * AMB
-                    hd = self._fwd_chain(self.disc, self.Xd, self.Hd, Rd)
-                    self._fwd(self.disc_head, hd, self.HD, Rd)
-                    if self.enc_chain:
-                        he = self._fwd_chain(self.enc_chain, self.Xd[:AMB], self.He, AMB)
-                        self._fwd(self.enc_head, he, self.E, AMB)
-                    be.disc_head(self.HD, self.dHD, self.disc_head.gb[0], self.acc, AMB, self.AMBg, c['disc_coef'])
-                    if self.has_enc:
-                        src, sidx, srm = amp_streams[0]   # enc_latents = ase_latents[0:amp_minibatch] (learning/ase_agent.py:247)
-                        zsrc = ds['ase_latents'].view(ds['ase_latents'].shape[0], -1)
-                        be.gather_rows(zsrc, self.z, sidx, srm, AMB, self.enc_z)
-                        if self.enc_sep:
-                            be.enc_head(self.E, self.enc_z, self.dE, self.enc_head.gb[0], None, self.acc, AMB, self.AMBg,
-                                        self.z, c['enc_coef'])
-                        else:
-                            off = self.disc_head.parts[1][2]
-                            be.enc_head(self.HD[:AMB, off:], self.enc_z, self.dHD[:AMB, off:], self.disc_head.gb[1], None,
-                                        self.acc, AMB, self.AMBg, self.z, c['enc_coef'])
-                    self._wgrad(self.disc_head, self.dHD, hd, Rd)
-                    last = self.disc[-1]
-                    self._dgrad(self.disc_head, self.dHD, self.dZd[-1], Rd, self.Hd[-1], last.act)
-                    self._disc_backward()
-                    if self.enc_chain:
-                        self._wgrad(self.enc_head, self.dE, he, AMB)
-                        last = self.enc_chain[-1]
-                        self._dgrad(self.enc_head, self.dE, self.dZe[-1], AMB, self.He[-1], last.act)
-                        self._bwd_chain(self.enc_chain, self.Xd[:AMB], self.He, self.dZe, AMB)
-
-        # -- critic forward (side stream 0) next to the actor forward (main stream).  With ONE side stream
-        # (ASE_SIDE_STREAMS=1) its order is critic forward -> discriminator branch -> critic backward: two balanced lanes.
-        one_lane = self.multi_stream and self._side(0) is self._side(1)
-        if not one_lane:
-            disc_branch()
-        with self._Branch(self._side(0)) as br_critic:
-            hc = self._fwd_chain(self.critic, self.Xc, self.Hc, M)
-            self._fwd(self.value_head, hc, self.V, M)
-        if one_lane:
-            disc_branch()
+        # The actor chain (2 M rows with the diversity pass) is the longest: it is launched FIRST on the main stream, the
+        # critic and the discriminator branches follow on their streams, forked from the events above.
         if self.style:
             sd = self.actor[0].split_dst
             h = self._fwd_chain(self.style[:-1], self.Zs, self.Hs, Ra)
             self._fwd(self.style[-1], h, self.Xa[:, sd:], Ra)
         ha = self._fwd_chain(self.actor, self.Xa, self.Ha, Ra)
         self._fwd(self.mu_head, ha, self.MU, Ra)
+
+        with self._Branch(self._side(0), fork1) as br_critic:
+            hc = self._fwd_chain(self.critic, self.Xc, self.Hc, M)
+            self._fwd(self.value_head, hc, self.V, M)
+
+        # -- discriminator (+ encoder) branch: normalise, forward, heads, backward, gradient penalty, its optimizer step
+        br_disc = None
+        if self.has_disc:
+            tnq, self._tn_queue = self._tn_queue, []          # the branch queues (and flushes) its own weight gradients
+            with self._Branch(self._side(1), fork0) as br_disc:
+                if self._amp_stats_in_branch():
+                    self._amp_moments(amp_streams)
+                if norm_amp:
+                    be.rms_finalize(self.amp_state, self.amp, self.amp_sums, self.AMBg if self.shard else self.AMB, 3,
+                                    self.amp_mean, self.amp_std)
+                else:
+                    self._identity_stats(self.amp_mean, self.amp_std)
+                xd = [self.Xd[s * AMB:(s + 1) * AMB] for s in range(3)]
+                if self.amp % 4 == 0 and all(src.stride(0) % 4 == 0 for src, _, _ in amp_streams):
+                    be.rms_normalize_multi(amp_streams, self.amp, AMB, [self.amp_mean[s] for s in range(3)],
+                                           [self.amp_std[s] for s in range(3)], xd)
+                else:                          # rows that are not whole 16-byte chunks: one launch per stream
+                    for s, (src, sidx, srm) in enumerate(amp_streams):
+                        be.rms_normalize(src, self.amp, sidx, srm, AMB, self.amp_mean[s], self.amp_std[s], [xd[s]])
+                Rd = 3 * AMB
+                hd = self._fwd_chain(self.disc, self.Xd, self.Hd, Rd)
+                self._fwd(self.disc_head, hd, self.HD, Rd)
+                if self.enc_chain:
+                    he = self._fwd_chain(self.enc_chain, self.Xd[:AMB], self.He, AMB)
+                    self._fwd(self.enc_head, he, self.E, AMB)
+                amb_den = self.AMBg if self.shard else self.AMB
+                be.disc_head(self.HD, self.dHD, self.disc_head.gb[0], self.acc, AMB, amb_den, c['disc_coef'])
+                if self.has_enc:
+                    src, sidx, srm = amp_streams[0]   # enc_latents = ase_latents[0:amp_minibatch] (learning/ase_agent.py:247)
+                    zsrc = ds['ase_latents'].view(ds['ase_latents'].shape[0], -1)
+                    be.gather_rows(zsrc, self.z, sidx, srm, AMB, self.enc_z)
+                    if self.enc_sep:
+                        be.enc_head(self.E, self.enc_z, self.dE, self.enc_head.gb[0], None, self.acc, AMB, amb_den,
+                                    self.z, c['enc_coef'])
+                    else:
+                        off = self.disc_head.parts[1][2]
+                        be.enc_head(self.HD[:AMB, off:], self.enc_z, self.dHD[:AMB, off:], self.disc_head.gb[1], None,
+                                    self.acc, AMB, amb_den, self.z, c['enc_coef'])
+                self._wgrad(self.disc_head, self.dHD, hd, Rd)
+                last = self.disc[-1]
+                self._dgrad(self.disc_head, self.dHD, self.dZd[-1], Rd, self.Hd[-1], last.act)
+                self._disc_backward()
+                if self.enc_chain:
+                    self._wgrad(self.enc_head, self.dE, he, AMB)
+                    last = self.enc_chain[-1]
+                    self._dgrad(self.enc_head, self.dE, self.dZe[-1], AMB, self.He[-1], last.act)
+                    self._bwd_chain(self.enc_chain, self.Xd[:AMB], self.He, self.dZe, AMB)
+                self._finish_branch('disc', inline_apply)
+            self._tn_queue = tnq
         self._join_branch(br_critic)
 
         # -- PPO loss head (value + gradient w.r.t. mu / value + head bias gradients)
         be.ppo_head(self.MU, self.V, self.mb, self.new_z if self.div_on else None, self.logstd, self.dMU, self.dV,
-                    self.mu_head.gb[0], self.value_head.gb[0], self.acc, M, self.Mg, self.act, self.z, self.masked,
-                    self.div_on, self.mu_tanh, c['clip_value'], c['e_clip'], c['critic_coef'],
+                    self.mu_head.gb[0], self.value_head.gb[0], self.acc, M, self.Mg if self.shard else self.M, self.act, self.z,
+                    self.masked, self.div_on, self.mu_tanh, c['clip_value'], c['e_clip'], c['critic_coef'],
                     self.bounds_coef, c.get('amp_diversity_bonus', 0.0), c.get('amp_diversity_tar', 0.0))
+        fork2 = self._mark()
 
-        # -- critic backward (side stream 0) next to the actor (+ style) backward
-        with self._Branch(self._side(0)):
-            self._wgrad(self.value_head, self.dV, hc, M)
-            last = self.critic[-1]
-            self._dgrad(self.value_head, self.dV, self.dZc[-1], M, self.Hc[-1], last.act)
-            self._bwd_chain(self.critic, self.Xc, self.Hc, self.dZc, M)
+        # -- actor (+ style) backward on the main stream, critic backward beside it
         self._wgrad(self.mu_head, self.dMU, ha, Ra)
         last = self.actor[-1]
         self._dgrad(self.mu_head, self.dMU, self.dZa[-1], Ra, self.Ha[-1], last.act)
@@ -646,12 +696,30 @@ class UpdateEngine:
                 p = self.style[-2]
                 self._dgrad(sdn, self.dStyle, self.dZs[-1], Ra, self.Hs[-1], p.act)
                 self._bwd_chain(self.style[:-1], self.Zs, self.Hs, self.dZs, Ra)
-        self._join(0)
-        if self.has_disc:
-            self._join(1)
-        self._flush_tn()
+        tn_actor, self._tn_queue = self._tn_queue, []
+        with self._Branch(self._side(0), fork2) as br_cb:
+            self._wgrad(self.value_head, self.dV, hc, M)
+            last = self.critic[-1]
+            self._dgrad(self.value_head, self.dV, self.dZc[-1], M, self.Hc[-1], last.act)
+            self._bwd_chain(self.critic, self.Xc, self.Hc, self.dZc, M)
+            tn_critic, self._tn_queue = self._tn_queue, []
+        self._join_branch(br_cb)
+        # the policy's weight gradients (actor + critic: one parameter bucket) as the last grouped launch of the step
+        self._tn_queue = tn_actor + tn_critic
+        self._finish_branch('policy', inline_apply, last=True)
+        if br_disc is not None:
+            self._join_branch(br_disc)
 
-    # ---- phase C: weight-only loss terms, optimizer, shadows, reported scalars --------------------
+    def phase_finish(self):
+        """After the inline per-branch optimizer steps: loss partial sums over the ranks (weight-norm slots are local),
+        reported scalars."""
+        c = self.cfg
+        if self._dist_on() and self.shard:
+            self._ar(self.acc[1:L.ACC_LOGIT_W2])
+        self.be.finalize_scalars(self.acc, self.res, self.Mg if self.shard else self.M, self.AMBg if self.shard else self.AMB,
+                                 self.masked, self.has_disc, self.has_enc, self.div_on, c)
+
+    # ---- phase C (end-of-step form): weight-only loss terms, optimizer, shadows, reported scalars ------
     def phase_apply(self, apply=True):
         be, c = self.be, self.cfg
         if apply and self._fused_apply:
@@ -678,8 +746,8 @@ class UpdateEngine:
                 be.adam(self.params[:self.n_train], self.grads[:self.n_train], self.adam_m[:self.n_train],
                         self.adam_v[:self.n_train], self.opt_state)
                 self.refresh_shadows()
-        be.finalize_scalars(self.acc, self.res, self.Mg, self.AMBg, self.masked, self.has_disc, self.has_enc,
-                            self.div_on, c)
+        be.finalize_scalars(self.acc, self.res, self.Mg if self.shard else self.M, self.AMBg if self.shard else self.AMB,
+                            self.masked, self.has_disc, self.has_enc, self.div_on, c)
 
     def _disc_backward(self):
         """Discriminator trunk backward with the gradient penalty riding on the same launches.

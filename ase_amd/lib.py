@@ -45,7 +45,7 @@ SIGNATURES = {
     "ase_hip_gp_seed": [_p, _i64, _p, _p, _i64, _i, _i, _f, _i, _p],
     "ase_hip_sqnorm": [_p, _i64, _i, _i, _p, _i, _d, _i, _p],
     "ase_hip_finalize_scalars": [_p, _p, _i, _i, _i, _i, _i, _i] + [_f] * 10 + [_p],
-    "ase_hip_begin_step": [_p, _p, _i, _p],
+    "ase_hip_begin_step": [_p, _p, _i, _p, _i, _p, _p],
     "ase_hip_adam": [_p, _p, _p, _p, _i64, _p, _p],
     "ase_hip_axpy": [_p, _p, _i64, _f, _p],
     "ase_hip_disc_reward": [_p, _i64, _p, _i64, _f, _p],
@@ -53,7 +53,9 @@ SIGNATURES = {
     "ase_hip_gae": [_p, _p, _p, _p, _p, _p, _f, _f, _f, _d, _d, _p, _p, _i, _i, _p],
     "ase_hip_adv_norm": [_p, _p, _p, _p, _p, _i64, _i, _i, _p],
     "ase_hip_ring_store": [_p, _i64, _i, _p, _i, _i, _i, _p, _i64, _i64, _p],
-    "ase_hip_sample_latents": [_p, _i, _i, _p, _i64, _p],
+    "ase_hip_sample_latents": [_p, _i, _i, _p, _i64, _i, _p],
+    "ase_hip_rms_moments_multi": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p],
+    "ase_hip_rms_normalize_multi": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "ase_hip_normalize_rows": [_p, _i64, _p, _i64, _i, _i, _p],
     "ase_hip_sample_actions": [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "ase_hip_debug_nt_profile": [_p],

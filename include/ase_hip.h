@@ -124,6 +124,16 @@ int ase_hip_refresh_shadow_multi(const int64_t* desc, int n_layers, int dtype, v
 int ase_hip_rms_moments(const float* src, int64_t ld_src, int D, const int32_t* idx, int remap_h,
                         int remap_n, int M, const double* state, double* sums, void* stream);
 
+/* The same for up to 4 streams of equal width D and row count M in ONE launch (agent / replay / demo AMP observations,
+ * learning/amp_agent.py:280-289): HOST arrays of per-stream sources, index maps and partial-sum buffers. */
+int ase_hip_rms_moments_multi(const float* const* srcs, const int64_t* ld_srcs, const int32_t* const* idxs,
+                              const int* remap_h, const int* remap_n, double* const* sums, int n_streams, int D, int M,
+                              const double* state, void* stream);
+int ase_hip_rms_normalize_multi(const float* const* srcs, const int64_t* ld_srcs, const int32_t* const* idxs,
+                                const int* remap_h, const int* remap_n, const float* const* means,
+                                const float* const* stds, void* const* outs, const int64_t* ld_outs, int n_streams, int D,
+                                int M, int dtype, void* stream);
+
 /* Sequentially merge n_streams batches (sums[s][2*D], counts[s] rows each; counts are the GLOBAL
  * row counts) into `state` exactly as RunningMeanStd.forward does in training mode, and after
  * each merge emit mean_f32[s][D] and std_f32[s][D] = sqrt(f32(var)+1e-5).  n_streams == 0 emits
@@ -242,7 +252,10 @@ int ase_hip_finalize_scalars(const double* acc, float* out, int m_global, int am
  * advanced and the bias corrections recomputed on device by ase_hip_begin_step (graph-replay safe),
  * which also zeroes the n_acc accumulators.
  * ------------------------------------------------------------------------------------------- */
-int ase_hip_begin_step(double* opt_state, double* acc, int n_acc, void* stream);
+/* One small launch at the head of every optimisation step: + zeroes a second f64 buffer (the per-step partial statistics the
+ * ranks exchange) and advances the Philox stream of the in-step latent draw (ase_hip_sample_latents with advance = 0). */
+int ase_hip_begin_step(double* opt_state, double* acc, int n_acc, double* zero2, int n_zero2, uint64_t* rng_bump,
+                       void* stream);
 int ase_hip_adam(float* w, const float* g, float* m, float* v, int64_t n, const double* opt_state,
                  void* stream);
 /* g[i] += c * w[i]  (the weight-only loss terms: learning/amp_agent.py:449-466) */
@@ -288,8 +301,8 @@ int ase_hip_sample_actions(const float* mu, int64_t ld_mu, const float* logstd, 
 /* z[r,:] = normalize(N(0,I))  (learning/ase_network_builder.py:221-225); counter-based Philox,
  * stream position read from and advanced in rng_state (u64[2] = {seed, offset}).  Row r draws the elements
  * (row_offset + r) * dim .. of the stream: data-parallel ranks pass the global index of their first row, so the R-rank
- * draw equals the 1-rank draw. */
-int ase_hip_sample_latents(float* z, int rows, int dim, uint64_t* rng_state, int64_t row_offset, void* stream);
+ * draw equals the 1-rank draw.  advance = 0: the stream position is left alone (ase_hip_begin_step moved it). */
+int ase_hip_sample_latents(float* z, int rows, int dim, uint64_t* rng_state, int64_t row_offset, int advance, void* stream);
 
 /* The whole optimizer step of every dense layer in ONE launch: weight-only gradient terms (g += c * w: discriminator
  * weight decay / logit regulariser / encoder weight decay), their reported sums of squares (pre-update weights, into

@@ -84,7 +84,7 @@ class EmuBackend:
             return True
         return M % 64 == 0 and bias_rows % 64 == 0 and n_real >= 128 and K >= 128      # any dtype: exercises the deferral on CPU
 
-    def make_tn_plan(self, problems):
+    def make_tn_plan(self, problems, target_wg=0):
         return {'keep': problems}
 
     def gemm_tn_grouped(self, plan):
@@ -132,6 +132,14 @@ class EmuBackend:
         d = (x - shift).double()
         sums[:D] += d.sum(0)
         sums[D:2 * D] += (d * d).sum(0)
+
+    def rms_moments_multi(self, streams, D, M, state, sums_list):
+        for (src, idx, remap), sums in zip(streams, sums_list):
+            self.rms_moments(src, D, idx, remap, M, state, sums)
+
+    def rms_normalize_multi(self, streams, D, M, means, stds, outs):
+        for (src, idx, remap), mean, std, out in zip(streams, means, stds, outs):
+            self.rms_normalize(src, D, idx, remap, M, mean, std, [out])
 
     def rms_finalize(self, state, D, sums, count, n_streams, mean_out, std_out):
         mean, var, cnt = state[:D].clone(), state[D:2 * D].clone(), state[2 * D].clone()
@@ -321,9 +329,13 @@ class EmuBackend:
         out[L.RES_LOSS] = loss
 
     # ------------------------------------------------------------------ optimizer
-    def begin_step(self, opt_state, acc):
+    def begin_step(self, opt_state, acc, zero2=None, rng_bump=None):
         if acc is not None:
             acc.zero_()
+        if zero2 is not None:
+            zero2.zero_()
+        if rng_bump is not None:
+            rng_bump[1] += 1
         if opt_state is not None:
             opt_state[0] += 1
             opt_state[5] = 1.0 - float(opt_state[2]) ** float(opt_state[0])
@@ -416,9 +428,10 @@ class EmuBackend:
             rand_mask.view(-1)[:n] = keep
         rng_state[1] += 1
 
-    def sample_latents(self, z, rows, dim, rng_state, row_offset=0):
+    def sample_latents(self, z, rows, dim, rng_state, row_offset=0, advance=True):
         # counter-based like the kernel: the draw is a function of (seed, offset, global row), not of call history
         g = torch.Generator().manual_seed(int(rng_state[0]) * 1000003 + int(rng_state[1]))
         v = torch.randn(row_offset + rows, dim, generator=g)[row_offset:]
         z[:rows, :dim] = v / v.norm(dim=-1, keepdim=True).clamp_min(1e-12)
-        rng_state[1] += 1
+        if advance:
+            rng_state[1] += 1
