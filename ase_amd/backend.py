@@ -47,7 +47,43 @@ class HipBackend:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def zero_(self, t):
-        t.zero_()
+        assert t.is_contiguous()
+        L.check(self.lib.ase_hip_memset(_ptr(t), 0, t.numel() * t.element_size(), self._stream()), "memset")
+
+    def copy_(self, dst, src):
+        assert dst.is_contiguous() and src.is_contiguous() and dst.dtype == src.dtype and dst.numel() == src.numel()
+        L.check(self.lib.ase_hip_memcpy(_ptr(dst), _ptr(src), dst.numel() * dst.element_size(), self._stream()), "memcpy")
+
+    # ------------------------------------------------------------------ streams: fork / join, launch programs
+    def mark(self):
+        """Event at the current position of torch's current stream -> id (fork point / branch completion)."""
+        ev = C.c_int(0)
+        L.check(self.lib.ase_hip_mark(self._stream(), C.byref(ev)), "mark")
+        return ev.value
+
+    def wait(self, ev):
+        """torch's current stream waits for the event."""
+        L.check(self.lib.ase_hip_wait(self._stream(), int(ev)), "wait")
+
+    def prog_create(self):
+        p = C.c_void_p()
+        L.check(self.lib.ase_hip_prog_create(C.byref(p)), "prog_create")
+        return p
+
+    def prog_begin(self, prog):
+        L.check(self.lib.ase_hip_prog_begin(prog), "prog_begin")
+
+    def prog_end(self, prog):
+        L.check(self.lib.ase_hip_prog_end(prog), "prog_end")
+
+    def prog_launch(self, prog):
+        L.check(self.lib.ase_hip_prog_launch(prog), "prog_launch")
+
+    def prog_size(self, prog):
+        return self.lib.ase_hip_prog_size(prog)
+
+    def prog_destroy(self, prog):
+        self.lib.ase_hip_prog_destroy(prog)
 
     def _gemm_code(self, dtype):
         c = _code(dtype)

@@ -211,10 +211,10 @@ extern "C" int ase_hip_build_amp_obs(const float* root_pos, const float* root_ro
     ASE_CHECK_ARG(lds <= 64 * 1024, "build_amp_obs: frame of %d floats does not fit the staging tile", a.F);
     if (shift && n_steps > 1) {
         const int64_t cols = (int64_t)n_envs * a.F;
-        hipLaunchKernelGGL(amp_hist_shift_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, (hipStream_t)stream, hist,
+        ASE_LAUNCH(amp_hist_shift_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, (hipStream_t)stream, hist,
                            cols, n_steps, a.F);
     }
-    hipLaunchKernelGGL(amp_obs_kernel, dim3((n_envs + kEnvPerBlock - 1) / kEnvPerBlock), dim3(kEnvPerBlock), lds,
+    ASE_LAUNCH(amp_obs_kernel, dim3((n_envs + kEnvPerBlock - 1) / kEnvPerBlock), dim3(kEnvPerBlock), lds,
                        (hipStream_t)stream, a);
     ASE_CHECK_LAUNCH("build_amp_obs");
     return ASE_OK;
@@ -251,7 +251,7 @@ extern "C" int ase_hip_motion_state(const float* gts, const float* grs, const fl
         ASE_CHECK_ARG(key_body_ids[k] >= 0 && key_body_ids[k] < n_bodies, "motion_state: key body %d out of range", key_body_ids[k]);
         a.key_body[k] = key_body_ids[k];
     }
-    hipLaunchKernelGGL(motion_state_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, a);
+    ASE_LAUNCH(motion_state_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, a);
     ASE_CHECK_LAUNCH("motion_state");
     return ASE_OK;
 }

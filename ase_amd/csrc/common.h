@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include "../../include/ase_hip.h"
+#include "prog.h"
 
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;

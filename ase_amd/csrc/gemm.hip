@@ -427,7 +427,7 @@ int launch_nt(const NTParams& p0, hipStream_t stream) {
     NTParams p = p0;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
-    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(WGM * WGN * 64), lds, stream, p);
+    ASE_LAUNCH(kern, dim3(p.tiles_m * p.tiles_n), dim3(WGM * WGN * 64), lds, stream, p);
     ASE_CHECK_LAUNCH("gemm_nt");
     return ASE_OK;
 }
@@ -865,7 +865,7 @@ template <typename T, int V, bool SW = false> int launch_nt8(const NTParams& p0,
     p.prof = g_nt_prof;
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = (p.N + 255) / 256;
-    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(512), lds, stream, p);
+    ASE_LAUNCH(kern, dim3(p.tiles_m * p.tiles_n), dim3(512), lds, stream, p);
     ASE_CHECK_LAUNCH("gemm_nt8");
     return ASE_OK;
 }
@@ -1495,7 +1495,7 @@ template <int V> int launch_tn8(TNParams p, hipStream_t stream) {
     splits = (p.M + chunk - 1) / chunk;
     p.m_chunk = chunk;
     p.prof = g_nt_prof;
-    hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(512), lds, stream, p);
+    ASE_LAUNCH(kern, dim3(tiles, 1, splits), dim3(512), lds, stream, p);
     ASE_CHECK_LAUNCH("gemm_tn8");
     return ASE_OK;
 }
@@ -1513,7 +1513,7 @@ template <int V> int launch_tn8g(const int64_t* problems, const int32_t* work, i
         }
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(n_work), dim3(512), lds, stream, problems, work, n_work, g_nt_prof);
+    ASE_LAUNCH(kern, dim3(n_work), dim3(512), lds, stream, problems, work, n_work, g_nt_prof);
     ASE_CHECK_LAUNCH("gemm_tn_grouped");
     return ASE_OK;
 }
@@ -1553,7 +1553,7 @@ template <typename T> int launch_tn(TNParams p, hipStream_t stream) {
     chunk = (chunk + Gm::BKM - 1) / Gm::BKM * Gm::BKM;
     splits = (p.M + chunk - 1) / chunk;
     p.m_chunk = chunk;
-    hipLaunchKernelGGL(kern, dim3(tiles, 1, splits), dim3(kThreads), lds, stream, p);
+    ASE_LAUNCH(kern, dim3(tiles, 1, splits), dim3(kThreads), lds, stream, p);
     ASE_CHECK_LAUNCH("gemm_tn");
     return ASE_OK;
 }
@@ -1641,9 +1641,9 @@ extern "C" int ase_hip_refresh_shadow_multi(const int64_t* desc, int n_layers, i
     ASE_CHECK_ARG(desc && n_layers > 0, "refresh_shadow_multi: null/empty operand");
     const dim3 grid(256, n_layers);
     if (dtype == ASE_BF16)
-        hipLaunchKernelGGL(refresh_multi_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, desc);
+        ASE_LAUNCH(refresh_multi_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, desc);
     else if (dtype == ASE_F32)
-        hipLaunchKernelGGL(refresh_multi_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, desc);
+        ASE_LAUNCH(refresh_multi_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, desc);
     else
         ASE_CHECK_ARG(false, "refresh_shadow_multi: bad dtype %d", dtype);
     ASE_CHECK_LAUNCH("refresh_shadow_multi");
@@ -1809,10 +1809,10 @@ extern "C" int ase_hip_refresh_shadow(const float* W, int n_real, int k_real, vo
     const dim3 grid((k_real + 31) / 32, (n_real + 31) / 32), block(256);
     const int gap = split_dst - split_src;
     if (dtype == ASE_BF16)
-        hipLaunchKernelGGL(refresh_shadow_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, W, n_real, k_real,
+        ASE_LAUNCH(refresh_shadow_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, W, n_real, k_real,
                            (bf16_t*)Ws, ldws, (bf16_t*)Wts, ldwts, split_src, gap);
     else if (dtype == ASE_F32)
-        hipLaunchKernelGGL(refresh_shadow_kernel<float>, grid, block, 0, (hipStream_t)stream, W, n_real, k_real,
+        ASE_LAUNCH(refresh_shadow_kernel<float>, grid, block, 0, (hipStream_t)stream, W, n_real, k_real,
                            (float*)Ws, ldws, (float*)Wts, ldwts, split_src, gap);
     else
         ASE_CHECK_ARG(false, "refresh_shadow: bad dtype %d", dtype);

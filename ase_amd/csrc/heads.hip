@@ -387,7 +387,7 @@ inline int grid_for(int64_t n, int block = 256, int cap = 2048) {
 
 extern "C" int ase_hip_reduce_sum(const float* x, int64_t n, int square, double* acc, int slot, void* stream) {
     ASE_CHECK_ARG(x && acc && n > 0 && slot >= 0, "reduce_sum: null/empty operand");
-    hipLaunchKernelGGL(reduce_sum_kernel, dim3(grid_for(n, 1024, 128)), dim3(256), 0, (hipStream_t)stream, x, n, square,
+    ASE_LAUNCH(reduce_sum_kernel, dim3(grid_for(n, 1024, 128)), dim3(256), 0, (hipStream_t)stream, x, n, square,
                        acc + slot);
     ASE_CHECK_LAUNCH("reduce_sum");
     return ASE_OK;
@@ -420,13 +420,13 @@ extern "C" int ase_hip_ppo_head(const float* mu, int64_t ld_mu, const float* val
     const dim3 grid(min((M + rows - 1) / rows, 1024));       // scratch holds 1024 x 8 doubles
     ASE_CHECK_ARG(dtype == ASE_BF16 || dtype == ASE_F32, "ppo_head: bad dtype %d", dtype);
     if (act_dim <= 32) {
-        if (dtype == ASE_BF16) hipLaunchKernelGGL((ppo_head_kernel<bf16_t, 32>), grid, dim3(256), 0, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((ppo_head_kernel<float, 32>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        if (dtype == ASE_BF16) ASE_LAUNCH((ppo_head_kernel<bf16_t, 32>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else ASE_LAUNCH((ppo_head_kernel<float, 32>), grid, dim3(256), 0, (hipStream_t)stream, p);
     } else {
-        if (dtype == ASE_BF16) hipLaunchKernelGGL((ppo_head_kernel<bf16_t, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((ppo_head_kernel<float, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        if (dtype == ASE_BF16) ASE_LAUNCH((ppo_head_kernel<bf16_t, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else ASE_LAUNCH((ppo_head_kernel<float, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
     }
-    hipLaunchKernelGGL(ppo_head_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, (int)grid.x, acc, div_on);
+    ASE_LAUNCH(ppo_head_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, (int)grid.x, acc, div_on);
     ASE_CHECK_LAUNCH("ppo_head");
     return ASE_OK;
 }
@@ -436,10 +436,10 @@ extern "C" int ase_hip_disc_head(const float* logit, int64_t ld_l, void* d_logit
     ASE_CHECK_ARG(logit && d_logit && acc && amb > 0 && amb_global >= amb, "disc_head: null/empty operand");
     const dim3 grid((3 * amb + 255) / 256);
     if (dtype == ASE_BF16)
-        hipLaunchKernelGGL(disc_head_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, logit, ld_l,
+        ASE_LAUNCH(disc_head_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, logit, ld_l,
                            (bf16_t*)d_logit, ld_d, db_logit, acc, amb, amb_global, disc_coef);
     else if (dtype == ASE_F32)
-        hipLaunchKernelGGL(disc_head_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, logit, ld_l,
+        ASE_LAUNCH(disc_head_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, logit, ld_l,
                            (float*)d_logit, ld_d, db_logit, acc, amb, amb_global, disc_coef);
     else ASE_CHECK_ARG(false, "disc_head: bad dtype %d", dtype);
     ASE_CHECK_LAUNCH("disc_head");
@@ -453,10 +453,10 @@ extern "C" int ase_hip_enc_head(const float* e, int64_t ld_e, const float* z, in
     ASE_CHECK_ARG(z_dim >= 1 && z_dim <= 128, "enc_head: z_dim %d not in [1,128]", z_dim);
     const dim3 grid(min((amb + 3) / 4, 128));
     if (dtype == ASE_BF16)
-        hipLaunchKernelGGL(enc_head_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, e, ld_e, z, ld_z,
+        ASE_LAUNCH(enc_head_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, e, ld_e, z, ld_z,
                            (bf16_t*)d_e, ld_de, db_enc, enc_out, acc, amb, amb_global, z_dim, enc_coef);
     else if (dtype == ASE_F32)
-        hipLaunchKernelGGL(enc_head_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, e, ld_e, z, ld_z,
+        ASE_LAUNCH(enc_head_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, e, ld_e, z, ld_z,
                            (float*)d_e, ld_de, db_enc, enc_out, acc, amb, amb_global, z_dim, enc_coef);
     else ASE_CHECK_ARG(false, "enc_head: bad dtype %d", dtype);
     ASE_CHECK_LAUNCH("enc_head");
@@ -468,10 +468,10 @@ extern "C" int ase_hip_gp_seed(const void* h, int64_t ld_h, const float* w, void
     ASE_CHECK_ARG(h && w && g && rows > 0 && width > 0, "gp_seed: null/empty operand");
     const dim3 grid(grid_for((int64_t)rows * width));
     if (dtype == ASE_BF16)
-        hipLaunchKernelGGL(gp_seed_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h, ld_h, w,
+        ASE_LAUNCH(gp_seed_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h, ld_h, w,
                            (bf16_t*)g, ld_g, rows, width, scale);
     else if (dtype == ASE_F32)
-        hipLaunchKernelGGL(gp_seed_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)h, ld_h, w,
+        ASE_LAUNCH(gp_seed_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)h, ld_h, w,
                            (float*)g, ld_g, rows, width, scale);
     else ASE_CHECK_ARG(false, "gp_seed: bad dtype %d", dtype);
     ASE_CHECK_LAUNCH("gp_seed");
@@ -485,11 +485,11 @@ extern "C" int ase_hip_sqnorm(const void* x, int64_t ld, int rows, int cols, dou
     const bool wide = cols % vec == 0 && (ld * es) % 16 == 0 && ((uintptr_t)x % 16) == 0;
     const dim3 grid(grid_for((int64_t)rows * cols / (wide ? vec : 1), 2048, 256));
     if (dtype == ASE_BF16) {
-        if (wide) hipLaunchKernelGGL((sqnorm_kernel<bf16_t, 8>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, rows, cols, acc + slot, scale);
-        else hipLaunchKernelGGL((sqnorm_kernel<bf16_t, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, rows, cols, acc + slot, scale);
+        if (wide) ASE_LAUNCH((sqnorm_kernel<bf16_t, 8>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, rows, cols, acc + slot, scale);
+        else ASE_LAUNCH((sqnorm_kernel<bf16_t, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, rows, cols, acc + slot, scale);
     } else if (dtype == ASE_F32) {
-        if (wide) hipLaunchKernelGGL((sqnorm_kernel<float, 4>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ld, rows, cols, acc + slot, scale);
-        else hipLaunchKernelGGL((sqnorm_kernel<float, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ld, rows, cols, acc + slot, scale);
+        if (wide) ASE_LAUNCH((sqnorm_kernel<float, 4>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ld, rows, cols, acc + slot, scale);
+        else ASE_LAUNCH((sqnorm_kernel<float, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ld, rows, cols, acc + slot, scale);
     } else ASE_CHECK_ARG(false, "sqnorm: bad dtype %d", dtype);
     ASE_CHECK_LAUNCH("sqnorm");
     return ASE_OK;
@@ -507,7 +507,7 @@ extern "C" int ase_hip_finalize_scalars(const double* acc, float* out, int m_glo
     a.disc_coef = disc_coef; a.disc_logit_reg = disc_logit_reg; a.disc_grad_penalty = disc_grad_penalty;
     a.disc_weight_decay = disc_weight_decay; a.enc_coef = enc_coef; a.enc_weight_decay = enc_weight_decay;
     a.div_coef = div_coef;
-    hipLaunchKernelGGL(finalize_scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, acc, out, a);
+    ASE_LAUNCH(finalize_scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, acc, out, a);
     ASE_CHECK_LAUNCH("finalize_scalars");
     return ASE_OK;
 }

@@ -157,7 +157,7 @@ inline int grid_for(int64_t n) {
 extern "C" int ase_hip_begin_step(double* opt_state, double* acc, int n_acc, double* zero2, int n_zero2,
                                   uint64_t* rng_bump, void* stream) {
     ASE_CHECK_ARG((opt_state || acc || zero2 || rng_bump) && n_acc >= 0 && n_zero2 >= 0, "begin_step: nothing to do");
-    hipLaunchKernelGGL(begin_step_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, opt_state, acc, acc ? n_acc : 0, zero2,
+    ASE_LAUNCH(begin_step_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, opt_state, acc, acc ? n_acc : 0, zero2,
                        zero2 ? n_zero2 : 0, (unsigned long long*)rng_bump);
     ASE_CHECK_LAUNCH("begin_step");
     return ASE_OK;
@@ -166,14 +166,14 @@ extern "C" int ase_hip_begin_step(double* opt_state, double* acc, int n_acc, dou
 extern "C" int ase_hip_adam(float* w, const float* g, float* m, float* v, int64_t n, const double* opt_state,
                             void* stream) {
     ASE_CHECK_ARG(w && g && m && v && opt_state && n > 0, "adam: null/empty operand");
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, w, g, m, v, n, opt_state);
+    ASE_LAUNCH(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, w, g, m, v, n, opt_state);
     ASE_CHECK_LAUNCH("adam");
     return ASE_OK;
 }
 
 extern "C" int ase_hip_axpy(float* g, const float* w, int64_t n, float c, void* stream) {
     ASE_CHECK_ARG(g && w && n > 0, "axpy: null/empty operand");
-    hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, w, n, c);
+    ASE_LAUNCH(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, w, n, c);
     ASE_CHECK_LAUNCH("axpy");
     return ASE_OK;
 }
@@ -184,9 +184,9 @@ extern "C" int ase_hip_apply_multi(const int64_t* desc, int n_layers, const doub
     ASE_CHECK_ARG(opt_state == nullptr || acc != nullptr, "apply_multi: optimizer step without the accumulator array");
     const dim3 grid(256, n_layers);
     if (dtype == ASE_BF16)
-        hipLaunchKernelGGL(apply_multi_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, desc, opt_state, acc);
+        ASE_LAUNCH(apply_multi_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, desc, opt_state, acc);
     else if (dtype == ASE_F32)
-        hipLaunchKernelGGL(apply_multi_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, desc, opt_state, acc);
+        ASE_LAUNCH(apply_multi_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, desc, opt_state, acc);
     else
         ASE_CHECK_ARG(false, "apply_multi: bad dtype %d", dtype);
     ASE_CHECK_LAUNCH("apply_multi");

@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void gather_multi_kernel(const int64_t* __rest
 extern "C" int ase_hip_gather_multi(const int64_t* desc, int n_fields, const int32_t* idx, int remap_h, int remap_n,
                                     int M, void* stream) {
     ASE_CHECK_ARG(desc && n_fields > 0 && M > 0, "gather_multi: null/empty operand");
-    hipLaunchKernelGGL(gather_multi_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, desc, n_fields, idx, remap_h,
+    ASE_LAUNCH(gather_multi_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, desc, n_fields, idx, remap_h,
                        remap_n, M);
     ASE_CHECK_LAUNCH("gather_multi");
     return ASE_OK;
@@ -295,13 +295,13 @@ extern "C" int ase_hip_rms_moments(const float* src, int64_t ld_src, int D, cons
     //  same dependent index -> row loads; kept for wide, un-gathered inputs)
     if (idx == nullptr && D % 4 == 0 && ld_src % 4 == 0 && ((uintptr_t)src % 16) == 0) {
         const dim3 grid((D / 4 + 63) / 64, (M + kRowsPerBlock - 1) / kRowsPerBlock);
-        hipLaunchKernelGGL(rms_moments4_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, D, idx, remap_h,
+        ASE_LAUNCH(rms_moments4_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, D, idx, remap_h,
                            remap_n, M, state, sums);
     } else {
         RmsStreams S = {};
         S.src[0] = src; S.ld[0] = ld_src; S.idx[0] = idx; S.rh[0] = remap_h; S.rn[0] = remap_n; S.sums[0] = sums;
         const dim3 grid((D + 63) / 64, (M + kRowsPerBlock - 1) / kRowsPerBlock, 1);
-        hipLaunchKernelGGL(rms_moments_multi_kernel, grid, dim3(256), 0, (hipStream_t)stream, S, D, M, state);
+        ASE_LAUNCH(rms_moments_multi_kernel, grid, dim3(256), 0, (hipStream_t)stream, S, D, M, state);
     }
     ASE_CHECK_LAUNCH("rms_moments");
     return ASE_OK;
@@ -318,7 +318,7 @@ extern "C" int ase_hip_rms_moments_multi(const float* const* srcs, const int64_t
         S.src[s] = srcs[s]; S.ld[s] = ld_srcs[s]; S.idx[s] = idxs[s]; S.rh[s] = remap_h[s]; S.rn[s] = remap_n[s]; S.sums[s] = sums[s];
     }
     const dim3 grid((D + 63) / 64, (M + kRowsPerBlock - 1) / kRowsPerBlock, n_streams);
-    hipLaunchKernelGGL(rms_moments_multi_kernel, grid, dim3(256), 0, (hipStream_t)stream, S, D, M, state);
+    ASE_LAUNCH(rms_moments_multi_kernel, grid, dim3(256), 0, (hipStream_t)stream, S, D, M, state);
     ASE_CHECK_LAUNCH("rms_moments_multi");
     return ASE_OK;
 }
@@ -341,8 +341,8 @@ extern "C" int ase_hip_rms_normalize_multi(const float* const* srcs, const int64
         S.mean[s] = means[s]; S.stdv[s] = stds[s]; S.out[s] = outs[s]; S.ld_out[s] = ld_outs[s];
     }
     const dim3 grid((D / 4 + 63) / 64, (M + 3) / 4, n_streams);
-    if (dtype == ASE_BF16) hipLaunchKernelGGL(rms_normalize_multi_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, S, D, M);
-    else hipLaunchKernelGGL(rms_normalize_multi_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, S, D, M);
+    if (dtype == ASE_BF16) ASE_LAUNCH(rms_normalize_multi_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, S, D, M);
+    else ASE_LAUNCH(rms_normalize_multi_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, S, D, M);
     ASE_CHECK_LAUNCH("rms_normalize_multi");
     return ASE_OK;
 }
@@ -360,7 +360,7 @@ extern "C" int ase_hip_rms_finalize(double* state, int D, const double* sums, co
         ASE_CHECK_ARG(count > 1, "rms_finalize: need at least 2 rows for an unbiased variance");
     }
     // one workgroup (the count is read before it is rewritten); 1024 threads: the 1400 AMP columns take 2 passes, not 6
-    hipLaunchKernelGGL(rms_finalize_kernel, dim3(1), dim3(D > 256 ? 1024 : 256), 0, (hipStream_t)stream, state, D, sums, count,
+    ASE_LAUNCH(rms_finalize_kernel, dim3(1), dim3(D > 256 ? 1024 : 256), 0, (hipStream_t)stream, state, D, sums, count,
                        n_streams, mean_out, std_out);
     ASE_CHECK_LAUNCH("rms_finalize");
     return ASE_OK;
@@ -378,20 +378,20 @@ extern "C" int ase_hip_rms_normalize(const float* src, int64_t ld_src, int D, co
     if (wide && (dtype == ASE_BF16 || dtype == ASE_F32)) {
         const dim3 g4((D / 4 + 63) / 64, (M + 3) / 4);
         if (dtype == ASE_BF16)
-            hipLaunchKernelGGL(rms_normalize4_kernel<bf16_t>, g4, dim3(256), 0, (hipStream_t)stream, src, ld_src, D, idx,
+            ASE_LAUNCH(rms_normalize4_kernel<bf16_t>, g4, dim3(256), 0, (hipStream_t)stream, src, ld_src, D, idx,
                                remap_h, remap_n, M, mean, stdv, out0, ld0, out1, ld1, out2, ld2);
         else
-            hipLaunchKernelGGL(rms_normalize4_kernel<float>, g4, dim3(256), 0, (hipStream_t)stream, src, ld_src, D, idx,
+            ASE_LAUNCH(rms_normalize4_kernel<float>, g4, dim3(256), 0, (hipStream_t)stream, src, ld_src, D, idx,
                                remap_h, remap_n, M, mean, stdv, out0, ld0, out1, ld1, out2, ld2);
         ASE_CHECK_LAUNCH("rms_normalize");
         return ASE_OK;
     }
     const dim3 grid((D + 255) / 256, (M + 3) / 4);
     if (dtype == ASE_BF16)
-        hipLaunchKernelGGL(rms_normalize_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, D, idx,
+        ASE_LAUNCH(rms_normalize_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, D, idx,
                            remap_h, remap_n, M, mean, stdv, out0, ld0, out1, ld1, out2, ld2);
     else if (dtype == ASE_F32)
-        hipLaunchKernelGGL(rms_normalize_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, D, idx,
+        ASE_LAUNCH(rms_normalize_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, D, idx,
                            remap_h, remap_n, M, mean, stdv, out0, ld0, out1, ld1, out2, ld2);
     else
         ASE_CHECK_ARG(false, "rms_normalize: bad dtype %d", dtype);
@@ -402,7 +402,7 @@ extern "C" int ase_hip_rms_normalize(const float* src, int64_t ld_src, int D, co
 extern "C" int ase_hip_rms_unnormalize(const double* state, const float* x, float* y, int64_t n, void* stream) {
     ASE_CHECK_ARG(state && x && y && n > 0, "rms_unnormalize: null/empty operand");
     const int blocks = (int)min((int64_t)2048, (n + 255) / 256);
-    hipLaunchKernelGGL(rms_unnormalize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, state, x, y, n);
+    ASE_LAUNCH(rms_unnormalize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, state, x, y, n);
     ASE_CHECK_LAUNCH("rms_unnormalize");
     return ASE_OK;
 }
@@ -415,10 +415,10 @@ extern "C" int ase_hip_gather_rows(const float* src, int64_t ld_src, int D, cons
     const dim3 block(W, 256 / W);
     const dim3 grid((M + block.y - 1) / block.y);
     if (dst_dtype == ASE_BF16)
-        hipLaunchKernelGGL(gather_rows_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, src, ld_src, D, idx,
+        ASE_LAUNCH(gather_rows_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, src, ld_src, D, idx,
                            remap_h, remap_n, M, (bf16_t*)dst, ld_dst);
     else if (dst_dtype == ASE_F32)
-        hipLaunchKernelGGL(gather_rows_kernel<float>, grid, block, 0, (hipStream_t)stream, src, ld_src, D, idx,
+        ASE_LAUNCH(gather_rows_kernel<float>, grid, block, 0, (hipStream_t)stream, src, ld_src, D, idx,
                            remap_h, remap_n, M, (float*)dst, ld_dst);
     else
         ASE_CHECK_ARG(false, "gather_rows: bad dtype %d", dst_dtype);

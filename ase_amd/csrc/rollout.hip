@@ -225,7 +225,7 @@ inline int grid_for(int64_t n) {
 
 extern "C" int ase_hip_disc_reward(const float* logit, int64_t ld_l, float* r, int64_t n, float scale, void* stream) {
     ASE_CHECK_ARG(logit && r && n > 0, "disc_reward: null/empty operand");
-    hipLaunchKernelGGL(disc_reward_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, logit, ld_l, r, n, scale);
+    ASE_LAUNCH(disc_reward_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, logit, ld_l, r, n, scale);
     ASE_CHECK_LAUNCH("disc_reward");
     return ASE_OK;
 }
@@ -233,7 +233,7 @@ extern "C" int ase_hip_disc_reward(const float* logit, int64_t ld_l, float* r, i
 extern "C" int ase_hip_enc_reward(const float* e, int64_t ld_e, const float* z, int64_t ld_z, float* r, int64_t n,
                                   int z_dim, float scale, void* stream) {
     ASE_CHECK_ARG(e && z && r && n > 0 && z_dim >= 1 && z_dim <= 128, "enc_reward: bad operand");
-    hipLaunchKernelGGL(enc_reward_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, e, ld_e, z,
+    ASE_LAUNCH(enc_reward_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, e, ld_e, z,
                        ld_z, r, n, z_dim, scale);
     ASE_CHECK_LAUNCH("enc_reward");
     return ASE_OK;
@@ -244,7 +244,7 @@ extern "C" int ase_hip_gae(const uint8_t* dones, const float* values, const floa
                            double gamma, double tau, float* advs, float* returns, int H, int N, void* stream) {
     ASE_CHECK_ARG(dones && values && next_values && r_task && advs && returns && H > 0 && N > 0,
                   "gae: null/empty operand");
-    hipLaunchKernelGGL(gae_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, dones, values, next_values,
+    ASE_LAUNCH(gae_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, dones, values, next_values,
                        r_task, r_disc, r_enc, w_task, w_disc, w_enc, (float)gamma, (float)(gamma * tau), advs, returns,
                        H, N);
     ASE_CHECK_LAUNCH("gae");
@@ -255,11 +255,11 @@ extern "C" int ase_hip_adv_norm(const float* returns, const float* values, const
                                 int64_t n, int normalize, int phase, void* stream) {
     ASE_CHECK_ARG(returns && values && acc3 && n > 1, "adv_norm: null/empty operand");
     if (phase == 0) {
-        hipLaunchKernelGGL(adv_moments_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, returns, values,
+        ASE_LAUNCH(adv_moments_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, returns, values,
                            mask, acc3, n);
     } else {
         ASE_CHECK_ARG(adv, "adv_norm: null output");
-        hipLaunchKernelGGL(adv_apply_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, returns, values, adv,
+        ASE_LAUNCH(adv_apply_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, returns, values, adv,
                            acc3, n, normalize, mask != nullptr);
     }
     ASE_CHECK_LAUNCH("adv_norm");
@@ -269,7 +269,7 @@ extern "C" int ase_hip_adv_norm(const float* returns, const float* values, const
 extern "C" int ase_hip_ring_store(const float* src, int64_t ld_src, int D, const int32_t* idx, int remap_h, int remap_n,
                                   int n, float* dst, int64_t size, int64_t head, void* stream) {
     ASE_CHECK_ARG(src && dst && D > 0 && n > 0 && n <= size && head >= 0 && head < size, "ring_store: bad operand");
-    hipLaunchKernelGGL(ring_store_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, src, ld_src, D, idx,
+    ASE_LAUNCH(ring_store_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, src, ld_src, D, idx,
                        remap_h, remap_n, n, dst, size, head);
     ASE_CHECK_LAUNCH("ring_store");
     return ASE_OK;
@@ -277,7 +277,7 @@ extern "C" int ase_hip_ring_store(const float* src, int64_t ld_src, int D, const
 
 extern "C" int ase_hip_normalize_rows(const float* x, int64_t ld_x, float* y, int64_t ld_y, int n, int dim, void* stream) {
     ASE_CHECK_ARG(x && y && n > 0 && dim >= 1 && dim <= 128 && ld_x >= dim && ld_y >= dim, "normalize_rows: bad operand");
-    hipLaunchKernelGGL(normalize_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ld_x, y, ld_y, n, dim);
+    ASE_LAUNCH(normalize_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ld_x, y, ld_y, n, dim);
     ASE_CHECK_LAUNCH("normalize_rows");
     return ASE_OK;
 }
@@ -287,9 +287,9 @@ extern "C" int ase_hip_sample_actions(const float* mu, int64_t ld_mu, const floa
                                       float* neglogp, float* rand_mask, int n, int act_dim, int mu_tanh, void* stream) {
     ASE_CHECK_ARG(mu && logstd && rng_state && mu_out && sigma_out && actions && neglogp && n > 0 && act_dim >= 1 &&
                       act_dim <= 64 && ld_mu >= act_dim, "sample_actions: bad operand");
-    hipLaunchKernelGGL(sample_actions_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, mu, ld_mu, logstd,
+    ASE_LAUNCH(sample_actions_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, mu, ld_mu, logstd,
                        rand_probs, rng_state, mu_out, sigma_out, actions, neglogp, rand_mask, n, act_dim, mu_tanh);
-    hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng_state);
+    ASE_LAUNCH(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng_state);
     ASE_CHECK_LAUNCH("sample_actions");
     return ASE_OK;
 }
@@ -297,9 +297,9 @@ extern "C" int ase_hip_sample_actions(const float* mu, int64_t ld_mu, const floa
 extern "C" int ase_hip_sample_latents(float* z, int rows, int dim, uint64_t* rng_state, int64_t row_offset, int advance,
                                       void* stream) {
     ASE_CHECK_ARG(z && rng_state && rows > 0 && dim >= 1 && dim <= 128 && row_offset >= 0, "sample_latents: bad operand");
-    hipLaunchKernelGGL(sample_latents_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, z, rows, dim,
+    ASE_LAUNCH(sample_latents_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, z, rows, dim,
                        rng_state, row_offset);
-    if (advance) hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng_state);
+    if (advance) ASE_LAUNCH(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng_state);
     ASE_CHECK_LAUNCH("sample_latents");
     return ASE_OK;
 }

@@ -535,39 +535,33 @@ class UpdateEngine:
         return self._side_streams[k % len(self._side_streams)]
 
     class _Branch:
-        """Run a block of launches on a side stream: it starts after `after` (an event on the main stream; default: everything
-        the main stream holds so far) and leaves `done` for whoever needs its results."""
+        """Run a block of launches on a side stream: it starts after `after` (a mark on the main stream; default: everything
+        the main stream holds so far) and leaves `done` for whoever needs its results.  Marks / waits go through the
+        backend (ase_hip_mark / ase_hip_wait), so a recorded launch program contains them."""
 
-        def __init__(self, stream, after=None):
-            self.stream, self.after = stream, after
+        def __init__(self, eng, stream, after=None):
+            self.eng, self.stream, self.after = eng, stream, after
 
         def __enter__(self):
             if self.stream is not None:
-                if self.after is not None:
-                    self.stream.wait_event(self.after)
-                else:
-                    self.stream.wait_stream(torch.cuda.current_stream())
+                after = self.after if self.after is not None else self.eng.be.mark()
                 self.ctx = torch.cuda.stream(self.stream)
                 self.ctx.__enter__()
+                self.eng.be.wait(after)
             return self
 
         def __exit__(self, *a):
             if self.stream is not None:
-                self.done = torch.cuda.Event()
-                self.done.record(self.stream)
+                self.done = self.eng.be.mark()
                 self.ctx.__exit__(*a)
 
     def _join_branch(self, br):
         if br.stream is not None:
-            torch.cuda.current_stream().wait_event(br.done)
+            self.be.wait(br.done)
 
     def _mark(self):
-        """Event at the current position of the main stream (fork point of later branches), None without streams."""
-        if not self.multi_stream:
-            return None
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
-        return ev
+        """Mark at the current position of the main stream (fork point of later branches), None without streams."""
+        return self.be.mark() if self.multi_stream else None
 
     def _finish_branch(self, group, inline_apply, last=False):
         """Tail of a branch: its weight gradients as one grouped launch, then (inline_apply) the exchange of its gradient
@@ -603,7 +597,7 @@ class UpdateEngine:
         fork1 = self._mark()                 # critic: observations normalised, latents in place (gather_minibatch)
         if self.div_on:
             if new_z is not None:
-                self.new_z.copy_(new_z)
+                be.copy_(self.new_z, new_z.contiguous())
             else:
                 # element index = GLOBAL minibatch row: rank r of a sharded step draws rows [r M, (r + 1) M)
                 be.sample_latents(self.new_z, M, self.z, self.rng_state,
@@ -619,7 +613,7 @@ class UpdateEngine:
         ha = self._fwd_chain(self.actor, self.Xa, self.Ha, Ra)
         self._fwd(self.mu_head, ha, self.MU, Ra)
 
-        with self._Branch(self._side(0), fork1) as br_critic:
+        with self._Branch(self, self._side(0), fork1) as br_critic:
             hc = self._fwd_chain(self.critic, self.Xc, self.Hc, M)
             self._fwd(self.value_head, hc, self.V, M)
 
@@ -627,7 +621,7 @@ class UpdateEngine:
         br_disc = None
         if self.has_disc:
             tnq, self._tn_queue = self._tn_queue, []          # the branch queues (and flushes) its own weight gradients
-            with self._Branch(self._side(1), fork0) as br_disc:
+            with self._Branch(self, self._side(1), fork0) as br_disc:
                 if self._amp_stats_in_branch():
                     self._amp_moments(amp_streams)
                 if norm_amp:
@@ -697,7 +691,7 @@ class UpdateEngine:
                 self._dgrad(sdn, self.dStyle, self.dZs[-1], Ra, self.Hs[-1], p.act)
                 self._bwd_chain(self.style[:-1], self.Zs, self.Hs, self.dZs, Ra)
         tn_actor, self._tn_queue = self._tn_queue, []
-        with self._Branch(self._side(0), fork2) as br_cb:
+        with self._Branch(self, self._side(0), fork2) as br_cb:
             self._wgrad(self.value_head, self.dV, hc, M)
             last = self.critic[-1]
             self._dgrad(self.value_head, self.dV, self.dZc[-1], M, self.Hc[-1], last.act)

@@ -527,41 +527,54 @@ class CommonAgent:
         return self.engine.step(self._ds, idx, self._remap, streams, new_z=new_z)
 
     def _graph_step(self, idx, streams):
-        """Replay the optimisation step from captured hipGraphs.  Single GPU: one graph for the whole step.
-        Data parallel: three graphs (local statistics | forward-backward | optimizer) with the two RCCL all-reduces
-        issued between them.  One graph (set) per minibatch position: the index tensors are slices of persistent
-        per-mini-epoch buffers (permutation, composed demo / replay indices), so a replay needs no copies."""
+        """Replay the optimisation step from a recorded launch sequence.  config['graph_capture']:
+          True / 'program'  the library's own launch program (ase_hip_prog_*): the step's launches + fork / join points over
+                            the engine's three streams, replayed with ~1 us of host work per launch, branch -> stream mapping
+                            fixed by us;
+          'hipgraph'        a captured hipGraph (torch.cuda.CUDAGraph): the runtime chooses how its branches map to queues.
+        Single GPU: one program for the whole step.  Data parallel: three (local statistics | forward-backward | optimizer)
+        with the RCCL all-reduces issued between them.  One program (set) per minibatch position: the index tensors are
+        slices of persistent per-mini-epoch buffers (permutation, composed demo / replay indices), so a replay needs no
+        copies."""
         eng = self.engine
         key = (int(idx.data_ptr()),) + (tuple((int(s[0].data_ptr()), int(s[1].data_ptr())) for s in streams) if streams else ())
         g = self._graphs.get(key)
+        hipgraph = self.config.get('graph_capture') == 'hipgraph'
+        single = self.world_size == 1 and not eng.force_dist
         if g is None:
             eng.step(self._ds, idx, self._remap, streams)                # this call's real step; also warms up lazies
             torch.cuda.synchronize()
-            if self.world_size == 1 and not eng.force_dist:
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    eng.step(self._ds, idx, self._remap, streams)
-                graphs = [graph]
-            else:
-                ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga):
-                    eng.phase_stats(self._ds, idx, self._remap, streams)
-                with torch.cuda.graph(gb):
-                    eng.phase_main(self._ds, idx, self._remap, streams)
-                with torch.cuda.graph(gc):
-                    eng.phase_apply(True)
-                graphs = [ga, gb, gc]
-            # keep the captured index views alive: the graphs read through their addresses on every replay
-            self._graphs[key] = {'graphs': graphs, 'keep': (idx, streams)}
+            phases = [lambda: eng.step(self._ds, idx, self._remap, streams)] if single else \
+                [lambda: eng.phase_stats(self._ds, idx, self._remap, streams),
+                 lambda: eng.phase_main(self._ds, idx, self._remap, streams),
+                 lambda: eng.phase_apply(True)]
+            graphs = []
+            for fn in phases:
+                if hipgraph:
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        fn()
+                    graphs.append(graph)
+                else:
+                    prog = self.backend.prog_create()
+                    self.backend.prog_begin(prog)
+                    try:
+                        fn()
+                    finally:
+                        self.backend.prog_end(prog)
+                    graphs.append(prog)
+            # keep the captured index views alive: the replays read through their addresses
+            self._graphs[key] = {'graphs': graphs, 'keep': (idx, streams), 'hipgraph': hipgraph}
             return eng.res
+        run = (lambda x: x.replay()) if g['hipgraph'] else self.backend.prog_launch
         if len(g['graphs']) == 1:
-            g['graphs'][0].replay()
+            run(g['graphs'][0])
         else:
-            g['graphs'][0].replay()
+            run(g['graphs'][0])
             eng._allreduce_stats()
-            g['graphs'][1].replay()
+            run(g['graphs'][1])
             eng._allreduce_grads()
-            g['graphs'][2].replay()
+            run(g['graphs'][2])
         return eng.res
 
     def calc_gradients(self, input_dict):

@@ -64,6 +64,16 @@ SIGNATURES = {
     "ase_hip_gemm_nt_kernel_id": [_i, _i, _i, _i],
     "ase_hip_apply_multi": [_p, _i, _p, _p, _i, _p],
     "ase_hip_gemm_tn_grouped_plan": [_p, _i, _i, _p, _i, _p],
+    "ase_hip_prog_create": [_p],
+    "ase_hip_prog_destroy": [_p],
+    "ase_hip_prog_begin": [_p],
+    "ase_hip_prog_end": [_p],
+    "ase_hip_prog_size": [_p],
+    "ase_hip_prog_launch": [_p],
+    "ase_hip_mark": [_p, _p],
+    "ase_hip_wait": [_p, _i],
+    "ase_hip_memset": [_p, _i, _i64, _p],
+    "ase_hip_memcpy": [_p, _p, _i64, _p],
     "ase_hip_gemm_tn_grouped": [_p, _p, _i, _i, _p],
 }
 

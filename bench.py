@@ -216,7 +216,8 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'f32', 'bf16x3'])
-    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='eager launches from Python (no recorded launch program)')
+    ap.add_argument('--hipgraph', action='store_true', help='replay captured hipGraphs instead of the library launch programs')
     ap.add_argument('--no-multi-stream', action='store_true', help='launch the three network branches on ONE stream')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=2)
@@ -244,7 +245,7 @@ def main():
         else:
             dist.init_process_group(args.dist_backend)                            # (test rigs without one GPU per rank)
 
-    use_graph = not args.no_graph
+    use_graph = False if args.no_graph else ('hipgraph' if args.hipgraph else 'program')
     t_setup = time.time()
     _dbg('init done')
     agent, cfg, spec = make_agent(device, args.precision, use_graph, world, rank, force_dist=args.force_dist,
@@ -380,7 +381,7 @@ def main():
                                       '(amp 4096) x 6 mini-epochs = 48 optimisation steps per update; random-init weights',
                           'samples_per_step': B, 'optimisation_steps_per_step': cfg['mini_epochs'] * (B // cfg['minibatch_size']),
                           'ms_epoch_tail': round(ms_tail, 3), 'ms_optimisation_steps_only': round(ms_per_step - ms_tail, 3),
-                          'hipgraph': use_graph, 'parallelism': f'dp{world} (minibatch rows sharded, RCCL grad all-reduce)'
+                          'replay': use_graph if use_graph else 'eager', 'parallelism': f'dp{world} (minibatch rows sharded, RCCL grad all-reduce)'
                           if world > 1 else 'single GPU'},
                'roofline': roof, 'cpu_baseline': cpu, 'last_train_result': {k: round(v, 6) for k, v in last.items()}}
         sys.stdout.flush()

@@ -346,6 +346,24 @@ int ase_hip_motion_state(const float* gts, const float* grs, const float* lrs, c
                          const int32_t* key_body_ids, int n_key, float* root_pos, float* root_rot, float* dof_pos,
                          float* root_vel, float* root_ang_vel, float* dof_vel, float* key_pos, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Launch programs: record a sequence of the calls above ONCE (nothing is launched while recording), replay it with ~1 us
+ * of host work per launch on the same HIP streams - the optimisation step as one call, with OUR branch -> stream mapping
+ * (a captured hipGraph picks its own; eager launches from Python fall behind the GPU).  Recording is per thread.
+ * ase_hip_mark / ase_hip_wait are the fork / join points between streams (event record / stream-wait-event); outside a
+ * recording they act immediately on a pool of events.  ase_hip_memset / ase_hip_memcpy: recordable fills / device copies.
+ * ------------------------------------------------------------------------------------------- */
+int ase_hip_prog_create(void** prog);
+int ase_hip_prog_destroy(void* prog);
+int ase_hip_prog_begin(void* prog);
+int ase_hip_prog_end(void* prog);
+int ase_hip_prog_size(void* prog);          /* entries recorded (launches + fork / join points); < 0: null program */
+int ase_hip_prog_launch(void* prog);
+int ase_hip_mark(void* stream, int* id);
+int ase_hip_wait(void* stream, int id);
+int ase_hip_memset(void* dst, int value, int64_t bytes, void* stream);
+int ase_hip_memcpy(void* dst, const void* src, int64_t bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

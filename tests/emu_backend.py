@@ -34,6 +34,15 @@ class EmuBackend:
     def zero_(self, t):
         t.zero_()
 
+    def copy_(self, dst, src):
+        dst.copy_(src)
+
+    def mark(self):
+        return 0
+
+    def wait(self, ev):
+        pass
+
     # ------------------------------------------------------------------ GEMMs
     def gemm_nt(self, A, B, Cm, M, N, K, bias=None, aux=None, aux_mode=L.AUX_NONE, colsum=None, colsum_n=0,
                 act=L.ACT_NONE, alpha=1.0, aux_split=0, aux_delta=0, mask_out=None):
