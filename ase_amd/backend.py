@@ -332,6 +332,7 @@ class HipBackend:
                                                 _ptr(sigma_out), _ptr(actions), _ptr(neglogp), _ptr(rand_mask), n, act_dim,
                                                 int(mu_tanh), self._stream()), "sample_actions")
 
-    def sample_latents(self, z, rows, dim, rng_state, row_offset=0, advance=True):
-        L.check(self.lib.ase_hip_sample_latents(_ptr(z), rows, dim, _ptr(rng_state), int(row_offset), int(advance),
-                                                self._stream()), "sample_latents")
+    def sample_latents(self, z, rows, dim, rng_state, row_offset=0, advance=True, z2=None):
+        L.check(self.lib.ase_hip_sample_latents(_ptr(z), rows, dim, _ptr(rng_state), int(row_offset), int(advance), _ptr(z2),
+                                                _ld(z2), _code(z2.dtype) if z2 is not None else 0, self._stream()),
+                "sample_latents")

@@ -49,13 +49,14 @@ template <> __device__ __forceinline__ f32s_t from_f32<f32s_t>(float x) { return
 
 // ---- dataset row map (see ase_hip.h) -------------------------------------------------------
 __device__ __forceinline__ int64_t map_row(int r, const int32_t* __restrict__ idx, int remap_h, int remap_n) {
-    int64_t p = idx ? (int64_t)idx[r] : (int64_t)r;
+    // 32-bit unsigned arithmetic (row numbers are int32): a 64-bit signed division per row cost more than the row's loads
+    uint32_t p = idx ? (uint32_t)idx[r] : (uint32_t)r;
     if (remap_h > 0) {
-        int64_t env = p / remap_h;
-        int64_t t = p - env * remap_h;
-        p = t * remap_n + env;
+        const uint32_t env = p / (uint32_t)remap_h;
+        const uint32_t t = p - env * (uint32_t)remap_h;
+        p = t * (uint32_t)remap_n + env;
     }
-    return p;
+    return (int64_t)p;
 }
 
 // ---- reductions ------------------------------------------------------------------------------

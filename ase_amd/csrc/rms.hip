@@ -255,24 +255,29 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 }
 
 // fields of one minibatch gathered by ONE launch: desc[f] = {src, ld_src, D, dst, ld_dst, dst_dtype} (int64 each)
-// One wave per minibatch row, ALL fields of that row: the row index is mapped once and the (up to ~12) field loads of a
-// lane are independent, so they are all in flight together (the per-field grid ran at 0.7 TB/s: two dependent
-// index -> element round trips per thread and an integer division per element).
+// All fields of 16 minibatch rows per workgroup: the 16 row indices are mapped once (LDS), then the (row, column) items of
+// every field are spread over the 256 threads - consecutive threads take consecutive columns of a row (narrow fields:
+// consecutive rows) - so every load of a thread is independent of the others and nearly all lanes are busy whatever the
+// field width (1 ... 64 columns).
 __global__ __launch_bounds__(256) void gather_multi_kernel(const int64_t* __restrict__ desc, int n_fields,
                                                            const int32_t* __restrict__ idx, int remap_h, int remap_n, int M) {
-    const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= M) return;
-    const int64_t p = map_row(r, idx, remap_h, remap_n);
+    __shared__ int64_t prow[16];
+    const int r0 = blockIdx.x * 16;
+    if (threadIdx.x < 16 && r0 + threadIdx.x < M) prow[threadIdx.x] = map_row(r0 + threadIdx.x, idx, remap_h, remap_n);
+    __syncthreads();
+    const int nrows = min(16, M - r0);
     for (int f = 0; f < n_fields; ++f) {
         const int64_t* d = desc + 6 * f;
         const float* src = reinterpret_cast<const float*>(d[0]);
         const int64_t ld_src = d[1], ld_dst = d[4];
-        const int D = (int)d[2], dt = (int)d[5];
-        for (int j = lane; j < D; j += 64) {
-            const float v = src[p * ld_src + j];
-            if (dt == ASE_BF16) reinterpret_cast<bf16_t*>(d[3])[(int64_t)r * ld_dst + j] = (bf16_t)v;
-            else reinterpret_cast<float*>(d[3])[(int64_t)r * ld_dst + j] = v;
+        const uint32_t D = (uint32_t)d[2];
+        const int dt = (int)d[5];
+        const uint32_t items = (uint32_t)nrows * D;
+        for (uint32_t i = threadIdx.x; i < items; i += 256) {
+            const uint32_t rr = i / D, j = i - rr * D;
+            const float v = src[prow[rr] * ld_src + j];
+            if (dt == ASE_BF16) reinterpret_cast<bf16_t*>(d[3])[(int64_t)(r0 + rr) * ld_dst + j] = (bf16_t)v;
+            else reinterpret_cast<float*>(d[3])[(int64_t)(r0 + rr) * ld_dst + j] = v;
         }
     }
 }
@@ -282,8 +287,8 @@ __global__ __launch_bounds__(256) void gather_multi_kernel(const int64_t* __rest
 extern "C" int ase_hip_gather_multi(const int64_t* desc, int n_fields, const int32_t* idx, int remap_h, int remap_n,
                                     int M, void* stream) {
     ASE_CHECK_ARG(desc && n_fields > 0 && M > 0, "gather_multi: null/empty operand");
-    ASE_LAUNCH(gather_multi_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, desc, n_fields, idx, remap_h,
-                       remap_n, M);
+    ASE_LAUNCH(gather_multi_kernel, dim3((M + 15) / 16), dim3(256), 0, (hipStream_t)stream, desc, n_fields, idx, remap_h,
+               remap_n, M);
     ASE_CHECK_LAUNCH("gather_multi");
     return ASE_OK;
 }

@@ -598,11 +598,13 @@ class UpdateEngine:
         if self.div_on:
             if new_z is not None:
                 be.copy_(self.new_z, new_z.contiguous())
+                be.gather_rows(self.new_z, self.z, None, (0, 0), M, self.Zs[M:])
             else:
-                # element index = GLOBAL minibatch row: rank r of a sharded step draws rows [r M, (r + 1) M)
+                # element index = GLOBAL minibatch row: rank r of a sharded step draws rows [r M, (r + 1) M); the kernel
+                # also writes the compute-dtype copy the style MLP reads
                 be.sample_latents(self.new_z, M, self.z, self.rng_state,
-                                  row_offset=self.rank * M if (self.shard and self.R > 1) else 0, advance=False)
-            be.gather_rows(self.new_z, self.z, None, (0, 0), M, self.Zs[M:])
+                                  row_offset=self.rank * M if (self.shard and self.R > 1) else 0, advance=False,
+                                  z2=self.Zs[M:])
 
         # The actor chain (2 M rows with the diversity pass) is the longest: it is launched FIRST on the main stream, the
         # critic and the discriminator branches follow on their streams, forked from the events above.
@@ -675,11 +677,24 @@ class UpdateEngine:
                     self.bounds_coef, c.get('amp_diversity_bonus', 0.0), c.get('amp_diversity_tar', 0.0))
         fork2 = self._mark()
 
-        # -- actor (+ style) backward on the main stream, critic backward beside it
+        # -- actor backward on the main stream, critic backward beside it.  The wide layers' weight gradients of BOTH
+        # (one parameter bucket) go out as one grouped launch on the critic's stream as soon as the actor's data-gradient
+        # chain is through, next to the small kernels of the style-MLP backward that end the main stream's chain.
         self._wgrad(self.mu_head, self.dMU, ha, Ra)
         last = self.actor[-1]
         self._dgrad(self.mu_head, self.dMU, self.dZa[-1], Ra, self.Ha[-1], last.act)
         self._bwd_chain(self.actor, self.Xa, self.Ha, self.dZa, Ra)
+        tn_actor, self._tn_queue = self._tn_queue, []
+        actor_done = self._mark()
+        with self._Branch(self, self._side(0), fork2) as br_cb:
+            self._wgrad(self.value_head, self.dV, hc, M)
+            last = self.critic[-1]
+            self._dgrad(self.value_head, self.dV, self.dZc[-1], M, self.Hc[-1], last.act)
+            self._bwd_chain(self.critic, self.Xc, self.Hc, self.dZc, M)
+            if actor_done is not None:
+                be.wait(actor_done)
+            self._tn_queue = tn_actor + self._tn_queue
+            self._flush_tn(0)
         if self.style:
             a0, sdn = self.actor[0], self.style[-1]
             sd = a0.split_dst
@@ -690,17 +705,8 @@ class UpdateEngine:
                 p = self.style[-2]
                 self._dgrad(sdn, self.dStyle, self.dZs[-1], Ra, self.Hs[-1], p.act)
                 self._bwd_chain(self.style[:-1], self.Zs, self.Hs, self.dZs, Ra)
-        tn_actor, self._tn_queue = self._tn_queue, []
-        with self._Branch(self, self._side(0), fork2) as br_cb:
-            self._wgrad(self.value_head, self.dV, hc, M)
-            last = self.critic[-1]
-            self._dgrad(self.value_head, self.dV, self.dZc[-1], M, self.Hc[-1], last.act)
-            self._bwd_chain(self.critic, self.Xc, self.Hc, self.dZc, M)
-            tn_critic, self._tn_queue = self._tn_queue, []
         self._join_branch(br_cb)
-        # the policy's weight gradients (actor + critic: one parameter bucket) as the last grouped launch of the step
-        self._tn_queue = tn_actor + tn_critic
-        self._finish_branch('policy', inline_apply, last=True)
+        self._finish_branch('policy', inline_apply, last=True)        # (flushes what the style MLP queued, if anything)
         if br_disc is not None:
             self._join_branch(br_disc)
 

@@ -53,7 +53,7 @@ SIGNATURES = {
     "ase_hip_gae": [_p, _p, _p, _p, _p, _p, _f, _f, _f, _d, _d, _p, _p, _i, _i, _p],
     "ase_hip_adv_norm": [_p, _p, _p, _p, _p, _i64, _i, _i, _p],
     "ase_hip_ring_store": [_p, _i64, _i, _p, _i, _i, _i, _p, _i64, _i64, _p],
-    "ase_hip_sample_latents": [_p, _i, _i, _p, _i64, _i, _p],
+    "ase_hip_sample_latents": [_p, _i, _i, _p, _i64, _i, _p, _i64, _i, _p],
     "ase_hip_rms_moments_multi": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p],
     "ase_hip_rms_normalize_multi": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "ase_hip_normalize_rows": [_p, _i64, _p, _i64, _i, _i, _p],

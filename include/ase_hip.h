@@ -302,7 +302,9 @@ int ase_hip_sample_actions(const float* mu, int64_t ld_mu, const float* logstd, 
  * stream position read from and advanced in rng_state (u64[2] = {seed, offset}).  Row r draws the elements
  * (row_offset + r) * dim .. of the stream: data-parallel ranks pass the global index of their first row, so the R-rank
  * draw equals the 1-rank draw.  advance = 0: the stream position is left alone (ase_hip_begin_step moved it). */
-int ase_hip_sample_latents(float* z, int rows, int dim, uint64_t* rng_state, int64_t row_offset, int advance, void* stream);
+int ase_hip_sample_latents(float* z, int rows, int dim, uint64_t* rng_state, int64_t row_offset, int advance,
+                           void* z2 /* nullable: a second copy [rows, ld_z2] in z2_dtype (the GEMM input buffer) */,
+                           int64_t ld_z2, int z2_dtype, void* stream);
 
 /* The whole optimizer step of every dense layer in ONE launch: weight-only gradient terms (g += c * w: discriminator
  * weight decay / logit regulariser / encoder weight decay), their reported sums of squares (pre-update weights, into

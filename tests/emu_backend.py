@@ -437,10 +437,12 @@ class EmuBackend:
             rand_mask.view(-1)[:n] = keep
         rng_state[1] += 1
 
-    def sample_latents(self, z, rows, dim, rng_state, row_offset=0, advance=True):
+    def sample_latents(self, z, rows, dim, rng_state, row_offset=0, advance=True, z2=None):
         # counter-based like the kernel: the draw is a function of (seed, offset, global row), not of call history
         g = torch.Generator().manual_seed(int(rng_state[0]) * 1000003 + int(rng_state[1]))
         v = torch.randn(row_offset + rows, dim, generator=g)[row_offset:]
         z[:rows, :dim] = v / v.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+        if z2 is not None:
+            z2[:rows, :dim] = z[:rows, :dim].to(z2.dtype)
         if advance:
             rng_state[1] += 1

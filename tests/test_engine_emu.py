@@ -74,6 +74,7 @@ def test_deferred_weight_gradients(name, golden_dir):
     G = torch.load(os.path.join(golden_dir, name + '.pt'), weights_only=False)
     be = EmuBackend(group_all=True)
     net, eng = first_step(G, be, torch.float32)
-    assert be.grouped_launches == (1 if G['kind'] == 'ppo' else 2) and not eng._tn_queue
+    # discriminator branch | actor + critic (beside the style-MLP backward) | what the style MLP queued after that
+    assert be.grouped_launches == {'ppo': 1, 'amp': 2, 'ase': 3}[G['kind']] and not eng._tn_queue
     lr = G['cfg']['learning_rate']
     check_first_step(G, net, eng, rtol=2e-5, gtol=2e-4, wtol=lr * 0.05)
