@@ -97,7 +97,10 @@ class UpdateEngine:
         self._side_streams = None
         self._tn_defer = bool(getattr(backend, 'grouped_tn_ok', None)) and os.environ.get('ASE_TN_GROUPED', '1') != '0'
         self._tn_queue, self._tn_plans = [], {}          # weight gradients queued by the CURRENT branch (see _flush_tn)
-        self._tn_wg_side = int(os.environ.get('ASE_TN_WG_SIDE', '128'))
+        self._tn_wg_side = int(os.environ.get('ASE_TN_WG_SIDE', '64'))
+        # policy weight gradients as soon as the actor's data-gradient chain is through (beside the style-MLP tail) or as the
+        # last launch of the step
+        self._tn_early = os.environ.get('ASE_TN_EARLY', '1') != '0'
         self._apply_groups = None
         self._use_bits = os.environ.get('ASE_RELU_BITS', '1') != '0'
         self._fused_apply = hasattr(backend, 'apply_multi') and os.environ.get('ASE_FUSED_APPLY', '1') != '0'
@@ -691,10 +694,14 @@ class UpdateEngine:
             last = self.critic[-1]
             self._dgrad(self.value_head, self.dV, self.dZc[-1], M, self.Hc[-1], last.act)
             self._bwd_chain(self.critic, self.Xc, self.Hc, self.dZc, M)
-            if actor_done is not None:
-                be.wait(actor_done)
-            self._tn_queue = tn_actor + self._tn_queue
-            self._flush_tn(0)
+            if self._tn_early:
+                if actor_done is not None:
+                    be.wait(actor_done)
+                self._tn_queue = tn_actor + self._tn_queue
+                self._flush_tn(0)
+            else:
+                tn_actor = tn_actor + self._tn_queue
+                self._tn_queue = []
         if self.style:
             a0, sdn = self.actor[0], self.style[-1]
             sd = a0.split_dst
@@ -706,7 +713,9 @@ class UpdateEngine:
                 self._dgrad(sdn, self.dStyle, self.dZs[-1], Ra, self.Hs[-1], p.act)
                 self._bwd_chain(self.style[:-1], self.Zs, self.Hs, self.dZs, Ra)
         self._join_branch(br_cb)
-        self._finish_branch('policy', inline_apply, last=True)        # (flushes what the style MLP queued, if anything)
+        if not self._tn_early:
+            self._tn_queue = tn_actor + self._tn_queue
+        self._finish_branch('policy', inline_apply, last=True)        # (flushes what is still queued)
         if br_disc is not None:
             self._join_branch(br_disc)
 
