@@ -673,7 +673,8 @@ class CommonAgent:
                 if self.rank == 0:
                     os.makedirs(self.nn_dir, exist_ok=True)
                     self.save(model_output_file)
-                    print('MAX EPOCHS NUM!')
+                    if self.print_stats:
+                        print('MAX EPOCHS NUM!')
                 return self.last_mean_rewards, epoch_num
 
     def _get_mean_rewards(self):

@@ -129,3 +129,69 @@ class SyntheticSource:
         if z is not None:
             exp['ase_latents'] = z
         return exp
+
+
+class _Space:
+    def __init__(self, n, low=None, high=None):
+        import numpy as np
+        self.shape = (n,)
+        self.low = np.full(n, -1.0 if low is None else low, dtype=np.float32)
+        self.high = np.full(n, 1.0 if high is None else high, dtype=np.float32)
+
+
+class SyntheticVecEnv:
+    """Stepping stand-in for the Isaac Gym vectorised task (ase/env/tasks/humanoid_amp.py behind rl_games' vecenv): the
+    interface the agents' rollout loop and the players use - ``reset(env_ids)``, ``step(actions)`` ->
+    (obs, rewards, dones, infos{'terminate', 'amp_obs'}), ``task.progress_buf / num_envs / get_task_obs_size()``,
+    ``fetch_amp_obs_demo(n)`` - with seeded random observations of the right shapes: the dynamics are not the
+    point, the data path is.  ``env`` is the object itself (the reference reaches through ``vec_env.env``).
+    task_obs_size > 0 appends task observations (the HRL tasks' goal features) to the character observation."""
+
+    def __init__(self, spec, seed=0, device='cpu', task_obs_size=0):
+        self.spec, self.device = spec, torch.device(device)
+        self.gen = torch.Generator().manual_seed(seed)
+        self.task_obs_size = task_obs_size
+        self.obs_fs = FeatureScale(spec.obs_size + task_obs_size, self.gen)
+        self.amp_fs = FeatureScale(spec.amp_obs_size, self.gen) if spec.amp_obs_size else None
+        n = spec.num_envs
+        self.observation_space = _Space(spec.obs_size + task_obs_size, low=-float('inf'), high=float('inf'))
+        self.action_space = _Space(spec.act_size)
+        self.amp_observation_space = _Space(spec.amp_obs_size) if spec.amp_obs_size else None
+        self.env = self
+        self.task = self
+        self.num_envs = n
+        self.viewer = None
+        self.progress_buf = torch.zeros(n, dtype=torch.int32, device=self.device)
+        self._obs = self.obs_fs.draw(n, self.gen).to(self.device)
+        self.last_actions = None
+        self.steps = 0
+
+    def get_task_obs_size(self):
+        return self.task_obs_size
+
+    def fetch_amp_obs_demo(self, n):
+        return self.amp_fs.draw(n, self.gen, mean=0.3).to(self.device)
+
+    def reset(self, env_ids=None):
+        if env_ids is None:
+            ids = torch.arange(self.num_envs)
+        else:
+            ids = torch.as_tensor(env_ids, dtype=torch.long).cpu().view(-1)
+        if len(ids) > 0:
+            self._obs[ids.to(self.device)] = self.obs_fs.draw(len(ids), self.gen).to(self.device)
+            self.progress_buf[ids.to(self.device)] = 0
+        return {'obs': self._obs.clone()}
+
+    def step(self, actions):
+        n = self.num_envs
+        self.last_actions = actions
+        self.steps += 1
+        self._obs = self.obs_fs.draw(n, self.gen).to(self.device)
+        self.progress_buf += 1
+        dones = (torch.rand(n, generator=self.gen) < 1.0 / self.spec.episode_length)
+        terminate = dones & (torch.rand(n, generator=self.gen) < 0.5)
+        infos = {'terminate': terminate.to(self.device)}
+        if self.amp_fs is not None:
+            infos['amp_obs'] = self.amp_fs.draw(n, self.gen).to(self.device)
+        rewards = torch.ones(n, device=self.device)                       # humanoid.py:638-642: task reward == 1
+        return {'obs': self._obs.clone()}, rewards, dones.to(torch.uint8).to(self.device), infos

@@ -23,17 +23,12 @@ import os
 import sys
 import time
 
-# The captured step runs its three network branches on three streams.  How many of their kernels the runtime lets run
-# side by side is set by its hardware-queue count, read when libamdhip64 loads: measured on MI355X 85.4 ms per update
-# with 3 queues (= what an unset variable gave on most boxes), 94 ms with 4, 136 ms with 8 (every launch fills the chip;
-# more co-running launches only thrash L2), and a crash inside hipGraphLaunch with fewer queues than branches.
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '3')
-
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+import ase_amd          # noqa: E402  (first: it settles the runtime's hardware-queue count before HIP initialises, see its docstring)
+import torch            # noqa: E402
 
 MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3, 'bf16x3': 2500.0 / 3}   # x3: three bf16 MFMAs per product        # /opt/skills/guides/MI355X_MICROARCH.md (dense)
 

@@ -1,0 +1,255 @@
+"""The plugin boundary beyond train_epoch, on CPU with the op emulator: the training loop rl_games'
+Runner.run drives (``train()``), the rollout loop with the device-side action head (eps-greedy substitution, neglogp,
+per-environment latents), players restored from agent checkpoints, and the HRL agent's ``env_step`` over a frozen low-level
+controller - checked against plain-torch restatements of the reference statements they replace (cited inline)."""
+import copy
+import math
+import os
+import types
+
+import pytest
+import torch
+
+from ase_amd.learning import agents, models, players
+from ase_amd.synthetic import EnvSpec, SyntheticVecEnv
+from tests.emu_backend import EmuBackend
+from tests.helpers import BUILDERS
+
+MODELS = {'ase': models.ModelASEContinuous, 'amp': models.ModelAMPContinuous, 'ppo': models.ModelHRLContinuous}
+AGENTS = {'ase': agents.ASEAgent, 'amp': agents.AMPAgent, 'ppo': agents.CommonAgent}
+PLAYERS = {'ase': players.ASEPlayer, 'amp': players.AMPPlayerContinuous, 'ppo': players.CommonPlayer}
+GOLD = {'ase': 'ase_tiny', 'amp': 'amp_tiny', 'ppo': 'ppo_tiny'}
+_DEV = 'cpu'                 # tests/test_gpu_boundary.py re-runs these functions with the HIP backend on cuda:0
+_BE = EmuBackend
+
+
+def _load(golden_dir, kind):
+    return torch.load(os.path.join(golden_dir, GOLD[kind] + '.pt'), weights_only=False)
+
+
+def _env(G, seed=3, task_obs=0):
+    s = G['spec']
+    spec = EnvSpec(num_envs=s['num_envs'], horizon=G['cfg']['horizon_length'], obs_size=s['obs_size'] - task_obs,
+                   act_size=s['act_size'], amp_obs_size=s.get('amp_obs_size', 0) or 0,
+                   latent_dim=G['cfg'].get('latent_dim', 0), latent_steps_min=G['cfg'].get('latent_steps_min', 1),
+                   latent_steps_max=G['cfg'].get('latent_steps_max', 4), episode_length=5)
+    return SyntheticVecEnv(spec, seed=seed, task_obs_size=task_obs, device=_DEV)
+
+
+def _agent(G, env, be=None, **extra):
+    kind = G['kind']
+    b = BUILDERS[kind]()
+    b.load(G['net'])
+    cfg = dict(G['cfg'])
+    info = {'observation_space': env.observation_space, 'action_space': env.action_space}
+    if env.amp_observation_space is not None:
+        info['amp_observation_space'] = env.amp_observation_space
+    cfg.update(network=MODELS[kind](b), num_actors=env.num_envs, device=_DEV, backend=be or _BE(), precision='f32',
+               env_info=info, vec_env=env, print_stats=False, seed=5)
+    cfg.update(extra)
+    return AGENTS[kind]('t', cfg), cfg
+
+
+@pytest.mark.parametrize('kind', ['ase', 'amp', 'ppo'])
+def test_train_loop_runs_like_runner(kind, golden_dir, tmp_path):
+    """agent.train() (learning/common_agent.py:82-155): epochs of rollout + update until max_epochs, frame counters, reward
+    meters, periodic checkpoint in the reference's dictionary layout."""
+    G = _load(golden_dir, kind)
+    env = _env(G)
+    ag, cfg = _agent(G, env, max_epochs=2, save_frequency=1, train_dir=str(tmp_path), name='run')
+    w0 = ag.model.a2c_network.flat_params.clone()
+    last_mean_rewards, epoch_num = ag.train()
+    assert epoch_num == 3 and ag.epoch_num == 3                       # the loop stops once epoch_num > max_epochs
+    assert ag.frame == 3 * ag.batch_size
+    assert env.steps == 3 * ag.horizon_length
+    assert not torch.equal(w0, ag.model.a2c_network.flat_params)      # the optimizer ran
+    assert ag.game_rewards.current_size > 0 and ag.game_lengths.get_mean() > 0
+    for tag in ('losses/a_loss', 'losses/c_loss', 'info/kl', 'performance/total_fps', 'rewards0/frame'):
+        assert tag in ag.writer.scalars, tag
+    if kind != 'ppo':
+        assert 'losses/disc_loss' in ag.writer.scalars and 'info/disc_reward_mean' in ag.writer.scalars
+    ck = torch.load(os.path.join(str(tmp_path), 'run.pth'), weights_only=False)
+    assert {'model', 'optimizer', 'epoch', 'frame', 'running_mean_std'} <= set(ck)
+    assert ck['epoch'] == 3 and math.isfinite(float(ag.writer.scalars['losses/a_loss'][0]))
+
+
+def test_rollout_action_head_semantics(golden_dir):
+    """get_action_values(obs, ase_latents, rand_action_probs) (learning/ase_agent.py:117-148): deterministic rows take mu,
+    the stored neglogp is the sampled action's, the mask follows the per-env probabilities, values are un-normalised."""
+    G = _load(golden_dir, 'ase')
+    env = _env(G)
+    ag, cfg = _agent(G, env)
+    ag.obs = ag.env_reset()
+    n, A = env.num_envs, env.action_space.shape[0]
+    z = ag._ase_latents
+    assert torch.allclose(z.norm(dim=-1).cpu(), torch.ones(n), atol=1e-5)   # env_reset drew unit latents (ase_agent.py:310-321,352-360)
+    probs = torch.zeros(n, device=_DEV)
+    probs[: n // 2] = 1.0
+    res = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in ag.get_action_values(ag.obs, z, probs).items()}
+    mask = res['rand_action_mask']
+    assert torch.equal(mask, probs)                                    # p = 1 -> stochastic, p = 0 -> deterministic
+    det = mask == 0
+    assert torch.equal(res['actions'][det], res['mus'][det])
+    assert not torch.equal(res['actions'][~det], res['mus'][~det])
+    # reference arithmetic on the same network outputs (rl_games neglogp, learning/amp_models.py:29-36)
+    mu, sigma = res['mus'], res['sigmas']
+    assert torch.allclose(sigma, torch.exp(ag.engine.logstd).expand_as(sigma))
+    a = res['actions'][~det]
+    nlp = 0.5 * (((a - mu[~det]) / sigma[~det]) ** 2).sum(-1) + 0.5 * math.log(2 * math.pi) * A + torch.log(sigma[~det]).sum(-1)
+    assert torch.allclose(res['neglogpacs'][~det], nlp, rtol=1e-5, atol=1e-5)
+    # the same forward through the network-level API on pre-normalised observations (what the reference's model() sees)
+    proc = ag._preproc_obs(ag.obs['obs'])
+    mu_ref, _ = ag.model.a2c_network.eval_actor(proc, z)
+    assert torch.allclose(mu, mu_ref, rtol=1e-5, atol=1e-6)
+    v_ref = ag._eval_critic(ag.obs, z)
+    assert torch.allclose(res['values'], v_ref, rtol=1e-5, atol=1e-6)
+    # two calls draw different noise (the stream position advances on the device)
+    res2 = ag.get_action_values(ag.obs, z, probs)
+    assert not torch.equal(res2['actions'][~det], res['actions'][~det])
+
+
+def test_latents_follow_progress(golden_dir):
+    """_update_latents (learning/ase_agent.py:366-379): environments whose progress reached their reset step get a new
+    latent and a later reset step; the others keep theirs."""
+    G = _load(golden_dir, 'ase')
+    env = _env(G)
+    ag, cfg = _agent(G, env)
+    ag.obs = ag.env_reset()
+    z0, steps0 = ag._ase_latents.clone(), ag._latent_reset_steps.clone()
+    env.progress_buf[:] = 0
+    ag._update_latents()
+    assert torch.equal(ag._ase_latents, z0)                            # reset steps are >= 1 > progress 0
+    env.progress_buf[:4] = 100
+    ag._update_latents()
+    assert not torch.equal(ag._ase_latents[:4], z0[:4]) and torch.equal(ag._ase_latents[4:], z0[4:])
+    assert bool((ag._latent_reset_steps[:4] > steps0[:4]).all()) and torch.equal(ag._latent_reset_steps[4:], steps0[4:])
+
+
+@pytest.mark.parametrize('kind', ['ase', 'amp', 'ppo'])
+def test_player_restores_agent_checkpoint(kind, golden_dir, tmp_path):
+    """Players (learning/common_player.py, amp_players.py, ase_players.py) restore what the agent saved - weights and the
+    input normalisers - and act with the same policy; run() plays episodes on the environment."""
+    G = _load(golden_dir, kind)
+    env = _env(G)
+    ag, cfg = _agent(G, env, max_epochs=1, train_dir=str(tmp_path), name='p')
+    ag.train()
+    fn = os.path.join(str(tmp_path), 'p.pth')
+    pcfg = dict(cfg)
+    penv = _env(G, seed=9)
+    pcfg.update(vec_env=penv, env_info=None, backend=_BE(), player={'games_num': 3, 'print_stats': False})
+    if kind == 'ase':
+        pcfg['env_info'] = None
+    pl = PLAYERS[kind](pcfg)
+    pl.restore(fn)
+    assert torch.equal(pl.model.a2c_network.flat_params, ag.model.a2c_network.flat_params)
+    assert torch.equal(pl.engine.obs_state, ag.engine.obs_state)
+    if kind != 'ppo':
+        assert torch.equal(pl.engine.amp_state, ag.engine.amp_state)
+    obs = penv.reset()['obs']
+    z = None
+    if kind == 'ase':
+        pl._reset_latents()
+        z = pl._ase_latents
+    act = pl.get_action({'obs': obs}, True) if kind != 'ase' else None
+    mu = ag.engine.policy_forward(obs, z)['mu'].clone()
+    if kind == 'ase':
+        pl._latent_step_count = 5                                      # keep the latents through get_action
+        act = pl.get_action({'obs': obs}, True)
+    assert torch.allclose(act, torch.clamp(mu, -1.0, 1.0), rtol=1e-5, atol=1e-6)
+    if kind != 'ppo':
+        amp = penv.fetch_amp_obs_demo(6)
+        assert torch.allclose(pl._calc_disc_rewards(amp), ag._calc_disc_rewards(amp), rtol=1e-5, atol=1e-6)
+    pl.run()
+    assert pl.games_played >= 3 and pl.sum_steps > 0
+
+
+def _hrl_setup(golden_dir, tmp_path):
+    GL = _load(golden_dir, 'ase')            # the low-level controller: the tiny ASE net
+    GH = copy.deepcopy(_load(golden_dir, 'ppo'))
+    task = 5
+    sl = GL['spec']
+    spec = EnvSpec(num_envs=GH['spec']['num_envs'], horizon=GH['cfg']['horizon_length'], obs_size=sl['obs_size'],
+                   act_size=sl['act_size'], amp_obs_size=sl['amp_obs_size'], latent_dim=GL['cfg']['latent_dim'],
+                   episode_length=7)
+    env = SyntheticVecEnv(spec, seed=11, task_obs_size=task, device=_DEV)
+    # an LLC checkpoint as ASEAgent.save writes it
+    lenv = _env(GL, seed=2)
+    llc, _ = _agent(GL, lenv, max_epochs=1, train_dir=str(tmp_path), name='llc')
+    llc.train()
+    llc_cfg = dict(GL['cfg'])
+    llc_cfg['minibatch_size'] = spec.num_envs * GL['cfg']['horizon_length'] // 2
+    llc_cfg['amp_minibatch_size'] = min(llc_cfg['amp_minibatch_size'], llc_cfg['minibatch_size'])
+    b = BUILDERS['ppo']()
+    b.load(GH['net'])
+    cfg = dict(GH['cfg'])
+    cfg.update(network=models.ModelHRLContinuous(b), num_actors=spec.num_envs, device=_DEV, backend=_BE(),
+               precision='f32', vec_env=env, print_stats=False, seed=1,
+               env_info={'observation_space': env.observation_space, 'action_space': env.action_space},
+               llc_config={'params': {'network': GL['net'], 'config': llc_cfg}},
+               llc_checkpoint=os.path.join(str(tmp_path), 'llc.pth'), llc_steps=3, task_reward_w=0.5, disc_reward_w=0.5,
+               minibatch_size=spec.num_envs * GH['cfg']['horizon_length'] // 2)
+    return cfg, env, llc, GL, GH
+
+
+def test_hrl_env_step_with_frozen_llc(golden_dir, tmp_path):
+    """HRLAgent.env_step / _compute_llc_action / _calc_disc_reward (learning/hrl_agent.py:45-82,231-249) against the same
+    statements written with plain torch on the LLC's network-level API."""
+    cfg, env, llc, GL, GH = _hrl_setup(golden_dir, tmp_path)
+    ag = agents.HRLAgent('hrl', cfg)
+    assert ag.actions_num == GL['cfg']['latent_dim'] and ag._task_size == 5
+    L = ag._llc_agent
+    assert torch.equal(L.model.a2c_network.flat_params, llc.model.a2c_network.flat_params)
+    ag.obs = ag.env_reset()
+    obs0 = ag.obs['obs'].clone()
+    actions = (torch.randn(env.num_envs, ag.actions_num, generator=torch.Generator().manual_seed(0)) * 2.0).to(_DEV)
+    # --- reference statements, step by step, on a twin environment
+    twin = SyntheticVecEnv(env.spec, seed=11, task_obs_size=5, device=_DEV)
+    twin.reset()
+    a = torch.clamp(actions, -1.0, 1.0)
+    obs = obs0
+    rew = disc = dcount = tcount = 0.0
+    for t in range(3):
+        llc_obs = obs[..., :obs.shape[-1] - 5]
+        proc = L._preproc_obs(llc_obs)
+        z = torch.nn.functional.normalize(a, dim=-1)
+        mu, _ = L.model.a2c_network.eval_actor(obs=proc, ase_latents=z)
+        llc_action = agents.rescale_actions(L.actions_low, L.actions_high, torch.clamp(mu, -1.0, 1.0))
+        o, r, d, info = twin.step(llc_action)
+        obs = o['obs']
+        rew = rew + r
+        dcount = dcount + d.float()
+        tcount = tcount + info['terminate'].float()
+        disc = disc + L._calc_disc_rewards(info['amp_obs'])
+    # --- the agent
+    new_obs, rewards, dones, infos = ag.env_step(actions)
+    assert torch.allclose(env.last_actions, twin.last_actions, rtol=1e-5, atol=1e-6)       # same LLC actions reached the env
+    assert torch.equal(new_obs['obs'], obs)
+    assert torch.allclose(rewards.view(-1), rew / 3) and rewards.shape == (env.num_envs, 1)
+    assert torch.equal(dones, (dcount > 0).float()) and torch.equal(infos['terminate'], (tcount > 0).float())
+    assert torch.allclose(infos['disc_rewards'], disc / 3, rtol=1e-5, atol=1e-6)
+
+
+def test_hrl_train_and_player(golden_dir, tmp_path):
+    """Config 4 end to end on the synthetic environment: HRL rollout (5 -> 3 inner LLC steps per high-level step), reward mix
+    task_reward_w * r + disc_reward_w * r_disc into GAE, plain PPO update of the high-level net; HRLPlayer on the result."""
+    cfg, env, llc, GL, GH = _hrl_setup(golden_dir, tmp_path)
+    cfg.update(max_epochs=1, train_dir=str(tmp_path), name='hlc')
+    ag = agents.HRLAgent('hrl', cfg)
+    w_llc = ag._llc_agent.model.a2c_network.flat_params.clone()
+    ag.train()
+    assert env.steps == 2 * ag.horizon_length * 3
+    assert torch.equal(w_llc, ag._llc_agent.model.a2c_network.flat_params)                  # the LLC stayed frozen
+    E = ag.experience
+    exp_r = 0.5 * E['rewards'] + 0.5 * E['disc_rewards']
+    # GAE with the mixed reward, last step of the horizon (learning/common_agent.py:437-449): adv_T = r_T + gamma next_v_T - v_T
+    T = ag.horizon_length - 1
+    adv_T = exp_r[T] + ag.gamma * E['next_values'][T] - E['values'][T]
+    assert torch.allclose(ag._tail_info['mb_advs'].view(ag.horizon_length, -1, 1)[T], adv_T, rtol=1e-4, atol=1e-5)
+    pcfg = dict(cfg)
+    pcfg.update(vec_env=SyntheticVecEnv(env.spec, seed=4, task_obs_size=5), env_info=None, backend=EmuBackend(),
+                player={'games_num': 2, 'print_stats': False})
+    pl = players.HRLPlayer(pcfg)
+    pl.restore(os.path.join(str(tmp_path), 'hlc.pth'))
+    assert torch.equal(pl.model.a2c_network.flat_params, ag.model.a2c_network.flat_params)
+    pl.run()
+    assert pl.games_played >= 2
