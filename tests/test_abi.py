@@ -145,3 +145,17 @@ def test_grouped_plan_random_layer_sets():
             for t in range(((nr + 255) // 256) * ((K + 255) // 256)):
                 segs = sorted(cover[(p, t)])
                 assert segs[0][0] == 0 and segs[-1][1] == M and all(a[1] == b[0] for a, b in zip(segs, segs[1:])), (trial, p, t)
+
+
+def test_torch_library_ops_registered():
+    """The custom-operator layer registers its schemas without a GPU; calling one on CPU tensors is refused by PyTorch
+    itself (no CPU kernel exists - the product has no fallback)."""
+    import pytest
+    import torch
+    import ase_amd.ops  # noqa: F401
+    for name in ('linear_act', 'linear_bwd_data', 'linear_bwd_weight', 'rms_update_normalize', 'rms_normalize', 'gae',
+                 'masked_norm', 'gather_rows', 'disc_reward', 'enc_reward', 'normalize_rows', 'sample_latents', 'fused_adam_'):
+        assert hasattr(torch.ops.ase_hip, name), name
+    assert str(torch.ops.ase_hip.linear_act.default._schema) == 'ase_hip::linear_act(Tensor x, Tensor w, Tensor b, str act) -> Tensor'
+    with pytest.raises(NotImplementedError):
+        torch.ops.ase_hip.linear_act(torch.zeros(4, 8), torch.zeros(3, 8), torch.zeros(3), 'relu')

@@ -246,7 +246,7 @@ def test_hrl_train_and_player(golden_dir, tmp_path):
     adv_T = exp_r[T] + ag.gamma * E['next_values'][T] - E['values'][T]
     assert torch.allclose(ag._tail_info['mb_advs'].view(ag.horizon_length, -1, 1)[T], adv_T, rtol=1e-4, atol=1e-5)
     pcfg = dict(cfg)
-    pcfg.update(vec_env=SyntheticVecEnv(env.spec, seed=4, task_obs_size=5), env_info=None, backend=EmuBackend(),
+    pcfg.update(vec_env=SyntheticVecEnv(env.spec, seed=4, task_obs_size=5, device=_DEV), env_info=None, backend=_BE(),
                 player={'games_num': 2, 'print_stats': False})
     pl = players.HRLPlayer(pcfg)
     pl.restore(os.path.join(str(tmp_path), 'hlc.pth'))
