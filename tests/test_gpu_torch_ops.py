@@ -30,7 +30,7 @@ def test_linear_act_forward_backward(dt, tol, act):
     pre = xr @ wq.t() + br
     yr = {'none': pre, 'relu': torch.relu(pre), 'tanh': torch.tanh(pre)}[act]
     assert y.shape == (M, N) and y.dtype == dt
-    scale = float(yr.abs().max())
+    scale = float(yr.detach().abs().max())
     assert float((y.float() - yr).abs().max()) <= tol * scale
     dy = torch.randn(M, N, generator=g).to(DEV)
     y.backward(dy.to(dt))
@@ -80,7 +80,8 @@ def test_rms_ops_follow_running_mean_std():
         mean, var, cnt = mean + delta * n / tot, (var * cnt + bv * n + delta ** 2 * cnt * n / tot) / tot, tot
         yr = torch.clamp((xc - mean.float()) / torch.sqrt(var.float() + 1e-5), -5, 5)
         assert torch.allclose(y.cpu(), yr, rtol=1e-4, atol=1e-5)
-    assert torch.allclose(state[:D].cpu(), mean, rtol=1e-9, atol=1e-9) and float(state[2 * D]) == cnt
+    # (the batch moments are f32 quantities in rl_games: torch's f32 mean and ours differ by summation order)
+    assert torch.allclose(state[:D].cpu(), mean, rtol=1e-6, atol=1e-6) and float(state[2 * D]) == cnt
     x = torch.randn(64, D, generator=g).to(DEV)
     before = state.clone()
     y = torch.ops.ase_hip.rms_normalize(x, state)
