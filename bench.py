@@ -56,6 +56,7 @@ class TimedBackend:
     def __init__(self, be):
         self._be = be
         self.records = []          # (kind, flops, start_event, end_event)
+        self.hbm = []              # (kernel, algorithmic bytes, start_event, end_event)
         self.bytes = {}            # algorithmic operand bytes per NT kernel class (A + B + C [+ mask operand / mask output])
 
     def __getattr__(self, k):
@@ -90,6 +91,52 @@ class TimedBackend:
         flops = sum(2.0 * M * nr * kr for (A, B, G, gb, br, M, N, K, nr, kr, ss, sd, al) in plan['keep'])
         self._shape = (0, len(plan['keep']), plan['n_work'])       # grouped: N = problems, K = work items
         self._timed('tn', flops, self._be.gemm_tn_grouped, plan)
+
+    # ---- HBM-bound kernels: algorithmic bytes per launch, HIP events around the launch
+    def _hbm(self, name, nbytes, fn, *a, **kw):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn(*a, **kw)
+        e.record()
+        self.hbm.append((name, float(nbytes), s, e))
+
+    def rms_moments(self, src, D, idx, remap, M, state, sums):
+        self._hbm('rms_moments (obs)' if D < 1000 else 'rms_moments', M * D * 4, self._be.rms_moments, src, D, idx, remap, M, state, sums)
+
+    def rms_moments_multi(self, streams, D, M, state, sums_list):
+        self._hbm('rms_moments_multi (3 amp streams)', len(streams) * M * D * 4, self._be.rms_moments_multi, streams, D, M, state, sums_list)
+
+    def rms_normalize(self, src, D, idx, remap, M, mean, std, outs):
+        wb = sum(o.element_size() for o in outs if o is not None)
+        self._hbm('rms_normalize', M * D * (4 + wb), self._be.rms_normalize, src, D, idx, remap, M, mean, std, outs)
+
+    def rms_normalize_multi(self, streams, D, M, means, stds, outs):
+        self._hbm('rms_normalize_multi (3 amp streams)', len(streams) * M * D * (4 + outs[0].element_size()),
+                  self._be.rms_normalize_multi, streams, D, M, means, stds, outs)
+
+    def gather_multi(self, desc, items, idx, remap, M):
+        nb = sum(M * D * (4 + dst.element_size()) for (src, D, dst) in items)
+        self._hbm('gather_multi', nb, self._be.gather_multi, desc, items, idx, remap, M)
+
+    def apply_multi(self, desc, items, dtype, opt_state, acc):
+        n = sum(it[0].numel() + it[5].numel() for it in items)
+        # per parameter: read w, g, m, v (16 B), write w, m, v (12 B), write the two compute-dtype shadows (2 x 2 B)
+        self._hbm('apply_multi', n * 32, self._be.apply_multi, desc, items, dtype, opt_state, acc)
+
+    def ring_store(self, src, D, idx, remap, n, dst, size, head):
+        self._hbm('ring_store', n * D * 8, self._be.ring_store, src, D, idx, remap, n, dst, size, head)
+
+    def hbm_summary(self, peak_gbps=8000.0):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, nb, s, e in self.hbm:
+            a = agg.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += nb
+            a[2] += s.elapsed_time(e)
+        return [{'kernel': k, 'launches': v[0], 'algorithmic_bytes_per_launch': round(v[1] / v[0]), 'avg_us': round(v[2] * 1e3 / v[0], 2),
+                 'GBps': round(v[1] / (v[2] * 1e-3) / 1e9, 1), 'frac_of_8TBps': round(v[1] / (v[2] * 1e-3) / 1e9 / peak_gbps, 4)}
+                for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])]
 
     def summary(self):
         torch.cuda.synchronize()
@@ -158,14 +205,27 @@ def make_agent(device, precision, use_graph, world, rank, seed=0, force_dist=Fal
     return agents.ASEAgent('bench', cfg), cfg, spec
 
 
-def cpu_baseline(agent, cfg, steps=2):
-    """The reference's arithmetic (oracle/restated.py, f32, torch CPU threads = host cores) on a bounded sample
-    of the SAME workload: `steps` full-size optimisation steps (minibatch 16384 / amp 4096); the update rate is
-    extrapolated to the 48 steps of one update (the once-per-epoch tail is < 2% and left out)."""
+def _rms_dict(vec):
+    D = (vec.numel() - 1) // 2
+    v = vec.detach().cpu()
+    return {'mean': v[:D].clone(), 'var': v[D:2 * D].clone(), 'count': v[2 * D].clone()}
+
+
+def cpu_baseline_and_parity(agent, cfg, steps=8, mode='bf16'):
+    """The reference's arithmetic (oracle/restated.py, f32, torch CPU threads = host cores) on a bounded sample of the SAME
+    workload: `steps` full-size optimisation steps (minibatch 16384 / amp 4096, median step time), extrapolated to the 48
+    steps of one update (the once-per-epoch tail is < 2 % and left out).
+
+    Parity: the FIRST of those steps is also executed by the GPU engine on identical inputs - same weights (whatever the
+    timed updates left), same running statistics, same minibatch rows, same demo rows, same diversity latents - without
+    the optimizer step, and every reported loss scalar and every gradient tensor is compared with the oracle's."""
     from oracle import restated as R
+    from ase_amd import lib as L
     ncpu = host_cores()
     torch.set_num_threads(ncpu)
-    B, MB = agent.batch_size, agent.minibatch_size
+    eng = agent.engine
+    dev = eng.dev
+    B, MB, AMB = agent.batch_size, agent.minibatch_size, cfg['amp_minibatch_size']
     H, N = agent._remap
     env_major = lambda t: t.view(H, N, -1).transpose(0, 1).reshape(H * N, -1)
     ds = {k: env_major(v).cpu() for k, v in agent._ds.items()}
@@ -173,29 +233,62 @@ def cpu_baseline(agent, cfg, steps=2):
         ds[k] = ds[k].view(-1)
     ds['amp_obs_replay'] = ds['amp_obs']
     g = torch.Generator().manual_seed(0)
-    demo = agent._amp_obs_demo_buffer.data.cpu()
-    ds['amp_obs_demo'] = demo[torch.randint(0, demo.shape[0], (B,), generator=g)]
+    demo = agent._amp_obs_demo_buffer.data
+    dsel = torch.randint(0, demo.shape[0], (B,), generator=g)
+    ds['amp_obs_demo'] = demo.cpu()[dsel]
     sd = R.canonical_sd(agent.model.state_dict(), False,
                         requires_grad=[k.replace('a2c_network.', '', 1) for k, p in agent.model.named_parameters() if p.requires_grad])
     sd = {k: (v.cpu().detach().requires_grad_(True) if v.requires_grad else v.cpu()) for k, v in sd.items()}
-    rms = {'obs': R.rms_new(253), 'amp': R.rms_new(1400)}
+    rms = {'obs': _rms_dict(eng.obs_state), 'amp': _rms_dict(eng.amp_state)}
     adam = R.adam_new()
     perm = torch.randperm(B, generator=g)
-    times = []
-    for i in range(steps + 1):
-        idx = perm[i * MB:(i + 1) * MB]
+    times, parity = [], None
+    for i in range(steps):
+        pos = i % (B // MB)
+        idx = perm[pos * MB:(pos + 1) * MB]
         mb = {k: v[idx] for k, v in ds.items()}
         z = R.sample_latents(MB, 64, g)
+        if i == 0:
+            # ---- the GPU engine on the same step (no optimizer step; its running statistics advance like the oracle's)
+            idx_d = idx.to(torch.int32).to(dev)
+            arows = idx_d[:AMB].contiguous()
+            streams = [(agent._ds['amp_obs'], arows, agent._remap), (agent._ds['amp_obs'], arows, agent._remap),
+                       (demo, dsel[idx[:AMB]].to(torch.int32).to(dev), (0, 0))]
+            eng.step(agent._ds, idx_d, agent._remap, streams, new_z=z.to(dev), apply=False)
+            torch.cuda.synchronize()
+            res_g = {k: v.detach().cpu().clone() for k, v in eng.results().items()}
+            grads_g = {k: v.detach().cpu().clone() for k, v in eng.export_grads().items()}
         t0 = time.time()
-        R.calc_gradients('ase', sd, rms, mb, cfg, z)
+        res = R.calc_gradients('ase', sd, rms, mb, cfg, z)
+        if i == 0:
+            scale = {'actor_loss': 1.0, 'enc_loss': 1.0}          # means of signed O(1) summands: error relative to the summand scale
+            loss_rel = {}
+            for k in ('actor_loss', 'critic_loss', 'b_loss', 'entropy', 'kl', 'actor_clip_frac', 'disc_loss', 'disc_grad_penalty',
+                      'disc_logit_loss', 'disc_agent_acc', 'disc_demo_acc', 'enc_loss', 'amp_diversity_loss'):
+                r = float(res[k].mean())
+                loss_rel[k] = abs(float(res_g[k].mean()) - r) / max(abs(r), scale.get(k, 0.0), 1e-12)
+            grad_rel = {}
+            for k, p in sd.items():
+                if p.requires_grad:
+                    grad_rel[k] = float((grads_g[k].double() - p.grad.double()).norm() / p.grad.double().norm().clamp_min(1e-30))
+            wk = max(grad_rel, key=grad_rel.get)
+            wl = max(loss_rel, key=loss_rel.get)
+            parity = {'mode': mode, 'what': f'first oracle step (minibatch {MB}, amp {AMB}) re-run by the GPU engine on identical '
+                                            'inputs, no optimizer step; reference = oracle/restated.py in f32 on the host',
+                      'max_loss_rel': float(f'{loss_rel[wl]:.3e}'), 'max_loss_rel_scalar': wl,
+                      'loss_rel': {k: float(f'{v:.2e}') for k, v in loss_rel.items()},
+                      'worst_grad_rel_l2': float(f'{grad_rel[wk]:.3e}'), 'worst_grad_tensor': wk,
+                      'median_grad_rel_l2': float(f'{sorted(grad_rel.values())[len(grad_rel) // 2]:.3e}')}
         R.adam_step(sd, adam, cfg['learning_rate'])
         times.append(time.time() - t0)
-    t_step = sum(times[1:]) / steps            # first call = warm-up
+    tt = sorted(times[1:]) if len(times) > 1 else times           # first call = warm-up
+    t_step = tt[len(tt) // 2]
     n_steps = cfg['mini_epochs'] * (B // MB)
-    return {'value': B / (n_steps * t_step), 'unit': 'samples/s', 'cores': ncpu, 'kind': 'port',
-            'sample': f'{steps} of the {n_steps} optimisation steps of one update at full size (minibatch {MB}, amp '
-                      f'{cfg["amp_minibatch_size"]}), {t_step:.2f} s/step on {ncpu} threads, extrapolated x{n_steps}; '
-                      'oracle/restated.py (f32 torch CPU)'}
+    cpu = {'value': B / (n_steps * t_step), 'unit': 'samples/s', 'cores': ncpu, 'kind': 'port',
+           'sample': f'{len(tt)} of the {n_steps} optimisation steps of one update at full size (minibatch {MB}, amp {AMB}; one '
+                     f'more as warm-up), median {t_step:.2f} s/step on {ncpu} threads, extrapolated x{n_steps}; '
+                     'oracle/restated.py (f32 torch CPU)'}
+    return cpu, parity
 
 
 def _dbg(msg):
@@ -215,7 +308,8 @@ def main():
     ap.add_argument('--hipgraph', action='store_true', help='replay captured hipGraphs instead of the library launch programs')
     ap.add_argument('--no-multi-stream', action='store_true', help='launch the three network branches on ONE stream')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--cpu-steps', type=int, default=8)
+    ap.add_argument('--no-parity-mode', action='store_true', help='skip the extra f32 (parity mode) timing + parity check')
     ap.add_argument('--force-dist', action='store_true', help='run the collectives even with one rank (RCCL smoke)')
     ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'])
     ap.add_argument('--breakdown', action='store_true', help='per-shape GEMM time table on stderr')
@@ -356,11 +450,35 @@ def main():
                              'launches_per_update': launches, 'gemm_ms_per_update': round(gemm_ms, 3),
                              'algorithmic_tflop_per_update': round(alg / 1e12, 3)},
                 'per_kind': {k: {'launches': v['launches'], 'ms': round(v['ms'], 3),
-                                 'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1)} for k, v in summ.items()}}
+                                 'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1)} for k, v in summ.items()},
+                'hbm_kernels': tb.hbm_summary()}
 
-    cpu = None
+    cpu = parity = parity_mode = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(agent, cfg, steps=args.cpu_steps)
+        cpu, parity = cpu_baseline_and_parity(agent, cfg, steps=args.cpu_steps + 1, mode=args.precision)
+        if args.precision != 'f32' and not args.no_parity_mode:
+            # the same workload in the parity mode (exact-f32 MFMA): throughput of 2 updates + the same parity measurement
+            del agent
+            torch.cuda.empty_cache()
+            ag32, cfg32, _ = make_agent(device, 'f32', use_graph, world, rank)
+            with torch.no_grad():
+                ag32.set_eval()
+                exp = ag32.vec_env.experience(ag32._cpu_policy())
+                for k, v in exp.items():
+                    if k in ag32.experience:
+                        ag32.experience[k].copy_(v.to(device))
+                ag32._init_amp_demo_buf()
+            for _ in range(2):
+                ag32.update(ag32._play_steps_tail())
+            torch.cuda.synchronize()
+            t32 = time.perf_counter()
+            for _ in range(2):
+                ag32.update(ag32._play_steps_tail())
+            torch.cuda.synchronize()
+            ms32 = (time.perf_counter() - t32) / 2 * 1e3
+            _, p32 = cpu_baseline_and_parity(ag32, cfg32, steps=1, mode='f32')
+            parity_mode = {'dtype': 'f32', 'value': round(B / (ms32 * 1e-3), 1), 'unit': 'samples/s', 'ms_per_step': round(ms32, 3),
+                           'steps': 2, 'parity': p32}
 
     if world > 1 or args.force_dist:
         import torch.distributed as dist
@@ -378,7 +496,8 @@ def main():
                           'ms_epoch_tail': round(ms_tail, 3), 'ms_optimisation_steps_only': round(ms_per_step - ms_tail, 3),
                           'replay': use_graph if use_graph else 'eager', 'parallelism': f'dp{world} (minibatch rows sharded, RCCL grad all-reduce)'
                           if world > 1 else 'single GPU'},
-               'roofline': roof, 'cpu_baseline': cpu, 'last_train_result': {k: round(v, 6) for k, v in last.items()}}
+               'roofline': roof, 'cpu_baseline': cpu, 'parity': parity, 'parity_mode': parity_mode,
+               'last_train_result': {k: round(v, 6) for k, v in last.items()}}
         sys.stdout.flush()
         try:        # RCCL's version banner sits in the C stdio buffer until exit: push it out BEFORE the JSON line
             import ctypes
