@@ -58,6 +58,19 @@ CFG_ASE = {
 def _case(kind):
     net = copy.deepcopy(NET_ASE)
     cfg = copy.deepcopy(CFG_ASE)
+    if kind == 'amp_cfg1':
+        # BASELINE.json configs[0]: AMP agent, 64 envs x horizon 16, obs 253 / act 31, 2-layer [256, 128] MLPs, the other
+        # hyper-parameters of ase/data/cfg/train/rlg/amp_humanoid.yaml (SURVEY §8d 'Config 1': minibatch 256, amp minibatch 64,
+        # 6 mini-epochs = 24 steps).  The demo / replay rings are shrunk (512 / 2048 rows instead of 200000): their size only
+        # enters through the sampling indices, which are recorded.
+        n, c = _case('amp')
+        n['mlp']['units'] = [256, 128]
+        n['disc']['units'] = [256, 128]
+        c.update(horizon_length=16, minibatch_size=256, mini_epochs=6, amp_minibatch_size=64, amp_batch_size=128,
+                 amp_obs_demo_buffer_size=512, amp_replay_buffer_size=2048, amp_replay_keep_prob=0.01, disc_reward_scale=2,
+                 task_reward_w=0.0, disc_reward_w=1.0, learning_rate=5e-5, disc_grad_penalty=5, disc_logit_reg=0.05,
+                 disc_weight_decay=0.0001)
+        return n, c
     if kind == 'amp':
         net['name'] = 'amp'
         del net['enc']
@@ -125,9 +138,13 @@ def _rms_state(m):
     return {'mean': m.running_mean.clone(), 'var': m.running_var.clone(), 'count': m.count.clone()}
 
 
-def make_case(name, kind, seed, num_envs=16, obs_size=37, act_size=7, amp_size=44, epochs=2):
-    akind = 'ase' if kind == 'ase_sep' else kind
+def make_case(name, kind, seed, num_envs=16, obs_size=37, act_size=7, amp_size=44, epochs=2, slim=False, regen=False):
+    """slim: leave out what only the single-step tests read (first-step gradients / weights, the checkpoint dictionary);
+    regen: leave out every tensor the test can regenerate from the seeded synthetic source (observations, AMP observations,
+    demo stream - tests/test_agent_emu.py:regenerate) and the duplicated dataset rows."""
+    akind = {'ase_sep': 'ase', 'amp_cfg1': 'amp'}.get(kind, kind)
     net, cfg = _case(kind)
+    akind_kind = kind
     spec = EnvSpec(num_envs=num_envs, horizon=cfg['horizon_length'], obs_size=obs_size, act_size=act_size,
                    amp_obs_size=amp_size if akind != 'ppo' else 0, latent_dim=cfg.get('latent_dim', 0),
                    latent_steps_min=cfg.get('latent_steps_min', 1), latent_steps_max=cfg.get('latent_steps_max', 2),
@@ -197,7 +214,7 @@ def make_case(name, kind, seed, num_envs=16, obs_size=37, act_size=7, amp_size=4
             steps.append({k: (v.detach().clone() if torch.is_tensor(v) else torch.tensor(float(v)))
                           for k, v in A.train_result.items()})
         A.calc_gradients = calc
-        A.play_steps = lambda: _tail(A, kind)
+        A.play_steps = lambda: _tail(A, akind if kind == 'amp_cfg1' else kind)
         if akind != 'ppo':
             E['replay_total_before'] = A._amp_replay_buffer.get_total_count()
             E['replay_head_before'] = A._amp_replay_buffer._head
@@ -233,7 +250,20 @@ def make_case(name, kind, seed, num_envs=16, obs_size=37, act_size=7, amp_size=4
     # the reference's checkpoint dictionary after the two epochs (rl_games A2CBase.get_full_state_weights through
     # learning/amp_agent.py:47-52 get_stats_weights): what save() writes and restore() reads
     import copy
-    G['ckpt_after'] = copy.deepcopy(A.get_full_state_weights())
+    if not slim:
+        G['ckpt_after'] = copy.deepcopy(A.get_full_state_weights())
+    if slim:
+        for E in G['epochs']:
+            for k in ('sd_after_step0', 'first_grads'):
+                E.pop(k, None)
+    if regen:
+        G['regen'] = {'source_seed': 1234 + seed, 'episode_length': 20}
+        G.pop('demo_init', None)
+        for E in G['epochs']:
+            for k in ('obses', 'next_obses', 'amp_obs', 'ase_latents', 'rewards', 'dones', 'rand_action_mask'):
+                E['exp'].pop(k, None)
+            for k in ('dataset', 'first_minibatch', 'demo_fetched', 'replay_data_after'):
+                E.pop(k, None)
 
     os.makedirs(OUT, exist_ok=True)
     path = os.path.join(OUT, name + '.pt')
@@ -247,3 +277,7 @@ if __name__ == '__main__':
     make_case('amp_tiny', 'amp', seed=1)
     make_case('ppo_tiny', 'ppo', seed=2)
     make_case('ase_sep_tiny', 'ase_sep', seed=3)
+    # more seeds of the ASE case (seeds {0, 1, 2}) and BASELINE config 1's exact shape, as slim fixtures
+    make_case('ase_tiny_s1', 'ase', seed=11, slim=True)
+    make_case('ase_tiny_s2', 'ase', seed=12, slim=True)
+    make_case('amp_cfg1', 'amp_cfg1', seed=21, num_envs=64, obs_size=253, act_size=31, amp_size=1400, epochs=1, slim=True, regen=True)

@@ -48,9 +48,38 @@ def make_agent(G, backend, device='cpu', precision='f32', **extra):
     return ag
 
 
+def regenerate(G):
+    """Slim fixtures (oracle/make_golden.py regen=True) leave out every tensor that does not depend on the reference's
+    policy: observations, AMP observations, dones, masks and the demo stream are redrawn here from the seeded synthetic
+    source in the order make_golden.py drew them (demo ring fill -> per epoch: rollout, then the demo refresh)."""
+    import math
+    from ase_amd.synthetic import EnvSpec, SyntheticSource
+    if 'regen' not in G or 'demo_init' in G:
+        return G
+    cfg, sp, kind = G['cfg'], G['spec'], G['kind']
+    spec = EnvSpec(num_envs=sp['num_envs'], horizon=cfg['horizon_length'], obs_size=sp['obs_size'], act_size=sp['act_size'],
+                   amp_obs_size=sp['amp_obs_size'] if kind != 'ppo' else 0, latent_dim=cfg.get('latent_dim', 0),
+                   latent_steps_min=cfg.get('latent_steps_min', 1), latent_steps_max=cfg.get('latent_steps_max', 2),
+                   episode_length=G['regen']['episode_length'])
+    src = SyntheticSource(spec, seed=G['regen']['source_seed'])
+    if kind != 'ppo':
+        bs = int(cfg['amp_batch_size'])
+        G['demo_init'] = torch.cat([src.fetch_amp_obs_demo(bs) for _ in range(math.ceil(cfg['amp_obs_demo_buffer_size'] / bs))])
+    H, N = cfg['horizon_length'], sp['num_envs']
+    dummy = lambda obs, z: (torch.zeros(H * N, sp['act_size']), torch.ones(H * N, sp['act_size']), torch.zeros(H * N, 1))
+    for E in G['epochs']:
+        exp = src.experience(dummy, with_amp=kind != 'ppo', with_latents=kind == 'ase')
+        exp.update(E['exp'])                   # the policy-dependent tensors the reference recorded
+        E['exp'] = exp
+        if kind != 'ppo':
+            E['demo_fetched'] = src.fetch_amp_obs_demo(int(cfg['amp_batch_size']))
+    return G
+
+
 def replay_epochs(G, ag, rtol, wtol, check=True):
     kind, cfg = G['kind'], G['cfg']
     dev = ag.ppo_device
+    regenerate(G)
     if kind != 'ppo':
         ag.vec_env.q.append(G['demo_init'].clone())
         ag._amp_obs_demo_buffer._sample_idx = G['demo_sample_perm0'].to(dev)
@@ -64,6 +93,7 @@ def replay_epochs(G, ag, rtol, wtol, check=True):
         batch = ag._play_steps_tail()
         if check:
             close(batch['mb_advs'].view(-1), E['tail']['mb_advs'].reshape(-1), rtol, rtol, 'gae advs')
+        if check and 'dataset' in E:
             H, N = ag._remap
             em = lambda t: t.view(H, N, -1).transpose(0, 1).reshape(H * N, -1)      # physical -> env-major
             close(em(batch['advantages']).view(-1), E['dataset']['advantages'], rtol * 5, rtol * 5, 'advantages')
@@ -100,16 +130,19 @@ def replay_epochs(G, ag, rtol, wtol, check=True):
                 close(st[key]['running_var'], E['rms_after'][nm]['var'].view(-1), 1e-4, 1e-6, nm + ' var')
                 close(st[key]['count'], E['rms_after'][nm]['count'], 0, 0, nm + ' count')
         if kind != 'ppo':
-            close(ag._amp_replay_buffer.data, E['replay_data_after'], 0, 0, 'replay ring')
+            if 'replay_data_after' in E:
+                close(ag._amp_replay_buffer.data, E['replay_data_after'], 0, 0, 'replay ring')
             assert ag._amp_replay_buffer._head == E['replay_head_after']
     return all_info
 
 
-@pytest.mark.parametrize('name', ['ase_tiny', 'amp_tiny', 'ppo_tiny', 'ase_sep_tiny'])
+@pytest.mark.parametrize('name', ['ase_tiny', 'amp_tiny', 'ppo_tiny', 'ase_sep_tiny', 'ase_tiny_s1', 'ase_tiny_s2', 'amp_cfg1'])
 def test_two_epochs_emulated(name, golden_dir):
     G = torch.load(os.path.join(golden_dir, name + '.pt'), weights_only=False)
     ag = make_agent(G, EmuBackend())
-    replay_epochs(G, ag, rtol=2e-4, wtol=G['cfg']['learning_rate'] * 0.05)
+    # (weights: Adam moves an element by ~lr per step whatever the gradient's size, so elements whose gradient is rounding
+    #  noise may differ by a fraction of lr after 16 steps)
+    replay_epochs(G, ag, rtol=2e-4, wtol=G['cfg']['learning_rate'] * 0.1)
 
 
 def test_checkpoint_keys_match_reference(golden_dir):
