@@ -297,6 +297,9 @@ class HipBackend:
         L.check(self.lib.ase_hip_adam(_ptr(w), _ptr(g), _ptr(m), _ptr(v), w.numel(), _ptr(opt_state), self._stream()),
                 "adam")
 
+    def clip_scale(self, g, acc, slot, max_norm):
+        L.check(self.lib.ase_hip_clip_scale(_ptr(g), g.numel(), _ptr(acc[slot:]), float(max_norm), self._stream()), "clip_scale")
+
     def axpy(self, g, w, c):
         L.check(self.lib.ase_hip_axpy(_ptr(g), _ptr(w), g.numel(), float(c), self._stream()), "axpy")
 

@@ -152,7 +152,23 @@ inline int grid_for(int64_t n) {
     return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
 }
 
+// g *= min(1, max_norm / (sqrt(sqnorm) + 1e-6)): torch.nn.utils.clip_grad_norm_ with the squared total norm already on the
+// device (learning/ase_agent.py:273-288, the truncate_grads branch)
+__global__ __launch_bounds__(256) void clip_scale_kernel(float* __restrict__ g, int64_t n, const double* __restrict__ sqnorm,
+                                                         float max_norm) {
+    const float total = (float)sqrt(*sqnorm);
+    const float coef = fminf(max_norm / (total + 1e-6f), 1.0f);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) g[i] *= coef;
+}
+
 }  // namespace
+
+extern "C" int ase_hip_clip_scale(float* g, int64_t n, const double* sqnorm, float max_norm, void* stream) {
+    ASE_CHECK_ARG(g && sqnorm && n > 0 && max_norm > 0.f, "clip_scale: bad operand");
+    ASE_LAUNCH(clip_scale_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, n, sqnorm, max_norm);
+    ASE_CHECK_LAUNCH("clip_scale");
+    return ASE_OK;
+}
 
 extern "C" int ase_hip_begin_step(double* opt_state, double* acc, int n_acc, double* zero2, int n_zero2,
                                   uint64_t* rng_bump, void* stream) {

@@ -80,6 +80,10 @@ class UpdateEngine:
         self.Mg, self.AMBg = minibatch, amp_minibatch
         self.M, self.AMB = minibatch // div, amp_minibatch // div
         # flags resolved once (rl_games defaults: normalize_value False, bounds_loss_coef None = no bound loss)
+        # truncate_grads: global-norm clip of the whole gradient before Adam (learning/ase_agent.py:273-288): the norm needs every
+        # gradient (weight-only loss terms included), so the per-branch optimizer steps give way to the end-of-step form
+        self.truncate = bool(cfg.get('truncate_grads', False))
+        self.grad_norm = float(cfg.get('grad_norm', 1.0))
         self.norm_value = bool(cfg.get('normalize_value', False))
         self.bounds_coef = float(cfg.get('bounds_loss_coef') or 0.0)
         self.obs, self.act = net.obs_size, net.actions_num
@@ -492,7 +496,7 @@ class UpdateEngine:
         its bucket, optimizer step of its parameters - so the discriminator's tail overlaps the policy's backward."""
         self.phase_stats(ds, idx, remap, amp_streams, advance=apply)
         self._allreduce_stats()
-        inline = apply and self._fused_apply
+        inline = apply and self._fused_apply and not self.truncate
         self.phase_main(ds, idx, remap, amp_streams, new_z, inline_apply=inline)
         if inline:
             self.phase_finish()
@@ -731,7 +735,7 @@ class UpdateEngine:
     # ---- phase C (end-of-step form): weight-only loss terms, optimizer, shadows, reported scalars ------
     def phase_apply(self, apply=True):
         be, c = self.be, self.cfg
-        if apply and self._fused_apply:
+        if apply and self._fused_apply and not self.truncate:
             # weight-only loss terms + their reported norms + Adam + shadow refresh of every layer: ONE launch
             self._build_apply_desc()
             be.apply_multi(self._apply_desc, self._apply_items, self.dtype, self.opt_state, self.acc)
@@ -751,6 +755,10 @@ class UpdateEngine:
                     for W, gW, coef, slot in self.l2_terms:
                         if slot == L.ACC_ENC_W2:
                             be.reduce_sum(W.view(-1), W.numel(), True, self.acc, L.ACC_ENC_W2)
+            if apply and self.truncate:
+                g = self.grads[:self.n_train]
+                be.reduce_sum(g, g.numel(), True, self.acc, L.ACC_GRAD_SQ)
+                be.clip_scale(g, self.acc, L.ACC_GRAD_SQ, self.grad_norm)
             if apply:
                 be.adam(self.params[:self.n_train], self.grads[:self.n_train], self.adam_m[:self.n_train],
                         self.adam_v[:self.n_train], self.opt_state)

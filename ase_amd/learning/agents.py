@@ -120,8 +120,8 @@ class CommonAgent:
         self.critic_coef, self.entropy_coef = config['critic_coef'], config['entropy_coef']
         self.gamma, self.tau = config['gamma'], config['tau']
         self.bounds_loss_coef = config.get('bounds_loss_coef', None)
-        self.truncate_grads = config.get('truncate_grads', False)
-        assert not self.truncate_grads, "truncate_grads: SURVEY §8(f) row N4 (off in every reference config)"
+        self.truncate_grads = config.get('truncate_grads', False)       # global-norm clip (UpdateEngine.truncate)
+        self.grad_norm = config.get('grad_norm', 1.0)
         assert not config.get('mixed_precision', False), "use config['precision'] = 'bf16' | 'f32'"
         assert config.get('lr_schedule', 'constant') in ('constant', None)
         self.multi_gpu = config.get('multi_gpu', False)

@@ -182,6 +182,7 @@ enum {
     ASE_ACC_LOGIT_W2,       /* sum w_logit^2                                 */
     ASE_ACC_DISC_W2,        /* sum over all disc weights^2                   */
     ASE_ACC_ENC_W2,         /* sum over all enc weights^2                    */
+    ASE_ACC_GRAD_SQ,        /* sum of all gradients^2 (truncate_grads: global-norm clip) */
     ASE_ACC_COUNT = 24
 };
 
@@ -252,6 +253,11 @@ int ase_hip_finalize_scalars(const double* acc, float* out, int m_global, int am
  * advanced and the bias corrections recomputed on device by ase_hip_begin_step (graph-replay safe),
  * which also zeroes the n_acc accumulators.
  * ------------------------------------------------------------------------------------------- */
+/* Global-norm gradient clipping, torch.nn.utils.clip_grad_norm_(parameters, grad_norm) (learning/ase_agent.py:273-288,
+ * truncate_grads): g *= min(1, max_norm / (sqrt(*sqnorm) + 1e-6)); *sqnorm = sum of g^2 over all parameters (device f64,
+ * e.g. accumulated by ase_hip_reduce_sum with square = 1). */
+int ase_hip_clip_scale(float* g, int64_t n, const double* sqnorm, float max_norm, void* stream);
+
 /* One small launch at the head of every optimisation step: + zeroes a second f64 buffer (the per-step partial statistics the
  * ranks exchange) and advances the Philox stream of the in-step latent draw (ase_hip_sample_latents with advance = 0). */
 int ase_hip_begin_step(double* opt_state, double* acc, int n_acc, double* zero2, int n_zero2, uint64_t* rng_bump,

@@ -360,6 +360,10 @@ class EmuBackend:
         denom = v.sqrt() / bc2s + eps
         w.sub_(step_size * (m / denom))
 
+    def clip_scale(self, g, acc, slot, max_norm):
+        total = float(acc[slot]) ** 0.5
+        g.mul_(min(max_norm / (total + 1e-6), 1.0))
+
     def axpy(self, g, w, c):
         g.add_(c * w)
 

@@ -78,3 +78,40 @@ def test_deferred_weight_gradients(name, golden_dir):
     assert be.grouped_launches == {'ppo': 1, 'amp': 2, 'ase': 3}[G['kind']] and not eng._tn_queue
     lr = G['cfg']['learning_rate']
     check_first_step(G, net, eng, rtol=2e-5, gtol=2e-4, wtol=lr * 0.05)
+
+
+@pytest.mark.parametrize('name', ['ase_tiny', 'ppo_tiny'])
+def test_truncate_grads_matches_clip_grad_norm(name, golden_dir):
+    """truncate_grads: the step with the global-norm clip equals the oracle's step with
+    torch.nn.utils.clip_grad_norm_ restated (learning/ase_agent.py:273-288) - gradients after the clip and post-Adam weights.
+    grad_norm is set below the actual norm so that the clip is active."""
+    import copy
+    from oracle import restated as R
+    G = copy.deepcopy(torch.load(os.path.join(golden_dir, name + '.pt'), weights_only=False))
+    E = G['epochs'][0]
+    total0 = float(torch.sqrt(sum((g.double() ** 2).sum() for g in E['first_grads'].values())))
+    G['cfg'].update(truncate_grads=True, grad_norm=0.5 * total0)
+    net, eng = first_step(G, EmuBackend(), torch.float32)
+    assert eng.truncate
+    grads = eng.export_grads()
+    tot = float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())))
+    assert abs(tot - 0.5 * total0) <= 1e-4 * total0                       # clipped to grad_norm
+    for k, g in E['first_grads'].items():
+        close(grads[k], g * 0.5, 2e-4, 2e-4 * float(g.abs().max()) + 1e-12, 'clipped grad ' + k)
+    # oracle: reference gradients -> clip -> Adam
+    sd = {k: (v.clone().requires_grad_(k in G['trainable'])) for k, v in G['init_sd'].items()}
+    for k, g in E['first_grads'].items():
+        sd[k].grad = g.clone()
+    tn = R.clip_grad_norm(sd, 0.5 * total0)
+    assert abs(float(tn) - total0) <= 1e-5 * total0
+    # the restatement against torch's own clip_grad_norm_ on the same gradients
+    ps = [torch.nn.Parameter(G['init_sd'][k].clone()) for k in E['first_grads']]
+    for p_, g in zip(ps, E['first_grads'].values()):
+        p_.grad = g.clone()
+    torch.nn.utils.clip_grad_norm_(ps, 0.5 * total0)
+    for p_, k in zip(ps, E['first_grads']):
+        assert torch.allclose(p_.grad, sd[k].grad, rtol=1e-6, atol=0)
+    R.adam_step(sd, R.adam_new(), G['cfg']['learning_rate'])
+    got = net.state_dict()
+    for k in G['trainable']:
+        close(got[k], sd[k].detach(), 1e-6, G['cfg']['learning_rate'] * 0.05, 'weight ' + k)

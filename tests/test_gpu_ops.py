@@ -613,3 +613,123 @@ def test_motion_state_matches_reference(be, golden_dir):
     want = A.build_amp_observations(o['root_pos'], o['root_rot'], o['root_vel'], o['root_ang_vel'], o['dof_pos'], o['dof_vel'],
                                     o['key_pos'], True, True, c['dof_offsets'])
     close(hist[:, 0].cpu(), want, 1e-4, 1e-4, 'demo amp obs')
+
+
+# ------------------------------------------------------------------------------------------------ round-2 operators
+def test_sample_latents_rank_offsets(be):
+    """Rows drawn with row_offset = the global index of a rank's first row equal the corresponding rows of the one-rank draw
+    (data-parallel ranks draw disjoint parts of ONE stream); advance=False leaves the stream position alone; the second
+    output is the compute-dtype copy."""
+    st = torch.tensor([99, 5], dtype=torch.int64).cuda()
+    full = torch.zeros(4096, 64).cuda()
+    be.sample_latents(full, 4096, 64, st, advance=False)
+    assert int(st[1]) == 5
+    part = torch.zeros(1024, 64).cuda()
+    copy = torch.zeros(1024, 64, dtype=torch.bfloat16).cuda()
+    be.sample_latents(part, 1024, 64, st, row_offset=2048, advance=False, z2=copy)
+    assert torch.equal(part, full[2048:3072])
+    assert torch.equal(copy, part.to(torch.bfloat16))
+
+
+def test_sample_actions(be):
+    """ase_hip_sample_actions: mu / sigma passthrough (tanh option), Normal sample statistics, the reference's neglogp of
+    the SAMPLED action, eps-greedy substitution and mask frequencies (learning/amp_agent.py:139-169)."""
+    import math
+    n, A, ld = 50000, 31, 64
+    g = torch.Generator().manual_seed(0)
+    mu = (torch.randn(n, ld, generator=g) * 0.3).cuda()
+    logstd = torch.full((A,), -2.9).cuda()
+    probs = torch.rand(n, generator=g).cuda()
+    probs[:100] = 1.0
+    probs[100:200] = 0.0
+    st = torch.tensor([7, 0], dtype=torch.int64).cuda()
+    out = {k: torch.zeros(n, A).cuda() for k in ('mu', 'sigma', 'act')}
+    nlp, mask = torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    be.sample_actions(mu, logstd, probs, st, out['mu'], out['sigma'], out['act'], nlp, mask, n, A, mu_tanh=True)
+    assert int(st[1]) == 1
+    m = torch.tanh(mu[:, :A])
+    close(out['mu'], m, 1e-6, 1e-6, 'mu')
+    close(out['sigma'], torch.exp(logstd).expand(n, A), 1e-6, 0, 'sigma')
+    assert bool((mask[:100] == 1).all()) and bool((mask[100:200] == 0).all())
+    assert abs(float(mask.mean()) - float(probs.mean())) < 0.01                       # Bernoulli(p_row)
+    det = mask == 0
+    assert torch.equal(out['act'][det], out['mu'][det])
+    eps = (out['act'][~det] - m[~det]) / math.exp(-2.9)
+    assert abs(float(eps.mean())) < 0.01 and abs(float(eps.std()) - 1.0) < 0.01       # N(0, 1) noise
+    ref = 0.5 * (eps ** 2).sum(-1) + 0.5 * math.log(2 * math.pi) * A + A * (-2.9)
+    close(nlp[~det], ref, 1e-4, 1e-3, 'neglogp of the sampled action')
+    assert bool(torch.isfinite(nlp).all()) and float(nlp[det].std()) > 0              # deterministic rows keep the sample's neglogp
+
+
+def test_normalize_rows_and_clip_scale(be):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1000, 64, generator=g).cuda()
+    x[3] = 0
+    y = torch.zeros_like(x)
+    be.normalize_rows(x, y, 1000, 64)
+    close(y, torch.nn.functional.normalize(x, dim=-1), 1e-6, 1e-6, 'normalize_rows')
+    grad = torch.randn(100000, generator=g).cuda()
+    acc = torch.zeros(24, dtype=torch.float64).cuda()
+    be.reduce_sum(grad, grad.numel(), True, acc, 17)
+    ref = grad * min(1.0, 3.0 / (float(grad.norm()) + 1e-6))
+    be.clip_scale(grad, acc, 17, 3.0)
+    close(grad, ref, 1e-5, 1e-6, 'clip_scale')
+    big = grad.clone()
+    be.clip_scale(big, acc, 17, 1e9)                                                   # norm below the bound: unchanged
+    assert torch.equal(big, grad)
+
+
+def test_rms_multi_matches_single(be):
+    """The 3-stream moments / normalise launches equal three single-stream launches (identical sums by construction)."""
+    g = torch.Generator().manual_seed(2)
+    D, M = 1400, 4096
+    srcs = [(torch.randn(9000, D, generator=g) * (1 + s) + s).cuda() for s in range(3)]
+    idxs = [torch.randint(0, 9000, (M,), generator=g).to(torch.int32).cuda() for _ in range(3)]
+    state = torch.zeros(2 * D + 1, dtype=torch.float64).cuda()
+    state[D:] = 1.0
+    streams = [(srcs[s], idxs[s], (0, 0)) for s in range(3)]
+    a = torch.zeros(3, 2 * D, dtype=torch.float64).cuda()
+    b = torch.zeros(3, 2 * D, dtype=torch.float64).cuda()
+    be.rms_moments_multi(streams, D, M, state, [a[s] for s in range(3)])
+    for s in range(3):
+        be.rms_moments(srcs[s], D, idxs[s], (0, 0), M, state, b[s])
+    assert torch.equal(a, b)
+    ref = srcs[1][idxs[1].long()].double()
+    close(a[1][:D], ref.sum(0), 1e-9, 1e-6, 'sum')
+    mean, std = torch.zeros(3, D).cuda(), torch.zeros(3, D).cuda()
+    be.rms_finalize(state, D, a, M, 3, mean, std)
+    outs = [torch.zeros(M, 1408, dtype=torch.bfloat16).cuda() for _ in range(3)]
+    outs1 = [torch.zeros(M, 1408, dtype=torch.bfloat16).cuda() for _ in range(3)]
+    be.rms_normalize_multi(streams, D, M, [mean[s] for s in range(3)], [std[s] for s in range(3)], outs)
+    for s in range(3):
+        be.rms_normalize(srcs[s], D, idxs[s], (0, 0), M, mean[s], std[s], [outs1[s]])
+        assert torch.equal(outs[s], outs1[s])
+
+
+def test_launch_program_replay(be):
+    """A recorded launch program replays the same launches on the same streams (fork / join included) with new data in the
+    same buffers; nothing runs while recording."""
+    x = torch.randn(4096, 64).cuda()
+    y = torch.zeros(4096, 64).cuda()
+    w = torch.zeros(4096, 64).cuda()
+    side = torch.cuda.Stream()
+    prog = be.prog_create()
+    be.prog_begin(prog)
+    fork = be.mark()
+    with torch.cuda.stream(side):
+        be.wait(fork)
+        be.normalize_rows(x, y, 4096, 64)
+        done = be.mark()
+    be.zero_(w)
+    be.wait(done)
+    be.copy_(w, y)
+    be.prog_end(prog)
+    torch.cuda.synchronize()
+    assert float(y.abs().sum()) == 0 and be.prog_size(prog) == 7            # recorded, not executed
+    for _ in range(3):
+        x.normal_()
+        torch.cuda.synchronize()
+        be.prog_launch(prog)
+        torch.cuda.synchronize()
+        assert torch.allclose(w, torch.nn.functional.normalize(x, dim=-1), rtol=1e-6, atol=1e-6)
+    be.prog_destroy(prog)
