@@ -680,7 +680,8 @@ def test_normalize_rows_and_clip_scale(be):
 
 
 def test_rms_multi_matches_single(be):
-    """The 3-stream moments / normalise launches equal three single-stream launches (identical sums by construction)."""
+    """The 3-stream moments / normalise launches equal three single-stream launches (same per-workgroup partial sums; the
+    f64 atomics that combine the workgroups arrive in any order, hence equality to rounding of the f64 sums)."""
     g = torch.Generator().manual_seed(2)
     D, M = 1400, 4096
     srcs = [(torch.randn(9000, D, generator=g) * (1 + s) + s).cuda() for s in range(3)]
@@ -693,7 +694,7 @@ def test_rms_multi_matches_single(be):
     be.rms_moments_multi(streams, D, M, state, [a[s] for s in range(3)])
     for s in range(3):
         be.rms_moments(srcs[s], D, idxs[s], (0, 0), M, state, b[s])
-    assert torch.equal(a, b)
+    close(a, b, 1e-12, 1e-9, 'multi vs single moments')
     ref = srcs[1][idxs[1].long()].double()
     close(a[1][:D], ref.sum(0), 1e-9, 1e-6, 'sum')
     mean, std = torch.zeros(3, D).cuda(), torch.zeros(3, D).cuda()
@@ -703,7 +704,7 @@ def test_rms_multi_matches_single(be):
     be.rms_normalize_multi(streams, D, M, [mean[s] for s in range(3)], [std[s] for s in range(3)], outs)
     for s in range(3):
         be.rms_normalize(srcs[s], D, idxs[s], (0, 0), M, mean[s], std[s], [outs1[s]])
-        assert torch.equal(outs[s], outs1[s])
+        assert torch.equal(outs[s], outs1[s])          # (same means / stds in: identical outputs)
 
 
 def test_launch_program_replay(be):
