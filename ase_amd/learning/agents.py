@@ -705,7 +705,9 @@ class CommonAgent:
         self.set_train()
         self.curr_frames = batch_dict.pop('played_frames', self.batch_size)
         self.prepare_dataset(batch_dict)
-        MB, R, rk = self.minibatch_size, self.world_size, self.rank
+        MB = self.minibatch_size
+        # sharded mode: this rank's rows of every (global) minibatch; Horovod mode: the rank's own minibatches, whole
+        R, rk = (self.world_size, self.rank) if self.dp_mode == 'shard' else (1, 0)
         m = MB // R
         train_info = None
         step = 0
@@ -881,7 +883,7 @@ class AMPAgent(CommonAgent):
     def _amp_streams(self, idx):
         """agent / replay / demo rows of this minibatch as (source, index, remap) — the first amp_minibatch rows
         of the minibatch (learning/ase_agent.py:172-181), this rank's share of them."""
-        R, rk = self.world_size, self.rank
+        R, rk = (self.world_size, self.rank) if self.dp_mode == 'shard' else (1, 0)
         amb = self._amp_minibatch_size
         a = amb // R
         lo = self._mb_pos * self.minibatch_size + rk * a          # position of this rank's amp rows in the permutation

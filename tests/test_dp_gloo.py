@@ -37,6 +37,7 @@ def _worker(rank, world, port, name, out):
     dist.destroy_process_group()
 
 
+@pytest.mark.timeout(300)
 @pytest.mark.parametrize('name', ['ase_tiny', 'amp_tiny', 'ppo_tiny'])
 def test_two_ranks_match_reference_and_single_rank(name, tmp_path):
     G = torch.load(os.path.join(GOLDEN, name + '.pt'), weights_only=False)
@@ -47,3 +48,88 @@ def test_two_ranks_match_reference_and_single_rank(name, tmp_path):
     r = torch.load(out)
     # SUM-of-partials vs one pass: f32 summation order differs, compare at 1e-5 of the weight scale
     assert torch.allclose(r['flat'], ag1.model.a2c_network.flat_params, rtol=1e-5, atol=G['cfg']['learning_rate'] * 0.25)
+
+
+# ------------------------------------------------------------------------------------------------ round 2
+def _free_run(ag, G, epochs=2):
+    """Two updates with EVERYTHING drawn by the agent itself (dataset permutations, ring sample permutations, replay keep
+    masks, diversity latents on the 'device'): only the experience and the demo stream are given."""
+    from tests.test_agent_emu import regenerate
+    regenerate(G)
+    kind = G['kind']
+    if kind != 'ppo':
+        ag.vec_env.q.append(G['demo_init'].clone())
+    infos = []
+    for E in G['epochs'][:epochs]:
+        ag.update_epoch()
+        for k, v in E['exp'].items():
+            if k in ag.experience:
+                ag.experience[k].copy_(v)
+        batch = ag._play_steps_tail()
+        if kind != 'ppo':
+            ag.vec_env.q.append(E['demo_fetched'].clone())
+        infos.append(ag.update(batch))
+    return infos
+
+
+def _worker_free(rank, world, port, name, out, mode):
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    torch.manual_seed(1000 + 17 * rank)                  # the ranks' global torch RNG streams DIFFER on purpose
+    G = torch.load(os.path.join(GOLDEN, name + '.pt'), weights_only=False)
+    ag = make_agent(G, EmuBackend(), world_size=world, rank=rank, seed=5, dp_mode=mode)
+    if rank == 1:
+        # a rank that starts (or restores) with different weights / statistics is overwritten by rank 0's
+        # (rl_games HorovodWrapper.setup_algo: broadcast_parameters + broadcast_optimizer_state)
+        ag.model.a2c_network.flat_params.add_(0.01)
+        ag.engine.obs_state[0] = 3.0
+    ag._sync_initial_state()                             # (a collective: every rank calls it, as in train() / restore())
+    infos = _free_run(ag, G)
+    if mode == 'horovod':
+        ag.curr_frames = ag.batch_size
+        ag.sync_stats()
+    flat = ag.model.a2c_network.flat_params.clone()
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    if rank == 0:
+        torch.save({'flat': flat, 'others': gathered, 'kl': torch.stack([x.float() for x in infos[-1]['kl']]),
+                    'obs_state': ag.engine.obs_state.clone(), 'frames': ag.curr_frames}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('name', ['ase_tiny', 'amp_tiny'])
+def test_two_ranks_draw_like_one_rank(name, tmp_path):
+    """Sharded mode with NOTHING injected: dataset permutations, ring sample permutations, keep masks come from the agents'
+    shared-seed generator, the diversity latents from the counter-based stream indexed by the GLOBAL row - so two ranks
+    (whose global torch RNGs differ) reproduce the one-rank update, and rank 1's deliberately wrong initial weights are
+    replaced by rank 0's."""
+    G = torch.load(os.path.join(GOLDEN, name + '.pt'), weights_only=False)
+    torch.manual_seed(4242)
+    ag1 = make_agent(G, EmuBackend(), seed=5)
+    _free_run(ag1, G)
+    out = str(tmp_path / 'r0.pt')
+    mp.spawn(_worker_free, args=(2, _free_port(), name, out, 'shard'), nprocs=2, join=True)
+    r = torch.load(out)
+    lr = G['cfg']['learning_rate']
+    assert torch.equal(r['others'][0], r['others'][1])                     # replicas identical
+    assert torch.allclose(r['flat'], ag1.model.a2c_network.flat_params, rtol=1e-5, atol=lr * 0.25)
+    assert torch.allclose(r['obs_state'], ag1.engine.obs_state, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.timeout(300)
+def test_horovod_mode_semantics(tmp_path):
+    """The reference's own multi-GPU semantics (rl_games HorovodWrapper): every rank updates on its OWN minibatches with
+    local statistics, gradients are averaged (replicas stay identical), running statistics are averaged per epoch and the
+    frame counters summed (learning/common_agent.py:94-107)."""
+    name = 'amp_tiny'
+    out = str(tmp_path / 'r0.pt')
+    mp.spawn(_worker_free, args=(2, _free_port(), name, out, 'horovod'), nprocs=2, join=True)
+    r = torch.load(out)
+    G = torch.load(os.path.join(GOLDEN, name + '.pt'), weights_only=False)
+    assert torch.equal(r['others'][0], r['others'][1])                     # averaged gradients: identical replicas
+    assert bool(torch.isfinite(r['flat']).all()) and bool(torch.isfinite(r['kl']).all())
+    H, N = G['cfg']['horizon_length'], G['spec']['num_envs']
+    assert r['frames'] == 2 * H * N                                        # summed over the two ranks
