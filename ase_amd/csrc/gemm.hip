@@ -875,6 +875,7 @@ template <typename T, int V, bool SW = false> int launch_nt8(const NTParams& p0,
 //   1: 128 x 128 tile, 4 waves   grids that would leave a 256 x 256 tiling with a ragged round
 //   2: 256 x 256 tile, 8 waves, PHASED (bf16, K in whole 128-byte steps)   192+ tiles in whole rounds
 //   3: 256 x 256 tile, 8 waves, lock-step (the f32 / bf16x3 storage types, or ASE_NT_PHASED=0)
+//   4:  64 x 128 tile, 4 waves / 5: 64 x 64 tile, 4 waves   small grids (M = 2048 ... 4096 rows, or N = 512): two workgroups per CU
 int nt_choice(int M, int N, int K, int es, bool bf16) {
     static int force = -1, phased = 1;
     if (force < 0) {
@@ -886,8 +887,15 @@ int nt_choice(int M, int N, int K, int es, bool bf16) {
     if (N <= 64) return 0;
     const int t256 = ((M + 255) / 256) * ((N + 255) / 256);
     const bool big = (force == 256) || (force == 0 && N % 256 == 0 && t256 >= 192 && (t256 <= 256 || t256 % 256 == 0 || t256 >= 1024));
-    if (!big || force == 128) return 1;
-    return (bf16 && phased && (K * es) % 128 == 0) ? 2 : 3;
+    if (big && force != 128) return (bf16 && phased && (K * es) % 128 == 0) ? 2 : 3;
+    if (force == 128 || (K * es) % 128 != 0) return 1;
+    // grids that do not fill the phased kernel's rounds: the LARGEST of the 128 x 128 / 64 x 128 / 64 x 64 tiles that still
+    // gives two workgroups per CU (measured: 4096 x 1024 x 1024  21.1 -> 17.6 us, 4096 x 512 x 1024  19.3 -> 11.4 us,
+    // 2048 x 1024 x 1024 - one rank's shard at 8 GPUs -  19.3 -> 11.4 us; 16384 x 512 stays on 128 x 128)
+    const int t128 = ((M + 127) / 128) * ((N + 127) / 128), t64x128 = ((M + 63) / 64) * ((N + 127) / 128);
+    if (t128 >= 512) return 1;
+    if (t64x128 >= 512) return 4;
+    return 5;
 }
 
 template <typename T> int dispatch_nt(const NTParams& p, hipStream_t s) {
@@ -908,6 +916,10 @@ template <typename T> int dispatch_nt(const NTParams& p, hipStream_t s) {
             case 15: return launch_nt<T, 2, 2, 2, 2, 64, 4, 2>(p, s);    // 128 x 128, 64-byte rows, 4 stages, 64 KB
             case 16: return launch_nt<T, 2, 2, 2, 2, 64, 3, 3>(p, s);    // 128 x 128, 48 KB => three workgroups per CU
             case 17: return launch_nt<T, 2, 2, 2, 4, 64, 2, 2>(p, s);    // 128 x 256, 4 waves, 2 stages (48 KB => 3 per CU by LDS)
+            case 20: if (k128) return launch_nt<T, 2, 2, 1, 2, 128, 2, 2>(p, s); break;   // 64 x 128 tile (small M: more workgroups)
+            case 21: if (k128) return launch_nt<T, 2, 2, 2, 1, 128, 2, 2>(p, s); break;   // 128 x 64 tile
+            case 22: if (k128) return launch_nt<T, 2, 2, 1, 2, 128, 3, 2>(p, s); break;   // 64 x 128, 3 stages
+            case 23: if (k128) return launch_nt<T, 2, 2, 1, 1, 128, 4, 2>(p, s); break;   // 64 x 64, 128-byte rows, 4 stages
             default: break;
         }
     }
@@ -947,6 +959,8 @@ template <typename T> int dispatch_nt(const NTParams& p, hipStream_t s) {
         case 3:
             if (k128) return launch_nt<T, 4, 2, 2, 4, 128, 2>(p, s);
             return launch_nt<T, 4, 2, 2, 4, 64, 4>(p, s);                 // 64-byte rows, 4-stage ring (128 KB)
+        case 4: return launch_nt<T, 2, 2, 1, 2, 128, 2, 2>(p, s);            // 64 x 128 tile (K in whole 128-byte steps)
+        case 5: return launch_nt<T, 2, 2, 1, 1, 128, 4, 2>(p, s);            // 64 x 64 tile, 128-byte rows, 4 stages
         default:
             if (k128) return launch_nt<T, 2, 2, 2, 2, 128, 2>(p, s);
             return launch_nt<T, 2, 2, 2, 2, 64, 4>(p, s);                 // 64-byte rows, 4-stage ring (64 KB)

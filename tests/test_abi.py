@@ -115,7 +115,10 @@ def test_nt_kernel_choice_is_reported():
     lib = L.load()
     assert lib.ase_hip_gemm_nt_kernel_id(16384, 1024, 1024, L.BF16) == 2      # phased 256 x 256
     assert lib.ase_hip_gemm_nt_kernel_id(16384, 1024, 1024, L.F32) == 3       # lock-step 256 x 256 (exact f32)
-    assert lib.ase_hip_gemm_nt_kernel_id(4096, 512, 1024, L.BF16) == 1        # 128 x 128
+    assert lib.ase_hip_gemm_nt_kernel_id(16384, 512, 1024, L.BF16) == 1       # 128 x 128 (512 workgroups)
+    assert lib.ase_hip_gemm_nt_kernel_id(4096, 1024, 1024, L.BF16) == 4       # 64 x 128: 128 x 128 would give 256 workgroups
+    assert lib.ase_hip_gemm_nt_kernel_id(4096, 512, 1024, L.BF16) == 5        # 64 x 64
+    assert lib.ase_hip_gemm_nt_kernel_id(2048, 1024, 1024, L.BF16) == 5       # one rank's shard at 8 GPUs
     assert lib.ase_hip_gemm_nt_kernel_id(16384, 64, 512, L.BF16) == 0         # narrow head
 
 
