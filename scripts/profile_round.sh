@@ -1,13 +1,14 @@
 #!/bin/bash
 # Round profile of the benchmark command on the GPU box (run through gpurun from the repo root):
-#   kernel-trace summaries (default graph run + a serial run whose per-kernel averages are comparable with bench.py's
+#   kernel-trace summaries (default replay run + a serial eager run whose per-kernel averages are comparable with bench.py's
 #   HIP-event roofline pass) and the PMC passes (one counter group per run, --kernel-trace only).
 # Output: gpurun_out/profile/*.txt  (copy what is to be kept into profiles/).
-OUT=gpurun_out/profile; mkdir -p $OUT
+OUT=gpurun_out/profile; mkdir -p $OUT; rm -f $OUT/pmc_summary.txt
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 R=/tmp/prof_round; rm -rf $R
-rocprofv3 --kernel-trace --stats -d $R/g -o t -- python bench.py --no-cpu-baseline > $OUT/bench_graph.log 2>&1
-python scripts/rocpd_stats.py $R/g/t_results.db 40 > $OUT/kernel_stats_graph.txt
+rocprofv3 --kernel-trace --stats -d $R/g -o t -- python bench.py --no-cpu-baseline > $OUT/bench_replay.log 2>&1
+python scripts/rocpd_stats.py $R/g/t_results.db 40 > $OUT/kernel_stats_replay.txt
+python scripts/rocpd_timeline.py $R/g/t_results.db 60 > $OUT/timeline_replay.txt
 rm -rf $R/g
 SER="python bench.py --no-graph --no-multi-stream --steps 2 --warmup 1 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats -d $R/s -o t -- $SER > $OUT/bench_serial.log 2>&1
@@ -19,9 +20,9 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM
   i=$((i+1))
   rocprofv3 --pmc $c --kernel-trace -d $R/p$i -o t -- $PMC > /dev/null 2>&1
   echo "## $c" >> $OUT/pmc_summary.txt
-  python scripts/pmc_summary.py $R/p$i/t_results.db | head -40 >> $OUT/pmc_summary.txt
+  python scripts/pmc_summary.py $R/p$i/t_results.db | head -44 >> $OUT/pmc_summary.txt
   echo >> $OUT/pmc_summary.txt
   rm -rf $R/p$i
 done
-tail -1 $OUT/bench_graph.log > $OUT/bench_graph.json
-tail -1 $OUT/bench_serial.log > $OUT/bench_serial.json
+grep -h "^{\"metric\"" $OUT/bench_replay.log > $OUT/bench_replay.json
+grep -h "^{\"metric\"" $OUT/bench_serial.log > $OUT/bench_serial.json
