@@ -1244,10 +1244,15 @@ __device__ __forceinline__ bf16x8 tn8_join(const tr_pair& f) {
 
 // 8 MFMAs of one phase (+ 2 for the bias gradient when this wave owns one of the two live A fragments: bias_sel 0 / 1
 // picks it with VALU selects, bvec is all ones or - outside bias_rows - all zeros)
-template <bool BIAS>
+// KIND >= 0: the two DMA pieces of unit KIND (K-tile `tile`) are issued after the first and the third MFMA pair of the
+// block (see nt8_mma_issue: an LDS-DMA costs ~60 issue cycles beside MFMAs, 100-185 in the read half of a phase)
+template <bool BIAS, int KIND>
 __device__ __forceinline__ void tn8_mma(f32x16& c00, f32x16& c01, f32x16& c10, f32x16& c11, f32x16& bacc,
-                                        const tr_pair (&a)[2][2], const tr_pair (&b)[2][2], int bias_sel, bf16x8 bvec) {
+                                        const tr_pair (&a)[2][2], const tr_pair (&b)[2][2], int bias_sel, bf16x8 bvec,
+                                        const TN8Lane& L, char* smem, int tile, bool live) {
     bf16x8 a0[2], a1[2];
+    char* buf = smem + (tile & 1) * 65536;
+    const int64_t koff = (int64_t)tile * L.kstep[(KIND < 0 ? 0 : KIND) & 1];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         a0[ks] = tn8_join(a[0][ks]);
@@ -1255,6 +1260,12 @@ __device__ __forceinline__ void tn8_mma(f32x16& c00, f32x16& c01, f32x16& c10, f
         const bf16x8 b0 = tn8_join(b[0][ks]), b1 = tn8_join(b[1][ks]);
         c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[ks], b0, c00, 0, 0, 0);
         c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ks], b0, c10, 0, 0, 0);
+        if constexpr (KIND >= 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (live)
+                __builtin_amdgcn_global_load_lds((gptr_t*)(L.src[KIND][ks] + koff), (lptr_t*)(buf + L.dst[KIND][ks]), 16, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[ks], b1, c01, 0, 0, 0);
         c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ks], b1, c11, 0, 0, 0);
     }
@@ -1280,8 +1291,9 @@ __device__ __forceinline__ void tn8_half(int t, int nk, const TN8Lane& L, char* 
     constexpr int RO = HALF * 2 * 8192;           // k-steps 2 HALF, 2 HALF + 1
     const int U = 4 * nk;
     const bool live = !TAIL || (HALF == 0 ? t + 1 < nk : t + 2 < nk);
+    const int itile = HALF == 0 ? t + 1 : t + 2;  // K-tile whose units this half issues (B / A of its lo or hi rows)
     tr_pair a[2][2], b[2][2];
-    // ---- even phase: A fragments 0, 1 + both B fragments of this half
+    // ---- even phase: A fragments 0, 1 + both B fragments of this half; its DMA unit goes out inside the MFMA block
     tn8_read<32768 + RO>(b[0][0], adB[0]);
     tn8_read<32768 + RO + 8192>(b[0][1], adB[0]);
     tn8_read<32768 + RO>(b[1][0], adB[1]);
@@ -1290,28 +1302,22 @@ __device__ __forceinline__ void tn8_half(int t, int nk, const TN8Lane& L, char* 
     tn8_read<RO + 8192>(a[0][1], adA[0]);
     tn8_read<RO>(a[1][0], adA[1]);
     tn8_read<RO + 8192>(a[1][1], adA[1]);
-    // (the DMA is issued AFTER the fragment reads, as in the NT kernel)
-    if (live) {
-        if (HALF == 0) tn8_issue<2>(L, smem, t + 1);
-        else tn8_issue<0>(L, smem, t + 2);
-    }
     nt8_sync_in<V>();
-    tn8_mma<BIAS>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], bacc, a, b, bias_frag < 2 ? bias_frag : -1, bvec);
+    tn8_mma<BIAS, HALF == 0 ? 2 : 0>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], bacc, a, b, bias_frag < 2 ? bias_frag : -1,
+                                     bvec, L, smem, itile, live);
     nt8_sync_out<V>();
-    // ---- odd phase: A fragments 2, 3; the wait retires what the next phase reads
+    // ---- odd phase: A fragments 2, 3; the wait retires what the next phase reads (the newest issued unit is the even
+    // phase's: three units may stay in flight)
     tn8_read<RO>(a[0][0], adA[2]);
     tn8_read<RO + 8192>(a[0][1], adA[2]);
     tn8_read<RO>(a[1][0], adA[3]);
     tn8_read<RO + 8192>(a[1][1], adA[3]);
-    if (live) {
-        if (HALF == 0) tn8_issue<3>(L, smem, t + 1);
-        else tn8_issue<1>(L, smem, t + 2);
-    }
-    if (!TAIL) wait_dma_units<4>();
-    else if (HALF == 0) wait_dma_units_rt(min(U, 4 * t + 8) - (4 * t + 4));
-    else if (t + 1 < nk) wait_dma_units_rt(min(U, 4 * t + 10) - (4 * t + 6));
+    if (!TAIL) wait_dma_units<3>();
+    else if (HALF == 0) wait_dma_units_rt(min(U, 4 * t + 7) - (4 * t + 4));
+    else if (t + 1 < nk) wait_dma_units_rt(min(U, 4 * t + 9) - (4 * t + 6));
     nt8_sync_in<V>();
-    tn8_mma<BIAS>(acc[2][0], acc[2][1], acc[3][0], acc[3][1], bacc, a, b, bias_frag >= 2 ? bias_frag - 2 : -1, bvec);
+    tn8_mma<BIAS, HALF == 0 ? 3 : 1>(acc[2][0], acc[2][1], acc[3][0], acc[3][1], bacc, a, b, bias_frag >= 2 ? bias_frag - 2 : -1,
+                                     bvec, L, smem, itile, live);
     nt8_sync_out<V>();
 }
 
