@@ -41,7 +41,8 @@ template <int RB> __device__ __forceinline__ int lds_swz(int r) { return RB == 1
 
 template <> struct Mma<bf16_t> {
     // one staged row = RB/2 k-values = RB/32 steps of 16
-    template <int FM, int FN, int RB>
+    // SW: D = B-fragment x A-fragment (transposed accumulator block: a lane owns one output row, see nt_epilogue_rows)
+    template <int FM, int FN, int RB, bool SW = false>
     static __device__ __forceinline__ void tile(const char* sA, const char* sB, int lane, f32x16 (&acc)[FM][FN]) {
         const int r = lane & 31, h = lane >> 5, sw = lds_swz<RB>(r);
 #pragma unroll
@@ -57,8 +58,10 @@ template <> struct Mma<bf16_t> {
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < FN; ++j) {
+                    if constexpr (SW) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                }
         }
     }
 };
@@ -325,8 +328,60 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x16 (&acc)[FM]
     else nt_epilogue_impl<T, FM, FN, FMC, FNC, 1>(p, acc, slab, lane, mrow0, ncol0);
 }
 
+// ---- row-per-lane epilogue of the lock-step kernels (bf16, swapped MFMA operands): the general FM x FN form of
+// nt8_epilogue_rows further down - see there.  acc[i][j]: lane (r = lane & 31, h = lane >> 5) owns output row i*32 + r
+// and the columns j*32 + 8 g + 4 h + q.  bits[i][j]: the ReLU mask word of (row, 32-column fragment), loaded by the caller.
+template <int FM, int FN, int AUXK>
+__device__ __forceinline__ void nt_epilogue_rows(const NTParams& p, f32x16 (&acc)[FM][FN], int lane, int mrow0, int ncol0,
+                                                 const uint32_t (&bits)[FM][FN]) {
+    if (ncol0 >= p.N) return;                                   // wave-uniform: N is a multiple of the wave tile's width
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        f32x4 bias[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (p.bias) bias[g] = *reinterpret_cast<const f32x4*>(p.bias + ncol0 + j * 32 + 8 * g + 4 * h);
+            else bias[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int m = mrow0 + i * 32 + r;
+            const bool row_ok = m < p.M;
+            char* crow = p.C + (int64_t)m * p.ldc + (int64_t)(ncol0 + j * 32) * 2 + h * 16;
+            uint32_t pk[4][2];
+            uint32_t mb = 0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16_t o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v = p.alpha * acc[i][j][g * 4 + q] + bias[g][q];
+                    if (p.act == ASE_ACT_RELU) v = fmaxf(v, 0.f);
+                    if constexpr (AUXK == 2) v = ((bits[i][j] >> (8 * g + 4 * h + q)) & 1u) ? v : 0.f;
+                    o[q] = (bf16_t)v;
+                    mb |= ((float)o[q] > 0.f ? 1u : 0u) << (8 * g + 4 * h + q);
+                }
+                pk[g][0] = (uint32_t)__builtin_bit_cast(uint16_t, o[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, o[1]) << 16);
+                pk[g][1] = (uint32_t)__builtin_bit_cast(uint16_t, o[2]) | ((uint32_t)__builtin_bit_cast(uint16_t, o[3]) << 16);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                const auto s0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
+                if (row_ok) *reinterpret_cast<uint4*>(crow + 8 * g * 2) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+            }
+            if (p.mask_out) {
+                const auto w = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);   // own 16 bits | the other half-wave's
+                if (row_ok && h == 0) p.mask_out[(int64_t)m * p.ldmask + ((ncol0 + j * 32) >> 5)] = w[0] | w[1];
+            }
+        }
+    }
+}
+
 // WPE = minimum waves per SIMD the register allocation must leave room for (k workgroups of T threads per CU <=> k T / 256)
-template <typename T, int WGM, int WGN, int FM, int FN, int RB, int S, int WPE = 1>
+// SW (bf16): swapped MFMA operands + row-per-lane epilogue (16-byte stores from registers, no LDS slab)
+template <typename T, int WGM, int WGN, int FM, int FN, int RB, int S, int WPE = 1, bool SW = false>
 __global__ __launch_bounds__(WGM * WGN * 64, WPE) void gemm_nt_kernel(NTParams p) {
     constexpr int BM = WGM * FM * 32, BN = WGN * FN * 32;
     constexpr int BK = RB / (int)sizeof(T);
@@ -372,6 +427,24 @@ __global__ __launch_bounds__(WGM * WGN * 64, WPE) void gemm_nt_kernel(NTParams p
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    // row-per-lane epilogue: the wave tile's mask words.  With a 2-stage ring every K-tile waits vmcnt(0), so the words
+    // can be requested up front (they retire with the first K-tile wherever the compiler places the loads); deeper rings
+    // use counted waits and fetch them after the loop.
+    uint32_t row_bits[FM][FN];
+    auto load_bits = [&]() {
+        if (p.aux_mode == ASE_AUX_RELU_BITS && bn0 + wn * FN * 32 < p.N) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int m = min(bm0 + wm * FM * 32 + i * 32 + (lane & 31), p.M - 1);
+                const int ma = (m >= p.aux_split) ? m - p.aux_delta : m;
+                const uint32_t* w = reinterpret_cast<const uint32_t*>(p.aux + (int64_t)ma * p.ldaux) + ((bn0 + wn * FN * 32) >> 5);
+#pragma unroll
+                for (int j = 0; j < FN; ++j) row_bits[i][j] = w[j];
+            }
+        }
+    };
+    if constexpr (SW && S == 2) load_bits();
+
     // S-stage ring of LDS buffers, DMA prefetch distance S-1 tiles, ONE barrier per K-tile:
     //   wait (counted vmcnt: only the newest S-2 tiles may still be in flight) -> barrier (tile kt has landed for
     //   every wave AND every wave is done reading tile kt-1) -> issue the DMA of tile kt+S-1 into the buffer tile
@@ -396,8 +469,15 @@ __global__ __launch_bounds__(WGM * WGN * 64, WPE) void gemm_nt_kernel(NTParams p
         }
         const char* sA = smem + buf * kBuf + (wm * FM * 32) * RB;
         const char* sB = smem + buf * kBuf + (BM + wn * FN * 32) * RB;
-        Mma<T>::template tile<FM, FN, RB>(sA, sB, lane, acc);
+        if constexpr (SW) Mma<T>::template tile<FM, FN, RB, true>(sA, sB, lane, acc);
+        else Mma<T>::template tile<FM, FN, RB>(sA, sB, lane, acc);
         buf = (buf + 1 == S) ? 0 : buf + 1;
+    }
+    if constexpr (SW) {
+        if constexpr (S != 2) load_bits();
+        if (p.aux_mode == ASE_AUX_RELU_BITS) nt_epilogue_rows<FM, FN, 2>(p, acc, lane, bm0 + wm * FM * 32, bn0 + wn * FN * 32, row_bits);
+        else nt_epilogue_rows<FM, FN, 0>(p, acc, lane, bm0 + wm * FM * 32, bn0 + wn * FN * 32, row_bits);
+        return;
     }
     __syncthreads();                                   // everyone is done with the ring before it becomes the epilogue slab
 
@@ -406,7 +486,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, WPE) void gemm_nt_kernel(NTParams p
     nt_epilogue<T, FM, FN, FM, FNC>(p, acc, slab, lane, bm0 + wm * FM * 32, bn0 + wn * FN * 32);
 }
 
-template <typename T, int WGM, int WGN, int FM, int FN, int RB, int S, int WPE = 1>
+template <typename T, int WGM, int WGN, int FM, int FN, int RB, int S, int WPE = 1, bool SW = false>
 int launch_nt(const NTParams& p0, hipStream_t stream) {
     constexpr int BM = WGM * FM * 32, BN = WGN * FN * 32;
     constexpr int ring = S * (BM + BN) * RB;
@@ -414,7 +494,7 @@ int launch_nt(const NTParams& p0, hipStream_t stream) {
     constexpr int lds = ring > slab ? ring : slab;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
-    auto kern = gemm_nt_kernel<T, WGM, WGN, FM, FN, RB, S, WPE>;
+    auto kern = gemm_nt_kernel<T, WGM, WGN, FM, FN, RB, S, WPE, SW>;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -898,6 +978,18 @@ int nt_choice(int M, int N, int K, int es, bool bf16) {
     return 5;
 }
 
+// row-per-lane epilogue (swapped MFMA operands): bf16 output in whole wave-tile column blocks, no column sums, no tanh,
+// mask operand absent or a bit matrix; ASE_NT_ROWS=0 keeps the LDS-slab epilogue (A/B switch)
+static bool rows_epi(const NTParams& p, int wave_cols) {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("ASE_NT_ROWS");
+        on = e ? atoi(e) : 1;
+    }
+    return on && !p.out_f32 && p.N % wave_cols == 0 && p.colsum == nullptr && p.act != ASE_ACT_TANH &&
+           (p.aux_mode == ASE_AUX_NONE || p.aux_mode == ASE_AUX_RELU_BITS);
+}
+
 template <typename T> int dispatch_nt(const NTParams& p, hipStream_t s) {
     const bool k128 = (p.K * (int)sizeof(T)) % 128 == 0;       // 128-byte staged rows need K in whole 128-byte steps
     if constexpr (sizeof(T) == 2) {
@@ -959,9 +1051,14 @@ template <typename T> int dispatch_nt(const NTParams& p, hipStream_t s) {
         case 3:
             if (k128) return launch_nt<T, 4, 2, 2, 4, 128, 2>(p, s);
             return launch_nt<T, 4, 2, 2, 4, 64, 4>(p, s);                 // 64-byte rows, 4-stage ring (128 KB)
-        case 4: return launch_nt<T, 2, 2, 1, 2, 128, 2, 2>(p, s);            // 64 x 128 tile (K in whole 128-byte steps)
-        case 5: return launch_nt<T, 2, 2, 1, 1, 128, 4, 2>(p, s);            // 64 x 64 tile, 128-byte rows, 4 stages
+        case 4:
+            if constexpr (sizeof(T) == 2) if (rows_epi(p, 64)) return launch_nt<T, 2, 2, 1, 2, 128, 2, 2, true>(p, s);
+            return launch_nt<T, 2, 2, 1, 2, 128, 2, 2>(p, s);            // 64 x 128 tile (K in whole 128-byte steps)
+        case 5:
+            if constexpr (sizeof(T) == 2) if (rows_epi(p, 32)) return launch_nt<T, 2, 2, 1, 1, 128, 4, 2, true>(p, s);
+            return launch_nt<T, 2, 2, 1, 1, 128, 4, 2>(p, s);            // 64 x 64 tile, 128-byte rows, 4 stages
         default:
+            if constexpr (sizeof(T) == 2) if (k128 && rows_epi(p, 64)) return launch_nt<T, 2, 2, 2, 2, 128, 2, 1, true>(p, s);
             if (k128) return launch_nt<T, 2, 2, 2, 2, 128, 2>(p, s);
             return launch_nt<T, 2, 2, 2, 2, 64, 4>(p, s);                 // 64-byte rows, 4-stage ring (64 KB)
     }
