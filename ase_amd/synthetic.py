@@ -180,7 +180,7 @@ class SyntheticVecEnv:
         if len(ids) > 0:
             self._obs[ids.to(self.device)] = self.obs_fs.draw(len(ids), self.gen).to(self.device)
             self.progress_buf[ids.to(self.device)] = 0
-        return {'obs': self._obs.clone()}
+        return self._obs.clone()          # a bare tensor, as RLGPUEnv.reset without global observations (ase/run.py:115-133)
 
     def step(self, actions):
         n = self.num_envs
@@ -194,4 +194,4 @@ class SyntheticVecEnv:
         if self.amp_fs is not None:
             infos['amp_obs'] = self.amp_fs.draw(n, self.gen).to(self.device)
         rewards = torch.ones(n, device=self.device)                       # humanoid.py:638-642: task reward == 1
-        return {'obs': self._obs.clone()}, rewards, dones.to(torch.uint8).to(self.device), infos
+        return self._obs.clone(), rewards, dones.to(torch.uint8).to(self.device), infos

@@ -76,5 +76,27 @@ class A2CBase:
         return state
 
 
+def rescale_actions(low, high, action):
+    """rl_games.algos_torch.players / a2c_common.rescale_actions (1.1.4)"""
+    d = (high - low) / 2.0
+    m = (high + low) / 2.0
+    return action * d + m
+
+
 class ContinuousA2CBase(A2CBase):
-    pass
+    def preprocess_actions(self, actions):
+        """rl_games ContinuousA2CBase.preprocess_actions (1.1.4): clamp to [-1, 1] and scale to the action space."""
+        import torch
+        if self.clip_actions:
+            rescaled_actions = rescale_actions(self.actions_low, self.actions_high, torch.clamp(actions, -1.0, 1.0))
+        else:
+            rescaled_actions = actions
+        if not self.is_tensor_obses:
+            rescaled_actions = rescaled_actions.cpu().numpy()
+        return rescaled_actions
+
+    def obs_to_tensors(self, obs):
+        """rl_games A2CBase.obs_to_tensors for tensor observations: wrap a bare tensor as {'obs': tensor}."""
+        if isinstance(obs, dict):
+            return {k: v for k, v in obs.items()}
+        return {'obs': obs}

@@ -145,7 +145,7 @@ def test_player_restores_agent_checkpoint(kind, golden_dir, tmp_path):
     assert torch.equal(pl.engine.obs_state, ag.engine.obs_state)
     if kind != 'ppo':
         assert torch.equal(pl.engine.amp_state, ag.engine.amp_state)
-    obs = penv.reset()['obs']
+    obs = penv.reset()
     z = None
     if kind == 'ase':
         pl._reset_latents()
@@ -215,7 +215,7 @@ def test_hrl_env_step_with_frozen_llc(golden_dir, tmp_path):
         mu, _ = L.model.a2c_network.eval_actor(obs=proc, ase_latents=z)
         llc_action = agents.rescale_actions(L.actions_low, L.actions_high, torch.clamp(mu, -1.0, 1.0))
         o, r, d, info = twin.step(llc_action)
-        obs = o['obs']
+        obs = o
         rew = rew + r
         dcount = dcount + d.float()
         tcount = tcount + info['terminate'].float()
@@ -253,3 +253,38 @@ def test_hrl_train_and_player(golden_dir, tmp_path):
     assert torch.equal(pl.model.a2c_network.flat_params, ag.model.a2c_network.flat_params)
     pl.run()
     assert pl.games_played >= 2
+
+
+def test_hrl_env_step_matches_reference_golden(golden_dir):
+    """tests/golden/hrl_step.pt was recorded from the REFERENCE'S OWN HRLAgent.env_step / _compute_llc_action /
+    _calc_disc_reward (learning/hrl_agent.py:45-82,231-249, oracle/make_golden_hrl.py) over a frozen reference ASE agent on
+    the seeded synthetic environment: same LLC weights and running statistics, same environment seed, same high-level
+    actions -> the same low-level actions reach the environment, the same rewards / dones / terminate / discriminator
+    rewards come back."""
+    G = torch.load(os.path.join(golden_dir, 'hrl_step.pt'), weights_only=False)
+    sp, L, Hc = G['spec'], G['llc'], G['hlc']
+    spec = EnvSpec(num_envs=sp['num_envs'], horizon=Hc['cfg']['horizon_length'], obs_size=sp['obs_size'], act_size=sp['act_size'],
+                   amp_obs_size=sp['amp_obs_size'], latent_dim=L['cfg']['latent_dim'], episode_length=G['episode_length'])
+    env = SyntheticVecEnv(spec, seed=G['env_seed'], task_obs_size=sp['task'], device=_DEV)
+    llc_ckpt = {'model': L['sd'], 'running_mean_std': L['running_mean_std'], 'amp_input_mean_std': L['amp_input_mean_std'],
+                'reward_mean_std': L['reward_mean_std'], 'epoch': 0, 'frame': 0,
+                'optimizer': {'state': {}, 'param_groups': [{'lr': L['cfg']['learning_rate']}]}}
+    b = BUILDERS['ppo']()
+    b.load(Hc['net'])
+    cfg = dict(Hc['cfg'])
+    cfg.update(network=models.ModelHRLContinuous(b), num_actors=spec.num_envs, device=_DEV, backend=_BE(), precision='f32',
+               vec_env=env, print_stats=False, env_info={'observation_space': env.observation_space, 'action_space': env.action_space},
+               llc_config={'params': {'network': L['net'], 'config': dict(L['cfg'])}}, llc_checkpoint=llc_ckpt,
+               llc_steps=G['llc_steps'])
+    ag = agents.HRLAgent('hrl', cfg)
+    ag.obs = ag.env_reset()
+    assert torch.equal(ag.obs['obs'].cpu(), G['obs0'])
+    actions = G['actions'].to(_DEV)
+    a0 = ag._compute_llc_action(ag.obs['obs'], ag.preprocess_actions(actions))
+    assert torch.allclose(a0.cpu(), G['llc_action0'], rtol=1e-4, atol=2e-5)
+    obs1, rewards, dones, infos = ag.env_step(actions)
+    assert torch.allclose(env.last_actions.cpu(), G['env_last_actions'], rtol=1e-4, atol=2e-5)
+    assert torch.equal(obs1['obs'].cpu(), G['obs1'])
+    assert torch.allclose(rewards.cpu(), G['rewards']) and torch.equal(dones.cpu().float(), G['dones'].float())
+    assert torch.equal(infos['terminate'].cpu().float(), G['terminate'].float())
+    assert torch.allclose(infos['disc_rewards'].cpu(), G['disc_rewards'], rtol=1e-4, atol=2e-5)

@@ -38,3 +38,7 @@ def test_hrl_env_step_gpu(golden_dir, tmp_path):
 
 def test_hrl_train_and_player_gpu(golden_dir, tmp_path):
     T.test_hrl_train_and_player(golden_dir, tmp_path)
+
+
+def test_hrl_env_step_matches_reference_golden_gpu(golden_dir):
+    T.test_hrl_env_step_matches_reference_golden(golden_dir)
