@@ -272,10 +272,15 @@ def cpu_baseline_and_parity(agent, cfg, steps=8, mode='bf16'):
                 if p.requires_grad:
                     grad_rel[k] = float((grads_g[k].double() - p.grad.double()).norm() / p.grad.double().norm().clamp_min(1e-30))
             wk = max(grad_rel, key=grad_rel.get)
-            wl = max(loss_rel, key=loss_rel.get)
+            # counting statistics (fractions of samples on one side of a threshold) move in steps of 1/rows whenever a
+            # near-threshold sample flips: reported separately from the continuous loss scalars
+            counts = ('actor_clip_frac', 'disc_agent_acc', 'disc_demo_acc')
+            wl = max((k for k in loss_rel if k not in counts), key=loss_rel.get)
+            wc = max(counts, key=loss_rel.get)
             parity = {'mode': mode, 'what': f'first oracle step (minibatch {MB}, amp {AMB}) re-run by the GPU engine on identical '
                                             'inputs, no optimizer step; reference = oracle/restated.py in f32 on the host',
                       'max_loss_rel': float(f'{loss_rel[wl]:.3e}'), 'max_loss_rel_scalar': wl,
+                      'max_count_stat_rel': float(f'{loss_rel[wc]:.3e}'), 'max_count_stat': wc,
                       'loss_rel': {k: float(f'{v:.2e}') for k, v in loss_rel.items()},
                       'worst_grad_rel_l2': float(f'{grad_rel[wk]:.3e}'), 'worst_grad_tensor': wk,
                       'median_grad_rel_l2': float(f'{sorted(grad_rel.values())[len(grad_rel) // 2]:.3e}')}

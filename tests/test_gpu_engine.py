@@ -221,11 +221,13 @@ def test_self_consistent_parity_config2():
     """BASELINE config 2 at full size in the self-consistent setting of real training: the rollout's mu / neglogp / values come
     from the engine's OWN inference path in the same precision, one update runs, then one optimisation step (minibatch 16384,
     amp 4096) is executed by the GPU engine and by the f32 CPU oracle on identical inputs (bench.py's parity measurement).
-    Documented bounds: bf16 - every loss scalar within 2e-3 of the oracle relative to its scale (measured
-    1e-4 ... 9e-4: the importance-ratio error cancels when old and new log-probabilities share the arithmetic), gradient
-    tensors within 40 % relative L2 (cancelling advantage-weighted sums, median 7-18 %); f32 - 1e-4 on every loss scalar."""
+    Documented bounds: bf16 - every continuous loss scalar within 2e-3 of the oracle relative to its scale
+    (measured 1e-4 ... 9e-4: the importance-ratio error cancels when old and new log-probabilities share the arithmetic),
+    the counting statistics (accuracies, clip fraction: a few near-threshold samples of 8192 / 16384 flip) within 1e-2,
+    gradient tensors within 40 % relative L2 (cancelling advantage-weighted sums, median 7-18 %); f32 - 1e-4 on every
+    loss scalar, counting statistics within 1e-3."""
     import bench
-    for mode, loss_tol, grad_tol in (('bf16', 2e-3, 0.4), ('f32', 1e-4, 2e-3)):
+    for mode, loss_tol, count_tol, grad_tol in (('bf16', 2e-3, 1e-2, 0.4), ('f32', 1e-4, 1e-3, 2e-3)):
         agent, cfg, spec = bench.make_agent('cuda:0', mode, False, 1, 0)
         with torch.no_grad():
             agent.set_eval()
@@ -239,6 +241,7 @@ def test_self_consistent_parity_config2():
         _, p = bench.cpu_baseline_and_parity(agent, cfg, steps=1, mode=mode)
         print(mode, p['max_loss_rel'], p['max_loss_rel_scalar'], p['worst_grad_rel_l2'], p['worst_grad_tensor'])
         assert p['max_loss_rel'] <= loss_tol, p
+        assert p['max_count_stat_rel'] <= count_tol, p
         assert p['worst_grad_rel_l2'] <= grad_tol, p
         del agent
         torch.cuda.empty_cache()
