@@ -1008,6 +1008,9 @@ template <typename T> int dispatch_nt(const NTParams& p, hipStream_t s) {
             case 15: return launch_nt<T, 2, 2, 2, 2, 64, 4, 2>(p, s);    // 128 x 128, 64-byte rows, 4 stages, 64 KB
             case 16: return launch_nt<T, 2, 2, 2, 2, 64, 3, 3>(p, s);    // 128 x 128, 48 KB => three workgroups per CU
             case 17: return launch_nt<T, 2, 2, 2, 4, 64, 2, 2>(p, s);    // 128 x 256, 4 waves, 2 stages (48 KB => 3 per CU by LDS)
+            case 30: if (k128 && rows_epi(p, 128)) return launch_nt<T, 2, 2, 4, 4, 128, 2, 1, true>(p, s); break;   // 256 x 256, FOUR waves (128 x 128 each, one per SIMD)
+            case 31: if (k128) return launch_nt<T, 2, 2, 4, 4, 128, 2, 1>(p, s); break;
+            case 32: if (k128 && rows_epi(p, 64)) return launch_nt<T, 2, 2, 4, 2, 128, 3, 1, true>(p, s); break;   // 256 x 128, four waves, 3-stage ring (144 KB)
             case 20: if (k128) return launch_nt<T, 2, 2, 1, 2, 128, 2, 2>(p, s); break;   // 64 x 128 tile (small M: more workgroups)
             case 21: if (k128) return launch_nt<T, 2, 2, 2, 1, 128, 2, 2>(p, s); break;   // 128 x 64 tile
             case 22: if (k128) return launch_nt<T, 2, 2, 1, 2, 128, 3, 2>(p, s); break;   // 64 x 128, 3 stages

@@ -102,9 +102,10 @@ class UpdateEngine:
         self._tn_defer = bool(getattr(backend, 'grouped_tn_ok', None)) and os.environ.get('ASE_TN_GROUPED', '1') != '0'
         self._tn_queue, self._tn_plans = [], {}          # weight gradients queued by the CURRENT branch (see _flush_tn)
         self._tn_wg_side = int(os.environ.get('ASE_TN_WG_SIDE', '64'))
-        # policy weight gradients as soon as the actor's data-gradient chain is through (beside the style-MLP tail) or as the
-        # last launch of the step
-        self._tn_early = os.environ.get('ASE_TN_EARLY', '1') != '0'
+        # policy weight gradients as soon as the actor's data-gradient chain is through (beside the style-MLP tail,
+        # ASE_TN_EARLY=1) or as the last launch of the step (default: ONE policy launch that also holds the style MLP's and
+        # the heads' narrow gradients - measured 70.4 ms either way, 96 instead of 432 weight-gradient launches per update)
+        self._tn_early = os.environ.get('ASE_TN_EARLY', '0') != '0'
         self._apply_groups = None
         self._use_bits = os.environ.get('ASE_RELU_BITS', '1') != '0'
         self._fused_apply = hasattr(backend, 'apply_multi') and os.environ.get('ASE_FUSED_APPLY', '1') != '0'

@@ -95,7 +95,8 @@ static int run_grouped(int reps) {
                             {16384, 1024, 1408}, {16384, 1024, 1024}, {16384, 512, 1024},     // discriminator (4 x 4096 rows)
                             {32768, 512, 64}, {32768, 256, 512}, {32768, 64, 256},            // style MLP
                             {32768, 32, 512}, {16384, 8, 512}, {16384, 72, 512}};             // heads (padded widths)
-    const int P = sizeof(shapes) / sizeof(shapes[0]), S = 24;
+    // LAB_TNG_N: how many of the shapes take part (9 = the wide layers only, 11 = + the two mid-size style-MLP layers, 15 = all)
+    const int P = getenv("LAB_TNG_N") ? atoi(getenv("LAB_TNG_N")) : (int)(sizeof(shapes) / sizeof(shapes[0])), S = 24;
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<bf16_t*> A(P), B(P); std::vector<float*> G(P), gb(P);

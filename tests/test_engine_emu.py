@@ -66,16 +66,19 @@ def test_first_step_f32_emulated(name, golden_dir):
     check_first_step(G, net, eng, rtol=2e-5, gtol=2e-4, wtol=lr * 0.05)
 
 
+@pytest.mark.parametrize('early', [False, True])
 @pytest.mark.parametrize('name', CASES)
-def test_deferred_weight_gradients(name, golden_dir):
+def test_deferred_weight_gradients(name, early, golden_dir, monkeypatch):
     """The grouped weight-gradient launches (all layers of a branch queued during its backward, ONE launch per branch
     group - discriminator | policy - at the end of the branch) read nothing the data-gradient chain overwrites: same
     golden result with every layer deferred."""
     G = torch.load(os.path.join(golden_dir, name + '.pt'), weights_only=False)
+    monkeypatch.setenv('ASE_TN_EARLY', '1' if early else '0')
     be = EmuBackend(group_all=True)
     net, eng = first_step(G, be, torch.float32)
-    # discriminator branch | actor + critic (beside the style-MLP backward) | what the style MLP queued after that
-    assert be.grouped_launches == {'ppo': 1, 'amp': 2, 'ase': 3}[G['kind']] and not eng._tn_queue
+    # discriminator branch | actor + critic + style MLP as the last launch of the step; with ASE_TN_EARLY the actor +
+    # critic layers go beside the style-MLP backward and what the style MLP queued after that is a third launch
+    assert be.grouped_launches == {'ppo': 1, 'amp': 2, 'ase': 3 if early else 2}[G['kind']] and not eng._tn_queue
     lr = G['cfg']['learning_rate']
     check_first_step(G, net, eng, rtol=2e-5, gtol=2e-4, wtol=lr * 0.05)
 
