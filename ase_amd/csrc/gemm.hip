@@ -950,6 +950,332 @@ template <typename T, int V, bool SW = false> int launch_nt8(const NTParams& p0,
     return ASE_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// NT, 256 x 256 tile as FOUR waves (bf16): one wave per SIMD, wave tile 128 x 128 = 4 x 4 blocks of 32 x 32 in 256
+// accumulator registers.  Why: with eight waves of 128 x 64 the fragment reads of one K-tile are 192 KB per CU and the
+// DMA writes 64 KB - at 128 B/clk that is as long as the K-tile's MFMAs themselves (2048 clk), so LDS and matrix pipe
+// have to overlap perfectly; with 128 x 128 wave tiles the reads are 128 KB (75 % of the MFMA time together with the
+// DMA).  One wave per SIMD has no partner to hide behind, so the overlap is inside the wave: every phase is
+//     counted vmcnt | s_barrier | 16 MFMAs with 8 ds_read_b128 (the NEXT phase's new fragment set) and the 4
+//     global_load_lds of one 16-KiB unit issued between them | lgkmcnt(0)
+// The K-tile image, the swizzle and the DMA units (A0, B0, B1, A1 = the two 64-row halves of every wave's A / B rows, in
+// order of first use) are those of the phased 8-wave kernel; 4 phases per K-tile walk the quadrants
+//     q0: A01 x B01   q1: A01 x B23   q2: A23 x B23   q3: A23 x B01
+// and read  q0: B23(t)  q1: A23(t)  q2: A01(t+1)  q3: B01(t+1)  - 8 reads per phase, every set read once per K-tile
+// (32 KB per wave and K-tile).  B01(t+1) lands in the registers B23(t) just left, so the two B buffers swap roles every
+// K-tile (the caller alternates them).  Unit u is read in phase u - 2; phase p issues unit p + 8 into the ring slot of
+// unit p (read in phase p - 2, complete before this phase's barrier: every phase ends with lgkmcnt(0)); at the top of
+// phase p unit p + 2 must have landed: five units (80 KB) stay in flight.
+// MEASURED (scripts/lab/run_r2k.sh .. r2m.sh): correct on every shape tried, main loop 25.2 us on the 16384 x 1024 x 1024
+// layer (the 8-wave kernel: 25.4), 8192^3 1143-1156 us (8-wave: 951; rocBLAS on the same random operands: 781).  Ablations
+// at 8192^3: no DMA 765, no reads 1107-1133, neither 527-533 - here the fragment reads DO hide (+35 us) but an LDS-DMA
+// instruction stalls the issuing wave ~175 cycles while four waves issue at once (~44 cycles of texture-path time per
+// 1-KiB piece) and a lone wave has no partner to feed the matrix pipe meanwhile; the chunk swizzle of the source
+// addresses is not the reason (linear sources: 1126).  Kept as a lab variant (ASE_NT_VARIANT=40 / 41), not dispatched.
+// The fragment reads are inline asm (behind the builtin hipcc drains the DMA queue in front of every LDS read that
+// follows a global_load_lds); the lgkmcnt(0) that retires them names the fragment registers as operands, so no MFMA
+// that uses them can move in front of it.
+// ------------------------------------------------------------------------------------------------
+struct NT4Lane {
+    const char* src[4][4];     // per-lane DMA source of unit kind (A0, B0, B1, A1) x piece, at K-tile 0
+    int dst[4][4];             // wave-uniform LDS byte offset of the piece inside a K-tile buffer
+    uint32_t adA[4], adB[4];   // per-lane LDS byte address (K-tile buffer 0) of the wave's A / B fragment rows, per k-step
+};
+
+template <int OFF> __device__ __forceinline__ void nt4_read1(i32x4& f, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(addr), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void nt4_retire(i32x4 (&f)[2][4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[0][2]), "+v"(f[0][3]), "+v"(f[1][0]), "+v"(f[1][1]), "+v"(f[1][2]),
+                   "+v"(f[1][3])
+                 :
+                 : "memory");
+}
+__device__ __forceinline__ void wait_vmcnt_rt4(int n) {             // wave-uniform, n = 4 x units (+ 8 mask pieces)
+    switch (n >> 2) {
+        case 0: wait_vmcnt<0>(); break;
+        case 1: wait_vmcnt<4>(); break;
+        case 2: wait_vmcnt<8>(); break;
+        case 3: wait_vmcnt<12>(); break;
+        case 4: wait_vmcnt<16>(); break;
+        case 5: wait_vmcnt<20>(); break;
+        case 6: wait_vmcnt<24>(); break;
+        case 7: wait_vmcnt<28>(); break;
+        case 8: wait_vmcnt<32>(); break;
+        default: wait_vmcnt<36>(); break;
+    }
+}
+
+// issue pattern of a phase: which of the 16 slots (one behind every MFMA) holds fragment read 0..7 / DMA piece 0..3.
+//   PAT 0: reads in slots 0-7, DMA in 8-11;  PAT 1: two reads, one DMA, ... over slots 0-11;  PAT 2: PAT 1 one slot later
+//   (odd waves under V & 2: the four waves of a workgroup do not all hit LDS / the texture path in the same cycle)
+__device__ constexpr int nt4_rd_index(int pat, int n) {
+    if (pat == 0) return n < 8 ? n : -1;
+    const int m = n - (pat - 1);
+    if (m < 0 || m >= 12 || m % 3 == 2) return -1;
+    return (m / 3) * 2 + (m % 3);
+}
+__device__ constexpr int nt4_dma_index(int pat, int n) {
+    if (pat == 0) return (n >= 8 && n < 12) ? n - 8 : -1;
+    const int m = n - (pat - 1);
+    if (m < 0 || m >= 12 || m % 3 != 2) return -1;
+    return m / 3;
+}
+
+// one phase: c{ij} += a[i] x b[j] over the 4 k-steps.  SUB: the fragment set read for the next phase = 64-row half SUB
+// (0 / 1) of the wave's A or B rows, at LDS addresses rd[ks]; KIND: the DMA unit issued (K-tile `itile`).
+template <int SUB, int KIND, int V, int PAT>
+__device__ __forceinline__ void nt4_phase(f32x16& c00, f32x16& c10, f32x16& c01, f32x16& c11, const i32x4 (&a)[2][4],
+                                          const i32x4 (&b)[2][4], i32x4 (&nx)[2][4], const uint32_t (&rd)[4], bool rd_live,
+                                          const NT4Lane& L, char* smem, int itile, bool dma_live) {
+    constexpr bool DM = !(V & 4), RD = !(V & 8), MM = !(V & 16);
+    char* buf = smem + (itile & 1) * 65536;
+    const int64_t koff = (int64_t)itile * 128;
+    auto slot = [&](int n) {
+        __builtin_amdgcn_sched_barrier(0);
+        const int ri = nt4_rd_index(PAT, n), di = nt4_dma_index(PAT, n);
+        if (ri >= 0) {
+            if (RD && rd_live) {
+                const int ks = ri & 3;
+                if (ri < 4) {
+                    if (ks == 0) nt4_read1<SUB * 8192>(nx[0][0], rd[0]);
+                    else if (ks == 1) nt4_read1<SUB * 8192>(nx[0][1], rd[1]);
+                    else if (ks == 2) nt4_read1<SUB * 8192>(nx[0][2], rd[2]);
+                    else nt4_read1<SUB * 8192>(nx[0][3], rd[3]);
+                } else {
+                    if (ks == 0) nt4_read1<SUB * 8192 + 4096>(nx[1][0], rd[0]);
+                    else if (ks == 1) nt4_read1<SUB * 8192 + 4096>(nx[1][1], rd[1]);
+                    else if (ks == 2) nt4_read1<SUB * 8192 + 4096>(nx[1][2], rd[2]);
+                    else nt4_read1<SUB * 8192 + 4096>(nx[1][3], rd[3]);
+                }
+            }
+        } else if (di >= 0) {
+            if (DM && dma_live)
+                __builtin_amdgcn_global_load_lds((gptr_t*)(L.src[KIND][di] + koff), (lptr_t*)(buf + L.dst[KIND][di]), 16, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if constexpr (!MM) {
+        asm volatile("" : "+v"(c00), "+v"(c10), "+v"(c01), "+v"(c11) : "v"(a[0][0]), "v"(a[1][3]), "v"(b[0][1]), "v"(b[1][2]));
+#pragma unroll
+        for (int n = 0; n < 16; ++n) slot(n);
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 b0 = __builtin_bit_cast(bf16x8, b[0][ks]), b1 = __builtin_bit_cast(bf16x8, b[1][ks]);
+            c00 = nt8_mfma<true>(a[0][ks], b0, c00);
+            slot(4 * ks + 0);
+            c10 = nt8_mfma<true>(a[1][ks], b0, c10);
+            slot(4 * ks + 1);
+            c01 = nt8_mfma<true>(a[0][ks], b1, c01);
+            slot(4 * ks + 2);
+            c11 = nt8_mfma<true>(a[1][ks], b1, c11);
+            slot(4 * ks + 3);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (RD && rd_live) nt4_retire(nx);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// top of phase p: unit p + 2 has landed for every wave.  RT = false: all units up to p + 7 exist and the mask pieces (if
+// any) are older than everything that may stay in flight.
+template <bool RT>
+__device__ __forceinline__ void nt4_top(int p, int U, int maskn) {
+    if constexpr (!RT) {
+        wait_vmcnt<20>();
+        NT8_BARRIER();
+    } else {
+        if (p + 2 < U) {
+            // in flight behind unit p + 2: units p + 3 .. min(U - 1, p + 7); the mask pieces sit between units 7 and 8
+            wait_vmcnt_rt4(4 * (min(U - 1, p + 7) - (p + 2)) + (p + 2 <= 7 ? maskn : 0));
+            NT8_BARRIER();
+        }
+    }
+}
+
+// one K-tile.  On entry X = A01(t), Bp = B01(t) are in registers; on exit X = A01(t + 1), Bq = B01(t + 1).
+template <bool RT, int V, int PAT>
+__device__ __forceinline__ void nt4_ktile(int t, int nk, int maskn, const NT4Lane& L, char* smem, f32x16 (&acc)[4][4],
+                                          i32x4 (&X)[2][4], i32x4 (&Y)[2][4], i32x4 (&Bp)[2][4], i32x4 (&Bq)[2][4]) {
+    const int U = 4 * nk, p = 4 * t;
+    const uint32_t cur = (t & 1) * 65536, nxt = 65536 - cur;
+    const bool more = !RT || t + 1 < nk, dma = !RT || t + 2 < nk;
+    uint32_t ra[4], rb[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        ra[ks] = L.adA[ks] + cur;
+        rb[ks] = L.adB[ks] + cur;
+    }
+    nt4_top<RT>(p, U, maskn);
+    nt4_phase<1, 0, V, PAT>(acc[0][0], acc[1][0], acc[0][1], acc[1][1], X, Bp, Bq, rb, true, L, smem, t + 2, dma);    // reads B23(t)
+    nt4_top<RT>(p + 1, U, maskn);
+    nt4_phase<1, 1, V, PAT>(acc[0][2], acc[1][2], acc[0][3], acc[1][3], X, Bq, Y, ra, true, L, smem, t + 2, dma);     // reads A23(t)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        ra[ks] = L.adA[ks] + nxt;
+        rb[ks] = L.adB[ks] + nxt;
+    }
+    nt4_top<RT>(p + 2, U, maskn);
+    nt4_phase<0, 2, V, PAT>(acc[2][2], acc[3][2], acc[2][3], acc[3][3], Y, Bq, X, ra, more, L, smem, t + 2, dma);     // reads A01(t + 1)
+    nt4_top<RT>(p + 3, U, maskn);
+    nt4_phase<0, 3, V, PAT>(acc[2][0], acc[3][0], acc[2][1], acc[3][1], Y, Bp, Bq, rb, more, L, smem, t + 2, dma);    // reads B01(t + 1)
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void gemm_nt4_kernel(NTParams p) {
+    static_assert(sizeof(T) == 2, "bf16 only");
+    constexpr int RB = 128, BM = 256, BK = 64;
+    constexpr int kBuf = 512 * RB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int tile = xcd_remap(blockIdx.x, nwg);
+    const int bm0 = (tile / p.tiles_n) * BM, bn0 = (tile % p.tiles_n) * 256;
+
+    if (p.prof && tid == 0) p.prof[blockIdx.x * 4 + 0] = wall_clock64();
+    NT4Lane L;
+    {
+        const int lr = lane >> 3, slot = lane & 7;
+#pragma unroll
+        for (int kind = 0; kind < 4; ++kind) {
+            const bool isB = (kind == 1 || kind == 2);
+            const int sub = (kind >= 2) ? 64 : 0;                       // A0, B0: rows 0-63 of every wave's half; B1, A1: 64-127
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r0 = (g >> 1) * 128 + sub + (g & 1) * 32 + wid * 8;
+                const int r = r0 + lr;
+                const int64_t grow = isB ? min(bn0 + r, p.N - 1) : min(bm0 + r, p.M - 1);
+                L.src[kind][g] = (isB ? p.B + grow * p.ldb : p.A + grow * p.lda) + ((slot ^ lds_swz<RB>(r)) << 4);
+                L.dst[kind][g] = (isB ? BM * RB : 0) + r0 * RB;
+            }
+        }
+        const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+        const int r = lane & 31, h = lane >> 5, sw = lds_swz<RB>(r);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const uint32_t ro = r * RB + (((ks * 2 + h) ^ sw) << 4);
+            L.adA[ks] = lds0 + wr * 128 * RB + ro;
+            L.adB[ks] = lds0 + BM * RB + wc * 128 * RB + ro;
+        }
+    }
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = p.K / BK, U = 4 * nk;
+    // prologue: the whole ring (units 0..7), then the mask words of the wave tile (128 rows x 4 words) as eight 4-byte
+    // DMA pieces into 2 KiB of LDS per wave past the ring
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        if (u < U) {
+            char* buf = smem + (u >> 2) * kBuf;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                __builtin_amdgcn_global_load_lds((gptr_t*)(L.src[u & 3][g] + (int64_t)(u >> 2) * 128), (lptr_t*)(buf + L.dst[u & 3][g]), 16, 0, 0);
+        }
+    }
+    const bool mask_dma = p.aux_mode == ASE_AUX_RELU_BITS && bn0 + wc * 128 < p.N;
+    if (mask_dma) {
+        char* mlds = smem + 2 * kBuf + wid * 2048;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = bm0 + wr * 128 + i * 32 + (lane & 31);
+            const int ma = (m >= p.aux_split) ? m - p.aux_delta : m;
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(p.aux + (int64_t)min(ma, p.M - 1) * p.ldaux) +
+                                ((bn0 + wc * 128) >> 5) + (lane >> 5);
+            __builtin_amdgcn_global_load_lds((gptr_t*)w, (lptr_t*)(mlds + (i * 2) * 256), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t*)(w + 2), (lptr_t*)(mlds + (i * 2 + 1) * 256), 4, 0, 0);
+        }
+    }
+    const int maskn = mask_dma ? 8 : 0;
+    // units 0, 1 (A0 / B0 of K-tile 0) have landed -> X = A01(0), P = B01(0)
+    wait_vmcnt_rt4(4 * (min(U, 8) - 2) + maskn);
+    NT8_BARRIER();
+    if (p.prof && tid == 0) p.prof[blockIdx.x * 4 + 1] = wall_clock64();
+    i32x4 X[2][4], Y[2][4], P[2][4], Q[2][4];
+    {
+        constexpr bool RD = !(V & 8);
+        if constexpr (RD) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                nt4_read1<0>(X[0][ks], L.adA[ks]);
+                nt4_read1<4096>(X[1][ks], L.adA[ks]);
+                nt4_read1<0>(P[0][ks], L.adB[ks]);
+                nt4_read1<4096>(P[1][ks], L.adB[ks]);
+            }
+            nt4_retire(X);
+            nt4_retire(P);
+        }
+    }
+    auto loop = [&](auto pat) {
+        constexpr int PAT = decltype(pat)::value;
+        nt4_ktile<true, V, PAT>(0, nk, maskn, L, smem, acc, X, Y, P, Q);
+        int t = 1;
+        for (; t + 3 < nk; t += 2) {
+            nt4_ktile<false, V, PAT>(t, nk, 0, L, smem, acc, X, Y, Q, P);
+            nt4_ktile<false, V, PAT>(t + 1, nk, 0, L, smem, acc, X, Y, P, Q);
+        }
+        for (; t < nk; t += 2) {                     // t is odd here: B01(t) sits in Q
+            nt4_ktile<true, V, PAT>(t, nk, maskn, L, smem, acc, X, Y, Q, P);
+            if (t + 1 < nk) nt4_ktile<true, V, PAT>(t + 1, nk, maskn, L, smem, acc, X, Y, P, Q);
+        }
+    };
+    if constexpr (V & 2) {
+        if (wid & 1) loop(std::integral_constant<int, 2>{});
+        else loop(std::integral_constant<int, 1>{});
+    } else loop(std::integral_constant<int, (V & 1)>{});
+    if (p.prof && tid == 0) p.prof[blockIdx.x * 4 + 2] = wall_clock64();
+    if ((V & 32) && p.alpha != 12345.f) return;      // ablation: no epilogue
+    uint32_t row_bits[4][4];
+    if (mask_dma) {
+        wait_vmcnt<0>();
+        const uint32_t* mw = reinterpret_cast<const uint32_t*>(smem + 2 * kBuf + wid * 2048);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) row_bits[i][j] = mw[(i * 2 + (j >> 1)) * 64 + (j & 1) * 32 + (lane & 31)];
+        nt_epilogue_rows<4, 4, 2>(p, acc, lane, bm0 + wr * 128, bn0 + wc * 128, row_bits);
+    } else
+        nt_epilogue_rows<4, 4, 0>(p, acc, lane, bm0 + wr * 128, bn0 + wc * 128, row_bits);
+    if (p.prof) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) p.prof[blockIdx.x * 4 + 3] = wall_clock64();
+    }
+}
+
+template <typename T, int V> int launch_nt4(const NTParams& p0, hipStream_t stream) {
+    constexpr int lds = 2 * 512 * 128 + 4 * 2048;
+    static bool attr_done = false;
+    auto kern = gemm_nt4_kernel<T, V>;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            ase_set_error("gemm_nt4: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return ASE_ELAUNCH;
+        }
+        attr_done = true;
+    }
+    NTParams p = p0;
+    p.prof = g_nt_prof;
+    p.tiles_m = (p.M + 255) / 256;
+    p.tiles_n = (p.N + 255) / 256;
+    ASE_LAUNCH(kern, dim3(p.tiles_m * p.tiles_n), dim3(256), lds, stream, p);
+    ASE_CHECK_LAUNCH("gemm_nt4");
+    return ASE_OK;
+}
+
 // Kernel choice of an NT launch (also reported by ase_hip_gemm_nt_kernel_id):
 //   0:  64 x  64 tile, 4 waves   narrow heads (N <= 64): more workgroups
 //   1: 128 x 128 tile, 4 waves   grids that would leave a 256 x 256 tiling with a ragged round
@@ -1011,6 +1337,9 @@ template <typename T> int dispatch_nt(const NTParams& p, hipStream_t s) {
             case 30: if (k128 && rows_epi(p, 128)) return launch_nt<T, 2, 2, 4, 4, 128, 2, 1, true>(p, s); break;   // 256 x 256, FOUR waves (128 x 128 each, one per SIMD)
             case 31: if (k128) return launch_nt<T, 2, 2, 4, 4, 128, 2, 1>(p, s); break;
             case 32: if (k128 && rows_epi(p, 64)) return launch_nt<T, 2, 2, 4, 2, 128, 3, 1, true>(p, s); break;   // 256 x 128, four waves, 3-stage ring (144 KB)
+            case 40: case 41:                                                           // 256 x 256, FOUR waves, pipelined inside the wave (lab)
+                if (k128 && rows_epi(p, 128)) return variant == 40 ? launch_nt4<T, 0>(p, s) : launch_nt4<T, 1>(p, s);
+                break;
             case 20: if (k128) return launch_nt<T, 2, 2, 1, 2, 128, 2, 2>(p, s); break;   // 64 x 128 tile (small M: more workgroups)
             case 21: if (k128) return launch_nt<T, 2, 2, 2, 1, 128, 2, 2>(p, s); break;   // 128 x 64 tile
             case 22: if (k128) return launch_nt<T, 2, 2, 1, 2, 128, 3, 2>(p, s); break;   // 64 x 128, 3 stages
