@@ -145,9 +145,11 @@ class SyntheticVecEnv:
     (obs, rewards, dones, infos{'terminate', 'amp_obs'}), ``task.progress_buf / num_envs / get_task_obs_size()``,
     ``fetch_amp_obs_demo(n)`` - with seeded random observations of the right shapes: the dynamics are not the
     point, the data path is.  ``env`` is the object itself (the reference reaches through ``vec_env.env``).
-    task_obs_size > 0 appends task observations (the HRL tasks' goal features) to the character observation."""
+    task_obs_size > 0 appends task observations (the HRL tasks' goal features) to the character observation.
+    demo_source: an ``ase_amd.motion_lib.AmpObsDemoSource`` - the demo observations then come from motion clips through the
+    device pipeline (HumanoidAMP.fetch_amp_obs_demo, humanoid_amp.py:63-84) instead of the seeded random stream."""
 
-    def __init__(self, spec, seed=0, device='cpu', task_obs_size=0):
+    def __init__(self, spec, seed=0, device='cpu', task_obs_size=0, demo_source=None):
         self.spec, self.device = spec, torch.device(device)
         self.gen = torch.Generator().manual_seed(seed)
         self.task_obs_size = task_obs_size
@@ -165,11 +167,16 @@ class SyntheticVecEnv:
         self._obs = self.obs_fs.draw(n, self.gen).to(self.device)
         self.last_actions = None
         self.steps = 0
+        self.demo_source = demo_source
+        if demo_source is not None:
+            assert demo_source.get_num_amp_obs() == spec.amp_obs_size, "demo source and env disagree on the AMP observation size"
 
     def get_task_obs_size(self):
         return self.task_obs_size
 
     def fetch_amp_obs_demo(self, n):
+        if self.demo_source is not None:
+            return self.demo_source.fetch_amp_obs_demo(n)
         return self.amp_fs.draw(n, self.gen, mean=0.3).to(self.device)
 
     def reset(self, env_ids=None):

@@ -450,3 +450,21 @@ class EmuBackend:
             z2[:rows, :dim] = z[:rows, :dim].to(z2.dtype)
         if advance:
             rng_state[1] += 1
+
+    # ---- N2 (demo-side AMP observations): the oracle restatements stand in for the two kernels
+    def motion_state(self, clips, motion_ids, times):
+        from oracle import amp_obs as A
+        c = dict(clips)
+        for k in ('num_frames', 'length_starts'):
+            c[k] = clips[k].long()
+        return A.motion_state(c, motion_ids.long(), times)
+
+    def build_amp_obs(self, root_pos, root_rot, root_vel, root_ang_vel, dof_pos, dof_vel, key_body_pos, dof_offsets,
+                      local_root_obs, root_height_obs, hist, shift=True):
+        from oracle import amp_obs as A
+        frame = A.build_amp_observations(root_pos, root_rot, root_vel, root_ang_vel, dof_pos, dof_vel, key_body_pos,
+                                         local_root_obs, root_height_obs, dof_offsets)
+        if shift:
+            A.push_history(hist, frame)
+        else:
+            hist[:, 0] = frame

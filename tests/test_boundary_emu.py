@@ -288,3 +288,59 @@ def test_hrl_env_step_matches_reference_golden(golden_dir):
     assert torch.allclose(rewards.cpu(), G['rewards']) and torch.equal(dones.cpu().float(), G['dones'].float())
     assert torch.equal(infos['terminate'].cpu().float(), G['terminate'].float())
     assert torch.allclose(infos['disc_rewards'].cpu(), G['disc_rewards'], rtol=1e-4, atol=2e-5)
+
+
+# ------------------------------------------------------------------------------------------------ N2: demo AMP observations
+def _demo_source(be, dev, local_root, root_h, golden_dir, generator=None):
+    from ase_amd.motion_lib import AmpObsDemoSource, DeviceMotionLib
+    M = torch.load(os.path.join(golden_dir, 'motion_state.pt'), weights_only=False)
+    G = torch.load(os.path.join(golden_dir, 'amp_obs_demo.pt'), weights_only=False)
+    ml = DeviceMotionLib.from_arrays(M['clips'], be, dev, weights=G['weights'], generator=generator)
+    src = AmpObsDemoSource(ml, be, num_amp_obs_steps=G['steps'], dt=G['dt'], local_root_obs=local_root, root_height_obs=root_h)
+    return ml, src, G
+
+
+@pytest.mark.parametrize('local_root,root_h', [(True, True), (False, False)])
+def test_fetch_amp_obs_demo_matches_reference(local_root, root_h, golden_dir):
+    """DeviceMotionLib.sample_motions / sample_time + AmpObsDemoSource.fetch_amp_obs_demo against the
+    reference's HumanoidAMP.fetch_amp_obs_demo (humanoid_amp.py:63-105; golden = the reference's own methods over its own
+    MotionLib on two shipped clips).  On the host generator (CPU run) the sampler draws the same motions and times as the
+    reference under the same torch seed and the whole fetch is compared; on the GPU the draws come from the device generator,
+    so the observations are compared at the golden's (motion, time) pairs and the fetch is checked for shape and range."""
+    ml, src, G = _demo_source(_BE(), _DEV, local_root, root_h, golden_dir)
+    case = G['cases'][(local_root, root_h)]
+    n, S, dt = G['n'], G['steps'], G['dt']
+    assert ml.num_motions() == 2 and src.get_num_amp_obs() == 1400
+    ids_g, t0_g = case['motion_ids'].to(_DEV), case['motion_times0'].to(_DEV)
+    want = case['amp_obs_demo']
+    if _DEV == 'cpu':
+        torch.manual_seed(G['seed'])
+        ids = ml.sample_motions(n)
+        t0 = ml.sample_time(ids, truncate_time=dt * (S - 1)) + dt * (S - 1)
+        assert torch.equal(ids, case['motion_ids'])
+        assert torch.allclose(t0, case['motion_times0'], rtol=0, atol=1e-6)
+        torch.manual_seed(G['seed'])
+        out = src.fetch_amp_obs_demo(n)
+        assert torch.allclose(out, want, rtol=1e-5, atol=1e-5)
+    # the observations at the reference's samples (interpolated rotations go through acos / sin on both sides: 1e-4 on device)
+    obs = src.build_amp_obs_demo(ids_g, t0_g)
+    assert obs.shape == (n, S, 140)
+    assert torch.allclose(obs.reshape(n, -1).cpu(), want, rtol=1e-4, atol=1e-4)
+    # newest frame first: slot k of a sample is the state k * dt before the sampled time
+    first = obs[:3, 1].clone()
+    late = src.build_amp_obs_demo(ids_g[:3], t0_g[:3] - dt)
+    assert torch.allclose(late[:, 0], first, atol=1e-4)
+    # a fresh fetch: right shape, finite, times inside [truncate, clip length], both clips drawn with the stated weights
+    big = 4096
+    ids = ml.sample_motions(big)
+    t0 = ml.sample_time(ids, truncate_time=dt * (S - 1)) + dt * (S - 1)
+    lens = ml.get_motion_length(ids)
+    assert bool((t0 >= dt * (S - 1) - 1e-6).all()) and bool((t0 <= lens + 1e-6).all())
+    frac1 = float((ids == 1).float().mean())
+    assert abs(frac1 - float(G['weights'][1])) < 0.05
+    out = src.fetch_amp_obs_demo(big)
+    assert out.shape == (big, 1400) and bool(torch.isfinite(out).all())
+    # the env hook the agents call (amp_agent.py:498-500 -> vec_env.env.fetch_amp_obs_demo)
+    from ase_amd.synthetic import EnvSpec, SyntheticVecEnv
+    env = SyntheticVecEnv(EnvSpec(num_envs=8, horizon=2), device=_DEV, demo_source=src)
+    assert env.fetch_amp_obs_demo(16).shape == (16, 1400)

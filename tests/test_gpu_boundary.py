@@ -42,3 +42,8 @@ def test_hrl_train_and_player_gpu(golden_dir, tmp_path):
 
 def test_hrl_env_step_matches_reference_golden_gpu(golden_dir):
     T.test_hrl_env_step_matches_reference_golden(golden_dir)
+
+
+@pytest.mark.parametrize('local_root,root_h', [(True, True), (False, False)])
+def test_fetch_amp_obs_demo_gpu(local_root, root_h, golden_dir):
+    T.test_fetch_amp_obs_demo_matches_reference(local_root, root_h, golden_dir)
