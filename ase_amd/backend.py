@@ -277,6 +277,18 @@ class HipBackend:
                                           _ptr(enc_out), _ptr(acc), amb, amb_global, z_dim, float(enc_coef),
                                           _code(d_e.dtype), self._stream()), "enc_head")
 
+    def enc_gp_seed(self, e, z, u, rows, z_dim, scale=1.0):
+        """u[:rows, :z_dim] = scale * d enc_err / d e (learning/ase_agent.py:431-434; e f32 pre-normalisation output)."""
+        assert e.dtype == torch.float32 and z.dtype == torch.float32
+        L.check(self.lib.ase_hip_enc_gp_seed(_ptr(e), _ld(e), _ptr(z), _ld(z), _ptr(u), _ld(u), rows, z_dim, float(scale),
+                                             _code(u.dtype), self._stream()), "enc_gp_seed")
+
+    def enc_gp_back(self, e, z, du, d_e, db_enc, rows, z_dim):
+        """d_e[:rows, :z_dim] += (d u / d e) du, the bias gradient follows the stored values."""
+        assert e.dtype == torch.float32 and z.dtype == torch.float32 and du.dtype == torch.float32
+        L.check(self.lib.ase_hip_enc_gp_back(_ptr(e), _ld(e), _ptr(z), _ld(z), _ptr(du), _ld(du), _ptr(d_e), _ld(d_e),
+                                             _ptr(db_enc), rows, z_dim, _code(d_e.dtype), self._stream()), "enc_gp_back")
+
     def gp_seed(self, h, w, g, rows, width, scale=1.0):
         L.check(self.lib.ase_hip_gp_seed(_ptr(h), _ld(h), _ptr(w), _ptr(g), _ld(g), rows, width, float(scale), _code(h.dtype),
                                          self._stream()), "gp_seed")
@@ -292,7 +304,7 @@ class HipBackend:
             float(c['critic_coef']), float(c['entropy_coef']), float(c.get('bounds_loss_coef') or 0.0), float(c.get('disc_coef', 0)),
             float(c.get('disc_logit_reg', 0)), float(c.get('disc_grad_penalty', 0)), float(c.get('disc_weight_decay', 0)),
             float(c.get('enc_coef', 0)), float(c.get('enc_weight_decay', 0)), float(c.get('amp_diversity_bonus', 0)),
-            self._stream()), "finalize_scalars")
+            float(c.get('enc_grad_penalty', 0)), self._stream()), "finalize_scalars")
 
     # ------------------------------------------------------------------ optimizer
     def begin_step(self, opt_state, acc, zero2=None, rng_bump=None):

@@ -288,6 +288,67 @@ __global__ __launch_bounds__(256) void enc_head_kernel(const float* __restrict__
     if (threadIdx.x == 0) atomic_add_f64(acc + ASE_ACC_ENC, part[0]);
 }
 
+// Encoder gradient penalty (learning/ase_agent.py:431-441), seed and return of the chain.  Per row, with n = |e|,
+// eh = e / n, a = eh . z, the error is err = -a and
+//   u = d err / d e = -(z - eh a) / n                                   (seed of the chain W_e^T u -> ... -> d err / d x)
+//   J = d u / d e  (symmetric):  J r = [z (eh . r) + eh (z . r) + a r - 3 a eh (eh . r)] / n^2
+// MODE 0: u_out = scale * u.   MODE 1: d_e += J du (du = what the chain's backward returns at u), the bias gradient
+// receives the change of the STORED d_e (db == column sums of what is stored).  One wave per row, z_dim <= 128.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void enc_gp_kernel(const float* __restrict__ e, int64_t ld_e, const float* __restrict__ z,
+                                                     int64_t ld_z, const float* __restrict__ du, int64_t ld_du,
+                                                     T* __restrict__ out, int64_t ld_out, float* __restrict__ db_enc,
+                                                     int rows, int z_dim, float scale) {
+    __shared__ float sdb[4][128];
+    float dbv[2] = {0.f, 0.f};
+    const int lane = threadIdx.x & 63;
+    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += gridDim.x * 4) {
+        float ev[2] = {0.f, 0.f}, zv[2] = {0.f, 0.f}, dv[2] = {0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int j = lane + 64 * q;
+            if (j < z_dim) {
+                ev[q] = e[(int64_t)r * ld_e + j];
+                zv[q] = z[(int64_t)r * ld_z + j];
+                if (MODE == 1) dv[q] = du[(int64_t)r * ld_du + j];
+            }
+        }
+        const float nrm = fmaxf(sqrtf(wave_sum(ev[0] * ev[0] + ev[1] * ev[1])), 1e-12f);
+        const float h0 = ev[0] / nrm, h1 = ev[1] / nrm;
+        const float a = wave_sum(h0 * zv[0] + h1 * zv[1]);
+        float hr = 0.f, zr = 0.f;
+        if (MODE == 1) {
+            hr = wave_sum(h0 * dv[0] + h1 * dv[1]);
+            zr = wave_sum(zv[0] * dv[0] + zv[1] * dv[1]);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int j = lane + 64 * q;
+            if (j < z_dim) {
+                const float h = q ? h1 : h0;
+                if (MODE == 0) {
+                    out[(int64_t)r * ld_out + j] = from_f32<T>(-scale * (zv[q] - h * a) / nrm);
+                } else {
+                    const float jr = (zv[q] * hr + h * zr + a * dv[q] - 3.f * a * h * hr) / (nrm * nrm);
+                    const float old = to_f32(out[(int64_t)r * ld_out + j]);
+                    const T nw = from_f32<T>(old + jr);
+                    out[(int64_t)r * ld_out + j] = nw;
+                    dbv[q] += to_f32(nw) - old;
+                }
+            }
+        }
+    }
+    if (MODE == 1 && db_enc) {
+        sdb[threadIdx.x >> 6][lane] = dbv[0];
+        sdb[threadIdx.x >> 6][lane + 64] = dbv[1];
+        __syncthreads();
+        if (threadIdx.x < z_dim) {
+            const float t = sdb[0][threadIdx.x] + sdb[1][threadIdx.x] + sdb[2][threadIdx.x] + sdb[3][threadIdx.x];
+            atomic_add_f32(db_enc + threadIdx.x, t);
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gp_seed_kernel(const T* __restrict__ h, int64_t ld_h, const float* __restrict__ w,
                                                       T* __restrict__ g, int64_t ld_g, int rows, int width, float scale) {
@@ -333,7 +394,7 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const T* __restrict__ x, in
 struct FinArgs {
     int m_global, amb_global, masked, has_disc, has_enc, has_div;
     float critic_coef, entropy_coef, bounds_coef, disc_coef, disc_logit_reg, disc_grad_penalty, disc_weight_decay,
-        enc_coef, enc_weight_decay, div_coef;
+        enc_coef, enc_weight_decay, div_coef, enc_grad_penalty;
 };
 
 __global__ void finalize_scalars_kernel(const double* __restrict__ acc, float* __restrict__ out, FinArgs a) {
@@ -366,9 +427,12 @@ __global__ void finalize_scalars_kernel(const double* __restrict__ acc, float* _
         out[ASE_RES_DISC_DEMO_ACC] = (float)(acc[ASE_ACC_DEMO_ACC] / amb);
     }
     if (a.has_enc) {
-        const double el = acc[ASE_ACC_ENC] / (double)a.amb_global + a.enc_weight_decay * acc[ASE_ACC_ENC_W2];
+        const double egp = acc[ASE_ACC_ENC_GP] / (double)a.amb_global;
+        const double el = acc[ASE_ACC_ENC] / (double)a.amb_global + a.enc_weight_decay * acc[ASE_ACC_ENC_W2] +
+                          a.enc_grad_penalty * egp;
         loss += a.enc_coef * el;
         out[ASE_RES_ENC_LOSS] = (float)el;
+        out[ASE_RES_ENC_GP] = (float)egp;
     }
     if (a.has_div) {
         const double dv = acc[ASE_ACC_DIV] / S;
@@ -463,6 +527,38 @@ extern "C" int ase_hip_enc_head(const float* e, int64_t ld_e, const float* z, in
     return ASE_OK;
 }
 
+extern "C" int ase_hip_enc_gp_seed(const float* e, int64_t ld_e, const float* z, int64_t ld_z, void* u, int64_t ld_u, int rows,
+                                   int z_dim, float scale, int dtype, void* stream) {
+    ASE_CHECK_ARG(e && z && u && rows > 0, "enc_gp_seed: null/empty operand");
+    ASE_CHECK_ARG(z_dim >= 1 && z_dim <= 128, "enc_gp_seed: z_dim %d not in [1,128]", z_dim);
+    const dim3 grid(min((rows + 3) / 4, 1024));
+    if (dtype == ASE_BF16)
+        ASE_LAUNCH((enc_gp_kernel<bf16_t, 0>), grid, dim3(256), 0, (hipStream_t)stream, e, ld_e, z, ld_z, (const float*)nullptr,
+                   (int64_t)0, (bf16_t*)u, ld_u, (float*)nullptr, rows, z_dim, scale);
+    else if (dtype == ASE_F32)
+        ASE_LAUNCH((enc_gp_kernel<float, 0>), grid, dim3(256), 0, (hipStream_t)stream, e, ld_e, z, ld_z, (const float*)nullptr,
+                   (int64_t)0, (float*)u, ld_u, (float*)nullptr, rows, z_dim, scale);
+    else ASE_CHECK_ARG(false, "enc_gp_seed: bad dtype %d", dtype);
+    ASE_CHECK_LAUNCH("enc_gp_seed");
+    return ASE_OK;
+}
+
+extern "C" int ase_hip_enc_gp_back(const float* e, int64_t ld_e, const float* z, int64_t ld_z, const float* du, int64_t ld_du,
+                                   void* d_e, int64_t ld_de, float* db_enc, int rows, int z_dim, int dtype, void* stream) {
+    ASE_CHECK_ARG(e && z && du && d_e && rows > 0, "enc_gp_back: null/empty operand");
+    ASE_CHECK_ARG(z_dim >= 1 && z_dim <= 128, "enc_gp_back: z_dim %d not in [1,128]", z_dim);
+    const dim3 grid(min((rows + 3) / 4, 128));          // <= 128 workgroups on the bias-gradient atomics (see enc_head)
+    if (dtype == ASE_BF16)
+        ASE_LAUNCH((enc_gp_kernel<bf16_t, 1>), grid, dim3(256), 0, (hipStream_t)stream, e, ld_e, z, ld_z, du, ld_du, (bf16_t*)d_e,
+                   ld_de, db_enc, rows, z_dim, 1.f);
+    else if (dtype == ASE_F32)
+        ASE_LAUNCH((enc_gp_kernel<float, 1>), grid, dim3(256), 0, (hipStream_t)stream, e, ld_e, z, ld_z, du, ld_du, (float*)d_e,
+                   ld_de, db_enc, rows, z_dim, 1.f);
+    else ASE_CHECK_ARG(false, "enc_gp_back: bad dtype %d", dtype);
+    ASE_CHECK_LAUNCH("enc_gp_back");
+    return ASE_OK;
+}
+
 extern "C" int ase_hip_gp_seed(const void* h, int64_t ld_h, const float* w, void* g, int64_t ld_g, int rows, int width,
                                float scale, int dtype, void* stream) {
     ASE_CHECK_ARG(h && w && g && rows > 0 && width > 0, "gp_seed: null/empty operand");
@@ -499,14 +595,14 @@ extern "C" int ase_hip_finalize_scalars(const double* acc, float* out, int m_glo
                                         int has_disc, int has_enc, int has_div, float critic_coef, float entropy_coef,
                                         float bounds_coef, float disc_coef, float disc_logit_reg,
                                         float disc_grad_penalty, float disc_weight_decay, float enc_coef,
-                                        float enc_weight_decay, float div_coef, void* stream) {
+                                        float enc_weight_decay, float div_coef, float enc_grad_penalty, void* stream) {
     ASE_CHECK_ARG(acc && out && m_global > 0, "finalize_scalars: null/empty operand");
     FinArgs a;
     a.m_global = m_global; a.amb_global = amb_global; a.masked = masked; a.has_disc = has_disc; a.has_enc = has_enc;
     a.has_div = has_div; a.critic_coef = critic_coef; a.entropy_coef = entropy_coef; a.bounds_coef = bounds_coef;
     a.disc_coef = disc_coef; a.disc_logit_reg = disc_logit_reg; a.disc_grad_penalty = disc_grad_penalty;
     a.disc_weight_decay = disc_weight_decay; a.enc_coef = enc_coef; a.enc_weight_decay = enc_weight_decay;
-    a.div_coef = div_coef;
+    a.div_coef = div_coef; a.enc_grad_penalty = enc_grad_penalty;
     ASE_LAUNCH(finalize_scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, acc, out, a);
     ASE_CHECK_LAUNCH("finalize_scalars");
     return ASE_OK;

@@ -94,7 +94,7 @@ class UpdateEngine:
         self.has_enc = kind == 'ase'
         self.div_on = kind == 'ase' and cfg.get('amp_diversity_bonus', 0) != 0
         self.enc_sep = bool(getattr(net, 'enc_separate', False))
-        assert cfg.get('enc_grad_penalty', 0) == 0, "enc_grad_penalty: not on the default path (SURVEY §8f N4)"
+        self.enc_gp = kind == 'ase' and cfg.get('enc_grad_penalty', 0) != 0 and cfg.get('enc_coef', 0) != 0
         self.mu_tanh = kind == 'ppo' and getattr(net, 'mu_tanh', False)
         self._scratch = {}
         self.multi_stream = bool(cfg.get('multi_stream', True)) and getattr(backend, 'name', '') == 'hip'
@@ -270,6 +270,15 @@ class UpdateEngine:
                 self.dE = zt(AMB, self.enc_head.n_pad)
             if self.has_enc:
                 self.enc_z = zt(AMB, self.z, f32)     # latents of the amp rows (first amp_minibatch rows of the GLOBAL minibatch)
+            if self.enc_gp:
+                # encoder gradient penalty (ase_agent.py:431-441): the chain over the AGENT rows, one buffer per stage
+                ech = self.enc_chain if self.enc_chain else self.disc
+                ehead = self.enc_head if self.enc_chain else self.disc_head
+                self.Ue = zt(AMB, ehead.n_pad)                           # s * d err / d e (the other head columns stay 0)
+                self.Re = [zt(AMB, d.n_pad) for d in ech]                # s * r_l
+                self.Ge = zt(AMB, ech[0].k_pad)                          # s * d err / d x
+                self.Qe = [zt(AMB, d.n_pad) for d in ech]                # s * (backward of the chain), masked
+                self.DUe = zt(AMB, ehead.n_pad, f32)                     # what the backward returns at u
             self.amp_mean = zt(3, self.amp, f32)
             self.amp_std = zt(3, self.amp, f32)
             self.amp_state = torch.zeros(2 * self.amp + 1, dtype=torch.float64, device=dev)
@@ -665,6 +674,8 @@ class UpdateEngine:
                         off = self.disc_head.parts[1][2]
                         be.enc_head(self.HD[:AMB, off:], self.enc_z, self.dHD[:AMB, off:], self.disc_head.gb[1], None,
                                     self.acc, AMB, amb_den, self.z, c['enc_coef'])
+                if self.enc_gp:
+                    self._enc_grad_penalty(he if self.enc_chain else hd[:AMB])
                 self._wgrad(self.disc_head, self.dHD, hd, Rd)
                 last = self.disc[-1]
                 self._dgrad(self.disc_head, self.dHD, self.dZd[-1], Rd, self.Hd[-1], last.act)
@@ -766,6 +777,63 @@ class UpdateEngine:
                 self.refresh_shadows()
         be.finalize_scalars(self.acc, self.res, self.Mg if self.shard else self.M, self.AMBg if self.shard else self.AMB,
                             self.masked, self.has_disc, self.has_enc, self.div_on, c)
+
+    def _enc_grad_penalty(self, h_top):
+        """Encoder gradient penalty  c * mean_rows |d err / d x|^2,  err = -<normalize(e), z>  (learning/ase_agent.py:431-441,
+        a double backward in the reference), x = the normalised AMP observation of the agent rows, c = enc_coef *
+        enc_grad_penalty.  With ReLU layers h_l = relu(W_l h_{l-1} + b_l), e = W_e h_L + b_e and masks m_l = [h_l > 0]:
+            u = d err / d e                       (per row: ase_hip_enc_gp_seed)
+            r_L = m_L * (W_e^T u),  r_{l-1} = m_{l-1} * (W_l^T r_l),  g = W_1^T r_1 = d err / d x     (data-gradient launches)
+            penalty = sum |g|^2 / AMB
+        and its gradient, with dg = (2 c / AMB) g  (masks are constants almost everywhere):
+            q_1 = m_1 * (W_1 dg),  q_l = m_l * (W_l q_{l-1}),  du = W_e q_L                          (forward-shaped launches)
+            gW_1 += r_1^T dg,  gW_l += r_l^T q_{l-1},  gW_e += u^T q_L                               (weight-gradient launches)
+            d_e += (d u / d e) du          (per row: ase_hip_enc_gp_back; from there the ordinary backward carries it,
+                                            including the bias gradients)
+        Everything is carried scaled by s = sqrt(2 c / AMB) so that the weight-gradient launches need alpha = 1.  Runs on the
+        agent rows only (AMB): with the shared trunk the layers are the discriminator's and u sits in the encoder columns of
+        the joint head (logit column 0), with enc.separate the encoder's own chain."""
+        be, c, AMB = self.be, self.cfg, self.AMB
+        sep = bool(self.enc_chain)
+        chain = self.enc_chain if sep else self.disc
+        head = self.enc_head if sep else self.disc_head
+        H = self.He if sep else [h[:AMB] for h in self.Hd]
+        X0 = self.Xd[:AMB]
+        for d in chain:
+            assert d.act == L.ACT_RELU, "analytic gradient penalty needs ReLU encoder layers"
+        if sep:
+            e, d_e, db, off = self.E, self.dE, self.enc_head.gb[0], 0
+        else:
+            off = self.disc_head.parts[1][2]
+            e, d_e, db = self.HD[:AMB, off:], self.dHD[:AMB, off:], self.disc_head.gb[1]
+        cg = c['enc_coef'] * c['enc_grad_penalty'] * 2.0 / (self.AMBg if self.shard else self.AMB)
+        s = math.sqrt(cg)
+        nl = len(chain)
+        be.enc_gp_seed(e, self.enc_z, self.Ue[:, off:], AMB, self.z, scale=s)
+        # the chain: a second data-gradient pass seeded with u
+        self._dgrad(head, self.Ue, self.Re[-1], AMB, H[-1], chain[-1].act)
+        for l in range(nl - 1, 0, -1):
+            self._dgrad(chain[l], self.Re[l], self.Re[l - 1], AMB, H[l - 1], chain[l - 1].act)
+        d0 = chain[0]
+        be.gemm_nt(self.Re[0], d0.Wts, self.Ge, AMB, d0.k_pad, d0.n_pad)                  # s * g
+        be.sqnorm(self.Ge, AMB, d0.k_pad, self.acc, L.ACC_ENC_GP, scale=1.0 / cg)
+        # its backward: forward-shaped launches without bias, masked by the same activations
+        x = self.Ge
+        for l in range(nl):
+            d = chain[l]
+            aux, mode = self._aux(H[l], L.AUX_RELU_MASK)
+            be.gemm_nt(x, d.Ws, self.Qe[l], AMB, d.n_pad, d.k_pad, aux=aux, aux_mode=mode)
+            x = self.Qe[l]
+        be.gemm_nt(x, head.Ws, self.DUe, AMB, head.n_pad, head.k_pad, alpha=s)            # du (unscaled)
+        # weight gradients (no bias terms: the chain has none)
+        for l in range(nl):
+            d = chain[l]
+            self._tn(self.Re[l], self.Ge if l == 0 else self.Qe[l - 1], d.gW[0], AMB, d.n_pad, d.k_pad, d.N, d.K,
+                     d.split_src, d.split_dst)
+        for (name, nr, poff), gW in zip(head.parts, head.gW):
+            if sep or poff == off:
+                self._tn(self.Ue[:, poff:], self.Qe[-1], gW, AMB, P(nr), head.k_pad, nr, head.K, head.split_src, head.split_dst)
+        be.enc_gp_back(e, self.enc_z, self.DUe[:, off:], d_e, db, AMB, self.z)
 
     def _disc_backward(self):
         """Discriminator trunk backward with the gradient penalty riding on the same launches.
@@ -871,6 +939,8 @@ class UpdateEngine:
                         'disc_demo_logit': logit[2 * AMB:]})
         if self.has_enc:
             out['enc_loss'] = r[L.RES_ENC_LOSS]
+            if self.enc_gp:
+                out['enc_grad_penalty'] = r[L.RES_ENC_GP]
         if self.div_on:
             out['amp_diversity_loss'] = r[L.RES_DIV_LOSS]
         return out

@@ -996,6 +996,8 @@ class ASEAgent(AMPAgent):
         std, mean = torch.std_mean(train_info['enc_rewards'])
         w.add_scalar('info/enc_reward_mean', mean.item(), frame)
         w.add_scalar('info/enc_reward_std', std.item(), frame)
+        if self._enc_grad_penalty != 0:                                  # learning/ase_agent.py:509-510
+            w.add_scalar('info/enc_grad_penalty', _mean_list(train_info['enc_grad_penalty']).item(), frame)
 
     def _experience_kwargs(self):
         return {'with_amp': True, 'with_latents': True}

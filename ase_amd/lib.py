@@ -15,12 +15,13 @@ AUX_NONE, AUX_RELU_MASK, AUX_TANH_GRAD, AUX_RELU_BITS = 0, 1, 2, 3
 
 # accumulator slots (ASE_ACC_*)
 (ACC_MASK_SUM, ACC_A_LOSS, ACC_B_LOSS, ACC_ENTROPY, ACC_CLIPPED, ACC_C_LOSS, ACC_KL, ACC_DIV, ACC_BCE_AGENT,
- ACC_BCE_DEMO, ACC_AGENT_ACC, ACC_DEMO_ACC, ACC_GP, ACC_ENC, ACC_LOGIT_W2, ACC_DISC_W2, ACC_ENC_W2, ACC_GRAD_SQ) = range(18)
+ ACC_BCE_DEMO, ACC_AGENT_ACC, ACC_DEMO_ACC, ACC_GP, ACC_ENC, ACC_ENC_GP, ACC_LOGIT_W2, ACC_DISC_W2, ACC_ENC_W2,
+ ACC_GRAD_SQ) = range(19)
 ACC_COUNT = 24
 # result slots (ASE_RES_*)
 (RES_A_LOSS, RES_C_LOSS, RES_B_LOSS, RES_ENTROPY, RES_CLIP_FRAC, RES_KL, RES_DISC_LOSS, RES_DISC_GP,
  RES_DISC_LOGIT_LOSS, RES_DISC_AGENT_ACC, RES_DISC_DEMO_ACC, RES_ENC_LOSS, RES_DIV_LOSS, RES_LOSS,
- RES_MASK_SUM) = range(15)
+ RES_MASK_SUM, RES_ENC_GP) = range(16)
 RES_COUNT = 16
 
 _p, _i, _i64, _f, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
@@ -44,7 +45,9 @@ SIGNATURES = {
     "ase_hip_enc_head": [_p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _i, _i, _i, _f, _i, _p],
     "ase_hip_gp_seed": [_p, _i64, _p, _p, _i64, _i, _i, _f, _i, _p],
     "ase_hip_sqnorm": [_p, _i64, _i, _i, _p, _i, _d, _i, _p],
-    "ase_hip_finalize_scalars": [_p, _p, _i, _i, _i, _i, _i, _i] + [_f] * 10 + [_p],
+    "ase_hip_finalize_scalars": [_p, _p, _i, _i, _i, _i, _i, _i] + [_f] * 11 + [_p],
+    "ase_hip_enc_gp_seed": [_p, _i64, _p, _i64, _p, _i64, _i, _i, _f, _i, _p],
+    "ase_hip_enc_gp_back": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i, _i, _i, _p],
     "ase_hip_clip_scale": [_p, _i64, _p, _f, _p],
     "ase_hip_begin_step": [_p, _p, _i, _p, _i, _p, _p],
     "ase_hip_adam": [_p, _p, _p, _p, _i64, _p, _p],

@@ -179,6 +179,8 @@ enum {
     ASE_ACC_DEMO_ACC,       /* count l > 0 (demo)                            */
     ASE_ACC_GP,             /* sum_rows |d logit / d x_demo|^2               */
     ASE_ACC_ENC,            /* sum_rows -<enc, z>                            */
+    ASE_ACC_ENC_GP,         /* sum_rows |d enc_err / d x_agent|^2 (enc_grad_penalty); slots up to here are per-row sums
+                               (the data-parallel ranks add them), the ones below depend on the weights only */
     ASE_ACC_LOGIT_W2,       /* sum w_logit^2                                 */
     ASE_ACC_DISC_W2,        /* sum over all disc weights^2                   */
     ASE_ACC_ENC_W2,         /* sum over all enc weights^2                    */
@@ -224,6 +226,16 @@ int ase_hip_enc_head(const float* e, int64_t ld_e, const float* z, int64_t ld_z,
                      int64_t ld_de, float* db_enc, float* enc_out, double* acc, int amb, int amb_global,
                      int z_dim, float enc_coef, int dtype, void* stream);
 
+/* Encoder gradient penalty (learning/ase_agent.py:431-441: mean_rows |d enc_err / d amp_obs|^2 with enc_err = -<normalize(e), z>),
+ * the two per-row pieces around the GEMM chain.  e f32 [rows, ld_e] pre-normalisation encoder output, z f32 [rows, ld_z].
+ *   seed: u[r, :] = scale * d enc_err / d e = -scale (z - eh <eh, z>) / |e|          (dtype [rows, ld_u]; eh = e / |e|)
+ *   back: d_e[r, :] += J du[r, :],  J = d u / d e (unscaled), du f32 [rows, ld_du] = what the chain's backward returns at u;
+ *         db_enc (nullable, f32 [z_dim]) += column sums of the change of the stored d_e. */
+int ase_hip_enc_gp_seed(const float* e, int64_t ld_e, const float* z, int64_t ld_z, void* u, int64_t ld_u, int rows,
+                        int z_dim, float scale, int dtype, void* stream);
+int ase_hip_enc_gp_back(const float* e, int64_t ld_e, const float* z, int64_t ld_z, const float* du, int64_t ld_du,
+                        void* d_e, int64_t ld_de, float* db_enc, int rows, int z_dim, int dtype, void* stream);
+
 /* Gradient-penalty seed: g[r,j] = (h[r,j] > 0) ? scale * w[j] : 0  (d logit / d last hidden, ReLU). */
 int ase_hip_gp_seed(const void* h, int64_t ld_h, const float* w, void* g, int64_t ld_g, int rows,
                     int width, float scale, int dtype, void* stream);
@@ -237,14 +249,14 @@ int ase_hip_sqnorm(const void* x, int64_t ld, int rows, int cols, double* acc, i
 enum {
     ASE_RES_A_LOSS = 0, ASE_RES_C_LOSS, ASE_RES_B_LOSS, ASE_RES_ENTROPY, ASE_RES_CLIP_FRAC, ASE_RES_KL,
     ASE_RES_DISC_LOSS, ASE_RES_DISC_GP, ASE_RES_DISC_LOGIT_LOSS, ASE_RES_DISC_AGENT_ACC,
-    ASE_RES_DISC_DEMO_ACC, ASE_RES_ENC_LOSS, ASE_RES_DIV_LOSS, ASE_RES_LOSS, ASE_RES_MASK_SUM,
+    ASE_RES_DISC_DEMO_ACC, ASE_RES_ENC_LOSS, ASE_RES_DIV_LOSS, ASE_RES_LOSS, ASE_RES_MASK_SUM, ASE_RES_ENC_GP,
     ASE_RES_COUNT = 16
 };
 int ase_hip_finalize_scalars(const double* acc, float* out, int m_global, int amb_global, int masked,
                              int has_disc, int has_enc, int has_div, float critic_coef,
                              float entropy_coef, float bounds_coef, float disc_coef, float disc_logit_reg,
                              float disc_grad_penalty, float disc_weight_decay, float enc_coef,
-                             float enc_weight_decay, float div_coef, void* stream);
+                             float enc_weight_decay, float div_coef, float enc_grad_penalty, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Optimizer (torch.optim.Adam(lr, eps=1e-8, weight_decay=0): learning/common_agent.py:45,

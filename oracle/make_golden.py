@@ -86,6 +86,10 @@ def _case(kind):
         net['space']['continuous']['sigma_init']['val'] = -2.3
     elif kind == 'ase_sep':
         net['enc']['separate'] = True
+    elif kind in ('ase_gp', 'ase_sep_gp'):
+        # the encoder's gradient penalty (learning/ase_agent.py:431-441) and weight decay switched on
+        net['enc']['separate'] = kind == 'ase_sep_gp'
+        cfg.update(enc_grad_penalty=5, enc_weight_decay=0.0001)
     return net, cfg
 
 
@@ -116,7 +120,7 @@ def _tail(A, kind):
     mb_next_values = td['next_values']
     mb_rewards = td['rewards']
     amp_rewards = {}
-    if kind in ('amp', 'ase', 'ase_sep'):
+    if kind in ('amp', 'ase', 'ase_sep', 'ase_gp', 'ase_sep_gp'):
         if kind == 'amp':
             amp_rewards = A._calc_amp_rewards(td['amp_obs'])
         else:
@@ -142,7 +146,7 @@ def make_case(name, kind, seed, num_envs=16, obs_size=37, act_size=7, amp_size=4
     """slim: leave out what only the single-step tests read (first-step gradients / weights, the checkpoint dictionary);
     regen: leave out every tensor the test can regenerate from the seeded synthetic source (observations, AMP observations,
     demo stream - tests/test_agent_emu.py:regenerate) and the duplicated dataset rows."""
-    akind = {'ase_sep': 'ase', 'amp_cfg1': 'amp'}.get(kind, kind)
+    akind = {'ase_sep': 'ase', 'amp_cfg1': 'amp', 'ase_gp': 'ase', 'ase_sep_gp': 'ase'}.get(kind, kind)
     net, cfg = _case(kind)
     akind_kind = kind
     spec = EnvSpec(num_envs=num_envs, horizon=cfg['horizon_length'], obs_size=obs_size, act_size=act_size,
@@ -273,6 +277,10 @@ def make_case(name, kind, seed, num_envs=16, obs_size=37, act_size=7, amp_size=4
 
 if __name__ == '__main__':
     torch.set_num_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == 'encgp':          # only the N4 cases (the others are unchanged)
+        make_case('ase_gp_tiny', 'ase_gp', seed=5, epochs=1)
+        make_case('ase_sep_gp_tiny', 'ase_sep_gp', seed=6, epochs=1)
+        sys.exit(0)
     make_case('ase_tiny', 'ase', seed=0)
     make_case('amp_tiny', 'amp', seed=1)
     make_case('ppo_tiny', 'ppo', seed=2)
@@ -280,4 +288,6 @@ if __name__ == '__main__':
     # more seeds of the ASE case (seeds {0, 1, 2}) and BASELINE config 1's exact shape, as slim fixtures
     make_case('ase_tiny_s1', 'ase', seed=11, slim=True)
     make_case('ase_tiny_s2', 'ase', seed=12, slim=True)
+    make_case('ase_gp_tiny', 'ase_gp', seed=5, epochs=1)
+    make_case('ase_sep_gp_tiny', 'ase_sep_gp', seed=6, epochs=1)
     make_case('amp_cfg1', 'amp_cfg1', seed=21, num_envs=64, obs_size=253, act_size=31, amp_size=1400, epochs=1, slim=True, regen=True)

@@ -300,6 +300,26 @@ class EmuBackend:
             enc_out[:amb, :z_dim] = h
         acc[L.ACC_ENC] += (-dot).double().sum()
 
+    def enc_gp_seed(self, e, z, u, rows, z_dim, scale=1.0):
+        ev, zv = e[:rows, :z_dim], z[:rows, :z_dim]
+        nrm = ev.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+        h = ev / nrm
+        a = (h * zv).sum(-1, keepdim=True)
+        u[:rows, :z_dim] = (-scale * (zv - h * a) / nrm).to(u.dtype)
+
+    def enc_gp_back(self, e, z, du, d_e, db_enc, rows, z_dim):
+        ev, zv, r = e[:rows, :z_dim], z[:rows, :z_dim], du[:rows, :z_dim]
+        nrm = ev.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+        h = ev / nrm
+        a = (h * zv).sum(-1, keepdim=True)
+        hr, zr = (h * r).sum(-1, keepdim=True), (zv * r).sum(-1, keepdim=True)
+        jr = (zv * hr + h * zr + a * r - 3 * a * h * hr) / (nrm * nrm)
+        old = d_e[:rows, :z_dim].float().clone()
+        new = (old + jr).to(d_e.dtype)
+        d_e[:rows, :z_dim] = new
+        if db_enc is not None:
+            db_enc[:z_dim] += (new.float() - old).sum(0)
+
     def gp_seed(self, h, w, g, rows, width, scale=1.0):
         g[:rows, :width] = torch.where(h[:rows, :width].float() > 0, (scale * w[:width]).expand(rows, width),
                                        torch.zeros(rows, width)).to(g.dtype)
@@ -328,9 +348,11 @@ class EmuBackend:
             out[L.RES_DISC_AGENT_ACC] = a[L.ACC_AGENT_ACC] / (2 * amb)
             out[L.RES_DISC_DEMO_ACC] = a[L.ACC_DEMO_ACC] / amb
         if has_enc:
-            el = a[L.ACC_ENC] / amb_global + c.get('enc_weight_decay', 0) * a[L.ACC_ENC_W2]
+            egp = a[L.ACC_ENC_GP] / amb_global
+            el = a[L.ACC_ENC] / amb_global + c.get('enc_weight_decay', 0) * a[L.ACC_ENC_W2] + c.get('enc_grad_penalty', 0) * egp
             loss += c['enc_coef'] * el
             out[L.RES_ENC_LOSS] = el
+            out[L.RES_ENC_GP] = egp
         if has_div:
             dv = a[L.ACC_DIV] / S
             loss += c['amp_diversity_bonus'] * dv

@@ -136,7 +136,8 @@ def replay_epochs(G, ag, rtol, wtol, check=True):
     return all_info
 
 
-@pytest.mark.parametrize('name', ['ase_tiny', 'amp_tiny', 'ppo_tiny', 'ase_sep_tiny', 'ase_tiny_s1', 'ase_tiny_s2', 'amp_cfg1'])
+@pytest.mark.parametrize('name', ['ase_tiny', 'amp_tiny', 'ppo_tiny', 'ase_sep_tiny', 'ase_tiny_s1', 'ase_tiny_s2', 'amp_cfg1', 'ase_gp_tiny',
+                                  'ase_sep_gp_tiny'])
 def test_two_epochs_emulated(name, golden_dir):
     G = torch.load(os.path.join(golden_dir, name + '.pt'), weights_only=False)
     ag = make_agent(G, EmuBackend())

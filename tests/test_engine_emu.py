@@ -12,7 +12,7 @@ from ase_amd.engine import UpdateEngine
 from tests.emu_backend import EmuBackend
 from tests.helpers import build_net, close, get_rms, set_rms
 
-CASES = ['ase_tiny', 'amp_tiny', 'ppo_tiny', 'ase_sep_tiny']
+CASES = ['ase_tiny', 'amp_tiny', 'ppo_tiny', 'ase_sep_tiny', 'ase_gp_tiny', 'ase_sep_gp_tiny']
 
 
 def first_step(G, be, dtype, device='cpu'):
@@ -35,7 +35,7 @@ def first_step(G, be, dtype, device='cpu'):
 
 
 SCALARS = ['entropy', 'b_loss', 'actor_loss', 'actor_clip_frac', 'kl', 'disc_loss', 'disc_grad_penalty',
-           'disc_logit_loss', 'disc_agent_acc', 'disc_demo_acc', 'enc_loss', 'amp_diversity_loss']
+           'disc_logit_loss', 'disc_agent_acc', 'disc_demo_acc', 'enc_loss', 'enc_grad_penalty', 'amp_diversity_loss']
 
 
 def check_first_step(G, net, eng, rtol, gtol, wtol):

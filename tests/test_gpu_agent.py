@@ -17,7 +17,8 @@ def be():
     return HipBackend()
 
 
-@pytest.mark.parametrize('name', ['ase_tiny', 'amp_tiny', 'ppo_tiny', 'ase_sep_tiny', 'ase_tiny_s1', 'ase_tiny_s2', 'amp_cfg1'])
+@pytest.mark.parametrize('name', ['ase_tiny', 'amp_tiny', 'ppo_tiny', 'ase_sep_tiny', 'ase_tiny_s1', 'ase_tiny_s2', 'amp_cfg1', 'ase_gp_tiny',
+                                  'ase_sep_gp_tiny'])
 def test_two_epochs_f32(be, name, golden_dir):
     G = torch.load(os.path.join(golden_dir, name + '.pt'), weights_only=False)
     ag = make_agent(G, be, device='cuda', precision='f32')

@@ -270,6 +270,44 @@ def test_disc_enc_heads(be, dt):
 
 
 @pytest.mark.parametrize('dt', DT)
+def test_enc_grad_penalty_row_ops(be, dt):
+    """ase_hip_enc_gp_seed / ase_hip_enc_gp_back (learning/ase_agent.py:431-441) against the emulator's
+    formulas on strided views of a joint head buffer, and the Jacobian against autograd of u(e) in f64."""
+    amb, Z, off = 333, 64, 64
+    g = torch.Generator().manual_seed(29)
+    HD = torch.zeros(amb, 128)
+    HD[:, off:] = torch.randn(amb, Z, generator=g) * 2
+    z = torch.randn(amb, Z, generator=g)
+    z = z / z.norm(dim=-1, keepdim=True)
+    DU = torch.zeros(amb, 128)
+    DU[:, off:] = torch.randn(amb, Z, generator=g)
+    d0 = (torch.randn(amb, 128, generator=g) * 0.1).to(dt)
+    outs = []
+    for dev in ('cuda', 'cpu'):
+        b = be if dev == 'cuda' else EmuBackend()
+        U = torch.zeros(amb, 128, dtype=dt, device=dev)
+        dHD = d0.clone().to(dev)
+        dbe = torch.zeros(Z, device=dev)
+        hd, zz, du = HD.to(dev), z.to(dev), DU.to(dev)
+        b.enc_gp_seed(hd[:, off:], zz, U[:, off:], amb, Z, scale=0.7)
+        b.enc_gp_back(hd[:, off:], zz, du[:, off:], dHD[:, off:], dbe, amb, Z)
+        outs.append((U.float().cpu(), dHD.float().cpu(), dbe.cpu()))
+    t = 2e-5 if dt == torch.float32 else 1e-2
+    assert float(outs[0][0][:, :off].abs().max()) == 0.0                 # only the encoder columns are written
+    close(outs[0][0], outs[1][0], t, t * float(outs[1][0].abs().max()), 'u')
+    close(outs[0][1], outs[1][1], t, t * float(outs[1][1].abs().max()), 'd_e')
+    close(outs[0][2], outs[1][2], t * 50, t * 20 * float(outs[1][1].abs().max()), 'db_enc')
+    assert torch.equal(outs[0][1][:, :off], d0.float()[:, :off])
+    if dt == torch.float32:
+        e = HD[:, off:].double().requires_grad_(True)
+        zz = z.double()
+        n = e.norm(dim=-1, keepdim=True)
+        u = -(zz - e / n * ((e / n) * zz).sum(-1, keepdim=True)) / n
+        jr = torch.autograd.grad(u, e, grad_outputs=DU[:, off:].double())[0]      # J is symmetric: J du = (du^T J)^T
+        close(outs[0][1][:, off:].double() - d0.float()[:, off:].double(), jr, 1e-4, 1e-5 * float(jr.abs().max()), 'J du vs autograd')
+
+
+@pytest.mark.parametrize('dt', DT)
 def test_gp_seed_sqnorm_reduce(be, dt):
     rows, width = 200, 512
     h = torch.randn(rows, 576).to(dt)
@@ -295,7 +333,8 @@ def test_gp_seed_sqnorm_reduce(be, dt):
 
 def test_finalize_begin_adam_axpy(be):
     cfg = dict(critic_coef=5, entropy_coef=0.0, bounds_loss_coef=10, disc_coef=5, disc_logit_reg=0.01,
-               disc_grad_penalty=5, disc_weight_decay=1e-4, enc_coef=5, enc_weight_decay=0.0, amp_diversity_bonus=0.01)
+               disc_grad_penalty=5, disc_weight_decay=1e-4, enc_coef=5, enc_weight_decay=0.0, amp_diversity_bonus=0.01,
+               enc_grad_penalty=3.0)
     n = 100003
     g = torch.Generator().manual_seed(2)
     w0, gr = torch.randn(n, generator=g), torch.randn(n, generator=g) * 1e-3

@@ -9,9 +9,9 @@ import torch
 
 from oracle import restated as R
 
-CASES = ['ase_tiny', 'amp_tiny', 'ppo_tiny', 'ase_sep_tiny']
+CASES = ['ase_tiny', 'amp_tiny', 'ppo_tiny', 'ase_sep_tiny', 'ase_gp_tiny', 'ase_sep_gp_tiny']
 SCALARS = ['entropy', 'b_loss', 'actor_loss', 'actor_clip_frac', 'critic_loss', 'kl', 'disc_loss',
-           'disc_grad_penalty', 'disc_logit_loss', 'disc_agent_acc', 'disc_demo_acc', 'enc_loss',
+           'disc_grad_penalty', 'disc_logit_loss', 'disc_agent_acc', 'disc_demo_acc', 'enc_loss', 'enc_grad_penalty',
            'amp_diversity_loss']
 
 
