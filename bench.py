@@ -211,14 +211,16 @@ def _rms_dict(vec):
     return {'mean': v[:D].clone(), 'var': v[D:2 * D].clone(), 'count': v[2 * D].clone()}
 
 
-def cpu_baseline_and_parity(agent, cfg, steps=8, mode='bf16'):
+def cpu_baseline_and_parity(agent, cfg, steps=8, mode='bf16', traj_steps=None):
     """The reference's arithmetic (oracle/restated.py, f32, torch CPU threads = host cores) on a bounded sample of the SAME
     workload: `steps` full-size optimisation steps (minibatch 16384 / amp 4096, median step time), extrapolated to the 48
     steps of one update (the once-per-epoch tail is < 2 % and left out).
 
     Parity: the FIRST of those steps is also executed by the GPU engine on identical inputs - same weights (whatever the
-    timed updates left), same running statistics, same minibatch rows, same demo rows, same diversity latents - without
-    the optimizer step, and every reported loss scalar and every gradient tensor is compared with the oracle's."""
+    timed updates left), same running statistics, same minibatch rows, same demo rows, same diversity latents - and every
+    reported loss scalar and every gradient tensor is compared with the oracle's.  Trajectory: both sides then take their
+    OWN Adam step (fresh optimizer state on both) and go on to the next minibatch - `traj_steps` (default: all `steps`)
+    consecutive optimisation steps, loss scalars compared at every one of them (errors of the weights compound)."""
     from oracle import restated as R
     from ase_amd import lib as L
     ncpu = host_cores()
@@ -243,13 +245,21 @@ def cpu_baseline_and_parity(agent, cfg, steps=8, mode='bf16'):
     adam = R.adam_new()
     perm = torch.randperm(B, generator=g)
     times, parity = [], None
+    n_traj = steps if traj_steps is None else min(steps, traj_steps)
+    # fresh optimizer state on the GPU side too (the oracle's is new): first / second moments and the step counter
+    eng.adam_m.zero_()
+    eng.adam_v.zero_()
+    eng.opt_state[0] = 0.0
+    counts = ('actor_clip_frac', 'disc_agent_acc', 'disc_demo_acc')
+    scale = {'actor_loss': 1.0, 'enc_loss': 1.0}          # means of signed O(1) summands: error relative to the summand scale
+    traj = []
     for i in range(steps):
         pos = i % (B // MB)
         idx = perm[pos * MB:(pos + 1) * MB]
         mb = {k: v[idx] for k, v in ds.items()}
         z = R.sample_latents(MB, 64, g)
-        if i == 0:
-            # ---- the GPU engine on the same step (no optimizer step; its running statistics advance like the oracle's)
+        if i < n_traj:
+            # ---- the GPU engine on the same step (its running statistics advance like the oracle's)
             idx_d = idx.to(torch.int32).to(dev)
             arows = idx_d[:AMB].contiguous()
             streams = [(agent._ds['amp_obs'], arows, agent._remap), (agent._ds['amp_obs'], arows, agent._remap),
@@ -257,16 +267,25 @@ def cpu_baseline_and_parity(agent, cfg, steps=8, mode='bf16'):
             eng.step(agent._ds, idx_d, agent._remap, streams, new_z=z.to(dev), apply=False)
             torch.cuda.synchronize()
             res_g = {k: v.detach().cpu().clone() for k, v in eng.results().items()}
-            grads_g = {k: v.detach().cpu().clone() for k, v in eng.export_grads().items()}
+            if i == 0:
+                grads_g = {k: v.detach().cpu().clone() for k, v in eng.export_grads().items()}
+            # its optimizer step (the weight-only loss terms are in the gradients already): step counter, Adam, shadows
+            eng.be.begin_step(eng.opt_state, None)
+            eng.be.adam(eng.params[:eng.n_train], eng.grads[:eng.n_train], eng.adam_m[:eng.n_train], eng.adam_v[:eng.n_train],
+                        eng.opt_state)
+            eng.refresh_shadows()
         t0 = time.time()
         res = R.calc_gradients('ase', sd, rms, mb, cfg, z)
-        if i == 0:
-            scale = {'actor_loss': 1.0, 'enc_loss': 1.0}          # means of signed O(1) summands: error relative to the summand scale
+        if i < n_traj:
             loss_rel = {}
             for k in ('actor_loss', 'critic_loss', 'b_loss', 'entropy', 'kl', 'actor_clip_frac', 'disc_loss', 'disc_grad_penalty',
                       'disc_logit_loss', 'disc_agent_acc', 'disc_demo_acc', 'enc_loss', 'amp_diversity_loss'):
                 r = float(res[k].mean())
                 loss_rel[k] = abs(float(res_g[k].mean()) - r) / max(abs(r), scale.get(k, 0.0), 1e-12)
+            wl_i = max((k for k in loss_rel if k not in counts), key=loss_rel.get)
+            wc_i = max(counts, key=loss_rel.get)
+            traj.append((loss_rel[wl_i], wl_i, loss_rel[wc_i], wc_i))
+        if i == 0:
             grad_rel = {}
             for k, p in sd.items():
                 if p.requires_grad:
@@ -274,7 +293,6 @@ def cpu_baseline_and_parity(agent, cfg, steps=8, mode='bf16'):
             wk = max(grad_rel, key=grad_rel.get)
             # counting statistics (fractions of samples on one side of a threshold) move in steps of 1/rows whenever a
             # near-threshold sample flips: reported separately from the continuous loss scalars
-            counts = ('actor_clip_frac', 'disc_agent_acc', 'disc_demo_acc')
             wl = max((k for k in loss_rel if k not in counts), key=loss_rel.get)
             wc = max(counts, key=loss_rel.get)
             parity = {'mode': mode, 'what': f'first oracle step (minibatch {MB}, amp {AMB}) re-run by the GPU engine on identical '
@@ -286,6 +304,14 @@ def cpu_baseline_and_parity(agent, cfg, steps=8, mode='bf16'):
                       'median_grad_rel_l2': float(f'{sorted(grad_rel.values())[len(grad_rel) // 2]:.3e}')}
         R.adam_step(sd, adam, cfg['learning_rate'])
         times.append(time.time() - t0)
+    if parity is not None and traj:
+        worst = max(range(len(traj)), key=lambda j: traj[j][0])
+        parity['trajectory'] = {
+            'what': f'{len(traj)} consecutive optimisation steps, GPU engine and oracle each with its own Adam (fresh state), same '
+                    'minibatches / demo rows / diversity latents; worst continuous loss scalar and worst counting statistic per step',
+            'steps': len(traj), 'max_loss_rel': float(f'{traj[worst][0]:.3e}'), 'max_loss_rel_scalar': traj[worst][1],
+            'max_loss_rel_step': worst, 'max_count_stat_rel': float(f'{max(t[2] for t in traj):.3e}'),
+            'per_step_max_loss_rel': [float(f'{t[0]:.2e}') for t in traj]}
     tt = sorted(times[1:]) if len(times) > 1 else times           # first call = warm-up
     t_step = tt[len(tt) // 2]
     n_steps = cfg['mini_epochs'] * (B // MB)
@@ -481,7 +507,7 @@ def main():
                 ag32.update(ag32._play_steps_tail())
             torch.cuda.synchronize()
             ms32 = (time.perf_counter() - t32) / 2 * 1e3
-            _, p32 = cpu_baseline_and_parity(ag32, cfg32, steps=1, mode='f32')
+            _, p32 = cpu_baseline_and_parity(ag32, cfg32, steps=4, mode='f32')
             parity_mode = {'dtype': 'f32', 'value': round(B / (ms32 * 1e-3), 1), 'unit': 'samples/s', 'ms_per_step': round(ms32, 3),
                            'steps': 2, 'parity': p32}
 
