@@ -106,6 +106,11 @@ class UpdateEngine:
         # ASE_TN_EARLY=1) or as the last launch of the step (default: ONE policy launch that also holds the style MLP's and
         # the heads' narrow gradients - measured 70.4 ms either way, 96 instead of 432 weight-gradient launches per update)
         self._tn_early = os.environ.get('ASE_TN_EARLY', '0') != '0'
+        # head of the discriminator branch (moments, normalisation, forward) submitted at the top of the step, into the
+        # ~80 us in which the main stream runs its chain of small prologue kernels (ASE_DISC_EARLY=0: where the branch
+        # used to start, behind the actor's and the critic's forward launches in submission order)
+        self._disc_early = os.environ.get('ASE_DISC_EARLY', '1') != '0'
+        self._early_fork = None
         self._apply_groups = None
         self._use_bits = os.environ.get('ASE_RELU_BITS', '1') != '0'
         self._fused_apply = hasattr(backend, 'apply_multi') and os.environ.get('ASE_FUSED_APPLY', '1') != '0'
@@ -523,6 +528,9 @@ class UpdateEngine:
         be.begin_step(self.opt_state if advance else None, self.acc, zero2=self.stats_flat,
                       rng_bump=self.rng_state if self.div_on else None)
         be.zero_(self.grads[:self.n_train])
+        # the discriminator branch needs nothing of what follows here (minibatch fields, observation moments): with its own
+        # stream and no exchange between the phases it may start as soon as the accumulators and gradients are zeroed
+        self._early_fork = self._mark() if (self.has_disc and self._amp_stats_in_branch() and self._disc_early) else None
         self.gather_minibatch(ds, idx, remap)
         if self.masked:
             be.reduce_sum(self.mb['rand_action_mask'], M, False, self.acc, L.ACC_MASK_SUM)
@@ -601,7 +609,36 @@ class UpdateEngine:
         Ra = self.Ra
         if inline_apply:
             self._build_apply_desc()
-        fork0 = self._mark()                 # the discriminator branch needs nothing of the observation prologue
+        fork0 = self._early_fork if self._early_fork is not None else self._mark()   # (nothing of the observation prologue)
+        disc_early = self.has_disc and self._early_fork is not None
+        amb_den = self.AMBg if self.shard else self.AMB
+        Rd = 3 * AMB
+
+        def disc_forward():
+            if self._amp_stats_in_branch():
+                self._amp_moments(amp_streams)
+            if norm_amp:
+                be.rms_finalize(self.amp_state, self.amp, self.amp_sums, amb_den, 3, self.amp_mean, self.amp_std)
+            else:
+                self._identity_stats(self.amp_mean, self.amp_std)
+            xd = [self.Xd[s * AMB:(s + 1) * AMB] for s in range(3)]
+            if self.amp % 4 == 0 and all(src.stride(0) % 4 == 0 for src, _, _ in amp_streams):
+                be.rms_normalize_multi(amp_streams, self.amp, AMB, [self.amp_mean[s] for s in range(3)],
+                                       [self.amp_std[s] for s in range(3)], xd)
+            else:                          # rows that are not whole 16-byte chunks: one launch per stream
+                for s, (src, sidx, srm) in enumerate(amp_streams):
+                    be.rms_normalize(src, self.amp, sidx, srm, AMB, self.amp_mean[s], self.amp_std[s], [xd[s]])
+            hd = self._fwd_chain(self.disc, self.Xd, self.Hd, Rd)
+            self._fwd(self.disc_head, hd, self.HD, Rd)
+            he = None
+            if self.enc_chain:
+                he = self._fwd_chain(self.enc_chain, self.Xd[:AMB], self.He, AMB)
+                self._fwd(self.enc_head, he, self.E, AMB)
+            return hd, he
+
+        if disc_early:
+            with self._Branch(self, self._side(1), fork0):
+                hd, he = disc_forward()
         if norm_in:
             be.rms_finalize(self.obs_state, self.obs, self.obs_sums, self.Mg if self.shard else self.M, 1, self.obs_mean,
                             self.obs_std)
@@ -641,27 +678,8 @@ class UpdateEngine:
         if self.has_disc:
             tnq, self._tn_queue = self._tn_queue, []          # the branch queues (and flushes) its own weight gradients
             with self._Branch(self, self._side(1), fork0) as br_disc:
-                if self._amp_stats_in_branch():
-                    self._amp_moments(amp_streams)
-                if norm_amp:
-                    be.rms_finalize(self.amp_state, self.amp, self.amp_sums, self.AMBg if self.shard else self.AMB, 3,
-                                    self.amp_mean, self.amp_std)
-                else:
-                    self._identity_stats(self.amp_mean, self.amp_std)
-                xd = [self.Xd[s * AMB:(s + 1) * AMB] for s in range(3)]
-                if self.amp % 4 == 0 and all(src.stride(0) % 4 == 0 for src, _, _ in amp_streams):
-                    be.rms_normalize_multi(amp_streams, self.amp, AMB, [self.amp_mean[s] for s in range(3)],
-                                           [self.amp_std[s] for s in range(3)], xd)
-                else:                          # rows that are not whole 16-byte chunks: one launch per stream
-                    for s, (src, sidx, srm) in enumerate(amp_streams):
-                        be.rms_normalize(src, self.amp, sidx, srm, AMB, self.amp_mean[s], self.amp_std[s], [xd[s]])
-                Rd = 3 * AMB
-                hd = self._fwd_chain(self.disc, self.Xd, self.Hd, Rd)
-                self._fwd(self.disc_head, hd, self.HD, Rd)
-                if self.enc_chain:
-                    he = self._fwd_chain(self.enc_chain, self.Xd[:AMB], self.He, AMB)
-                    self._fwd(self.enc_head, he, self.E, AMB)
-                amb_den = self.AMBg if self.shard else self.AMB
+                if not disc_early:
+                    hd, he = disc_forward()
                 be.disc_head(self.HD, self.dHD, self.disc_head.gb[0], self.acc, AMB, amb_den, c['disc_coef'])
                 if self.has_enc:
                     src, sidx, srm = amp_streams[0]   # enc_latents = ase_latents[0:amp_minibatch] (learning/ase_agent.py:247)
