@@ -111,6 +111,8 @@ class UpdateEngine:
         # used to start, behind the actor's and the critic's forward launches in submission order)
         self._disc_early = os.environ.get('ASE_DISC_EARLY', '1') != '0'
         self._early_fork = None
+        self._short_prologue = os.environ.get('ASE_SHORT_PROLOGUE', '1') != '0'
+        self._prep = None
         self._apply_groups = None
         self._use_bits = os.environ.get('ASE_RELU_BITS', '1') != '0'
         self._fused_apply = hasattr(backend, 'apply_multi') and os.environ.get('ASE_FUSED_APPLY', '1') != '0'
@@ -461,26 +463,30 @@ class UpdateEngine:
                 self._dgrad(d, dZ[l], dZ[l - 1], rows, H[l - 1], p.act)
 
     # ------------------------------------------------------------------ one optimisation step
-    def gather_minibatch(self, ds, idx, remap):
+    def gather_minibatch(self, ds, idx, remap, part=0):
         """All small per-row fields of the minibatch (learning/amp_datasets.py:21-22) in one launch - including the two
-        compute-dtype copies of the latents the first actor / critic layers read ([obs | z] without a concat)."""
+        compute-dtype copies of the latents the first actor / critic layers read ([obs | z] without a concat).
+        part 1: the fields only, part 2: the latent copies only (the short prologue launches them on different streams)."""
         key = tuple(ds[k].data_ptr() for k in self.mb)
         if self._mb_desc_key != key:
+            self._mb_desc, self._mb_items, self._mb_desc_key = {}, {}, key
+        if part not in self._mb_desc:
             rows, items = [], []
-            for k, dst in self.mb.items():
-                src = ds[k].view(ds[k].shape[0], -1)
-                rows.append([src.data_ptr(), src.stride(0), src.shape[1], dst.data_ptr(), dst.stride(0), L.F32])
-                items.append((src, src.shape[1], dst))
-            if self.z:
+            if part != 2:
+                for k, dst in self.mb.items():
+                    src = ds[k].view(ds[k].shape[0], -1)
+                    rows.append([src.data_ptr(), src.stride(0), src.shape[1], dst.data_ptr(), dst.stride(0), L.F32])
+                    items.append((src, src.shape[1], dst))
+            if self.z and part != 1:
                 src = ds['ase_latents'].view(ds['ase_latents'].shape[0], -1)
                 code = L.BF16 if self.dtype == torch.bfloat16 else L.F32
                 for dst in (self.Zs[:self.M], self.Xc[:, self.actor[0].split_dst:]):
                     rows.append([src.data_ptr(), src.stride(0), self.z, dst.data_ptr(), dst.stride(0), code])
                     items.append((src, self.z, dst))
-            self._mb_desc = torch.tensor(rows, dtype=torch.int64, device=self.dev)
-            self._mb_items = items
-            self._mb_desc_key = key
-        self.be.gather_multi(self._mb_desc, self._mb_items, idx, remap, self.M)
+            self._mb_desc[part] = torch.tensor(rows, dtype=torch.int64, device=self.dev) if rows else None
+            self._mb_items[part] = items
+        if self._mb_desc[part] is not None:
+            self.be.gather_multi(self._mb_desc[part], self._mb_items[part], idx, remap, self.M)
 
     def sync_from_rank0(self):
         """Start-up / restore: every rank takes rank 0's parameters, optimizer state, running statistics and latent
@@ -527,6 +533,23 @@ class UpdateEngine:
         # loss accumulators and per-step partial statistics zeroed, position of the diversity-latent stream advanced
         be.begin_step(self.opt_state if advance else None, self.acc, zero2=self.stats_flat,
                       rng_bump=self.rng_state if self.div_on else None)
+        self._prep = None
+        if self._short_prologue and self._amp_stats_in_branch():
+            # Short prologue (single GPU, streams): the actor chain - the critical path - needs only the observation
+            # moments and the latent copies.  Zeroing the gradients, the gather of the loss-head fields and the mask sum go
+            # to the critic's stream (first needed by the discriminator's loss head / the PPO loss head, ~300 us later):
+            # 89 -> ~40 us from the start of the step to the first matrix kernel.
+            with self._Branch(self, self._side(0)) as prep:
+                be.zero_(self.grads[:self.n_train])
+                self._early_fork = self._mark() if self.has_disc else None      # (the gradients are zeroed on THIS stream)
+                self.gather_minibatch(ds, idx, remap, part=1)
+                if self.masked:
+                    be.reduce_sum(self.mb['rand_action_mask'], M, False, self.acc, L.ACC_MASK_SUM)
+            self._prep = prep
+            self.gather_minibatch(ds, idx, remap, part=2)
+            if c.get('normalize_input', True):
+                be.rms_moments(ds['obs'], self.obs, idx, remap, M, self.obs_state, self.obs_sums)
+            return
         be.zero_(self.grads[:self.n_train])
         # the discriminator branch needs nothing of what follows here (minibatch fields, observation moments): with its own
         # stream and no exchange between the phases it may start as soon as the accumulators and gradients are zeroed
@@ -610,7 +633,7 @@ class UpdateEngine:
         if inline_apply:
             self._build_apply_desc()
         fork0 = self._early_fork if self._early_fork is not None else self._mark()   # (nothing of the observation prologue)
-        disc_early = self.has_disc and self._early_fork is not None
+        disc_early = self.has_disc and self._early_fork is not None and self._disc_early
         amb_den = self.AMBg if self.shard else self.AMB
         Rd = 3 * AMB
 
@@ -706,6 +729,8 @@ class UpdateEngine:
                 self._finish_branch('disc', inline_apply)
             self._tn_queue = tnq
         self._join_branch(br_critic)
+        if self._prep is not None:
+            self._join_branch(self._prep)      # (same stream as the critic branch: already implied; kept explicit)
 
         # -- PPO loss head (value + gradient w.r.t. mu / value + head bias gradients)
         be.ppo_head(self.MU, self.V, self.mb, self.new_z if self.div_on else None, self.logstd, self.dMU, self.dV,
