@@ -88,7 +88,7 @@ def main():
         print(json.dumps({'measurement': name, 'metric': 'PPO-update samples/sec', 'value': round(B / dt, 1), 'unit': 'samples/s',
                           'ms_per_update': round(dt * 1e3, 3), 'envs': envs, 'horizon': cfg['horizon_length'], 'batch': B,
                           'optimisation_steps': steps, 'precision': prec, 'params': int(ag.model.a2c_network.trainable_numel),
-                          'hipgraph': True, 'data': 'synthetic'}), flush=True)
+                          'replay': 'program', 'data': 'synthetic'}), flush=True)
         del ag
         torch.cuda.empty_cache()
     if not args.only or 'infer' in args.only.split(','):
@@ -150,6 +150,15 @@ def main():
         tt = (torch.rand(n, generator=g) * 3.3).cuda()
         us = timeit(lambda: be.motion_state(clips, ids, tt))
         print(json.dumps({'measurement': 'motion-clip sampler', 'samples': n, 'us_per_call': round(us, 1)}), flush=True)
+        # the wired pipeline: HumanoidAMP.fetch_amp_obs_demo for one demo-ring refill of config 2 (amp_batch_size 512 samples x 10 frames)
+        from ase_amd.motion_lib import AmpObsDemoSource, DeviceMotionLib
+        host = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in clips.items()}
+        ml = DeviceMotionLib.from_arrays(host, be, 'cuda:0')
+        src = AmpObsDemoSource(ml, be, num_amp_obs_steps=10, dt=1.0 / 30.0)
+        for ns in (512, 4096):
+            us = timeit(lambda: src.fetch_amp_obs_demo(ns), n=100)
+            print(json.dumps({'measurement': 'fetch_amp_obs_demo (sample motions + times, motion state, 10-frame observations)',
+                              'samples': ns, 'us_per_call': round(us, 1), 'out_bytes': ns * 1400 * 4}), flush=True)
 
 
 if __name__ == '__main__':
