@@ -112,7 +112,7 @@ class UpdateEngine:
         self._disc_early = os.environ.get('ASE_DISC_EARLY', '1') != '0'
         self._early_fork = None
         self._short_prologue = os.environ.get('ASE_SHORT_PROLOGUE', '1') != '0'
-        self._prep = None
+        self._prep = self._lat_ready = None
         self._apply_groups = None
         self._use_bits = os.environ.get('ASE_RELU_BITS', '1') != '0'
         self._fused_apply = hasattr(backend, 'apply_multi') and os.environ.get('ASE_FUSED_APPLY', '1') != '0'
@@ -515,7 +515,7 @@ class UpdateEngine:
         Phases separated by the exchange points of the data-parallel update (normaliser moments + mask sum; gradients).
         With apply (and the fused optimizer launch) every branch finishes by itself - weight gradients, gradient exchange of
         its bucket, optimizer step of its parameters - so the discriminator's tail overlaps the policy's backward."""
-        self.phase_stats(ds, idx, remap, amp_streams, advance=apply)
+        self.phase_stats(ds, idx, remap, amp_streams, advance=apply, new_z=new_z)
         self._allreduce_stats()
         inline = apply and self._fused_apply and not self.truncate
         self.phase_main(ds, idx, remap, amp_streams, new_z, inline_apply=inline)
@@ -527,7 +527,20 @@ class UpdateEngine:
         return self.res
 
     # ---- phase A: local partial statistics -------------------------------------------------------
-    def phase_stats(self, ds, idx, remap, amp_streams=None, advance=True):
+    def _draw_new_latents(self, new_z):
+        """Latents of the diversity pass (learning/ase_agent.py:451): injected, or drawn on the device."""
+        be, M = self.be, self.M
+        if new_z is not None:
+            be.copy_(self.new_z, new_z.contiguous())
+            be.gather_rows(self.new_z, self.z, None, (0, 0), M, self.Zs[M:])
+        else:
+            # element index = GLOBAL minibatch row: rank r of a sharded step draws rows [r M, (r + 1) M); the kernel
+            # also writes the compute-dtype copy the style MLP reads
+            be.sample_latents(self.new_z, M, self.z, self.rng_state,
+                              row_offset=self.rank * M if (self.shard and self.R > 1) else 0, advance=False,
+                              z2=self.Zs[M:])
+
+    def phase_stats(self, ds, idx, remap, amp_streams=None, advance=True, new_z=None):
         be, c, M, AMB = self.be, self.cfg, self.M, self.AMB
         # one launch: Adam step counter / bias corrections (advance=False - calc_gradients-style calls - leaves them),
         # loss accumulators and per-step partial statistics zeroed, position of the diversity-latent stream advanced
@@ -535,18 +548,22 @@ class UpdateEngine:
                       rng_bump=self.rng_state if self.div_on else None)
         self._prep = None
         if self._short_prologue and self._amp_stats_in_branch():
-            # Short prologue (single GPU, streams): the actor chain - the critical path - needs only the observation
-            # moments and the latent copies.  Zeroing the gradients, the gather of the loss-head fields and the mask sum go
-            # to the critic's stream (first needed by the discriminator's loss head / the PPO loss head, ~300 us later):
-            # 89 -> ~40 us from the start of the step to the first matrix kernel.
+            # Short prologue (single GPU, streams): the actor chain - the critical path - needs the observation moments
+            # on its own stream and nothing else in front of the normaliser.  The latent copies and the diversity draw
+            # (first read by the style MLP), then zeroing the gradients, the gather of the loss-head fields and the mask sum
+            # (first needed by the discriminator's loss head / the PPO loss head, ~300 us later) run beside it on the
+            # critic's stream.
             with self._Branch(self, self._side(0)) as prep:
+                self.gather_minibatch(ds, idx, remap, part=2)
+                if self.div_on:
+                    self._draw_new_latents(new_z)
+                self._lat_ready = self._mark()
                 be.zero_(self.grads[:self.n_train])
                 self._early_fork = self._mark() if self.has_disc else None      # (the gradients are zeroed on THIS stream)
                 self.gather_minibatch(ds, idx, remap, part=1)
                 if self.masked:
                     be.reduce_sum(self.mb['rand_action_mask'], M, False, self.acc, L.ACC_MASK_SUM)
             self._prep = prep
-            self.gather_minibatch(ds, idx, remap, part=2)
             if c.get('normalize_input', True):
                 be.rms_moments(ds['obs'], self.obs, idx, remap, M, self.obs_state, self.obs_sums)
             return
@@ -672,16 +689,10 @@ class UpdateEngine:
             outs.append(self.Xa[M:])
         be.rms_normalize(ds['obs'], self.obs, idx, remap, M, self.obs_mean[0], self.obs_std[0], outs)
         fork1 = self._mark()                 # critic: observations normalised, latents in place (gather_minibatch)
-        if self.div_on:
-            if new_z is not None:
-                be.copy_(self.new_z, new_z.contiguous())
-                be.gather_rows(self.new_z, self.z, None, (0, 0), M, self.Zs[M:])
-            else:
-                # element index = GLOBAL minibatch row: rank r of a sharded step draws rows [r M, (r + 1) M); the kernel
-                # also writes the compute-dtype copy the style MLP reads
-                be.sample_latents(self.new_z, M, self.z, self.rng_state,
-                                  row_offset=self.rank * M if (self.shard and self.R > 1) else 0, advance=False,
-                                  z2=self.Zs[M:])
+        if self._prep is not None:
+            be.wait(self._lat_ready)         # latent copies + diversity draw of the short prologue (critic's stream)
+        elif self.div_on:
+            self._draw_new_latents(new_z)
 
         # The actor chain (2 M rows with the diversity pass) is the longest: it is launched FIRST on the main stream, the
         # critic and the discriminator branches follow on their streams, forked from the events above.

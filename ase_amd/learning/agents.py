@@ -173,6 +173,8 @@ class CommonAgent:
                                    world_size=self.world_size, rank=self.rank, dp_mode=self.dp_mode)
         self.model.a2c_network.infer = InferenceEngine(self.model.a2c_network, self.engine)
         self.use_graph = bool(config.get('graph_capture', False))
+        self._snapshot_aside = os.environ.get('ASE_SNAPSHOT_ASIDE', '1') != '0'
+        self._snapshot_stream = None
         self._graphs = {}
         self._train_mode = True
         self.train_result = None
@@ -588,13 +590,27 @@ class CommonAgent:
         ds = {k: v for k, v in input_dict.items() if v is not None}
         self.engine.step(ds, idx, (0, 0), streams, new_z=input_dict.get('_new_z'))
         self.train_result = self._collect_result()
+        if self._snapshot_stream is not None:          # single-step callers read the result right away
+            torch.cuda.current_stream().wait_stream(self._snapshot_stream)
+            self._snapshot_stream = None
 
     def train_actor_critic(self, input_dict):
         self.calc_gradients(input_dict)
         return self.train_result
 
     def _collect_result(self):
-        r = dict(self.engine.results(snapshot=True))
+        eng = self.engine
+        side = eng._side(1) if (eng.multi_stream and self._snapshot_aside) else None
+        if side is not None:
+            # the two small snapshot copies (scalar vector, logit column) leave the main stream: they used to sit between
+            # one step's last kernel and the next step's first (13 us per step).  They run on the discriminator's stream -
+            # in front of the next step's discriminator work, which is what overwrites the logits; update() joins it.
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                r = dict(eng.results(snapshot=True))
+            self._snapshot_stream = side
+        else:
+            r = dict(eng.results(snapshot=True))
         r['last_lr'] = self.last_lr
         r['lr_mul'] = 1.0
         return r
@@ -732,6 +748,9 @@ class CommonAgent:
                 step += 1
             if perms is None:          # AMPDataset reshuffles after the last minibatch (learning/amp_datasets.py:24-30)
                 self.dataset_perm = self._randperm(self.batch_size)
+        if self._snapshot_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._snapshot_stream)
+            self._snapshot_stream = None
         self._post_update(batch_dict)
         return train_info
 
