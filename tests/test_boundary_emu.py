@@ -344,3 +344,23 @@ def test_fetch_amp_obs_demo_matches_reference(local_root, root_h, golden_dir):
     from ase_amd.synthetic import EnvSpec, SyntheticVecEnv
     env = SyntheticVecEnv(EnvSpec(num_envs=8, horizon=2), device=_DEV, demo_source=src)
     assert env.fetch_amp_obs_demo(16).shape == (16, 1400)
+
+
+def test_motion_lib_from_reference_object(golden_dir):
+    """DeviceMotionLib.from_reference takes a loaded reference MotionLib (duck-typed here: the attributes its loader
+    leaves, utils/motion_lib.py:174-252) - same state as from the arrays, weights normalised like motion_lib.py:213."""
+    import types
+    from ase_amd.motion_lib import DeviceMotionLib
+    M = torch.load(os.path.join(golden_dir, 'motion_state.pt'), weights_only=False)
+    c = M['clips']
+    ref = types.SimpleNamespace(gts=c['gts'], grs=c['grs'], lrs=c['lrs'], grvs=c['grvs'], gravs=c['gravs'], dvs=c['dvs'],
+                                _motion_lengths=c['lengths'], _motion_num_frames=c['num_frames'], _motion_dt=c['dt'],
+                                length_starts=c['length_starts'], _motion_weights=torch.tensor([1.0, 3.0]))
+    be = _BE()
+    a = DeviceMotionLib.from_reference(ref, be, _DEV, c['dof_body_ids'], c['dof_offsets'], c['key_body_ids'])
+    b = DeviceMotionLib.from_arrays(c, be, _DEV, weights=[0.25, 0.75])
+    assert torch.allclose(a._motion_weights.cpu(), torch.tensor([0.25, 0.75])) and a.num_motions() == b.num_motions() == 2
+    assert abs(a.get_total_length() - float(c['lengths'].sum())) < 1e-5
+    ids, t = M['motion_ids'][:16].to(_DEV), M['times'][:16].to(_DEV)
+    for x, y in zip(a.get_motion_state(ids, t), b.get_motion_state(ids, t)):
+        assert torch.equal(x, y)

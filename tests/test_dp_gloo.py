@@ -38,7 +38,7 @@ def _worker(rank, world, port, name, out):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize('name', ['ase_tiny', 'amp_tiny', 'ppo_tiny'])
+@pytest.mark.parametrize('name', ['ase_tiny', 'amp_tiny', 'ppo_tiny', 'ase_gp_tiny'])
 def test_two_ranks_match_reference_and_single_rank(name, tmp_path):
     G = torch.load(os.path.join(GOLDEN, name + '.pt'), weights_only=False)
     ag1 = make_agent(G, EmuBackend())
