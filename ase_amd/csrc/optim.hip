@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ g, const 
 // desc[l] (int64 x 24), one entry per weight matrix:
 //   0 W  1 n_real  2 k_real  3 Ws  4 ldws  5 Wts  6 ldwts  7 split_src  8 gap  9 bias  10 bias_shadow  11 tiles_k
 //   12 gW  13 mW  14 vW  15 gb  16 mb  17 vb  18 wd coefficient (f32 bits)  19 acc slot A (or -1)  20 acc slot B (or -1)
+//   21 wide (1: k_real, both shadow pitches, split_src and gap are multiples of 4, shadows 16-byte aligned -> 16-byte path)
 // Per 32 x 32 tile of W (rows coalesced): g += wd * w (weight-only loss terms), sum of w^2 of the PRE-update weights
 // into acc[slot A / B] (reported regularisers), Adam, then the fresh weight goes straight into the compute-dtype
 // shadows W_s (row-major) and W_s^T (through an LDS transpose).  The first workgroup of a layer also steps the bias.
@@ -60,10 +61,25 @@ __device__ __forceinline__ float adam_elem(float w, float gi, float& mi, float& 
     return w - step_size * (mi / denom);            // param.addcdiv_(exp_avg, denom, value=-step_size)
 }
 
+// 16-byte accesses on the flat f32 buffers (parameters / gradients / moments start at arbitrary 4-byte offsets behind the
+// odd-sized bias vectors: dword alignment is all the hardware asks of a global dwordx4)
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+template <typename T> __device__ __forceinline__ void store_shadow4(T* p, const float (&w)[4]);
+template <> __device__ __forceinline__ void store_shadow4<bf16_t>(bf16_t* p, const float (&w)[4]) {
+    bf16x4 v;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = (bf16_t)w[c];
+    *reinterpret_cast<bf16x4*>(p) = v;
+}
+template <> __device__ __forceinline__ void store_shadow4<float>(float* p, const float (&w)[4]) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{w[0], w[1], w[2], w[3]};
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void apply_multi_kernel(const int64_t* __restrict__ desc, const double* __restrict__ st,
                                                           double* __restrict__ acc) {
-    __shared__ float tile[32][33];
+    __shared__ float tile[32][129];          // scalar path: [32][33] of it
     __shared__ double red[16];
     const int64_t* d = desc + 24 * blockIdx.y;
     float* W = reinterpret_cast<float*>(d[0]);
@@ -104,6 +120,70 @@ __global__ __launch_bounds__(256) void apply_multi_kernel(const int64_t* __restr
         }
     }
     double w2[1] = {0.0};
+    // ---- wide path (desc[21]: rows in whole 16-byte chunks on every side): 32 x 128 tiles, one 16-byte access per array
+    // and thread for 4 weights, 16 transposed shadow values (32 / 64 bytes) per store instead of one
+    if (d[21]) {
+        const int tk = (k_real + 127) / 128;
+        const int tilesv = tk * ((n_real + 31) / 32);
+        const int vx = threadIdx.x & 31, vy = threadIdx.x >> 5;
+        for (int t = blockIdx.x; t < tilesv; t += gridDim.x) {
+            const int k0 = (t % tk) * 128, n0 = (t / tk) * 32;
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = n0 + vy + 8 * i, k = k0 + 4 * vx;
+                float w[4] = {0.f, 0.f, 0.f, 0.f};
+                if (n < n_real && k < k_real) {
+                    const int64_t o = (int64_t)n * k_real + k;
+                    const f4u wv = *reinterpret_cast<const f4u*>(W + o);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) w[c] = wv[c];
+                    if (adam) {
+                        f4u gv = *reinterpret_cast<const f4u*>(gW + o);
+                        f4u mv = *reinterpret_cast<const f4u*>(mW + o), vv = *reinterpret_cast<const f4u*>(vW + o);
+                        if (slot_a >= 0) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) w2[0] += (double)w[c] * (double)w[c];
+                        }
+                        if (wd != 0.f) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) gv[c] = gv[c] + wd * w[c];
+                            *reinterpret_cast<f4u*>(gW + o) = gv;      // the exported gradient includes the weight-only terms
+                        }
+                        f4u wn;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            float mi = mv[c], vi = vv[c];
+                            w[c] = adam_elem(w[c], gv[c], mi, vi, one_m_b1, b2, one_m_b2, eps, step_size, bc2_sqrt);
+                            mv[c] = mi; vv[c] = vi; wn[c] = w[c];
+                        }
+                        *reinterpret_cast<f4u*>(W + o) = wn;
+                        *reinterpret_cast<f4u*>(mW + o) = mv;
+                        *reinterpret_cast<f4u*>(vW + o) = vv;
+                    }
+                    store_shadow4<T>(Ws + (int64_t)n * ldws + ((k < split_src) ? k : k + gap), w);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) tile[vy + 8 * i][4 * vx + c] = w[c];
+            }
+            __syncthreads();
+            const int kk = threadIdx.x >> 1, half = threadIdx.x & 1;
+            const int k = k0 + kk, nb = n0 + 16 * half;
+            if (k < k_real && nb < n_real) {
+                T* dst = Wts + (int64_t)((k < split_src) ? k : k + gap) * ldwts + nb;
+                if (nb + 16 <= n_real) {
+#pragma unroll
+                    for (int q = 0; q < 16; q += 4) {
+                        const float w4[4] = {tile[16 * half + q][kk], tile[16 * half + q + 1][kk], tile[16 * half + q + 2][kk],
+                                             tile[16 * half + q + 3][kk]};
+                        store_shadow4<T>(dst + q, w4);
+                    }
+                } else {
+                    for (int q = 0; q < 16 && nb + q < n_real; ++q) dst[q] = from_f32<T>(tile[16 * half + q][kk]);
+                }
+            }
+        }
+    } else
     for (int t = blockIdx.x; t < tiles; t += gridDim.x) {
         const int k0 = (t % tiles_k) * 32, n0 = (t / tiles_k) * 32;
         __syncthreads();

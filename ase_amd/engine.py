@@ -116,6 +116,7 @@ class UpdateEngine:
         self._apply_groups = None
         self._use_bits = os.environ.get('ASE_RELU_BITS', '1') != '0'
         self._fused_apply = hasattr(backend, 'apply_multi') and os.environ.get('ASE_FUSED_APPLY', '1') != '0'
+        self._apply_wide = os.environ.get('ASE_APPLY_WIDE', '1') != '0'
         self._apply_desc = self._apply_items = None
         self.force_dist = bool(cfg.get('force_dist', False))   # exercise the collectives with a 1-rank group
         self._refresh_desc = None
@@ -358,10 +359,16 @@ class UpdateEngine:
                 assert len(slots) <= 2, slots
                 sa = slots[0] if len(slots) > 0 else -1
                 sb = slots[1] if len(slots) > 1 else -1
+                gap = d.split_dst - d.split_src
+                # 16-byte path of the kernel: rows in whole 4-element chunks on every side (the first layers' K = obs + z
+                # = 317 stays on the scalar path)
+                wide = int(self._apply_wide and d.K % 4 == 0 and ws.stride(0) % 4 == 0 and wts.stride(0) % 4 == 0
+                           and (d.split_src >= d.K or (d.split_src % 4 == 0 and gap % 4 == 0))
+                           and ws.data_ptr() % 16 == 0 and wts.data_ptr() % 16 == 0)
                 rows.append([W.data_ptr(), nr, d.K, ws.data_ptr(), ws.stride(0), wts.data_ptr(), wts.stride(0), d.split_src,
-                             d.split_dst - d.split_src, b.data_ptr(), bs.data_ptr(), (d.K + 31) // 32, gW.data_ptr(),
+                             gap, b.data_ptr(), bs.data_ptr(), (d.K + 31) // 32, gW.data_ptr(),
                              mW.data_ptr(), vW.data_ptr(), gb.data_ptr(), mb.data_ptr(), vb.data_ptr(),
-                             struct.unpack('<i', struct.pack('<f', float(coef)))[0], sa, sb, 0, 0, 0])
+                             struct.unpack('<i', struct.pack('<f', float(coef)))[0], sa, sb, wide, 0, 0])
                 items.append((W, ws, wts, d.split_src, d.split_dst, b, bs, gW.view(-1).view_as(W), mW.view_as(W), vW.view_as(W),
                               gb, mb, vb, float(coef), sa, sb))
         n_cov = sum(it[0].numel() + it[5].numel() for it in items)

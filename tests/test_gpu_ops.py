@@ -566,7 +566,10 @@ def test_apply_multi_fused_optimizer_step(be, dt):
     of the emulation (axpy / reduce_sum / adam / refresh_shadow) on two layers with concat column maps."""
     import struct
     g = torch.Generator().manual_seed(7)
-    specs = [(48, 53, 37, 64, 0.02, 3, 5), (130, 200, 200, 200, 0.0, -1, -1), (1, 70, 70, 70, 0.5, 4, -1)]
+    # (n, k, split_src, split_dst, coefficient, slot a, slot b, wide): wide = the kernel's 16-byte path (k, split and gap in
+    # whole 4-element chunks); its parameter / gradient / moment tensors start at an odd 4-byte offset of their buffers
+    specs = [(48, 53, 37, 64, 0.02, 3, 5, 0), (130, 200, 200, 200, 0.0, -1, -1, 0), (1, 70, 70, 70, 0.5, 4, -1, 0),
+             (130, 200, 200, 200, 0.0, -1, -1, 1), (300, 520, 256, 264, 0.01, 6, 7, 1), (31, 512, 512, 512, 0.0, -1, -1, 1)]
     outs = []
     for dev in ('cuda', 'cpu'):
         b = be if dev == 'cuda' else EmuBackend()
@@ -574,17 +577,18 @@ def test_apply_multi_fused_optimizer_step(be, dt):
         rows, items, keep = [], [], []
         acc = torch.zeros(8, dtype=torch.float64, device=dev)
         st = torch.tensor([3.0, 1e-3, 0.9, 0.999, 1e-8, 1 - 0.9 ** 3, 1 - 0.999 ** 3, 0.0], dtype=torch.float64, device=dev)
-        for (n, k, ss, sd, coef, sa, sb) in specs:
-            W, b_ = torch.randn(n, k, generator=gg).to(dev), torch.randn(n, generator=gg).to(dev)
-            gW, gb = torch.randn(n, k, generator=gg).to(dev), torch.randn(n, generator=gg).to(dev)
-            mW, vW = torch.randn(n, k, generator=gg).to(dev) * 0.1, torch.rand(n, k, generator=gg).to(dev) * 0.01
+        for (n, k, ss, sd, coef, sa, sb, wide) in specs:
+            odd = lambda t: torch.cat([t.new_zeros(1), t.reshape(-1)])[1:].view_as(t)       # 4-byte aligned only
+            W, b_ = odd(torch.randn(n, k, generator=gg).to(dev)), torch.randn(n, generator=gg).to(dev)
+            gW, gb = odd(torch.randn(n, k, generator=gg).to(dev)), torch.randn(n, generator=gg).to(dev)
+            mW, vW = odd(torch.randn(n, k, generator=gg).to(dev) * 0.1), odd(torch.rand(n, k, generator=gg).to(dev) * 0.01)
             mb, vb = torch.randn(n, generator=gg).to(dev) * 0.1, torch.rand(n, generator=gg).to(dev) * 0.01
             npad, kpad = (n + 63) // 64 * 64, (k + (sd - ss) + 63) // 64 * 64
             Ws, Wts = torch.zeros(npad, kpad, dtype=dt, device=dev), torch.zeros(kpad, npad, dtype=dt, device=dev)
             bs = torch.zeros(npad, device=dev)
             rows.append([W.data_ptr(), n, k, Ws.data_ptr(), Ws.stride(0), Wts.data_ptr(), Wts.stride(0), ss, sd - ss,
                          b_.data_ptr(), bs.data_ptr(), (k + 31) // 32, gW.data_ptr(), mW.data_ptr(), vW.data_ptr(),
-                         gb.data_ptr(), mb.data_ptr(), vb.data_ptr(), struct.unpack('<i', struct.pack('<f', coef))[0], sa, sb, 0, 0, 0])
+                         gb.data_ptr(), mb.data_ptr(), vb.data_ptr(), struct.unpack('<i', struct.pack('<f', coef))[0], sa, sb, wide, 0, 0])
             items.append((W, Ws, Wts, ss, sd, b_, bs[:n], gW, mW, vW, gb, mb, vb, coef, sa, sb))
             keep.append((W, b_, gW, mW, vW, mb, vb, Ws, Wts, bs))
         desc = torch.tensor(rows, dtype=torch.int64, device=dev)
