@@ -162,3 +162,12 @@ def test_torch_library_ops_registered():
     assert str(torch.ops.ase_hip.linear_act.default._schema) == 'ase_hip::linear_act(Tensor x, Tensor w, Tensor b, str act) -> Tensor'
     with pytest.raises(NotImplementedError):
         torch.ops.ase_hip.linear_act(torch.zeros(4, 8), torch.zeros(3, 8), torch.zeros(3), 'relu')
+
+
+def test_every_entry_point_is_documented():
+    """INTEGRATION.md (section C) names every function of the C ABI next to the reference statement it replaces - grouped
+    families are written as `ase_hip_prog_create / begin / ...`."""
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    for name in _header_decls():
+        stem, last = name.rsplit('_', 1)
+        assert name in doc or (stem in doc and re.search(r'[/ ]\s*' + re.escape(last) + r'\b', doc)), f'{name} is not mentioned in INTEGRATION.md'
