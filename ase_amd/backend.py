@@ -26,6 +26,8 @@ def _code(dtype):
         return L.BF16
     if dtype == torch.float32:
         return L.F32
+    if dtype == torch.float16:
+        return L.F16
     raise L.AseHipError(f"unsupported storage dtype {dtype}")
 
 
@@ -117,7 +119,7 @@ class HipBackend:
         LAB_TNG_N) the six narrow problems of a step add 67 us to the grouped launch against 156 us as seven launches of the
         128 x 128 kernel.  ASE_TN_GROUP_ALL=0 restores the round-1 rule (wide outputs only)."""
         import os
-        if dtype != torch.bfloat16 or M % 64 != 0 or bias_rows % 64 != 0:
+        if dtype not in (torch.bfloat16, torch.float16) or M % 64 != 0 or bias_rows % 64 != 0:
             return False
         if os.environ.get('ASE_TN_GROUP_ALL', '1') != '0':
             return True
@@ -130,7 +132,7 @@ class HipBackend:
         n = len(problems)
         tab = (C.c_int64 * (16 * n))()
         for i, (A, B, G, gb, br, M, N, K, nr, kr, ss, sd, alpha) in enumerate(problems):
-            assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and G.dtype == torch.float32
+            assert A.dtype in (torch.bfloat16, torch.float16) and B.dtype == A.dtype and G.dtype == torch.float32
             row = [A.data_ptr(), _ld(A), B.data_ptr(), _ld(B), G.data_ptr(), 0 if gb is None else gb.data_ptr(), int(br),
                    M, N, K, nr, kr, ss, sd, struct.unpack('<i', struct.pack('<f', float(alpha)))[0], 0]
             for j, v in enumerate(row):
@@ -143,10 +145,10 @@ class HipBackend:
         nw = n_work.value
         dev_tab = torch.tensor(list(tab), dtype=torch.int64, device=self.device)
         dev_work = torch.tensor(list(work[:4 * nw]), dtype=torch.int32, device=self.device)
-        return {'problems': dev_tab, 'work': dev_work, 'n_work': nw, 'keep': problems}
+        return {'problems': dev_tab, 'work': dev_work, 'n_work': nw, 'keep': problems, 'dtype': _code(problems[0][0].dtype)}
 
     def gemm_tn_grouped(self, plan):
-        L.check(self.lib.ase_hip_gemm_tn_grouped(_ptr(plan['problems']), _ptr(plan['work']), plan['n_work'], L.BF16,
+        L.check(self.lib.ase_hip_gemm_tn_grouped(_ptr(plan['problems']), _ptr(plan['work']), plan['n_work'], plan['dtype'],
                                                  self._stream()), "gemm_tn_grouped")
 
     def refresh_shadow(self, W, Ws, Wts, split_src, split_dst):
@@ -256,7 +258,7 @@ class HipBackend:
 
     def ppo_head(self, mu, value, mb, new_z, logstd, d_mu, d_value, db_mu, db_value, acc, M, m_global, act_dim,
                  z_dim, masked, div_on, mu_tanh, clip_value, e_clip, critic_coef, bounds_coef, div_coef, div_tar,
-                 mu_out=None):
+                 mu_out=None, grad_scale=1.0):
         L.check(self.lib.ase_hip_ppo_head(
             _ptr(mu), _ld(mu), _ptr(value), _ld(value), _ptr(mb['actions']), _ptr(mb['mu']), _ptr(mb['sigma']),
             _ptr(mb['old_logp_actions']), _ptr(mb['advantages']), _ptr(mb.get('old_values')), _ptr(mb['returns']),
@@ -264,17 +266,17 @@ class HipBackend:
             _ptr(d_mu), _ld(d_mu), _ptr(d_value), _ld(d_value), _ptr(db_mu), _ptr(db_value), _ptr(mu_out), _ptr(acc),
             _ptr(self._head_scratch),
             M, m_global, act_dim, z_dim, int(masked), int(div_on), int(mu_tanh), int(clip_value),
-            float(e_clip), float(critic_coef), float(bounds_coef), float(div_coef), float(div_tar),
+            float(e_clip), float(critic_coef), float(bounds_coef), float(div_coef), float(div_tar), float(grad_scale),
             _code(d_mu.dtype), self._stream()), "ppo_head")
 
-    def disc_head(self, logit, d_logit, db_logit, acc, amb, amb_global, disc_coef):
+    def disc_head(self, logit, d_logit, db_logit, acc, amb, amb_global, disc_coef, grad_scale=1.0):
         L.check(self.lib.ase_hip_disc_head(_ptr(logit), _ld(logit), _ptr(d_logit), _ld(d_logit), _ptr(db_logit),
-                                           _ptr(acc), amb, amb_global, float(disc_coef), _code(d_logit.dtype),
+                                           _ptr(acc), amb, amb_global, float(disc_coef), float(grad_scale), _code(d_logit.dtype),
                                            self._stream()), "disc_head")
 
-    def enc_head(self, e, z, d_e, db_enc, enc_out, acc, amb, amb_global, z_dim, enc_coef):
+    def enc_head(self, e, z, d_e, db_enc, enc_out, acc, amb, amb_global, z_dim, enc_coef, grad_scale=1.0):
         L.check(self.lib.ase_hip_enc_head(_ptr(e), _ld(e), _ptr(z), _ld(z), _ptr(d_e), _ld(d_e), _ptr(db_enc),
-                                          _ptr(enc_out), _ptr(acc), amb, amb_global, z_dim, float(enc_coef),
+                                          _ptr(enc_out), _ptr(acc), amb, amb_global, z_dim, float(enc_coef), float(grad_scale),
                                           _code(d_e.dtype), self._stream()), "enc_head")
 
     def enc_gp_seed(self, e, z, u, rows, z_dim, scale=1.0):
@@ -283,11 +285,12 @@ class HipBackend:
         L.check(self.lib.ase_hip_enc_gp_seed(_ptr(e), _ld(e), _ptr(z), _ld(z), _ptr(u), _ld(u), rows, z_dim, float(scale),
                                              _code(u.dtype), self._stream()), "enc_gp_seed")
 
-    def enc_gp_back(self, e, z, du, d_e, db_enc, rows, z_dim):
+    def enc_gp_back(self, e, z, du, d_e, db_enc, rows, z_dim, grad_scale=1.0):
         """d_e[:rows, :z_dim] += (d u / d e) du, the bias gradient follows the stored values."""
         assert e.dtype == torch.float32 and z.dtype == torch.float32 and du.dtype == torch.float32
         L.check(self.lib.ase_hip_enc_gp_back(_ptr(e), _ld(e), _ptr(z), _ld(z), _ptr(du), _ld(du), _ptr(d_e), _ld(d_e),
-                                             _ptr(db_enc), rows, z_dim, _code(d_e.dtype), self._stream()), "enc_gp_back")
+                                             _ptr(db_enc), rows, z_dim, float(grad_scale), _code(d_e.dtype), self._stream()),
+                "enc_gp_back")
 
     def gp_seed(self, h, w, g, rows, width, scale=1.0):
         L.check(self.lib.ase_hip_gp_seed(_ptr(h), _ld(h), _ptr(w), _ptr(g), _ld(g), rows, width, float(scale), _code(h.dtype),

@@ -10,6 +10,9 @@
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef _Float16 f16_t;                                    // IEEE half: 10 explicit mantissa bits (bf16: 7), same MFMA rate
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
@@ -41,11 +44,40 @@ struct f32s_t { float v; };
 __device__ __forceinline__ float to_f32(float x) { return x; }
 __device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }
 __device__ __forceinline__ float to_f32(f32s_t x) { return x.v; }
+__device__ __forceinline__ float to_f32(f16_t x) { return (float)x; }
 
 template <typename T> __device__ __forceinline__ T from_f32(float x);
 template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }  // RNE
 template <> __device__ __forceinline__ f32s_t from_f32<f32s_t>(float x) { return f32s_t{x}; }
+// f16: RNE, saturating at the largest finite half (a scaled gradient that overflows must not turn into inf -> NaN)
+template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float x) { return (f16_t)__builtin_amdgcn_fmed3f(x, -65504.f, 65504.f); }
+
+// ---- the two 16-bit storage types share every kernel: vector types and the matrix instruction by type -----------
+template <typename T> struct V16;
+template <> struct V16<bf16_t> { typedef bf16x8 x8; typedef bf16x4 x4; };
+template <> struct V16<f16_t> { typedef f16x8 x8; typedef f16x4 x4; };
+// (instantiated for 4-byte storage types only in dead branches)
+template <> struct V16<float> { typedef bf16x8 x8; typedef bf16x4 x4; };
+template <typename T> __device__ __forceinline__ f32x16 mfma16(typename V16<T>::x8 a, typename V16<T>::x8 b, f32x16 c);
+template <> __device__ __forceinline__ f32x16 mfma16<bf16_t>(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x16 mfma16<f16_t>(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// ---- host-side dispatch over the storage types of activations / shadow weights ----------------------------------
+template <typename T> struct StorageTag { typedef T type; };
+template <typename F> inline int ase_dispatch_storage(int dtype, F&& f) {
+    switch (dtype) {
+        case ASE_F32: return f(StorageTag<float>{});
+        case ASE_BF16: return f(StorageTag<bf16_t>{});
+        case ASE_F16: return f(StorageTag<f16_t>{});
+        default: return ASE_EUNSUPPORTED;
+    }
+}
+inline int ase_elem_size(int dtype) { return (dtype == ASE_BF16 || dtype == ASE_F16) ? 2 : 4; }
 
 // ---- dataset row map (see ase_hip.h) -------------------------------------------------------
 __device__ __forceinline__ int64_t map_row(int r, const int32_t* __restrict__ idx, int remap_h, int remap_n) {

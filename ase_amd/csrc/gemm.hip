@@ -39,7 +39,8 @@ template <typename T> struct Mma;
 // either way the 16 rows (distinct mod 16) of a ds_read_b128 lane group land on 16 distinct slots.
 template <int RB> __device__ __forceinline__ int lds_swz(int r) { return RB == 128 ? ((r >> 1) & 7) : ((r >> 2) & 3); }
 
-template <> struct Mma<bf16_t> {
+template <typename T> struct Mma16 {
+    typedef typename V16<T>::x8 x8;
     // one staged row = RB/2 k-values = RB/32 steps of 16
     // SW: D = B-fragment x A-fragment (transposed accumulator block: a lane owns one output row, see nt_epilogue_rows)
     template <int FM, int FN, int RB, bool SW = false>
@@ -47,24 +48,26 @@ template <> struct Mma<bf16_t> {
         const int r = lane & 31, h = lane >> 5, sw = lds_swz<RB>(r);
 #pragma unroll
         for (int ks = 0; ks < RB / 32; ++ks) {
-            bf16x8 a[FM], b[FN];
+            x8 a[FM], b[FN];
             const int off = r * RB + (((ks * 2 + h) ^ sw) << 4);
 #pragma unroll
             for (int i = 0; i < FM; ++i)
-                a[i] = *reinterpret_cast<const bf16x8*>(sA + i * 32 * RB + off);
+                a[i] = *reinterpret_cast<const x8*>(sA + i * 32 * RB + off);
 #pragma unroll
             for (int j = 0; j < FN; ++j)
-                b[j] = *reinterpret_cast<const bf16x8*>(sB + j * 32 * RB + off);
+                b[j] = *reinterpret_cast<const x8*>(sB + j * 32 * RB + off);
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j) {
-                    if constexpr (SW) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    if constexpr (SW) acc[i][j] = mfma16<T>(b[j], a[i], acc[i][j]);
+                    else acc[i][j] = mfma16<T>(a[i], b[j], acc[i][j]);
                 }
         }
     }
 };
+template <> struct Mma<bf16_t> : Mma16<bf16_t> {};
+template <> struct Mma<f16_t> : Mma16<f16_t> {};
 
 template <> struct Mma<float> {
     // one staged row = RB/4 k-values = RB/32 blocks of 8; within a block lane-half h holds k = 4h..4h+3
@@ -176,6 +179,7 @@ struct NTParams {
 template <typename T, int AUXK> struct AuxReg;
 template <typename T> struct AuxReg<T, 0> { char v; };
 template <> struct AuxReg<bf16_t, 1> { bf16x4 v; };
+template <> struct AuxReg<f16_t, 1> { f16x4 v; };
 template <> struct AuxReg<float, 1> { f32x4 v; };
 template <> struct AuxReg<f32s_t, 1> { f32x4 v; };
 template <typename T> struct AuxReg<T, 2> { uint32_t v; };
@@ -284,13 +288,14 @@ __device__ __forceinline__ void nt_epilogue_impl(const NTParams& p, f32x16 (&acc
                 if (p.out_f32 || sizeof(T) == 4) {
                     *reinterpret_cast<f32x4*>(p.C + (int64_t)m * p.ldc + (int64_t)n0 * 4) = v;
                 } else {
-                    bf16x4 o;
+                    typedef typename std::conditional<sizeof(T) == 2, T, bf16_t>::type S;     // (4-byte T: dead branch)
+                    typename V16<S>::x4 o;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        o[q] = (bf16_t)v[q];
+                        o[q] = from_f32<S>(v[q]);
                         v[q] = (float)o[q];
                     }
-                    *reinterpret_cast<bf16x4*>(p.C + (int64_t)m * p.ldc + (int64_t)n0 * 2) = o;
+                    *reinterpret_cast<typename V16<S>::x4*>(p.C + (int64_t)m * p.ldc + (int64_t)n0 * 2) = o;
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) cs[q] += v[q];
@@ -331,7 +336,7 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x16 (&acc)[FM]
 // ---- row-per-lane epilogue of the lock-step kernels (bf16, swapped MFMA operands): the general FM x FN form of
 // nt8_epilogue_rows further down - see there.  acc[i][j]: lane (r = lane & 31, h = lane >> 5) owns output row i*32 + r
 // and the columns j*32 + 8 g + 4 h + q.  bits[i][j]: the ReLU mask word of (row, 32-column fragment), loaded by the caller.
-template <int FM, int FN, int AUXK>
+template <typename T, int FM, int FN, int AUXK>
 __device__ __forceinline__ void nt_epilogue_rows(const NTParams& p, f32x16 (&acc)[FM][FN], int lane, int mrow0, int ncol0,
                                                  const uint32_t (&bits)[FM][FN]) {
     if (ncol0 >= p.N) return;                                   // wave-uniform: N is a multiple of the wave tile's width
@@ -353,13 +358,13 @@ __device__ __forceinline__ void nt_epilogue_rows(const NTParams& p, f32x16 (&acc
             uint32_t mb = 0;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                bf16_t o[4];
+                T o[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float v = p.alpha * acc[i][j][g * 4 + q] + bias[g][q];
                     if (p.act == ASE_ACT_RELU) v = fmaxf(v, 0.f);
                     if constexpr (AUXK == 2) v = ((bits[i][j] >> (8 * g + 4 * h + q)) & 1u) ? v : 0.f;
-                    o[q] = (bf16_t)v;
+                    o[q] = from_f32<T>(v);
                     mb |= ((float)o[q] > 0.f ? 1u : 0u) << (8 * g + 4 * h + q);
                 }
                 pk[g][0] = (uint32_t)__builtin_bit_cast(uint16_t, o[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, o[1]) << 16);
@@ -469,14 +474,16 @@ __global__ __launch_bounds__(WGM * WGN * 64, WPE) void gemm_nt_kernel(NTParams p
         }
         const char* sA = smem + buf * kBuf + (wm * FM * 32) * RB;
         const char* sB = smem + buf * kBuf + (BM + wn * FN * 32) * RB;
-        if constexpr (SW) Mma<T>::template tile<FM, FN, RB, true>(sA, sB, lane, acc);
+        if constexpr (SW && sizeof(T) == 2) Mma<T>::template tile<FM, FN, RB, true>(sA, sB, lane, acc);
         else Mma<T>::template tile<FM, FN, RB>(sA, sB, lane, acc);
         buf = (buf + 1 == S) ? 0 : buf + 1;
     }
     if constexpr (SW) {
         if constexpr (S != 2) load_bits();
-        if (p.aux_mode == ASE_AUX_RELU_BITS) nt_epilogue_rows<FM, FN, 2>(p, acc, lane, bm0 + wm * FM * 32, bn0 + wn * FN * 32, row_bits);
-        else nt_epilogue_rows<FM, FN, 0>(p, acc, lane, bm0 + wm * FM * 32, bn0 + wn * FN * 32, row_bits);
+        if constexpr (sizeof(T) == 2) {
+            if (p.aux_mode == ASE_AUX_RELU_BITS) nt_epilogue_rows<T, FM, FN, 2>(p, acc, lane, bm0 + wm * FM * 32, bn0 + wn * FN * 32, row_bits);
+            else nt_epilogue_rows<T, FM, FN, 0>(p, acc, lane, bm0 + wm * FM * 32, bn0 + wn * FN * 32, row_bits);
+        }
         return;
     }
     __syncthreads();                                   // everyone is done with the ring before it becomes the epilogue slab
@@ -567,21 +574,21 @@ __device__ __forceinline__ void nt8_read(i32x4 (&f)[4], const char* base, const 
 // SW: operands swapped in the MFMA (D = B-fragment x A-fragment): the accumulator then holds the TRANSPOSED 32 x 32
 // block - a lane owns one output ROW and 4 x 4 consecutive columns - which nt8_epilogue_rows stores straight from
 // registers (no LDS transposition).
-template <bool SW>
-__device__ __forceinline__ f32x16 nt8_mfma(const i32x4& a, const bf16x8& bv, const f32x16& c) {
-    if constexpr (SW) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv, __builtin_bit_cast(bf16x8, a), c, 0, 0, 0);
-    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), bv, c, 0, 0, 0);
+template <typename T, bool SW>
+__device__ __forceinline__ f32x16 nt8_mfma(const i32x4& a, const i32x4& b, const f32x16& c) {
+    typedef typename V16<T>::x8 x8;
+    if constexpr (SW) return mfma16<T>(__builtin_bit_cast(x8, b), __builtin_bit_cast(x8, a), c);
+    else return mfma16<T>(__builtin_bit_cast(x8, a), __builtin_bit_cast(x8, b), c);
 }
 
-template <bool LIVE = true, bool SW = false>
+template <typename T, bool LIVE = true, bool SW = false>
 __device__ __forceinline__ void nt8_mma(f32x16& c0, f32x16& c1, const i32x4 (&a0)[4], const i32x4 (&a1)[4],
                                         const i32x4 (&b)[4]) {
     if constexpr (!LIVE) { asm volatile("" : "+v"(c0), "+v"(c1) : "v"(a0[0]), "v"(a1[3]), "v"(b[2])); return; }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 bv = __builtin_bit_cast(bf16x8, b[ks]);
-        c0 = nt8_mfma<SW>(a0[ks], bv, c0);
-        c1 = nt8_mfma<SW>(a1[ks], bv, c1);
+        c0 = nt8_mfma<T, SW>(a0[ks], b[ks], c0);
+        c1 = nt8_mfma<T, SW>(a1[ks], b[ks], c1);
     }
 }
 
@@ -589,7 +596,7 @@ __device__ __forceinline__ void nt8_mma(f32x16& c0, f32x16& c1, const i32x4 (&a0
 // ~60 issue cycles beside MFMAs (the matrix pipe stays fed by the 32-cycle MFMA issue cadence) but 100-185 cycles in the
 // read half of a phase, where it sat on the critical path of the OTHER wave group's MFMA block (measured by ablation:
 // DMA and fragment reads were additive on top of the MFMA time)
-template <int KIND, bool DM, bool MM, bool SW>
+template <typename T, int KIND, bool DM, bool MM, bool SW>
 __device__ __forceinline__ void nt8_mma_issue(f32x16& c0, f32x16& c1, const i32x4 (&a0)[4], const i32x4 (&a1)[4],
                                               const i32x4 (&b)[4], const NT8Lane& L, char* smem, int tile, bool live) {
     if constexpr (!MM) {
@@ -602,9 +609,8 @@ __device__ __forceinline__ void nt8_mma_issue(f32x16& c0, f32x16& c1, const i32x
     const int64_t koff = (int64_t)tile * 128;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 bv = __builtin_bit_cast(bf16x8, b[ks]);
-        c0 = nt8_mfma<SW>(a0[ks], bv, c0);
-        c1 = nt8_mfma<SW>(a1[ks], bv, c1);
+        c0 = nt8_mfma<T, SW>(a0[ks], b[ks], c0);
+        c1 = nt8_mfma<T, SW>(a1[ks], b[ks], c1);
         if (DM && (ks == 0 || ks == 2)) {
             __builtin_amdgcn_sched_barrier(0);
             if (live)
@@ -643,7 +649,7 @@ template <int V> __device__ __forceinline__ void nt8_sync_out() {     // end of 
 // (t, p), but at the counted wait of a phase (in front of its first barrier) the newest issued unit is now the one of the
 // previous phase: three units may stay in flight instead of four.  RAW (read one phase after wait + barrier) is unchanged,
 // the WAR distance grows by half a phase.
-template <bool TAIL, int V, bool SW>
+template <typename T, bool TAIL, int V, bool SW>
 __device__ __forceinline__ void nt8_ktile_m(int t, int nk, const NT8Lane& L, char* smem, const char* aP, const char* bP,
                                             f32x16 (&acc)[4][2], i32x4 (&a0)[4], i32x4 (&a1)[4], i32x4 (&b0)[4],
                                             i32x4 (&b1)[4]) {
@@ -658,30 +664,30 @@ __device__ __forceinline__ void nt8_ktile_m(int t, int nk, const NT8Lane& L, cha
     if (!TAIL) wait_dma_units<3>();
     else wait_dma_units_rt(min(U, 4 * t + 6) - (4 * t + 3));
     nt8_sync_in<V>();
-    nt8_mma_issue<2, DM, MM, SW>(acc[0][0], acc[1][0], a0, a1, b0, L, smem, t + 1, l1);
+    nt8_mma_issue<T, 2, DM, MM, SW>(acc[0][0], acc[1][0], a0, a1, b0, L, smem, t + 1, l1);
     nt8_sync_out<V>();
     // ---- phase 1
     nt8_read<RD>(b1, bP + 32 * RB, L);
     if (!TAIL) wait_dma_units<3>();
     else wait_dma_units_rt(min(U, 4 * t + 7) - (4 * t + 4));
     nt8_sync_in<V>();
-    nt8_mma_issue<3, DM, MM, SW>(acc[0][1], acc[1][1], a0, a1, b1, L, smem, t + 1, l1);
+    nt8_mma_issue<T, 3, DM, MM, SW>(acc[0][1], acc[1][1], a0, a1, b1, L, smem, t + 1, l1);
     nt8_sync_out<V>();
     // ---- phase 2
     nt8_read<RD>(a0, aP + 64 * RB, L);
     nt8_read<RD>(a1, aP + 96 * RB, L);
     nt8_sync_in<V>();
-    nt8_mma_issue<0, DM, MM, SW>(acc[2][1], acc[3][1], a0, a1, b1, L, smem, t + 2, l2);
+    nt8_mma_issue<T, 0, DM, MM, SW>(acc[2][1], acc[3][1], a0, a1, b1, L, smem, t + 2, l2);
     nt8_sync_out<V>();
     // ---- phase 3
     if (!TAIL) wait_dma_units<3>();
     else if (t + 1 < nk) wait_dma_units_rt(min(U, 4 * t + 9) - (4 * t + 6));
     nt8_sync_in<V>();
-    nt8_mma_issue<1, DM, MM, SW>(acc[2][0], acc[3][0], a0, a1, b0, L, smem, t + 2, l2);
+    nt8_mma_issue<T, 1, DM, MM, SW>(acc[2][0], acc[3][0], a0, a1, b0, L, smem, t + 2, l2);
     nt8_sync_out<V>();
 }
 
-template <bool TAIL, int V, bool SW>
+template <typename T, bool TAIL, int V, bool SW>
 __device__ __forceinline__ void nt8_ktile(int t, int nk, const NT8Lane& L, char* smem, const char* aP, const char* bP,
                                           f32x16 (&acc)[4][2], i32x4 (&a0)[4], i32x4 (&a1)[4], i32x4 (&b0)[4],
                                           i32x4 (&b1)[4]) {
@@ -698,7 +704,7 @@ __device__ __forceinline__ void nt8_ktile(int t, int nk, const NT8Lane& L, char*
     if (!TAIL) wait_dma_units<4>();
     else wait_dma_units_rt(min(U, 4 * t + 7) - (4 * t + 3));
     nt8_sync_in<V>();
-    nt8_mma<MM, SW>(acc[0][0], acc[1][0], a0, a1, b0);
+    nt8_mma<T, MM, SW>(acc[0][0], acc[1][0], a0, a1, b0);
     nt8_sync_out<V>();
     // ---- phase 1: B fragment 1 -> quadrant (0, 1)
     if (IF && (!TAIL || t + 1 < nk)) nt8_issue<3, DM>(L, smem, t + 1);
@@ -707,7 +713,7 @@ __device__ __forceinline__ void nt8_ktile(int t, int nk, const NT8Lane& L, char*
     if (!TAIL) wait_dma_units<4>();
     else wait_dma_units_rt(min(U, 4 * t + 8) - (4 * t + 4));
     nt8_sync_in<V>();
-    nt8_mma<MM, SW>(acc[0][1], acc[1][1], a0, a1, b1);
+    nt8_mma<T, MM, SW>(acc[0][1], acc[1][1], a0, a1, b1);
     nt8_sync_out<V>();
     // ---- phase 2: A sub-tile 1 -> quadrant (1, 1)
     if (IF && (!TAIL || t + 2 < nk)) nt8_issue<0, DM>(L, smem, t + 2);
@@ -715,14 +721,14 @@ __device__ __forceinline__ void nt8_ktile(int t, int nk, const NT8Lane& L, char*
     nt8_read<RD>(a1, aP + 96 * RB, L);
     if (!IF && (!TAIL || t + 2 < nk)) nt8_issue<0, DM>(L, smem, t + 2);
     nt8_sync_in<V>();
-    nt8_mma<MM, SW>(acc[2][1], acc[3][1], a0, a1, b1);
+    nt8_mma<T, MM, SW>(acc[2][1], acc[3][1], a0, a1, b1);
     nt8_sync_out<V>();
     // ---- phase 3: quadrant (1, 0); the wait retires A0 / B0 of K-tile t + 1 for the next phase 0
     if (!TAIL || t + 2 < nk) nt8_issue<1, DM>(L, smem, t + 2);
     if (!TAIL) wait_dma_units<4>();
     else if (t + 1 < nk) wait_dma_units_rt(min(U, 4 * t + 10) - (4 * t + 6));
     nt8_sync_in<V>();
-    nt8_mma<MM, SW>(acc[2][0], acc[3][0], a0, a1, b0);
+    nt8_mma<T, MM, SW>(acc[2][0], acc[3][0], a0, a1, b0);
     nt8_sync_out<V>();
 }
 
@@ -736,7 +742,7 @@ __device__ __forceinline__ void nt8_ktile(int t, int nk, const NT8Lane& L, char*
 // bound by store ISSUE, not by bandwidth).  Mask words: one 32-bit word per (row, 32-column fragment) per lane - all 8 of
 // a wave tile are fetched before the main loop (bits[]); the forward's mask_out word is assembled from the two
 // half-waves' 16 bits each with one more swap.  Needs whole 64-column wave tiles (N % 64 == 0) and a bf16 output.
-template <int AUXK>
+template <typename T, int AUXK>
 __device__ __forceinline__ void nt8_epilogue_rows(const NTParams& p, f32x16 (&acc)[4][2], int lane, int mrow0, int ncol0,
                                                   const uint32_t (&bits)[4][2]) {
     if (ncol0 >= p.N) return;                                   // wave-uniform: N is a multiple of 64
@@ -761,13 +767,13 @@ __device__ __forceinline__ void nt8_epilogue_rows(const NTParams& p, f32x16 (&ac
             uint32_t mb = 0;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                bf16_t o[4];
+                T o[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float v = p.alpha * acc[i][j][g * 4 + q] + bias[j][g][q];
                     if (p.act == ASE_ACT_RELU) v = fmaxf(v, 0.f);
                     if constexpr (AUXK == 2) v = ((bits[i][j] >> (8 * g + 4 * h + q)) & 1u) ? v : 0.f;
-                    o[q] = (bf16_t)v;
+                    o[q] = from_f32<T>(v);
                     mb |= ((float)o[q] > 0.f ? 1u : 0u) << (8 * g + 4 * h + q);
                 }
                 pk[g][0] = (uint32_t)__builtin_bit_cast(uint16_t, o[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, o[1]) << 16);
@@ -797,7 +803,7 @@ __device__ __forceinline__ void nt8_epilogue_rows(const NTParams& p, f32x16 (&ac
 
 template <typename T, int V, bool SW>
 __global__ __launch_bounds__(512) void gemm_nt8_kernel(NTParams p) {
-    static_assert(sizeof(T) == 2, "the phased kernel is bf16 only");
+    static_assert(sizeof(T) == 2, "the phased kernel takes the 16-bit storage types");
     constexpr int RB = 128, BM = 256, BN = 256, BK = 64;
     constexpr int kBuf = (BM + BN) * RB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -893,13 +899,13 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(NTParams p) {
     int t = 0;
     for (; t + 2 < nk; ++t) {
         const char* buf = smem + (t & 1) * kBuf;
-        if constexpr (V & 64) nt8_ktile_m<false, V, SW>(t, nk, L, smem, buf + aoff, buf + boff, acc, a0, a1, b0, b1);
-        else nt8_ktile<false, V, SW>(t, nk, L, smem, buf + aoff, buf + boff, acc, a0, a1, b0, b1);
+        if constexpr (V & 64) nt8_ktile_m<T, false, V, SW>(t, nk, L, smem, buf + aoff, buf + boff, acc, a0, a1, b0, b1);
+        else nt8_ktile<T, false, V, SW>(t, nk, L, smem, buf + aoff, buf + boff, acc, a0, a1, b0, b1);
     }
     for (; t < nk; ++t) {
         const char* buf = smem + (t & 1) * kBuf;
-        if constexpr (V & 64) nt8_ktile_m<true, V, SW>(t, nk, L, smem, buf + aoff, buf + boff, acc, a0, a1, b0, b1);
-        else nt8_ktile<true, V, SW>(t, nk, L, smem, buf + aoff, buf + boff, acc, a0, a1, b0, b1);
+        if constexpr (V & 64) nt8_ktile_m<T, true, V, SW>(t, nk, L, smem, buf + aoff, buf + boff, acc, a0, a1, b0, b1);
+        else nt8_ktile<T, true, V, SW>(t, nk, L, smem, buf + aoff, buf + boff, acc, a0, a1, b0, b1);
     }
     if (wr == 0) NT8_BARRIER();
     __syncthreads();                             // the ring becomes the epilogue slab
@@ -915,8 +921,8 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(NTParams p) {
                 row_bits[i][0] = mw[i * 64 + (lane & 31)];
                 row_bits[i][1] = mw[i * 64 + 32 + (lane & 31)];
             }
-            nt8_epilogue_rows<2>(p, acc, lane, bm0 + wr * 128, bn0 + wc * 64, row_bits);
-        } else nt8_epilogue_rows<0>(p, acc, lane, bm0 + wr * 128, bn0 + wc * 64, row_bits);
+            nt8_epilogue_rows<T, 2>(p, acc, lane, bm0 + wr * 128, bn0 + wc * 64, row_bits);
+        } else nt8_epilogue_rows<T, 0>(p, acc, lane, bm0 + wr * 128, bn0 + wc * 64, row_bits);
     } else if (p.aux_mode == ASE_AUX_RELU_BITS)
         nt_epilogue_impl<T, 4, 2, 2, 2, 2, true>(p, acc, slab, lane, bm0 + wr * 128, bn0 + wc * 64, &pre_bits);
     else
@@ -950,350 +956,29 @@ template <typename T, int V, bool SW = false> int launch_nt8(const NTParams& p0,
     return ASE_OK;
 }
 
-// ------------------------------------------------------------------------------------------------
-// NT, 256 x 256 tile as FOUR waves (bf16): one wave per SIMD, wave tile 128 x 128 = 4 x 4 blocks of 32 x 32 in 256
-// accumulator registers.  Why: with eight waves of 128 x 64 the fragment reads of one K-tile are 192 KB per CU and the
-// DMA writes 64 KB - at 128 B/clk that is as long as the K-tile's MFMAs themselves (2048 clk), so LDS and matrix pipe
-// have to overlap perfectly; with 128 x 128 wave tiles the reads are 128 KB (75 % of the MFMA time together with the
-// DMA).  One wave per SIMD has no partner to hide behind, so the overlap is inside the wave: every phase is
-//     counted vmcnt | s_barrier | 16 MFMAs with 8 ds_read_b128 (the NEXT phase's new fragment set) and the 4
-//     global_load_lds of one 16-KiB unit issued between them | lgkmcnt(0)
-// The K-tile image, the swizzle and the DMA units (A0, B0, B1, A1 = the two 64-row halves of every wave's A / B rows, in
-// order of first use) are those of the phased 8-wave kernel; 4 phases per K-tile walk the quadrants
-//     q0: A01 x B01   q1: A01 x B23   q2: A23 x B23   q3: A23 x B01
-// and read  q0: B23(t)  q1: A23(t)  q2: A01(t+1)  q3: B01(t+1)  - 8 reads per phase, every set read once per K-tile
-// (32 KB per wave and K-tile).  B01(t+1) lands in the registers B23(t) just left, so the two B buffers swap roles every
-// K-tile (the caller alternates them).  Unit u is read in phase u - 2; phase p issues unit p + 8 into the ring slot of
-// unit p (read in phase p - 2, complete before this phase's barrier: every phase ends with lgkmcnt(0)); at the top of
-// phase p unit p + 2 must have landed: five units (80 KB) stay in flight.
-// MEASURED (scripts/lab/run_r2k.sh .. r2m.sh): correct on every shape tried, main loop 25.2 us on the 16384 x 1024 x 1024
-// layer (the 8-wave kernel: 25.4), 8192^3 1143-1156 us (8-wave: 951; rocBLAS on the same random operands: 781).  Ablations
-// at 8192^3: no DMA 765, no reads 1107-1133, neither 527-533 - here the fragment reads DO hide (+35 us) but an LDS-DMA
-// instruction stalls the issuing wave ~175 cycles while four waves issue at once (~44 cycles of texture-path time per
-// 1-KiB piece) and a lone wave has no partner to feed the matrix pipe meanwhile; the chunk swizzle of the source
-// addresses is not the reason (linear sources: 1126).  Kept as a lab variant (ASE_NT_VARIANT=40 / 41), not dispatched.
-// The fragment reads are inline asm (behind the builtin hipcc drains the DMA queue in front of every LDS read that
-// follows a global_load_lds); the lgkmcnt(0) that retires them names the fragment registers as operands, so no MFMA
-// that uses them can move in front of it.
-// ------------------------------------------------------------------------------------------------
-struct NT4Lane {
-    const char* src[4][4];     // per-lane DMA source of unit kind (A0, B0, B1, A1) x piece, at K-tile 0
-    int dst[4][4];             // wave-uniform LDS byte offset of the piece inside a K-tile buffer
-    uint32_t adA[4], adB[4];   // per-lane LDS byte address (K-tile buffer 0) of the wave's A / B fragment rows, per k-step
-};
-
-template <int OFF> __device__ __forceinline__ void nt4_read1(i32x4& f, uint32_t addr) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(addr), "n"(OFF) : "memory");
+// Tuning switches exist only in lab builds (scripts/lab/Makefile compiles this file with -DASE_LAB and reads ASE_* environment
+// variables once); the product build has no environment dependence: every knob is its measured default.
+#ifdef ASE_LAB
+static int lab_knob(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
 }
-__device__ __forceinline__ void nt4_retire(i32x4 (&f)[2][4]) {
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[0][2]), "+v"(f[0][3]), "+v"(f[1][0]), "+v"(f[1][1]), "+v"(f[1][2]),
-                   "+v"(f[1][3])
-                 :
-                 : "memory");
-}
-__device__ __forceinline__ void wait_vmcnt_rt4(int n) {             // wave-uniform, n = 4 x units (+ 8 mask pieces)
-    switch (n >> 2) {
-        case 0: wait_vmcnt<0>(); break;
-        case 1: wait_vmcnt<4>(); break;
-        case 2: wait_vmcnt<8>(); break;
-        case 3: wait_vmcnt<12>(); break;
-        case 4: wait_vmcnt<16>(); break;
-        case 5: wait_vmcnt<20>(); break;
-        case 6: wait_vmcnt<24>(); break;
-        case 7: wait_vmcnt<28>(); break;
-        case 8: wait_vmcnt<32>(); break;
-        default: wait_vmcnt<36>(); break;
-    }
-}
-
-// issue pattern of a phase: which of the 16 slots (one behind every MFMA) holds fragment read 0..7 / DMA piece 0..3.
-//   PAT 0: reads in slots 0-7, DMA in 8-11;  PAT 1: two reads, one DMA, ... over slots 0-11;  PAT 2: PAT 1 one slot later
-//   (odd waves under V & 2: the four waves of a workgroup do not all hit LDS / the texture path in the same cycle)
-__device__ constexpr int nt4_rd_index(int pat, int n) {
-    if (pat == 0) return n < 8 ? n : -1;
-    const int m = n - (pat - 1);
-    if (m < 0 || m >= 12 || m % 3 == 2) return -1;
-    return (m / 3) * 2 + (m % 3);
-}
-__device__ constexpr int nt4_dma_index(int pat, int n) {
-    if (pat == 0) return (n >= 8 && n < 12) ? n - 8 : -1;
-    const int m = n - (pat - 1);
-    if (m < 0 || m >= 12 || m % 3 != 2) return -1;
-    return m / 3;
-}
-
-// one phase: c{ij} += a[i] x b[j] over the 4 k-steps.  SUB: the fragment set read for the next phase = 64-row half SUB
-// (0 / 1) of the wave's A or B rows, at LDS addresses rd[ks]; KIND: the DMA unit issued (K-tile `itile`).
-template <int SUB, int KIND, int V, int PAT>
-__device__ __forceinline__ void nt4_phase(f32x16& c00, f32x16& c10, f32x16& c01, f32x16& c11, const i32x4 (&a)[2][4],
-                                          const i32x4 (&b)[2][4], i32x4 (&nx)[2][4], const uint32_t (&rd)[4], bool rd_live,
-                                          const NT4Lane& L, char* smem, int itile, bool dma_live) {
-    constexpr bool DM = !(V & 4), RD = !(V & 8), MM = !(V & 16);
-    char* buf = smem + (itile & 1) * 65536;
-    const int64_t koff = (int64_t)itile * 128;
-    auto slot = [&](int n) {
-        __builtin_amdgcn_sched_barrier(0);
-        const int ri = nt4_rd_index(PAT, n), di = nt4_dma_index(PAT, n);
-        if (ri >= 0) {
-            if (RD && rd_live) {
-                const int ks = ri & 3;
-                if (ri < 4) {
-                    if (ks == 0) nt4_read1<SUB * 8192>(nx[0][0], rd[0]);
-                    else if (ks == 1) nt4_read1<SUB * 8192>(nx[0][1], rd[1]);
-                    else if (ks == 2) nt4_read1<SUB * 8192>(nx[0][2], rd[2]);
-                    else nt4_read1<SUB * 8192>(nx[0][3], rd[3]);
-                } else {
-                    if (ks == 0) nt4_read1<SUB * 8192 + 4096>(nx[1][0], rd[0]);
-                    else if (ks == 1) nt4_read1<SUB * 8192 + 4096>(nx[1][1], rd[1]);
-                    else if (ks == 2) nt4_read1<SUB * 8192 + 4096>(nx[1][2], rd[2]);
-                    else nt4_read1<SUB * 8192 + 4096>(nx[1][3], rd[3]);
-                }
-            }
-        } else if (di >= 0) {
-            if (DM && dma_live)
-                __builtin_amdgcn_global_load_lds((gptr_t*)(L.src[KIND][di] + koff), (lptr_t*)(buf + L.dst[KIND][di]), 16, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    if constexpr (!MM) {
-        asm volatile("" : "+v"(c00), "+v"(c10), "+v"(c01), "+v"(c11) : "v"(a[0][0]), "v"(a[1][3]), "v"(b[0][1]), "v"(b[1][2]));
-#pragma unroll
-        for (int n = 0; n < 16; ++n) slot(n);
-    } else {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const bf16x8 b0 = __builtin_bit_cast(bf16x8, b[0][ks]), b1 = __builtin_bit_cast(bf16x8, b[1][ks]);
-            c00 = nt8_mfma<true>(a[0][ks], b0, c00);
-            slot(4 * ks + 0);
-            c10 = nt8_mfma<true>(a[1][ks], b0, c10);
-            slot(4 * ks + 1);
-            c01 = nt8_mfma<true>(a[0][ks], b1, c01);
-            slot(4 * ks + 2);
-            c11 = nt8_mfma<true>(a[1][ks], b1, c11);
-            slot(4 * ks + 3);
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (RD && rd_live) nt4_retire(nx);
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-// top of phase p: unit p + 2 has landed for every wave.  RT = false: all units up to p + 7 exist and the mask pieces (if
-// any) are older than everything that may stay in flight.
-template <bool RT>
-__device__ __forceinline__ void nt4_top(int p, int U, int maskn) {
-    if constexpr (!RT) {
-        wait_vmcnt<20>();
-        NT8_BARRIER();
-    } else {
-        if (p + 2 < U) {
-            // in flight behind unit p + 2: units p + 3 .. min(U - 1, p + 7); the mask pieces sit between units 7 and 8
-            wait_vmcnt_rt4(4 * (min(U - 1, p + 7) - (p + 2)) + (p + 2 <= 7 ? maskn : 0));
-            NT8_BARRIER();
-        }
-    }
-}
-
-// one K-tile.  On entry X = A01(t), Bp = B01(t) are in registers; on exit X = A01(t + 1), Bq = B01(t + 1).
-template <bool RT, int V, int PAT>
-__device__ __forceinline__ void nt4_ktile(int t, int nk, int maskn, const NT4Lane& L, char* smem, f32x16 (&acc)[4][4],
-                                          i32x4 (&X)[2][4], i32x4 (&Y)[2][4], i32x4 (&Bp)[2][4], i32x4 (&Bq)[2][4]) {
-    const int U = 4 * nk, p = 4 * t;
-    const uint32_t cur = (t & 1) * 65536, nxt = 65536 - cur;
-    const bool more = !RT || t + 1 < nk, dma = !RT || t + 2 < nk;
-    uint32_t ra[4], rb[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        ra[ks] = L.adA[ks] + cur;
-        rb[ks] = L.adB[ks] + cur;
-    }
-    nt4_top<RT>(p, U, maskn);
-    nt4_phase<1, 0, V, PAT>(acc[0][0], acc[1][0], acc[0][1], acc[1][1], X, Bp, Bq, rb, true, L, smem, t + 2, dma);    // reads B23(t)
-    nt4_top<RT>(p + 1, U, maskn);
-    nt4_phase<1, 1, V, PAT>(acc[0][2], acc[1][2], acc[0][3], acc[1][3], X, Bq, Y, ra, true, L, smem, t + 2, dma);     // reads A23(t)
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        ra[ks] = L.adA[ks] + nxt;
-        rb[ks] = L.adB[ks] + nxt;
-    }
-    nt4_top<RT>(p + 2, U, maskn);
-    nt4_phase<0, 2, V, PAT>(acc[2][2], acc[3][2], acc[2][3], acc[3][3], Y, Bq, X, ra, more, L, smem, t + 2, dma);     // reads A01(t + 1)
-    nt4_top<RT>(p + 3, U, maskn);
-    nt4_phase<0, 3, V, PAT>(acc[2][0], acc[3][0], acc[2][1], acc[3][1], Y, Bp, Bq, rb, more, L, smem, t + 2, dma);    // reads B01(t + 1)
-}
-
-template <typename T, int V>
-__global__ __launch_bounds__(256) void gemm_nt4_kernel(NTParams p) {
-    static_assert(sizeof(T) == 2, "bf16 only");
-    constexpr int RB = 128, BM = 256, BK = 64;
-    constexpr int kBuf = 512 * RB;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wid >> 1, wc = wid & 1;
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int tile = xcd_remap(blockIdx.x, nwg);
-    const int bm0 = (tile / p.tiles_n) * BM, bn0 = (tile % p.tiles_n) * 256;
-
-    if (p.prof && tid == 0) p.prof[blockIdx.x * 4 + 0] = wall_clock64();
-    NT4Lane L;
-    {
-        const int lr = lane >> 3, slot = lane & 7;
-#pragma unroll
-        for (int kind = 0; kind < 4; ++kind) {
-            const bool isB = (kind == 1 || kind == 2);
-            const int sub = (kind >= 2) ? 64 : 0;                       // A0, B0: rows 0-63 of every wave's half; B1, A1: 64-127
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int r0 = (g >> 1) * 128 + sub + (g & 1) * 32 + wid * 8;
-                const int r = r0 + lr;
-                const int64_t grow = isB ? min(bn0 + r, p.N - 1) : min(bm0 + r, p.M - 1);
-                L.src[kind][g] = (isB ? p.B + grow * p.ldb : p.A + grow * p.lda) + ((slot ^ lds_swz<RB>(r)) << 4);
-                L.dst[kind][g] = (isB ? BM * RB : 0) + r0 * RB;
-            }
-        }
-        const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-        const int r = lane & 31, h = lane >> 5, sw = lds_swz<RB>(r);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const uint32_t ro = r * RB + (((ks * 2 + h) ^ sw) << 4);
-            L.adA[ks] = lds0 + wr * 128 * RB + ro;
-            L.adB[ks] = lds0 + BM * RB + wc * 128 * RB + ro;
-        }
-    }
-
-    f32x16 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int nk = p.K / BK, U = 4 * nk;
-    // prologue: the whole ring (units 0..7), then the mask words of the wave tile (128 rows x 4 words) as eight 4-byte
-    // DMA pieces into 2 KiB of LDS per wave past the ring
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        if (u < U) {
-            char* buf = smem + (u >> 2) * kBuf;
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                __builtin_amdgcn_global_load_lds((gptr_t*)(L.src[u & 3][g] + (int64_t)(u >> 2) * 128), (lptr_t*)(buf + L.dst[u & 3][g]), 16, 0, 0);
-        }
-    }
-    const bool mask_dma = p.aux_mode == ASE_AUX_RELU_BITS && bn0 + wc * 128 < p.N;
-    if (mask_dma) {
-        char* mlds = smem + 2 * kBuf + wid * 2048;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = bm0 + wr * 128 + i * 32 + (lane & 31);
-            const int ma = (m >= p.aux_split) ? m - p.aux_delta : m;
-            const uint32_t* w = reinterpret_cast<const uint32_t*>(p.aux + (int64_t)min(ma, p.M - 1) * p.ldaux) +
-                                ((bn0 + wc * 128) >> 5) + (lane >> 5);
-            __builtin_amdgcn_global_load_lds((gptr_t*)w, (lptr_t*)(mlds + (i * 2) * 256), 4, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t*)(w + 2), (lptr_t*)(mlds + (i * 2 + 1) * 256), 4, 0, 0);
-        }
-    }
-    const int maskn = mask_dma ? 8 : 0;
-    // units 0, 1 (A0 / B0 of K-tile 0) have landed -> X = A01(0), P = B01(0)
-    wait_vmcnt_rt4(4 * (min(U, 8) - 2) + maskn);
-    NT8_BARRIER();
-    if (p.prof && tid == 0) p.prof[blockIdx.x * 4 + 1] = wall_clock64();
-    i32x4 X[2][4], Y[2][4], P[2][4], Q[2][4];
-    {
-        constexpr bool RD = !(V & 8);
-        if constexpr (RD) {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                nt4_read1<0>(X[0][ks], L.adA[ks]);
-                nt4_read1<4096>(X[1][ks], L.adA[ks]);
-                nt4_read1<0>(P[0][ks], L.adB[ks]);
-                nt4_read1<4096>(P[1][ks], L.adB[ks]);
-            }
-            nt4_retire(X);
-            nt4_retire(P);
-        }
-    }
-    auto loop = [&](auto pat) {
-        constexpr int PAT = decltype(pat)::value;
-        nt4_ktile<true, V, PAT>(0, nk, maskn, L, smem, acc, X, Y, P, Q);
-        int t = 1;
-        for (; t + 3 < nk; t += 2) {
-            nt4_ktile<false, V, PAT>(t, nk, 0, L, smem, acc, X, Y, Q, P);
-            nt4_ktile<false, V, PAT>(t + 1, nk, 0, L, smem, acc, X, Y, P, Q);
-        }
-        for (; t < nk; t += 2) {                     // t is odd here: B01(t) sits in Q
-            nt4_ktile<true, V, PAT>(t, nk, maskn, L, smem, acc, X, Y, Q, P);
-            if (t + 1 < nk) nt4_ktile<true, V, PAT>(t + 1, nk, maskn, L, smem, acc, X, Y, P, Q);
-        }
-    };
-    if constexpr (V & 2) {
-        if (wid & 1) loop(std::integral_constant<int, 2>{});
-        else loop(std::integral_constant<int, 1>{});
-    } else loop(std::integral_constant<int, (V & 1)>{});
-    if (p.prof && tid == 0) p.prof[blockIdx.x * 4 + 2] = wall_clock64();
-    if ((V & 32) && p.alpha != 12345.f) return;      // ablation: no epilogue
-    uint32_t row_bits[4][4];
-    if (mask_dma) {
-        wait_vmcnt<0>();
-        const uint32_t* mw = reinterpret_cast<const uint32_t*>(smem + 2 * kBuf + wid * 2048);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) row_bits[i][j] = mw[(i * 2 + (j >> 1)) * 64 + (j & 1) * 32 + (lane & 31)];
-        nt_epilogue_rows<4, 4, 2>(p, acc, lane, bm0 + wr * 128, bn0 + wc * 128, row_bits);
-    } else
-        nt_epilogue_rows<4, 4, 0>(p, acc, lane, bm0 + wr * 128, bn0 + wc * 128, row_bits);
-    if (p.prof) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) p.prof[blockIdx.x * 4 + 3] = wall_clock64();
-    }
-}
-
-template <typename T, int V> int launch_nt4(const NTParams& p0, hipStream_t stream) {
-    constexpr int lds = 2 * 512 * 128 + 4 * 2048;
-    static bool attr_done = false;
-    auto kern = gemm_nt4_kernel<T, V>;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) {
-            ase_set_error("gemm_nt4: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-            return ASE_ELAUNCH;
-        }
-        attr_done = true;
-    }
-    NTParams p = p0;
-    p.prof = g_nt_prof;
-    p.tiles_m = (p.M + 255) / 256;
-    p.tiles_n = (p.N + 255) / 256;
-    ASE_LAUNCH(kern, dim3(p.tiles_m * p.tiles_n), dim3(256), lds, stream, p);
-    ASE_CHECK_LAUNCH("gemm_nt4");
-    return ASE_OK;
-}
+#else
+static constexpr int lab_knob(const char*, int dflt) { return dflt; }
+#endif
 
 // Kernel choice of an NT launch (also reported by ase_hip_gemm_nt_kernel_id):
 //   0:  64 x  64 tile, 4 waves   narrow heads (N <= 64): more workgroups
 //   1: 128 x 128 tile, 4 waves   grids that would leave a 256 x 256 tiling with a ragged round
-//   2: 256 x 256 tile, 8 waves, PHASED (bf16, K in whole 128-byte steps)   192+ tiles in whole rounds
-//   3: 256 x 256 tile, 8 waves, lock-step (the f32 / bf16x3 storage types, or ASE_NT_PHASED=0)
+//   2: 256 x 256 tile, 8 waves, PHASED (16-bit storage, K in whole 128-byte steps)   192+ tiles in whole rounds
+//   3: 256 x 256 tile, 8 waves, lock-step (the f32 / bf16x3 storage types)
 //   4:  64 x 128 tile, 4 waves / 5: 64 x 64 tile, 4 waves   small grids (M = 2048 ... 4096 rows, or N = 512): two workgroups per CU
-int nt_choice(int M, int N, int K, int es, bool bf16) {
-    static int force = -1, phased = 1;
-    if (force < 0) {
-        const char* e = getenv("ASE_NT_TILE");
-        force = e ? atoi(e) : 0;
-        const char* v = getenv("ASE_NT_PHASED");
-        phased = v ? atoi(v) : 1;
-    }
+int nt_choice(int M, int N, int K, int es, bool b16) {
+    static const int force = lab_knob("ASE_NT_TILE", 0), phased = lab_knob("ASE_NT_PHASED", 1);
     if (N <= 64) return 0;
     const int t256 = ((M + 255) / 256) * ((N + 255) / 256);
     const bool big = (force == 256) || (force == 0 && N % 256 == 0 && t256 >= 192 && (t256 <= 256 || t256 % 256 == 0 || t256 >= 1024));
-    if (big && force != 128) return (bf16 && phased && (K * es) % 128 == 0) ? 2 : 3;
+    if (big && force != 128) return (b16 && phased && (K * es) % 128 == 0) ? 2 : 3;
     if (force == 128 || (K * es) % 128 != 0) return 1;
     // grids that do not fill the phased kernel's rounds: the LARGEST of the 128 x 128 / 64 x 128 / 64 x 64 tiles that still
     // gives two workgroups per CU (measured: 4096 x 1024 x 1024  21.1 -> 17.6 us, 4096 x 512 x 1024  19.3 -> 11.4 us,
@@ -1304,27 +989,20 @@ int nt_choice(int M, int N, int K, int es, bool bf16) {
     return 5;
 }
 
-// row-per-lane epilogue (swapped MFMA operands): bf16 output in whole wave-tile column blocks, no column sums, no tanh,
-// mask operand absent or a bit matrix; ASE_NT_ROWS=0 keeps the LDS-slab epilogue (A/B switch)
+// row-per-lane epilogue (swapped MFMA operands): 16-bit output in whole wave-tile column blocks, no column sums, no tanh,
+// mask operand absent or a bit matrix
 static bool rows_epi(const NTParams& p, int wave_cols) {
-    static int on = -1;
-    if (on < 0) {
-        const char* e = getenv("ASE_NT_ROWS");
-        on = e ? atoi(e) : 1;
-    }
+    static const int on = lab_knob("ASE_NT_ROWS", 1);
     return on && !p.out_f32 && p.N % wave_cols == 0 && p.colsum == nullptr && p.act != ASE_ACT_TANH &&
            (p.aux_mode == ASE_AUX_NONE || p.aux_mode == ASE_AUX_RELU_BITS);
 }
 
 template <typename T> int dispatch_nt(const NTParams& p, hipStream_t s) {
     const bool k128 = (p.K * (int)sizeof(T)) % 128 == 0;       // 128-byte staged rows need K in whole 128-byte steps
+#ifdef ASE_LAB
     if constexpr (sizeof(T) == 2) {
-        // tuning aid (scripts/lab): force one of the co-resident tilings (<= 80 KB of LDS => two workgroups per CU)
-        static int variant = -1;
-        if (variant < 0) {
-            const char* e = getenv("ASE_NT_VARIANT");
-            variant = e ? atoi(e) : 0;
-        }
+        // tuning aid: force one of the co-resident tilings (<= 80 KB of LDS => two workgroups per CU)
+        static const int variant = lab_knob("ASE_NT_VARIANT", 0);
         switch (variant) {
             case 10: return launch_nt<T, 2, 2, 2, 4, 64, 3, 2>(p, s);    // 128 x 256, 4 waves (64 x 128 each), 72 KB
             case 11: return launch_nt<T, 2, 2, 4, 2, 64, 3, 2>(p, s);    // 256 x 128, 4 waves (128 x 64 each), 72 KB
@@ -1334,12 +1012,9 @@ template <typename T> int dispatch_nt(const NTParams& p, hipStream_t s) {
             case 15: return launch_nt<T, 2, 2, 2, 2, 64, 4, 2>(p, s);    // 128 x 128, 64-byte rows, 4 stages, 64 KB
             case 16: return launch_nt<T, 2, 2, 2, 2, 64, 3, 3>(p, s);    // 128 x 128, 48 KB => three workgroups per CU
             case 17: return launch_nt<T, 2, 2, 2, 4, 64, 2, 2>(p, s);    // 128 x 256, 4 waves, 2 stages (48 KB => 3 per CU by LDS)
-            case 30: if (k128 && rows_epi(p, 128)) return launch_nt<T, 2, 2, 4, 4, 128, 2, 1, true>(p, s); break;   // 256 x 256, FOUR waves (128 x 128 each, one per SIMD)
+            case 30: if (k128 && rows_epi(p, 128)) return launch_nt<T, 2, 2, 4, 4, 128, 2, 1, true>(p, s); break;   // 256 x 256, FOUR waves
             case 31: if (k128) return launch_nt<T, 2, 2, 4, 4, 128, 2, 1>(p, s); break;
             case 32: if (k128 && rows_epi(p, 64)) return launch_nt<T, 2, 2, 4, 2, 128, 3, 1, true>(p, s); break;   // 256 x 128, four waves, 3-stage ring (144 KB)
-            case 40: case 41:                                                           // 256 x 256, FOUR waves, pipelined inside the wave (lab)
-                if (k128 && rows_epi(p, 128)) return variant == 40 ? launch_nt4<T, 0>(p, s) : launch_nt4<T, 1>(p, s);
-                break;
             case 20: if (k128) return launch_nt<T, 2, 2, 1, 2, 128, 2, 2>(p, s); break;   // 64 x 128 tile (small M: more workgroups)
             case 21: if (k128) return launch_nt<T, 2, 2, 2, 1, 128, 2, 2>(p, s); break;   // 128 x 64 tile
             case 22: if (k128) return launch_nt<T, 2, 2, 1, 2, 128, 3, 2>(p, s); break;   // 64 x 128, 3 stages
@@ -1347,22 +1022,17 @@ template <typename T> int dispatch_nt(const NTParams& p, hipStream_t s) {
             default: break;
         }
     }
-    switch (nt_choice(p.M, p.N, p.K, (int)sizeof(T), std::is_same<T, bf16_t>::value)) {
+#endif
+    switch (nt_choice(p.M, p.N, p.K, (int)sizeof(T), sizeof(T) == 2)) {
         case 0: return launch_nt<T, 2, 2, 1, 1, 64, 4>(p, s);
         case 2:
             if constexpr (sizeof(T) == 2) {
-                static int v8 = -1;                      // tuning aid: ablation builds of the phased kernel (timing only)
-                if (v8 == -1) {
-                    const char* e = getenv("ASE_NT8_V");
-                    v8 = e ? atoi(e) : -2;               // default: DMA inside the MFMA block + (where eligible) row-per-lane epilogue
-                }
-                // row-per-lane epilogue (swapped MFMA operands): bf16 output in whole 64-column wave tiles, no column sums,
-                // mask operand absent or a bit matrix
-                const bool rows_ok = !p.out_f32 && p.N % 64 == 0 && p.colsum == nullptr && p.act != ASE_ACT_TANH &&
-                                     (p.aux_mode == ASE_AUX_NONE || p.aux_mode == ASE_AUX_RELU_BITS);
+                // row-per-lane epilogue (swapped MFMA operands): 16-bit output in whole 64-column wave tiles, no column sums,
+                // mask operand absent or a bit matrix; otherwise the LDS-slab epilogue.  DMA issued inside the MFMA block (V = 64).
+                const bool rows_ok = rows_epi(p, 64);
+#ifdef ASE_LAB
+                static const int v8 = lab_knob("ASE_NT8_V", -2);   // ablation builds of the phased kernel (timing only)
                 if (rows_ok && v8 == 128) return launch_nt8<T, 0, true>(p, s);
-                if (rows_ok && (v8 == 192 || v8 == -2)) return launch_nt8<T, 64, true>(p, s);
-                if (v8 == -2) return launch_nt8<T, 64>(p, s);
                 switch (v8) {
                     case 4: return launch_nt8<T, 4>(p, s);
                     case 8: return launch_nt8<T, 8>(p, s);
@@ -1372,12 +1042,15 @@ template <typename T> int dispatch_nt(const NTParams& p, hipStream_t s) {
                     case 32: return launch_nt8<T, 32>(p, s);
                     case 2: return launch_nt8<T, 2>(p, s);
                     case 1: return launch_nt8<T, 1>(p, s);
-                    case 64: return launch_nt8<T, 64>(p, s);
                     case 66: return launch_nt8<T, 66>(p, s);
                     case 72: return launch_nt8<T, 72>(p, s);
                     case 80: return launch_nt8<T, 80>(p, s);
-                    default: return launch_nt8<T, 0>(p, s);
+                    case 0: return launch_nt8<T, 0>(p, s);
+                    default: break;
                 }
+#endif
+                if (rows_ok) return launch_nt8<T, 64, true>(p, s);
+                return launch_nt8<T, 64>(p, s);
             }
             [[fallthrough]];
         case 3:
@@ -1419,6 +1092,7 @@ template <typename T> struct TNGeom;
 // bf16 row pitch 256 + 64 B: the 8 (row, 16-column-group) blocks that the 32 lanes of one ds_read_b64_tr_b16 group
 // touch land on 8 distinct 32-byte bank slots (pitch = 16 dwords mod 64)
 template <> struct TNGeom<bf16_t> { static constexpr int BKM = 64, STRIDE = 256 + 64, CPR = 16; };
+template <> struct TNGeom<f16_t> { static constexpr int BKM = 64, STRIDE = 256 + 64, CPR = 16; };
 template <> struct TNGeom<float>  { static constexpr int BKM = 16, STRIDE = 512 + 16, CPR = 32; };
 template <> struct TNGeom<f32s_t> { static constexpr int BKM = 16, STRIDE = 512 + 16, CPR = 32; };
 
@@ -1465,7 +1139,7 @@ __device__ __forceinline__ void tn_colsum(const uint4 (&ra)[LOADS], float (&cs)[
     for (int i = 0; i < LOADS; ++i) {
         if (m0 + (tid + kThreads * i) / CPR >= bias_rows) continue;
         if constexpr (sizeof(T) == 2) {
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(&ra[i]);
+            const typename V16<T>::x8 v = *reinterpret_cast<const typename V16<T>::x8*>(&ra[i]);
 #pragma unroll
             for (int q = 0; q < 8; ++q) cs[q] += (float)v[q];
         } else {
@@ -1523,21 +1197,22 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(TNParams p) {
             const int acol = cg * 16 + (t & 3) * 4;
 #pragma unroll
             for (int ks = 0; ks < BKM / 16; ++ks) {
-                bf16x8 a[2], b[2];
+                typedef typename V16<T>::x8 x8;
+                x8 a[2], b[2];
 #pragma unroll
                 for (int f = 0; f < 2; ++f) {
                     const char* pa = sA + (ks * 16 + arow) * STRIDE + ((wi * 2 + f) * 32 + acol) * 2;
                     const char* pb = sB + (ks * 16 + arow) * STRIDE + ((wj * 2 + f) * 32 + acol) * 2;
                     const bf16x4 a0 = lds_tr_read(pa), a1 = lds_tr_read(pa + 4 * STRIDE);
                     const bf16x4 b0 = lds_tr_read(pb), b1 = lds_tr_read(pb + 4 * STRIDE);
-                    a[f] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    b[f] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    a[f] = __builtin_bit_cast(x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+                    b[f] = __builtin_bit_cast(x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma16<T>(a[i], b[j], acc[i][j]);
             }
         } else if constexpr (std::is_same<T, f32s_t>::value) {
             // one 16-deep step per staged tile (BKM = 16): lane (r, h) gathers rows 8 h .. 8 h + 7 of its column
@@ -1667,36 +1342,37 @@ template <int OFF> __device__ __forceinline__ void tn8_read(tr_pair& f, uint32_t
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.lo) : "v"(addr), "n"(OFF) : "memory");
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.hi) : "v"(addr), "n"(OFF + 4 * 512) : "memory");
 }
-__device__ __forceinline__ bf16x8 tn8_join(const tr_pair& f) {
-    return __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3, 4, 5, 6, 7);
+template <typename T> __device__ __forceinline__ typename V16<T>::x8 tn8_join(const tr_pair& f) {      // (raw 16-bit lanes)
+    return __builtin_bit_cast(typename V16<T>::x8, __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
 // 8 MFMAs of one phase (+ 2 for the bias gradient when this wave owns one of the two live A fragments: bias_sel 0 / 1
 // picks it with VALU selects, bvec is all ones or - outside bias_rows - all zeros)
 // KIND >= 0: the two DMA pieces of unit KIND (K-tile `tile`) are issued after the first and the third MFMA pair of the
 // block (see nt8_mma_issue: an LDS-DMA costs ~60 issue cycles beside MFMAs, 100-185 in the read half of a phase)
-template <bool BIAS, int KIND>
+template <typename T, bool BIAS, int KIND>
 __device__ __forceinline__ void tn8_mma(f32x16& c00, f32x16& c01, f32x16& c10, f32x16& c11, f32x16& bacc,
-                                        const tr_pair (&a)[2][2], const tr_pair (&b)[2][2], int bias_sel, bf16x8 bvec,
-                                        const TN8Lane& L, char* smem, int tile, bool live) {
-    bf16x8 a0[2], a1[2];
+                                        const tr_pair (&a)[2][2], const tr_pair (&b)[2][2], int bias_sel,
+                                        typename V16<T>::x8 bvec, const TN8Lane& L, char* smem, int tile, bool live) {
+    typedef typename V16<T>::x8 x8;
+    x8 a0[2], a1[2];
     char* buf = smem + (tile & 1) * 65536;
     const int64_t koff = (int64_t)tile * L.kstep[(KIND < 0 ? 0 : KIND) & 1];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-        a0[ks] = tn8_join(a[0][ks]);
-        a1[ks] = tn8_join(a[1][ks]);
-        const bf16x8 b0 = tn8_join(b[0][ks]), b1 = tn8_join(b[1][ks]);
-        c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[ks], b0, c00, 0, 0, 0);
-        c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ks], b0, c10, 0, 0, 0);
+        a0[ks] = tn8_join<T>(a[0][ks]);
+        a1[ks] = tn8_join<T>(a[1][ks]);
+        const x8 b0 = tn8_join<T>(b[0][ks]), b1 = tn8_join<T>(b[1][ks]);
+        c00 = mfma16<T>(a0[ks], b0, c00);
+        c10 = mfma16<T>(a1[ks], b0, c10);
         if constexpr (KIND >= 0) {
             __builtin_amdgcn_sched_barrier(0);
             if (live)
                 __builtin_amdgcn_global_load_lds((gptr_t*)(L.src[KIND][ks] + koff), (lptr_t*)(buf + L.dst[KIND][ks]), 16, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[ks], b1, c01, 0, 0, 0);
-        c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ks], b1, c11, 0, 0, 0);
+        c01 = mfma16<T>(a0[ks], b1, c01);
+        c11 = mfma16<T>(a1[ks], b1, c11);
     }
     if (BIAS) {
         if (bias_sel >= 0) {                         // wave-uniform
@@ -1706,17 +1382,17 @@ __device__ __forceinline__ void tn8_mma(f32x16& c00, f32x16& c01, f32x16& c10, f
                 i32x4 xs;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) xs[q] = bias_sel ? x1[q] : x0[q];
-                bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xs), bvec, bacc, 0, 0, 0);
+                bacc = mfma16<T>(__builtin_bit_cast(x8, xs), bvec, bacc);
             }
         }
     }
 }
 
 // HALF = 0 / 1: phases 0, 1 (rows 0-31 of the K-tile) / phases 2, 3 (rows 32-63)
-template <bool TAIL, int V, bool BIAS, int HALF>
+template <typename T, bool TAIL, int V, bool BIAS, int HALF>
 __device__ __forceinline__ void tn8_half(int t, int nk, const TN8Lane& L, char* smem, const uint32_t (&adA)[4],
-                                         const uint32_t (&adB)[2], int bias_frag, bf16x8 bvec, f32x16 (&acc)[4][2],
-                                         f32x16& bacc) {
+                                         const uint32_t (&adB)[2], int bias_frag, typename V16<T>::x8 bvec,
+                                         f32x16 (&acc)[4][2], f32x16& bacc) {
     constexpr int RO = HALF * 2 * 8192;           // k-steps 2 HALF, 2 HALF + 1
     const int U = 4 * nk;
     const bool live = !TAIL || (HALF == 0 ? t + 1 < nk : t + 2 < nk);
@@ -1732,7 +1408,7 @@ __device__ __forceinline__ void tn8_half(int t, int nk, const TN8Lane& L, char* 
     tn8_read<RO>(a[1][0], adA[1]);
     tn8_read<RO + 8192>(a[1][1], adA[1]);
     nt8_sync_in<V>();
-    tn8_mma<BIAS, HALF == 0 ? 2 : 0>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], bacc, a, b, bias_frag < 2 ? bias_frag : -1,
+    tn8_mma<T, BIAS, HALF == 0 ? 2 : 0>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], bacc, a, b, bias_frag < 2 ? bias_frag : -1,
                                      bvec, L, smem, itile, live);
     nt8_sync_out<V>();
     // ---- odd phase: A fragments 2, 3; the wait retires what the next phase reads (the newest issued unit is the even
@@ -1745,12 +1421,12 @@ __device__ __forceinline__ void tn8_half(int t, int nk, const TN8Lane& L, char* 
     else if (HALF == 0) wait_dma_units_rt(min(U, 4 * t + 7) - (4 * t + 4));
     else if (t + 1 < nk) wait_dma_units_rt(min(U, 4 * t + 9) - (4 * t + 6));
     nt8_sync_in<V>();
-    tn8_mma<BIAS, HALF == 0 ? 3 : 1>(acc[2][0], acc[2][1], acc[3][0], acc[3][1], bacc, a, b, bias_frag >= 2 ? bias_frag - 2 : -1,
+    tn8_mma<T, BIAS, HALF == 0 ? 3 : 1>(acc[2][0], acc[2][1], acc[3][0], acc[3][1], bacc, a, b, bias_frag >= 2 ? bias_frag - 2 : -1,
                                      bvec, L, smem, itile, live);
     nt8_sync_out<V>();
 }
 
-template <bool TAIL, int V, bool BIAS>
+template <typename T, bool TAIL, int V, bool BIAS>
 __device__ __forceinline__ void tn8_ktile(int t, int nk, const TN8Lane& L, char* smem, uint32_t lds0, int bias_frag,
                                           bool bias_on, f32x16 (&acc)[4][2], f32x16& bacc) {
     const uint32_t pa = lds0 + (t & 1) * 65536 + L.rbase;
@@ -1759,15 +1435,15 @@ __device__ __forceinline__ void tn8_ktile(int t, int nk, const TN8Lane& L, char*
     for (int i = 0; i < 4; ++i) adA[i] = pa + L.foffA[i];
 #pragma unroll
     for (int j = 0; j < 2; ++j) adB[j] = pa + L.foffB[j];
-    bf16x8 bvec;
+    typename V16<T>::x8 bvec;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) bvec[q] = (bf16_t)(bias_on ? 1.0f : 0.0f);
-    tn8_half<TAIL, V, BIAS, 0>(t, nk, L, smem, adA, adB, bias_frag, bvec, acc, bacc);
-    tn8_half<TAIL, V, BIAS, 1>(t, nk, L, smem, adA, adB, bias_frag, bvec, acc, bacc);
+    for (int q = 0; q < 8; ++q) bvec[q] = (T)(bias_on ? 1.0f : 0.0f);
+    tn8_half<T, TAIL, V, BIAS, 0>(t, nk, L, smem, adA, adB, bias_frag, bvec, acc, bacc);
+    tn8_half<T, TAIL, V, BIAS, 1>(t, nk, L, smem, adA, adB, bias_frag, bvec, acc, bacc);
 }
 
 // one work item: output tile (bn0, bk0) of problem p over the K-tiles [m_begin, m_begin + 64 nk)
-template <int V>
+template <typename T, int V>
 __device__ __forceinline__ void tn8_body(const TNParams& p, char* smem, int bn0, int bk0, int m_begin, int nk,
                                          unsigned long long* prof) {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1836,14 +1512,14 @@ __device__ __forceinline__ void tn8_body(const TNParams& p, char* smem, int bn0,
     int t = 0;
     if (bias_tiles > 0) {
         for (; t + 2 < nk; ++t)
-            tn8_ktile<false, V, true>(t, nk, L, smem, lds0, wc, t < bias_tiles, acc, bacc);
+            tn8_ktile<T, false, V, true>(t, nk, L, smem, lds0, wc, t < bias_tiles, acc, bacc);
         for (; t < nk; ++t)
-            tn8_ktile<true, V, true>(t, nk, L, smem, lds0, wc, t < bias_tiles, acc, bacc);
+            tn8_ktile<T, true, V, true>(t, nk, L, smem, lds0, wc, t < bias_tiles, acc, bacc);
     } else {
         for (; t + 2 < nk; ++t)
-            tn8_ktile<false, V, false>(t, nk, L, smem, lds0, wc, false, acc, bacc);
+            tn8_ktile<T, false, V, false>(t, nk, L, smem, lds0, wc, false, acc, bacc);
         for (; t < nk; ++t)
-            tn8_ktile<true, V, false>(t, nk, L, smem, lds0, wc, false, acc, bacc);
+            tn8_ktile<T, true, V, false>(t, nk, L, smem, lds0, wc, false, acc, bacc);
     }
     if (wr == 0) NT8_BARRIER();
     if (prof && tid == 0) prof[2] = wall_clock64();
@@ -1882,7 +1558,7 @@ __device__ __forceinline__ void tn8_body(const TNParams& p, char* smem, int bn0,
     }
 }
 
-template <int V>
+template <typename T, int V>
 __global__ __launch_bounds__(512) void gemm_tn8_kernel(TNParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nwg = p.tiles_n * p.tiles_k;
@@ -1890,14 +1566,14 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(TNParams p) {
     const int m_begin = blockIdx.z * p.m_chunk;
     const int m_end = min(p.M, m_begin + p.m_chunk);
     if (m_begin >= m_end) return;
-    tn8_body<V>(p, smem, (tile / p.tiles_k) * 256, (tile % p.tiles_k) * 256, m_begin, (m_end - m_begin) / 64,
+    tn8_body<T, V>(p, smem, (tile / p.tiles_k) * 256, (tile % p.tiles_k) * 256, m_begin, (m_end - m_begin) / 64,
                 p.prof ? p.prof + (blockIdx.z * gridDim.x + blockIdx.x) * 4 : nullptr);
 }
 
 // Grouped launch.  problems: device int64[n][16] = {A, lda, B, ldb, G, gbias, bias_rows, M, N, K, n_real, k_real,
 // split_src, split_dst, alpha (f32 bits), tiles_k}, leading dimensions in ELEMENTS; work: device int32[n_work][4] =
 // {problem, tile, m_begin, nk} (ase_hip_gemm_tn_grouped_plan).
-template <int V>
+template <typename T, int V>
 __global__ __launch_bounds__(512) void gemm_tn8g_kernel(const int64_t* __restrict__ problems,
                                                         const int32_t* __restrict__ work, int n_work,
                                                         unsigned long long* prof) {
@@ -1915,14 +1591,14 @@ __global__ __launch_bounds__(512) void gemm_tn8g_kernel(const int64_t* __restric
     p.n_real = (int)d[10]; p.k_real = (int)d[11]; p.split_src = (int)d[12]; p.split_dst = (int)d[13];
     p.alpha = __builtin_bit_cast(float, (int)d[14]);
     p.tiles_k = (int)d[15];
-    tn8_body<V>(p, smem, (tile / p.tiles_k) * 256, (tile % p.tiles_k) * 256, m_begin, nk,
+    tn8_body<T, V>(p, smem, (tile / p.tiles_k) * 256, (tile % p.tiles_k) * 256, m_begin, nk,
                 prof ? prof + blockIdx.x * 4 : nullptr);
 }
 
-template <int V> int launch_tn8(TNParams p, hipStream_t stream) {
+template <typename T, int V> int launch_tn8(TNParams p, hipStream_t stream) {
     constexpr int lds = 2 * 65536;
     static bool attr_done = false;
-    auto kern = gemm_tn8_kernel<V>;
+    auto kern = gemm_tn8_kernel<T, V>;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1949,10 +1625,10 @@ template <int V> int launch_tn8(TNParams p, hipStream_t stream) {
     return ASE_OK;
 }
 
-template <int V> int launch_tn8g(const int64_t* problems, const int32_t* work, int n_work, hipStream_t stream) {
+template <typename T, int V> int launch_tn8g(const int64_t* problems, const int32_t* work, int n_work, hipStream_t stream) {
     constexpr int lds = 2 * 65536;
     static bool attr_done = false;
-    auto kern = gemm_tn8g_kernel<V>;
+    auto kern = gemm_tn8g_kernel<T, V>;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1986,12 +1662,8 @@ template <typename T> int launch_tn(TNParams p, hipStream_t stream) {
     const int tiles = p.tiles_n * p.tiles_k;
     // Split M so that the grid is ONE resident wave of workgroups: 80 KB of LDS => 2 workgroups per CU => 512 slots
     // on 256 CUs.  More splits only add f32 atomics (splits x N x K of them) and a partial second wave.
-    static int target_wg = 0, target_forced = 0;
-    if (target_wg == 0) {
-        const char* e = getenv("ASE_TN_TARGET_WG");
-        target_forced = e != nullptr;
-        target_wg = e ? atoi(e) : 512;
-    }
+    static const int target_env = lab_knob("ASE_TN_TARGET_WG", 0);
+    const int target_forced = target_env > 0, target_wg = target_forced ? target_env : 512;
     // narrow outputs (<= 8 tiles): the partial-sum atomics outweigh the second resident workgroup per CU (measured:
     // 256 workgroups beat 512 by 20-30 % on the head / style-MLP gradients)
     int splits = ((tiles <= 8 && !target_forced) ? 256 : target_wg) / tiles;
@@ -2089,12 +1761,12 @@ __global__ __launch_bounds__(256) void refresh_multi_kernel(const int64_t* __res
 extern "C" int ase_hip_refresh_shadow_multi(const int64_t* desc, int n_layers, int dtype, void* stream) {
     ASE_CHECK_ARG(desc && n_layers > 0, "refresh_shadow_multi: null/empty operand");
     const dim3 grid(256, n_layers);
-    if (dtype == ASE_BF16)
-        ASE_LAUNCH(refresh_multi_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, desc);
-    else if (dtype == ASE_F32)
-        ASE_LAUNCH(refresh_multi_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, desc);
-    else
-        ASE_CHECK_ARG(false, "refresh_shadow_multi: bad dtype %d", dtype);
+    const int rc = ase_dispatch_storage(dtype, [&](auto tag) {
+        typedef typename decltype(tag)::type T;
+        ASE_LAUNCH(refresh_multi_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, desc);
+        return ASE_OK;
+    });
+    ASE_CHECK_ARG(rc == ASE_OK, "refresh_shadow_multi: bad dtype %d", dtype);
     ASE_CHECK_LAUNCH("refresh_shadow_multi");
     return ASE_OK;
 }
@@ -2105,15 +1777,15 @@ extern "C" int ase_hip_debug_nt_profile(void* buf) {
 }
 
 extern "C" int ase_hip_gemm_nt_kernel_id(int M, int N, int K, int dtype) {
-    return nt_choice(M, N, K, dtype == ASE_BF16 ? 2 : 4, dtype == ASE_BF16);
+    return nt_choice(M, N, K, ase_elem_size(dtype), ase_elem_size(dtype) == 2);
 }
 
 extern "C" int ase_hip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                                const float* bias, const void* aux, int64_t ldaux, int aux_split, int aux_delta,
                                float* colsum, int colsum_n, void* mask_out, int64_t ldmask, int M, int N, int K, int act,
                                int aux_mode, int out_f32, float alpha, int dtype, void* stream) {
-    const int es = (dtype == ASE_BF16) ? 2 : 4;
-    ASE_CHECK_ARG(dtype == ASE_F32 || dtype == ASE_BF16 || dtype == ASE_F32X3, "gemm_nt: bad dtype %d", dtype);
+    const int es = ase_elem_size(dtype);
+    ASE_CHECK_ARG(dtype == ASE_F32 || dtype == ASE_BF16 || dtype == ASE_F32X3 || dtype == ASE_F16, "gemm_nt: bad dtype %d", dtype);
     ASE_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0, "gemm_nt: null/empty operand (M=%d N=%d K=%d)", M, N, K);
     ASE_CHECK_ARG((K * es) % 64 == 0, "gemm_nt: K=%d is not a multiple of %d elements", K, 64 / es);
     ASE_CHECK_ARG(lda >= K && ldb >= K && ldc >= N, "gemm_nt: leading dimension too small");
@@ -2137,6 +1809,7 @@ extern "C" int ase_hip_gemm_nt(const void* A, int64_t lda, const void* B, int64_
     p.tiles_m = p.tiles_n = 0;
     p.prof = nullptr;
     if (dtype == ASE_BF16) return dispatch_nt<bf16_t>(p, (hipStream_t)stream);
+    if (dtype == ASE_F16) return dispatch_nt<f16_t>(p, (hipStream_t)stream);
     if (dtype == ASE_F32X3) return dispatch_nt<f32s_t>(p, (hipStream_t)stream);
     return dispatch_nt<float>(p, (hipStream_t)stream);
 }
@@ -2144,8 +1817,8 @@ extern "C" int ase_hip_gemm_nt(const void* A, int64_t lda, const void* B, int64_
 extern "C" int ase_hip_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* G, float* gbias,
                                int bias_rows, int M, int N, int K, int n_real, int k_real, int split_src, int split_dst, float alpha, int dtype,
                                void* stream) {
-    const int es = (dtype == ASE_BF16) ? 2 : 4;
-    ASE_CHECK_ARG(dtype == ASE_F32 || dtype == ASE_BF16 || dtype == ASE_F32X3, "gemm_tn: bad dtype %d", dtype);
+    const int es = ase_elem_size(dtype);
+    ASE_CHECK_ARG(dtype == ASE_F32 || dtype == ASE_BF16 || dtype == ASE_F32X3 || dtype == ASE_F16, "gemm_tn: bad dtype %d", dtype);
     ASE_CHECK_ARG(A && B && G && M > 0 && N > 0 && K > 0, "gemm_tn: null/empty operand");
     ASE_CHECK_ARG((N * es) % 16 == 0 && (K * es) % 16 == 0, "gemm_tn: N=%d / K=%d must cover whole 16-byte chunks", N, K);
     ASE_CHECK_ARG(lda >= N && ldb >= K, "gemm_tn: leading dimension too small");
@@ -2157,19 +1830,15 @@ extern "C" int ase_hip_gemm_tn(const void* A, int64_t lda, const void* B, int64_
     p.A = (const char*)A; p.lda = lda * es; p.B = (const char*)B; p.ldb = ldb * es; p.G = G; p.gbias = gbias; p.bias_rows = bias_rows > 0 ? bias_rows : M;
     p.M = M; p.N = N; p.K = K; p.n_real = n_real; p.k_real = k_real; p.split_src = split_src; p.split_dst = split_dst;
     p.alpha = alpha; p.tiles_n = p.tiles_k = p.m_chunk = 0; p.prof = nullptr;
-    if (dtype == ASE_BF16) {
-        static int tn8 = -1;
-        if (tn8 < 0) {
-            const char* e = getenv("ASE_TN8");
-            tn8 = e ? atoi(e) : 1;
-        }
+    if (es == 2) {
         // Single-problem launches take the phased 256 x 256 kernel only when few M-splits fill the chip (its split
         // reduction costs 256 KB of memory-side atomics per workgroup; see the grouped launch): whole 64-row K-tiles,
         // whole bias tiles, >= 32 K-tiles per split.
+        static const int tn8 = lab_knob("ASE_TN8", 1);
         const int t256 = ((n_real + 255) / 256) * ((K + 255) / 256);
-        if (tn8 && M % 64 == 0 && p.bias_rows % 64 == 0 && n_real >= 128 && K >= 128 && (int64_t)M * t256 >= 256 * 2048)
-            return launch_tn8<0>(p, (hipStream_t)stream);
-        return launch_tn<bf16_t>(p, (hipStream_t)stream);
+        const bool phased = tn8 && M % 64 == 0 && p.bias_rows % 64 == 0 && n_real >= 128 && K >= 128 && (int64_t)M * t256 >= 256 * 2048;
+        if (dtype == ASE_BF16) return phased ? launch_tn8<bf16_t, 0>(p, (hipStream_t)stream) : launch_tn<bf16_t>(p, (hipStream_t)stream);
+        return phased ? launch_tn8<f16_t, 0>(p, (hipStream_t)stream) : launch_tn<f16_t>(p, (hipStream_t)stream);
     }
     if (dtype == ASE_F32X3) return launch_tn<f32s_t>(p, (hipStream_t)stream);
     return launch_tn<float>(p, (hipStream_t)stream);
@@ -2193,10 +1862,7 @@ static int tn_problem_check(const int64_t* d, int i) {
 extern "C" int ase_hip_gemm_tn_grouped_plan(int64_t* problems, int n_problems, int target_wg, int32_t* work, int max_work,
                                             int* n_work) {
     ASE_CHECK_ARG(problems && work && n_work && n_problems > 0 && max_work > 0, "gemm_tn_grouped_plan: null/empty argument");
-    if (target_wg <= 0) {
-        const char* e = getenv("ASE_TN_GROUP_WG");
-        target_wg = e ? atoi(e) : 256;                       // one 8-wave workgroup per CU
-    }
+    if (target_wg <= 0) target_wg = lab_knob("ASE_TN_GROUP_WG", 256);      // one 8-wave workgroup per CU
     int64_t max_kt = 1;
     for (int i = 0; i < n_problems; ++i) {
         int64_t* d = problems + 16 * i;
@@ -2247,8 +1913,9 @@ extern "C" int ase_hip_gemm_tn_grouped_plan(int64_t* problems, int n_problems, i
 
 extern "C" int ase_hip_gemm_tn_grouped(const int64_t* problems, const int32_t* work, int n_work, int dtype, void* stream) {
     ASE_CHECK_ARG(problems && work && n_work > 0, "gemm_tn_grouped: null/empty argument");
-    ASE_CHECK_ARG(dtype == ASE_BF16, "gemm_tn_grouped: bf16 only (dtype %d)", dtype);
-    return launch_tn8g<0>(problems, work, n_work, (hipStream_t)stream);
+    ASE_CHECK_ARG(dtype == ASE_BF16 || dtype == ASE_F16, "gemm_tn_grouped: 16-bit storage types only (dtype %d)", dtype);
+    if (dtype == ASE_F16) return launch_tn8g<f16_t, 0>(problems, work, n_work, (hipStream_t)stream);
+    return launch_tn8g<bf16_t, 0>(problems, work, n_work, (hipStream_t)stream);
 }
 
 extern "C" int ase_hip_refresh_shadow(const float* W, int n_real, int k_real, void* Ws, int64_t ldws, void* Wts,
@@ -2257,14 +1924,13 @@ extern "C" int ase_hip_refresh_shadow(const float* W, int n_real, int k_real, vo
     ASE_CHECK_ARG(split_src <= split_dst && split_src <= k_real, "refresh_shadow: bad split");
     const dim3 grid((k_real + 31) / 32, (n_real + 31) / 32), block(256);
     const int gap = split_dst - split_src;
-    if (dtype == ASE_BF16)
-        ASE_LAUNCH(refresh_shadow_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, W, n_real, k_real,
-                           (bf16_t*)Ws, ldws, (bf16_t*)Wts, ldwts, split_src, gap);
-    else if (dtype == ASE_F32)
-        ASE_LAUNCH(refresh_shadow_kernel<float>, grid, block, 0, (hipStream_t)stream, W, n_real, k_real,
-                           (float*)Ws, ldws, (float*)Wts, ldwts, split_src, gap);
-    else
-        ASE_CHECK_ARG(false, "refresh_shadow: bad dtype %d", dtype);
+    const int rc = ase_dispatch_storage(dtype, [&](auto tag) {
+        typedef typename decltype(tag)::type T;
+        ASE_LAUNCH(refresh_shadow_kernel<T>, grid, block, 0, (hipStream_t)stream, W, n_real, k_real, (T*)Ws, ldws, (T*)Wts, ldwts,
+                   split_src, gap);
+        return ASE_OK;
+    });
+    ASE_CHECK_ARG(rc == ASE_OK, "refresh_shadow: bad dtype %d", dtype);
     ASE_CHECK_LAUNCH("refresh_shadow");
     return ASE_OK;
 }

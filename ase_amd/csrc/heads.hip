@@ -29,6 +29,7 @@ struct PpoArgs {
     double* scratch;              // [gridDim.x][8] per-workgroup partial sums (no contended atomics)
     int M, m_global, act_dim, z_dim, masked, div_on, mu_tanh, clip_value;
     float e_clip, critic_coef, bounds_coef, div_coef, div_tar;
+    float gs, inv_gs;             // the stored head gradients carry the static gradient scale (f16 storage), the bias gradients do not
 };
 
 // LPR lanes per row (act_dim <= LPR: 32 for the humanoid's 28 / 31 actions, 64 for the HRL high-level policy whose action
@@ -120,11 +121,11 @@ __global__ __launch_bounds__(256) void ppo_head_kernel(PpoArgs p) {
                 gm *= (1.f - m * m);
                 gm2 *= (1.f - m2 * m2);
             }
-            const T o1 = from_f32<T>(gm), o2 = from_f32<T>(gm2);
+            const T o1 = from_f32<T>(p.gs * gm), o2 = from_f32<T>(p.gs * gm2);
             reinterpret_cast<T*>(p.d_mu)[(int64_t)i * p.ld_dmu + lane] = o1;
             if (p.div_on) reinterpret_cast<T*>(p.d_mu)[(int64_t)(p.M + i) * p.ld_dmu + lane] = o2;
-            gm_out += to_f32(o1);
-            gm2_out += p.div_on ? to_f32(o2) : 0.f;
+            gm_out += p.inv_gs * to_f32(o1);
+            gm2_out += p.div_on ? p.inv_gs * to_f32(o2) : 0.f;
         }
 
         if (lane == 0) {
@@ -145,9 +146,9 @@ __global__ __launch_bounds__(256) void ppo_head_kernel(PpoArgs p) {
                 c = (R - v) * (R - v);
                 dv = 2.f * (v - R);
             }
-            const T ov = from_f32<T>(p.critic_coef * dv / (float)p.m_global);
+            const T ov = from_f32<T>(p.gs * (p.critic_coef * dv / (float)p.m_global));
             reinterpret_cast<T*>(p.d_value)[(int64_t)i * p.ld_dv] = ov;
-            dv_out += to_f32(ov);
+            dv_out += p.inv_gs * to_f32(ov);
             part[0] += (double)(mk * a_loss);
             part[1] += (double)(mk * b_row);
             part[2] += (double)(mk * ent_row);
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(256) void ppo_head_fold_kernel(const double* __rest
 template <typename T>
 __global__ __launch_bounds__(256) void disc_head_kernel(const float* __restrict__ logit, int64_t ld_l, T* __restrict__ d_logit,
                                                         int64_t ld_d, float* __restrict__ db_logit, double* __restrict__ acc,
-                                                        int amb, int amb_global, float disc_coef) {
+                                                        int amb, int amb_global, float disc_coef, float gs) {
     __shared__ double sm[5 * 16];
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     double part[5] = {0, 0, 0, 0, 0};  // bce agent, bce demo, agent acc, demo acc, sum of d_logit
@@ -219,9 +220,9 @@ __global__ __launch_bounds__(256) void disc_head_kernel(const float* __restrict_
             const float sig_neg = 1.f / (1.f + expf(l));
             g = -disc_coef * 0.5f * sig_neg / (float)amb_global;
         }
-        const T o = from_f32<T>(g);
+        const T o = from_f32<T>(gs * g);
         d_logit[(int64_t)r * ld_d] = o;
-        part[4] = (double)to_f32(o);
+        part[4] = (double)(to_f32(o) / gs);
     }
     block_sum<5>(part, sm);
     if (threadIdx.x == 0) {
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(256) void enc_head_kernel(const float* __restrict__
                                                        int64_t ld_z, T* __restrict__ d_e, int64_t ld_de,
                                                        float* __restrict__ db_enc, float* __restrict__ enc_out,
                                                        double* __restrict__ acc, int amb, int amb_global, int z_dim,
-                                                       float enc_coef) {
+                                                       float enc_coef, float gs) {
     __shared__ double sm[16];
     __shared__ float sdb[4][128];
     float dbv[2] = {0.f, 0.f};
@@ -267,9 +268,9 @@ __global__ __launch_bounds__(256) void enc_head_kernel(const float* __restrict__
             const int j = lane + 64 * q;
             if (j < z_dim) {
                 const float h = q ? h1 : h0;
-                const T o = from_f32<T>(-sc * (zv[q] - h * dot) / nrm);
+                const T o = from_f32<T>(gs * (-sc * (zv[q] - h * dot) / nrm));
                 d_e[(int64_t)r * ld_de + j] = o;
-                dbv[q] += to_f32(o);
+                dbv[q] += to_f32(o) / gs;
                 if (enc_out) enc_out[(int64_t)r * z_dim + j] = h;
             }
         }
@@ -330,10 +331,10 @@ __global__ __launch_bounds__(256) void enc_gp_kernel(const float* __restrict__ e
                     out[(int64_t)r * ld_out + j] = from_f32<T>(-scale * (zv[q] - h * a) / nrm);
                 } else {
                     const float jr = (zv[q] * hr + h * zr + a * dv[q] - 3.f * a * h * hr) / (nrm * nrm);
-                    const float old = to_f32(out[(int64_t)r * ld_out + j]);
-                    const T nw = from_f32<T>(old + jr);
+                    const float old = to_f32(out[(int64_t)r * ld_out + j]);      // (carries the gradient scale)
+                    const T nw = from_f32<T>(old + scale * jr);
                     out[(int64_t)r * ld_out + j] = nw;
-                    dbv[q] += to_f32(nw) - old;
+                    dbv[q] += (to_f32(nw) - old) / scale;
                 }
             }
         }
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const T* __restrict__ x, in
         const T* p = x + (int64_t)r * ld + j;
         float s = 0.f;
         if constexpr (VEC == 8) {
-            const bf16x8 q = *reinterpret_cast<const bf16x8*>(p);
+            const typename V16<T>::x8 q = *reinterpret_cast<const typename V16<T>::x8*>(p);
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const float t = (float)q[e]; s += t * t; }
         } else if constexpr (VEC == 4) {
@@ -464,7 +465,7 @@ extern "C" int ase_hip_ppo_head(const float* mu, int64_t ld_mu, const float* val
                                 const float* logstd, void* d_mu, int64_t ld_dmu, void* d_value, int64_t ld_dv,
                                 float* db_mu, float* db_value, float* mu_out, double* acc, double* scratch, int M, int m_global, int act_dim, int z_dim, int masked,
                                 int div_on, int mu_tanh, int clip_value, float e_clip, float critic_coef,
-                                float bounds_coef, float div_coef, float div_tar, int dtype, void* stream) {
+                                float bounds_coef, float div_coef, float div_tar, float grad_scale, int dtype, void* stream) {
     ASE_CHECK_ARG(mu && value && mb_actions && mb_old_mu && mb_old_sigma && mb_old_logp && mb_adv && mb_return &&
                       logstd && d_mu && d_value && acc && scratch && M > 0 && m_global >= M,
                   "ppo_head: null/empty operand");
@@ -472,6 +473,7 @@ extern "C" int ase_hip_ppo_head(const float* mu, int64_t ld_mu, const float* val
     ASE_CHECK_ARG(!masked || mb_mask, "ppo_head: masked reduction without a mask");
     ASE_CHECK_ARG(!div_on || (mb_z && new_z && z_dim > 0), "ppo_head: diversity loss without latents");
     ASE_CHECK_ARG(!clip_value || mb_old_value, "ppo_head: clip_value without old values");
+    ASE_CHECK_ARG(grad_scale > 0.f, "ppo_head: grad_scale must be positive");
     PpoArgs p;
     p.mu = mu; p.ld_mu = ld_mu; p.value = value; p.ld_v = ld_v;
     p.actions = mb_actions; p.old_mu = mb_old_mu; p.old_sigma = mb_old_sigma; p.old_logp = mb_old_logp;
@@ -479,50 +481,50 @@ extern "C" int ase_hip_ppo_head(const float* mu, int64_t ld_mu, const float* val
     p.logstd = logstd; p.d_mu = d_mu; p.ld_dmu = ld_dmu; p.d_value = d_value; p.ld_dv = ld_dv; p.db_mu = db_mu; p.db_value = db_value; p.mu_out = mu_out;
     p.acc = acc; p.scratch = scratch; p.M = M; p.m_global = m_global; p.act_dim = act_dim; p.z_dim = z_dim; p.masked = masked;
     p.div_on = div_on; p.mu_tanh = mu_tanh; p.clip_value = clip_value; p.e_clip = e_clip; p.critic_coef = critic_coef;
-    p.bounds_coef = bounds_coef; p.div_coef = div_coef; p.div_tar = div_tar;
+    p.bounds_coef = bounds_coef; p.div_coef = div_coef; p.div_tar = div_tar; p.gs = grad_scale; p.inv_gs = 1.f / grad_scale;
     const int rows = act_dim <= 32 ? 8 : 4;         // rows per workgroup (32 / 64 lanes per row)
     const dim3 grid(min((M + rows - 1) / rows, 1024));       // scratch holds 1024 x 8 doubles
-    ASE_CHECK_ARG(dtype == ASE_BF16 || dtype == ASE_F32, "ppo_head: bad dtype %d", dtype);
-    if (act_dim <= 32) {
-        if (dtype == ASE_BF16) ASE_LAUNCH((ppo_head_kernel<bf16_t, 32>), grid, dim3(256), 0, (hipStream_t)stream, p);
-        else ASE_LAUNCH((ppo_head_kernel<float, 32>), grid, dim3(256), 0, (hipStream_t)stream, p);
-    } else {
-        if (dtype == ASE_BF16) ASE_LAUNCH((ppo_head_kernel<bf16_t, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
-        else ASE_LAUNCH((ppo_head_kernel<float, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
-    }
+    const int rc = ase_dispatch_storage(dtype, [&](auto tag) {
+        typedef typename decltype(tag)::type T;
+        if (act_dim <= 32) ASE_LAUNCH((ppo_head_kernel<T, 32>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else ASE_LAUNCH((ppo_head_kernel<T, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        return ASE_OK;
+    });
+    ASE_CHECK_ARG(rc == ASE_OK, "ppo_head: bad dtype %d", dtype);
     ASE_LAUNCH(ppo_head_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, (int)grid.x, acc, div_on);
     ASE_CHECK_LAUNCH("ppo_head");
     return ASE_OK;
 }
 
 extern "C" int ase_hip_disc_head(const float* logit, int64_t ld_l, void* d_logit, int64_t ld_d, float* db_logit,
-                                 double* acc, int amb, int amb_global, float disc_coef, int dtype, void* stream) {
-    ASE_CHECK_ARG(logit && d_logit && acc && amb > 0 && amb_global >= amb, "disc_head: null/empty operand");
+                                 double* acc, int amb, int amb_global, float disc_coef, float grad_scale, int dtype,
+                                 void* stream) {
+    ASE_CHECK_ARG(logit && d_logit && acc && amb > 0 && amb_global >= amb && grad_scale > 0.f, "disc_head: null/empty operand");
     const dim3 grid((3 * amb + 255) / 256);
-    if (dtype == ASE_BF16)
-        ASE_LAUNCH(disc_head_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, logit, ld_l,
-                           (bf16_t*)d_logit, ld_d, db_logit, acc, amb, amb_global, disc_coef);
-    else if (dtype == ASE_F32)
-        ASE_LAUNCH(disc_head_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, logit, ld_l,
-                           (float*)d_logit, ld_d, db_logit, acc, amb, amb_global, disc_coef);
-    else ASE_CHECK_ARG(false, "disc_head: bad dtype %d", dtype);
+    const int rc = ase_dispatch_storage(dtype, [&](auto tag) {
+        typedef typename decltype(tag)::type T;
+        ASE_LAUNCH(disc_head_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, logit, ld_l, (T*)d_logit, ld_d, db_logit, acc, amb,
+                   amb_global, disc_coef, grad_scale);
+        return ASE_OK;
+    });
+    ASE_CHECK_ARG(rc == ASE_OK, "disc_head: bad dtype %d", dtype);
     ASE_CHECK_LAUNCH("disc_head");
     return ASE_OK;
 }
 
 extern "C" int ase_hip_enc_head(const float* e, int64_t ld_e, const float* z, int64_t ld_z, void* d_e, int64_t ld_de,
                                 float* db_enc, float* enc_out, double* acc, int amb, int amb_global, int z_dim, float enc_coef,
-                                int dtype, void* stream) {
-    ASE_CHECK_ARG(e && z && d_e && acc && amb > 0 && amb_global >= amb, "enc_head: null/empty operand");
+                                float grad_scale, int dtype, void* stream) {
+    ASE_CHECK_ARG(e && z && d_e && acc && amb > 0 && amb_global >= amb && grad_scale > 0.f, "enc_head: null/empty operand");
     ASE_CHECK_ARG(z_dim >= 1 && z_dim <= 128, "enc_head: z_dim %d not in [1,128]", z_dim);
     const dim3 grid(min((amb + 3) / 4, 128));
-    if (dtype == ASE_BF16)
-        ASE_LAUNCH(enc_head_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, e, ld_e, z, ld_z,
-                           (bf16_t*)d_e, ld_de, db_enc, enc_out, acc, amb, amb_global, z_dim, enc_coef);
-    else if (dtype == ASE_F32)
-        ASE_LAUNCH(enc_head_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, e, ld_e, z, ld_z,
-                           (float*)d_e, ld_de, db_enc, enc_out, acc, amb, amb_global, z_dim, enc_coef);
-    else ASE_CHECK_ARG(false, "enc_head: bad dtype %d", dtype);
+    const int rc = ase_dispatch_storage(dtype, [&](auto tag) {
+        typedef typename decltype(tag)::type T;
+        ASE_LAUNCH(enc_head_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, e, ld_e, z, ld_z, (T*)d_e, ld_de, db_enc, enc_out, acc,
+                   amb, amb_global, z_dim, enc_coef, grad_scale);
+        return ASE_OK;
+    });
+    ASE_CHECK_ARG(rc == ASE_OK, "enc_head: bad dtype %d", dtype);
     ASE_CHECK_LAUNCH("enc_head");
     return ASE_OK;
 }
@@ -532,29 +534,30 @@ extern "C" int ase_hip_enc_gp_seed(const float* e, int64_t ld_e, const float* z,
     ASE_CHECK_ARG(e && z && u && rows > 0, "enc_gp_seed: null/empty operand");
     ASE_CHECK_ARG(z_dim >= 1 && z_dim <= 128, "enc_gp_seed: z_dim %d not in [1,128]", z_dim);
     const dim3 grid(min((rows + 3) / 4, 1024));
-    if (dtype == ASE_BF16)
-        ASE_LAUNCH((enc_gp_kernel<bf16_t, 0>), grid, dim3(256), 0, (hipStream_t)stream, e, ld_e, z, ld_z, (const float*)nullptr,
-                   (int64_t)0, (bf16_t*)u, ld_u, (float*)nullptr, rows, z_dim, scale);
-    else if (dtype == ASE_F32)
-        ASE_LAUNCH((enc_gp_kernel<float, 0>), grid, dim3(256), 0, (hipStream_t)stream, e, ld_e, z, ld_z, (const float*)nullptr,
-                   (int64_t)0, (float*)u, ld_u, (float*)nullptr, rows, z_dim, scale);
-    else ASE_CHECK_ARG(false, "enc_gp_seed: bad dtype %d", dtype);
+    const int rc = ase_dispatch_storage(dtype, [&](auto tag) {
+        typedef typename decltype(tag)::type T;
+        ASE_LAUNCH((enc_gp_kernel<T, 0>), grid, dim3(256), 0, (hipStream_t)stream, e, ld_e, z, ld_z, (const float*)nullptr,
+                   (int64_t)0, (T*)u, ld_u, (float*)nullptr, rows, z_dim, scale);
+        return ASE_OK;
+    });
+    ASE_CHECK_ARG(rc == ASE_OK, "enc_gp_seed: bad dtype %d", dtype);
     ASE_CHECK_LAUNCH("enc_gp_seed");
     return ASE_OK;
 }
 
 extern "C" int ase_hip_enc_gp_back(const float* e, int64_t ld_e, const float* z, int64_t ld_z, const float* du, int64_t ld_du,
-                                   void* d_e, int64_t ld_de, float* db_enc, int rows, int z_dim, int dtype, void* stream) {
-    ASE_CHECK_ARG(e && z && du && d_e && rows > 0, "enc_gp_back: null/empty operand");
+                                   void* d_e, int64_t ld_de, float* db_enc, int rows, int z_dim, float grad_scale, int dtype,
+                                   void* stream) {
+    ASE_CHECK_ARG(e && z && du && d_e && rows > 0 && grad_scale > 0.f, "enc_gp_back: null/empty operand");
     ASE_CHECK_ARG(z_dim >= 1 && z_dim <= 128, "enc_gp_back: z_dim %d not in [1,128]", z_dim);
     const dim3 grid(min((rows + 3) / 4, 128));          // <= 128 workgroups on the bias-gradient atomics (see enc_head)
-    if (dtype == ASE_BF16)
-        ASE_LAUNCH((enc_gp_kernel<bf16_t, 1>), grid, dim3(256), 0, (hipStream_t)stream, e, ld_e, z, ld_z, du, ld_du, (bf16_t*)d_e,
-                   ld_de, db_enc, rows, z_dim, 1.f);
-    else if (dtype == ASE_F32)
-        ASE_LAUNCH((enc_gp_kernel<float, 1>), grid, dim3(256), 0, (hipStream_t)stream, e, ld_e, z, ld_z, du, ld_du, (float*)d_e,
-                   ld_de, db_enc, rows, z_dim, 1.f);
-    else ASE_CHECK_ARG(false, "enc_gp_back: bad dtype %d", dtype);
+    const int rc = ase_dispatch_storage(dtype, [&](auto tag) {
+        typedef typename decltype(tag)::type T;
+        ASE_LAUNCH((enc_gp_kernel<T, 1>), grid, dim3(256), 0, (hipStream_t)stream, e, ld_e, z, ld_z, du, ld_du, (T*)d_e, ld_de,
+                   db_enc, rows, z_dim, grad_scale);
+        return ASE_OK;
+    });
+    ASE_CHECK_ARG(rc == ASE_OK, "enc_gp_back: bad dtype %d", dtype);
     ASE_CHECK_LAUNCH("enc_gp_back");
     return ASE_OK;
 }
@@ -563,13 +566,12 @@ extern "C" int ase_hip_gp_seed(const void* h, int64_t ld_h, const float* w, void
                                float scale, int dtype, void* stream) {
     ASE_CHECK_ARG(h && w && g && rows > 0 && width > 0, "gp_seed: null/empty operand");
     const dim3 grid(grid_for((int64_t)rows * width));
-    if (dtype == ASE_BF16)
-        ASE_LAUNCH(gp_seed_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h, ld_h, w,
-                           (bf16_t*)g, ld_g, rows, width, scale);
-    else if (dtype == ASE_F32)
-        ASE_LAUNCH(gp_seed_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)h, ld_h, w,
-                           (float*)g, ld_g, rows, width, scale);
-    else ASE_CHECK_ARG(false, "gp_seed: bad dtype %d", dtype);
+    const int rc = ase_dispatch_storage(dtype, [&](auto tag) {
+        typedef typename decltype(tag)::type T;
+        ASE_LAUNCH(gp_seed_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)h, ld_h, w, (T*)g, ld_g, rows, width, scale);
+        return ASE_OK;
+    });
+    ASE_CHECK_ARG(rc == ASE_OK, "gp_seed: bad dtype %d", dtype);
     ASE_CHECK_LAUNCH("gp_seed");
     return ASE_OK;
 }
@@ -577,16 +579,17 @@ extern "C" int ase_hip_gp_seed(const void* h, int64_t ld_h, const float* w, void
 extern "C" int ase_hip_sqnorm(const void* x, int64_t ld, int rows, int cols, double* acc, int slot, double scale,
                               int dtype, void* stream) {
     ASE_CHECK_ARG(x && acc && rows > 0 && cols > 0 && slot >= 0, "sqnorm: null/empty operand");
-    const int es = dtype == ASE_BF16 ? 2 : 4, vec = 16 / es;
+    const int es = ase_elem_size(dtype), vec = 16 / es;
     const bool wide = cols % vec == 0 && (ld * es) % 16 == 0 && ((uintptr_t)x % 16) == 0;
     const dim3 grid(grid_for((int64_t)rows * cols / (wide ? vec : 1), 2048, 256));
-    if (dtype == ASE_BF16) {
-        if (wide) ASE_LAUNCH((sqnorm_kernel<bf16_t, 8>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, rows, cols, acc + slot, scale);
-        else ASE_LAUNCH((sqnorm_kernel<bf16_t, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, rows, cols, acc + slot, scale);
-    } else if (dtype == ASE_F32) {
-        if (wide) ASE_LAUNCH((sqnorm_kernel<float, 4>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ld, rows, cols, acc + slot, scale);
-        else ASE_LAUNCH((sqnorm_kernel<float, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ld, rows, cols, acc + slot, scale);
-    } else ASE_CHECK_ARG(false, "sqnorm: bad dtype %d", dtype);
+    const int rc = ase_dispatch_storage(dtype, [&](auto tag) {
+        typedef typename decltype(tag)::type T;
+        constexpr int VEC = 16 / (int)sizeof(T);
+        if (wide) ASE_LAUNCH((sqnorm_kernel<T, VEC>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, ld, rows, cols, acc + slot, scale);
+        else ASE_LAUNCH((sqnorm_kernel<T, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, ld, rows, cols, acc + slot, scale);
+        return ASE_OK;
+    });
+    ASE_CHECK_ARG(rc == ASE_OK, "sqnorm: bad dtype %d", dtype);
     ASE_CHECK_LAUNCH("sqnorm");
     return ASE_OK;
 }

@@ -72,6 +72,12 @@ template <> __device__ __forceinline__ void store_shadow4<bf16_t>(bf16_t* p, con
     for (int c = 0; c < 4; ++c) v[c] = (bf16_t)w[c];
     *reinterpret_cast<bf16x4*>(p) = v;
 }
+template <> __device__ __forceinline__ void store_shadow4<f16_t>(f16_t* p, const float (&w)[4]) {
+    f16x4 v;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = from_f32<f16_t>(w[c]);
+    *reinterpret_cast<f16x4*>(p) = v;
+}
 template <> __device__ __forceinline__ void store_shadow4<float>(float* p, const float (&w)[4]) {
     *reinterpret_cast<f32x4*>(p) = f32x4{w[0], w[1], w[2], w[3]};
 }
@@ -279,12 +285,12 @@ extern "C" int ase_hip_apply_multi(const int64_t* desc, int n_layers, const doub
     ASE_CHECK_ARG(desc && n_layers > 0, "apply_multi: null/empty operand");
     ASE_CHECK_ARG(opt_state == nullptr || acc != nullptr, "apply_multi: optimizer step without the accumulator array");
     const dim3 grid(256, n_layers);
-    if (dtype == ASE_BF16)
-        ASE_LAUNCH(apply_multi_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, desc, opt_state, acc);
-    else if (dtype == ASE_F32)
-        ASE_LAUNCH(apply_multi_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, desc, opt_state, acc);
-    else
-        ASE_CHECK_ARG(false, "apply_multi: bad dtype %d", dtype);
+    const int rc = ase_dispatch_storage(dtype, [&](auto tag) {
+        typedef typename decltype(tag)::type T;
+        ASE_LAUNCH(apply_multi_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, desc, opt_state, acc);
+        return ASE_OK;
+    });
+    ASE_CHECK_ARG(rc == ASE_OK, "apply_multi: bad dtype %d", dtype);
     ASE_CHECK_LAUNCH("apply_multi");
     return ASE_OK;
 }

@@ -130,10 +130,10 @@ __global__ __launch_bounds__(256) void rms_normalize_multi_kernel(RmsStreams S, 
 #pragma unroll
     for (int c = 0; c < 4; ++c) y[c] = fminf(fmaxf((x[c] - mu[c]) / sd[c], -5.f), 5.f);
     if constexpr (sizeof(T) == 2) {
-        bf16x4 v;
+        typename V16<T>::x4 v;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = (bf16_t)y[c];
-        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(S.out[s]) + (int64_t)r * S.ld_out[s] + j) = v;
+        for (int c = 0; c < 4; ++c) v[c] = from_f32<T>(y[c]);
+        *reinterpret_cast<typename V16<T>::x4*>(reinterpret_cast<T*>(S.out[s]) + (int64_t)r * S.ld_out[s] + j) = v;
     } else {
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(S.out[s]) + (int64_t)r * S.ld_out[s] + j) = y;
     }
@@ -223,10 +223,10 @@ __global__ __launch_bounds__(256) void rms_normalize4_kernel(const float* __rest
     for (int o = 0; o < 3; ++o) {
         if (!outs[o]) continue;
         if constexpr (sizeof(T) == 2) {
-            bf16x4 v;
+            typename V16<T>::x4 v;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = (bf16_t)y[c];
-            *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(outs[o]) + (int64_t)r * lds[o] + j) = v;
+            for (int c = 0; c < 4; ++c) v[c] = from_f32<T>(y[c]);
+            *reinterpret_cast<typename V16<T>::x4*>(reinterpret_cast<T*>(outs[o]) + (int64_t)r * lds[o] + j) = v;
         } else {
             *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(outs[o]) + (int64_t)r * lds[o] + j) = y;
         }
@@ -277,6 +277,7 @@ __global__ __launch_bounds__(256) void gather_multi_kernel(const int64_t* __rest
             const uint32_t rr = i / D, j = i - rr * D;
             const float v = src[prow[rr] * ld_src + j];
             if (dt == ASE_BF16) reinterpret_cast<bf16_t*>(d[3])[(int64_t)(r0 + rr) * ld_dst + j] = (bf16_t)v;
+            else if (dt == ASE_F16) reinterpret_cast<f16_t*>(d[3])[(int64_t)(r0 + rr) * ld_dst + j] = from_f32<f16_t>(v);
             else reinterpret_cast<float*>(d[3])[(int64_t)(r0 + rr) * ld_dst + j] = v;
         }
     }
@@ -334,8 +335,8 @@ extern "C" int ase_hip_rms_normalize_multi(const float* const* srcs, const int64
                                            int D, int M, int dtype, void* stream) {
     ASE_CHECK_ARG(srcs && ld_srcs && idxs && remap_h && remap_n && means && stds && outs && ld_outs && n_streams >= 1 &&
                       n_streams <= 4 && D > 0 && M > 0, "rms_normalize_multi: null/empty operand (1..4 streams)");
-    ASE_CHECK_ARG(dtype == ASE_BF16 || dtype == ASE_F32, "rms_normalize_multi: bad dtype %d", dtype);
-    const int es = dtype == ASE_BF16 ? 2 : 4;
+    ASE_CHECK_ARG(dtype == ASE_BF16 || dtype == ASE_F32 || dtype == ASE_F16, "rms_normalize_multi: bad dtype %d", dtype);
+    const int es = ase_elem_size(dtype);
     RmsStreams S = {};
     for (int s = 0; s < n_streams; ++s) {
         ASE_CHECK_ARG(srcs[s] && means[s] && stds[s] && outs[s], "rms_normalize_multi: stream %d: null operand", s);
@@ -346,8 +347,11 @@ extern "C" int ase_hip_rms_normalize_multi(const float* const* srcs, const int64
         S.mean[s] = means[s]; S.stdv[s] = stds[s]; S.out[s] = outs[s]; S.ld_out[s] = ld_outs[s];
     }
     const dim3 grid((D / 4 + 63) / 64, (M + 3) / 4, n_streams);
-    if (dtype == ASE_BF16) ASE_LAUNCH(rms_normalize_multi_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, S, D, M);
-    else ASE_LAUNCH(rms_normalize_multi_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, S, D, M);
+    ase_dispatch_storage(dtype, [&](auto tag) {
+        typedef typename decltype(tag)::type T;
+        ASE_LAUNCH(rms_normalize_multi_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, S, D, M);
+        return ASE_OK;
+    });
     ASE_CHECK_LAUNCH("rms_normalize_multi");
     return ASE_OK;
 }
@@ -376,30 +380,22 @@ extern "C" int ase_hip_rms_normalize(const float* src, int64_t ld_src, int D, co
                                      int64_t ld0, void* out1, int64_t ld1, void* out2, int64_t ld2, int dtype,
                                      void* stream) {
     ASE_CHECK_ARG(src && mean && stdv && out0 && D > 0 && M > 0, "rms_normalize: null/empty operand");
-    const int es = dtype == ASE_BF16 ? 2 : 4;
+    const int es = ase_elem_size(dtype);
     auto ok = [&](void* o, int64_t ld) { return o == nullptr || (ld % 4 == 0 && ((uintptr_t)o % (4 * es)) == 0); };
     const bool wide = D % 4 == 0 && ld_src % 4 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)mean % 16) == 0 &&
                       ((uintptr_t)stdv % 16) == 0 && ok(out0, ld0) && ok(out1, ld1) && ok(out2, ld2);
-    if (wide && (dtype == ASE_BF16 || dtype == ASE_F32)) {
-        const dim3 g4((D / 4 + 63) / 64, (M + 3) / 4);
-        if (dtype == ASE_BF16)
-            ASE_LAUNCH(rms_normalize4_kernel<bf16_t>, g4, dim3(256), 0, (hipStream_t)stream, src, ld_src, D, idx,
-                               remap_h, remap_n, M, mean, stdv, out0, ld0, out1, ld1, out2, ld2);
+    const dim3 g4((D / 4 + 63) / 64, (M + 3) / 4), grid((D + 255) / 256, (M + 3) / 4);
+    const int rc = ase_dispatch_storage(dtype, [&](auto tag) {
+        typedef typename decltype(tag)::type T;
+        if (wide)
+            ASE_LAUNCH(rms_normalize4_kernel<T>, g4, dim3(256), 0, (hipStream_t)stream, src, ld_src, D, idx, remap_h, remap_n, M, mean,
+                       stdv, out0, ld0, out1, ld1, out2, ld2);
         else
-            ASE_LAUNCH(rms_normalize4_kernel<float>, g4, dim3(256), 0, (hipStream_t)stream, src, ld_src, D, idx,
-                               remap_h, remap_n, M, mean, stdv, out0, ld0, out1, ld1, out2, ld2);
-        ASE_CHECK_LAUNCH("rms_normalize");
+            ASE_LAUNCH(rms_normalize_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, D, idx, remap_h, remap_n, M, mean,
+                       stdv, out0, ld0, out1, ld1, out2, ld2);
         return ASE_OK;
-    }
-    const dim3 grid((D + 255) / 256, (M + 3) / 4);
-    if (dtype == ASE_BF16)
-        ASE_LAUNCH(rms_normalize_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, D, idx,
-                           remap_h, remap_n, M, mean, stdv, out0, ld0, out1, ld1, out2, ld2);
-    else if (dtype == ASE_F32)
-        ASE_LAUNCH(rms_normalize_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, D, idx,
-                           remap_h, remap_n, M, mean, stdv, out0, ld0, out1, ld1, out2, ld2);
-    else
-        ASE_CHECK_ARG(false, "rms_normalize: bad dtype %d", dtype);
+    });
+    ASE_CHECK_ARG(rc == ASE_OK, "rms_normalize: bad dtype %d", dtype);
     ASE_CHECK_LAUNCH("rms_normalize");
     return ASE_OK;
 }
@@ -419,14 +415,12 @@ extern "C" int ase_hip_gather_rows(const float* src, int64_t ld_src, int D, cons
     while (W > 1 && W / 2 >= D) W /= 2;
     const dim3 block(W, 256 / W);
     const dim3 grid((M + block.y - 1) / block.y);
-    if (dst_dtype == ASE_BF16)
-        ASE_LAUNCH(gather_rows_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, src, ld_src, D, idx,
-                           remap_h, remap_n, M, (bf16_t*)dst, ld_dst);
-    else if (dst_dtype == ASE_F32)
-        ASE_LAUNCH(gather_rows_kernel<float>, grid, block, 0, (hipStream_t)stream, src, ld_src, D, idx,
-                           remap_h, remap_n, M, (float*)dst, ld_dst);
-    else
-        ASE_CHECK_ARG(false, "gather_rows: bad dtype %d", dst_dtype);
+    const int rc = ase_dispatch_storage(dst_dtype, [&](auto tag) {
+        typedef typename decltype(tag)::type T;
+        ASE_LAUNCH(gather_rows_kernel<T>, grid, block, 0, (hipStream_t)stream, src, ld_src, D, idx, remap_h, remap_n, M, (T*)dst, ld_dst);
+        return ASE_OK;
+    });
+    ASE_CHECK_ARG(rc == ASE_OK, "gather_rows: bad dtype %d", dst_dtype);
     ASE_CHECK_LAUNCH("gather_rows");
     return ASE_OK;
 }

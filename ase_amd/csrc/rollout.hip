@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
 // one wave per row, dim <= 128
 __global__ __launch_bounds__(256) void sample_latents_kernel(float* __restrict__ z, int rows, int dim,
                                                              const uint64_t* __restrict__ rng, int64_t row_offset,
-                                                             void* __restrict__ z2, int64_t ld_z2, int z2_bf16) {
+                                                             void* __restrict__ z2, int64_t ld_z2, int z2_dtype) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
@@ -215,7 +215,8 @@ __global__ __launch_bounds__(256) void sample_latents_kernel(float* __restrict__
             const float o = v[q] / nrm;
             z[(int64_t)r * dim + j] = o;
             if (z2) {
-                if (z2_bf16) reinterpret_cast<bf16_t*>(z2)[(int64_t)r * ld_z2 + j] = (bf16_t)o;
+                if (z2_dtype == ASE_BF16) reinterpret_cast<bf16_t*>(z2)[(int64_t)r * ld_z2 + j] = (bf16_t)o;
+                else if (z2_dtype == ASE_F16) reinterpret_cast<f16_t*>(z2)[(int64_t)r * ld_z2 + j] = from_f32<f16_t>(o);
                 else reinterpret_cast<float*>(z2)[(int64_t)r * ld_z2 + j] = o;
             }
         }
@@ -305,9 +306,9 @@ extern "C" int ase_hip_sample_actions(const float* mu, int64_t ld_mu, const floa
 extern "C" int ase_hip_sample_latents(float* z, int rows, int dim, uint64_t* rng_state, int64_t row_offset, int advance,
                                       void* z2, int64_t ld_z2, int z2_dtype, void* stream) {
     ASE_CHECK_ARG(z && rng_state && rows > 0 && dim >= 1 && dim <= 128 && row_offset >= 0, "sample_latents: bad operand");
-    ASE_CHECK_ARG(z2 == nullptr || ((z2_dtype == ASE_BF16 || z2_dtype == ASE_F32) && ld_z2 >= dim), "sample_latents: bad second output");
+    ASE_CHECK_ARG(z2 == nullptr || ((z2_dtype == ASE_BF16 || z2_dtype == ASE_F32 || z2_dtype == ASE_F16) && ld_z2 >= dim), "sample_latents: bad second output");
     ASE_LAUNCH(sample_latents_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, z, rows, dim,
-               rng_state, row_offset, z2, ld_z2, (int)(z2_dtype == ASE_BF16));
+               rng_state, row_offset, z2, ld_z2, z2_dtype);
     if (advance) ASE_LAUNCH(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng_state);
     ASE_CHECK_LAUNCH("sample_latents");
     return ASE_OK;

@@ -62,7 +62,7 @@ class UpdateEngine:
     """kind: 'ase' | 'amp' | 'ppo'.  sizes: rows handled by THIS rank (M, AMB) and global counts."""
 
     def __init__(self, kind, net, cfg, backend, *, minibatch, amp_minibatch=0, dtype=torch.bfloat16,
-                 world_size=1, rank=0, infer_rows=0, dp_mode='shard'):
+                 world_size=1, rank=0, infer_rows=0, dp_mode='shard', grad_scale=None):
         """dp_mode (world_size > 1):
           'shard'    every minibatch is row-sharded over the ranks; global denominators, normaliser moments summed over
                      the ranks, gradients SUM-reduced: the R-rank update equals the 1-rank update (BASELINE config 3);
@@ -79,6 +79,16 @@ class UpdateEngine:
         assert minibatch % div == 0 and amp_minibatch % div == 0
         self.Mg, self.AMBg = minibatch, amp_minibatch
         self.M, self.AMB = minibatch // div, amp_minibatch // div
+        # Static gradient scale of half storage (dtype float16: what the reference's mixed_precision flag computes in -
+        # torch.cuda.amp autocast + GradScaler, learning/ase_agent.py:216,271-288).  The loss heads store S * dL/d(head output);
+        # every data-gradient launch is linear, so the whole back-propagated chain carries S and the weight-gradient launches
+        # undo it through alpha = 1/S; bias gradients of the heads are formed unscaled inside the head kernels.  Head
+        # gradients are O(1/minibatch): S = the power of two nearest minibatch/4 puts them near 1 and leaves ~2^13 of
+        # headroom up to half's largest finite value and ~2^10 down to its subnormals for the deeper layers' gradients.
+        # Conversions saturate (no inf), S is a power of two (exact), so unlike GradScaler nothing is skipped or adapted.
+        if grad_scale is None:
+            grad_scale = 2.0 ** max(0, round(math.log2(max(minibatch, 4) / 4.0))) if dtype == torch.float16 else 1.0
+        self.gs = float(grad_scale)
         # flags resolved once (rl_games defaults: normalize_value False, bounds_loss_coef None = no bound loss)
         # truncate_grads: global-norm clip of the whole gradient before Adam (learning/ase_agent.py:273-288): the norm needs every
         # gradient (weight-only loss terms included), so the per-branch optimizer steps give way to the end-of-step form
@@ -275,6 +285,9 @@ class UpdateEngine:
             self.Gp = [z[Rd:] for z in self.dZd4]
             self.HD = zt(Rd, self.disc_head.n_pad, f32)
             self.dHD = zt(Rd, self.disc_head.n_pad)
+            # last launch of the gradient-penalty chain's backward: only its column sums are used (the penalty's gradient
+            # w.r.t. the logit weights), at true scale - f32 so that half storage cannot flush them
+            self.GpTop = zt(AMB, self.disc[-1].n_pad, f32)
             if self.enc_chain:
                 self.He, self.dZe = chain_bufs(self.enc_chain, AMB)
                 self.E = zt(AMB, self.enc_head.n_pad, f32)
@@ -444,6 +457,7 @@ class UpdateEngine:
         the data-gradient chain never overwrites, so phase_main launches all of them as ONE grid at its end
         (ase_hip_gemm_tn_grouped: the split-M reduction is paid once per step instead of once per layer)."""
         br = bias_rows if bias_rows > 0 else M
+        alpha = alpha / self.gs              # the back-propagated operand carries the gradient scale
         if self._tn_defer and self.be.grouped_tn_ok(A.dtype, M, n_real, K, br):
             self._tn_queue.append((A, B, G, gbias, br, M, N, K, n_real, k_real, split_src, split_dst, alpha))
         else:
@@ -489,7 +503,7 @@ class UpdateEngine:
                     items.append((src, src.shape[1], dst))
             if self.z and part != 1:
                 src = ds['ase_latents'].view(ds['ase_latents'].shape[0], -1)
-                code = L.BF16 if self.dtype == torch.bfloat16 else L.F32
+                code = {torch.bfloat16: L.BF16, torch.float16: L.F16}.get(self.dtype, L.F32)
                 for dst in (self.Zs[:self.M], self.Xc[:, self.actor[0].split_dst:]):
                     rows.append([src.data_ptr(), src.stride(0), self.z, dst.data_ptr(), dst.stride(0), code])
                     items.append((src, self.z, dst))
@@ -731,18 +745,19 @@ class UpdateEngine:
             with self._Branch(self, self._side(1), fork0) as br_disc:
                 if not disc_early:
                     hd, he = disc_forward()
-                be.disc_head(self.HD, self.dHD, self.disc_head.gb[0], self.acc, AMB, amb_den, c['disc_coef'])
+                be.disc_head(self.HD, self.dHD, self.disc_head.gb[0], self.acc, AMB, amb_den, c['disc_coef'],
+                             grad_scale=self.gs)
                 if self.has_enc:
                     src, sidx, srm = amp_streams[0]   # enc_latents = ase_latents[0:amp_minibatch] (learning/ase_agent.py:247)
                     zsrc = ds['ase_latents'].view(ds['ase_latents'].shape[0], -1)
                     be.gather_rows(zsrc, self.z, sidx, srm, AMB, self.enc_z)
                     if self.enc_sep:
                         be.enc_head(self.E, self.enc_z, self.dE, self.enc_head.gb[0], None, self.acc, AMB, amb_den,
-                                    self.z, c['enc_coef'])
+                                    self.z, c['enc_coef'], grad_scale=self.gs)
                     else:
                         off = self.disc_head.parts[1][2]
                         be.enc_head(self.HD[:AMB, off:], self.enc_z, self.dHD[:AMB, off:], self.disc_head.gb[1], None,
-                                    self.acc, AMB, amb_den, self.z, c['enc_coef'])
+                                    self.acc, AMB, amb_den, self.z, c['enc_coef'], grad_scale=self.gs)
                 if self.enc_gp:
                     self._enc_grad_penalty(he if self.enc_chain else hd[:AMB])
                 self._wgrad(self.disc_head, self.dHD, hd, Rd)
@@ -765,7 +780,7 @@ class UpdateEngine:
         be.ppo_head(self.MU, self.V, self.mb, self.new_z if self.div_on else None, self.logstd, self.dMU, self.dV,
                     self.mu_head.gb[0], self.value_head.gb[0], self.acc, M, self.Mg if self.shard else self.M, self.act, self.z,
                     self.masked, self.div_on, self.mu_tanh, c['clip_value'], c['e_clip'], c['critic_coef'],
-                    self.bounds_coef, c.get('amp_diversity_bonus', 0.0), c.get('amp_diversity_tar', 0.0))
+                    self.bounds_coef, c.get('amp_diversity_bonus', 0.0), c.get('amp_diversity_tar', 0.0), grad_scale=self.gs)
         fork2 = self._mark()
 
         # -- actor backward on the main stream, critic backward beside it.  The wide layers' weight gradients of BOTH
@@ -887,8 +902,11 @@ class UpdateEngine:
         for l in range(nl - 1, 0, -1):
             self._dgrad(chain[l], self.Re[l], self.Re[l - 1], AMB, H[l - 1], chain[l - 1].act)
         d0 = chain[0]
-        be.gemm_nt(self.Re[0], d0.Wts, self.Ge, AMB, d0.k_pad, d0.n_pad)                  # s * g
-        be.sqnorm(self.Ge, AMB, d0.k_pad, self.acc, L.ACC_ENC_GP, scale=1.0 / cg)
+        # (Ge and everything derived from it - the second operand of the weight-gradient pairs - carries the gradient
+        #  scale S, like the back-propagated operand of every other weight gradient)
+        S = self.gs
+        be.gemm_nt(self.Re[0], d0.Wts, self.Ge, AMB, d0.k_pad, d0.n_pad, alpha=S)         # S s * g
+        be.sqnorm(self.Ge, AMB, d0.k_pad, self.acc, L.ACC_ENC_GP, scale=1.0 / (cg * S * S))
         # its backward: forward-shaped launches without bias, masked by the same activations
         x = self.Ge
         for l in range(nl):
@@ -896,7 +914,7 @@ class UpdateEngine:
             aux, mode = self._aux(H[l], L.AUX_RELU_MASK)
             be.gemm_nt(x, d.Ws, self.Qe[l], AMB, d.n_pad, d.k_pad, aux=aux, aux_mode=mode)
             x = self.Qe[l]
-        be.gemm_nt(x, head.Ws, self.DUe, AMB, head.n_pad, head.k_pad, alpha=s)            # du (unscaled)
+        be.gemm_nt(x, head.Ws, self.DUe, AMB, head.n_pad, head.k_pad, alpha=s / S)        # du (unscaled)
         # weight gradients (no bias terms: the chain has none)
         for l in range(nl):
             d = chain[l]
@@ -905,7 +923,7 @@ class UpdateEngine:
         for (name, nr, poff), gW in zip(head.parts, head.gW):
             if sep or poff == off:
                 self._tn(self.Ue[:, poff:], self.Qe[-1], gW, AMB, P(nr), head.k_pad, nr, head.K, head.split_src, head.split_dst)
-        be.enc_gp_back(e, self.enc_z, self.DUe[:, off:], d_e, db, AMB, self.z)
+        be.enc_gp_back(e, self.enc_z, self.DUe[:, off:], d_e, db, AMB, self.z, grad_scale=S)
 
     def _disc_backward(self):
         """Discriminator trunk backward with the gradient penalty riding on the same launches.
@@ -938,8 +956,11 @@ class UpdateEngine:
             be.gemm_nt(self.dZd4[l], d.Wts, self.dZd4[l - 1], 4 * AMB, d.k_pad, d.n_pad, aux=aux, aux_mode=mode,
                        aux_split=Rd, aux_delta=AMB)
         d0 = self.disc[0]
-        be.gemm_nt(self.Gp[0], d0.Wts, self.G0, AMB, d0.k_pad, d0.n_pad)                 # s * g_0
-        be.sqnorm(self.G0, AMB, d0.k_pad, self.acc, L.ACC_GP, scale=1.0 / cg)
+        # (the chain's second-operand side - G0 and the dJ/dU_l derived from it - carries the gradient scale S so that the
+        #  stacked weight-gradient launches undo it for both row blocks with one alpha)
+        S = self.gs
+        be.gemm_nt(self.Gp[0], d0.Wts, self.G0, AMB, d0.k_pad, d0.n_pad, alpha=S)        # S s * g_0
+        be.sqnorm(self.G0, AMB, d0.k_pad, self.acc, L.ACC_GP, scale=1.0 / (cg * S * S))
         # backward of the chain (values scaled by s; see the docstring): dJ/dU_l, masked by the demo rows' ReLU masks
         aux, mode = self._aux(self.Hd[0][2 * AMB:], L.AUX_RELU_MASK)
         be.gemm_nt(self.G0, d0.Ws, self.dGp[0], AMB, d0.n_pad, d0.k_pad, aux=aux, aux_mode=mode)
@@ -947,8 +968,8 @@ class UpdateEngine:
             d = self.disc[l]
             last = l == nl - 1
             aux, mode = self._aux(self.Hd[l][2 * AMB:], L.AUX_RELU_MASK)
-            be.gemm_nt(self.dGp[l - 1], d.Ws, self.dGp[l], AMB, d.n_pad, d.k_pad, aux=aux,
-                       aux_mode=mode, alpha=s if last else 1.0,
+            be.gemm_nt(self.dGp[l - 1], d.Ws, self.GpTop if last else self.dGp[l], AMB, d.n_pad, d.k_pad, aux=aux,
+                       aux_mode=mode, alpha=s / S if last else 1.0,
                        colsum=self.disc_head.gW[0].view(-1) if last else None, colsum_n=d.N if last else 0)
         # weight (+ bias) gradients: one launch per layer over the stacked rows
         for l in range(nl):

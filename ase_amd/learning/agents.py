@@ -122,7 +122,8 @@ class CommonAgent:
         self.bounds_loss_coef = config.get('bounds_loss_coef', None)
         self.truncate_grads = config.get('truncate_grads', False)       # global-norm clip (UpdateEngine.truncate)
         self.grad_norm = config.get('grad_norm', 1.0)
-        assert not config.get('mixed_precision', False), "use config['precision'] = 'bf16' | 'f32'"
+        # mixed_precision (rl_games: torch.cuda.amp autocast = half arithmetic + GradScaler, learning/ase_agent.py:216,271-288)
+        # selects the half-storage mode: 'f16' below, with a static power-of-two gradient scale in the GradScaler's place
         assert config.get('lr_schedule', 'constant') in ('constant', None)
         self.multi_gpu = config.get('multi_gpu', False)
         self.world_size, self.rank = config.get('world_size', 1), config.get('rank', 0)
@@ -161,8 +162,11 @@ class CommonAgent:
         self.model.to(self.ppo_device)
         # precision: 'bf16' (bf16 storage + MFMA, throughput mode) | 'f32' (exact f32 MFMA) |
         #            'bf16x3' (f32 storage, every product as three bf16 MFMAs on a hi/lo split: f32-grade results)
-        precision = config.get('precision', 'bf16')
-        dtype = {'bf16': torch.bfloat16, 'f32': torch.float32, 'bf16x3': torch.float32}[precision]
+        #            'f16' (IEEE half storage + MFMA, f32 accumulate, static gradient scale: same rate as bf16, 3 more
+        #                   mantissa bits - the reference's mixed_precision=True arithmetic)
+        precision = config.get('precision', 'f16' if config.get('mixed_precision', False) else 'bf16')
+        dtype = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32, 'bf16x3': torch.float32}[precision]
+        self.precision = precision
         backend = config.get('backend', None)
         if backend is None:
             from ..backend import HipBackend
@@ -170,7 +174,8 @@ class CommonAgent:
         self.backend = backend
         self.engine = UpdateEngine(self.kind, self.model.a2c_network, config, backend, minibatch=self.minibatch_size,
                                    amp_minibatch=getattr(self, '_amp_minibatch_size', 0), dtype=dtype,
-                                   world_size=self.world_size, rank=self.rank, dp_mode=self.dp_mode)
+                                   world_size=self.world_size, rank=self.rank, dp_mode=self.dp_mode,
+                                   grad_scale=config.get('grad_scale', None))
         self.model.a2c_network.infer = InferenceEngine(self.model.a2c_network, self.engine)
         self.use_graph = bool(config.get('graph_capture', False))
         self._snapshot_aside = os.environ.get('ASE_SNAPSHOT_ASIDE', '1') != '0'

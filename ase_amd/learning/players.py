@@ -94,7 +94,7 @@ class CommonPlayer:
             backend = HipBackend(self.device)
         self.backend = backend
         prec = self.config.get('precision', 'bf16')
-        dtype = torch.bfloat16 if prec == 'bf16' else torch.float32
+        dtype = {'bf16': torch.bfloat16, 'f16': torch.float16}.get(prec, torch.float32)
         self.engine = UpdateEngine(net.kind, net, self._engine_cfg(), backend, minibatch=0, amp_minibatch=0, dtype=dtype)
         net.infer = InferenceEngine(net, self.engine)
         self.action_rng = torch.tensor([int(self.config.get('seed', 0)) ^ 0x91A7E5, 0], dtype=torch.int64, device=self.device)

@@ -9,7 +9,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libase_hip.so")
 
-F32, BF16, F32X3 = 0, 1, 2
+ABI_VERSION = 2
+F32, BF16, F32X3, F16 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 AUX_NONE, AUX_RELU_MASK, AUX_TANH_GRAD, AUX_RELU_BITS = 0, 1, 2, 3
 
@@ -40,14 +41,14 @@ SIGNATURES = {
     "ase_hip_rms_unnormalize": [_p, _p, _p, _i64, _p],
     "ase_hip_gather_rows": [_p, _i64, _i, _p, _i, _i, _i, _p, _i64, _i, _p],
     "ase_hip_reduce_sum": [_p, _i64, _i, _p, _i, _p],
-    "ase_hip_ppo_head": [_p, _i64, _p, _i64] + [_p] * 11 + [_p, _i64, _p, _i64, _p, _p, _p, _p, _p] + [_i] * 8 + [_f] * 5 + [_i, _p],
-    "ase_hip_disc_head": [_p, _i64, _p, _i64, _p, _p, _i, _i, _f, _i, _p],
-    "ase_hip_enc_head": [_p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _i, _i, _i, _f, _i, _p],
+    "ase_hip_ppo_head": [_p, _i64, _p, _i64] + [_p] * 11 + [_p, _i64, _p, _i64, _p, _p, _p, _p, _p] + [_i] * 8 + [_f] * 6 + [_i, _p],
+    "ase_hip_disc_head": [_p, _i64, _p, _i64, _p, _p, _i, _i, _f, _f, _i, _p],
+    "ase_hip_enc_head": [_p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _i, _i, _i, _f, _f, _i, _p],
     "ase_hip_gp_seed": [_p, _i64, _p, _p, _i64, _i, _i, _f, _i, _p],
     "ase_hip_sqnorm": [_p, _i64, _i, _i, _p, _i, _d, _i, _p],
     "ase_hip_finalize_scalars": [_p, _p, _i, _i, _i, _i, _i, _i] + [_f] * 11 + [_p],
     "ase_hip_enc_gp_seed": [_p, _i64, _p, _i64, _p, _i64, _i, _i, _f, _i, _p],
-    "ase_hip_enc_gp_back": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i, _i, _i, _p],
+    "ase_hip_enc_gp_back": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i, _i, _f, _i, _p],
     "ase_hip_clip_scale": [_p, _i64, _p, _f, _p],
     "ase_hip_begin_step": [_p, _p, _i, _p, _i, _p, _p],
     "ase_hip_adam": [_p, _p, _p, _p, _i64, _p, _p],
@@ -98,7 +99,7 @@ def load():
         fn = getattr(lib, name)       # AttributeError if the library does not export it
         fn.argtypes = argtypes
         fn.restype = C.c_int
-    if lib.ase_hip_abi_version() != 1:
+    if lib.ase_hip_abi_version() != ABI_VERSION:
         raise AseHipError("libase_hip.so ABI version mismatch")
     return lib
 

@@ -60,12 +60,12 @@ def _padded(x, cols, dtype=None):
 
 
 def _gemm_dtype(x):
-    _check(x.dtype in (torch.bfloat16, torch.float32), f'matrix operands must be bf16 or f32, got {x.dtype}')
+    _check(x.dtype in (torch.bfloat16, torch.float16, torch.float32), f'matrix operands must be bf16, f16 or f32, got {x.dtype}')
     return x.dtype
 
 
 def _kpad(k, dtype):
-    return _P(k, 32 if dtype == torch.bfloat16 else 16)          # whole 64-byte K steps
+    return _P(k, 32 if dtype in (torch.bfloat16, torch.float16) else 16)          # whole 64-byte K steps
 
 
 # ------------------------------------------------------------------------------------------------ dense layers
@@ -119,7 +119,7 @@ def linear_bwd_weight(dz: torch.Tensor, x: torch.Tensor) -> tuple[torch.Tensor, 
     _check(x.dtype == dt, 'linear_bwd_weight: dz and x must have the same dtype')
     M, N = dz.shape
     K = x.shape[1]
-    el = 8 if dt == torch.bfloat16 else 4
+    el = 8 if dt in (torch.bfloat16, torch.float16) else 4
     npad, kp = _P(N, el), _P(K, el)
     gw = torch.zeros(N, K, dtype=torch.float32, device=dz.device)
     gb = torch.zeros(N, dtype=torch.float32, device=dz.device)

@@ -31,9 +31,11 @@
 extern "C" {
 #endif
 
-#define ASE_HIP_ABI_VERSION 1
+#define ASE_HIP_ABI_VERSION 2
 
-enum { ASE_F32 = 0, ASE_BF16 = 1, ASE_F32X3 = 2 /* f32 storage, products as 3 bf16 MFMAs on a hi/lo split (GEMMs only) */ };
+enum { ASE_F32 = 0, ASE_BF16 = 1, ASE_F32X3 = 2 /* f32 storage, products as 3 bf16 MFMAs on a hi/lo split (GEMMs only) */,
+       ASE_F16 = 3 /* IEEE half storage + v_mfma_f32_32x32x16_f16, f32 accumulate: what the reference's mixed_precision flag
+                      (torch.cuda.amp autocast + GradScaler, learning/ase_agent.py:216,271-288) computes in; conversions saturate */ };
 enum { ASE_ACT_NONE = 0, ASE_ACT_RELU = 1, ASE_ACT_TANH = 2 };
 enum { ASE_AUX_NONE = 0, ASE_AUX_RELU_MASK = 1, ASE_AUX_TANH_GRAD = 2, ASE_AUX_RELU_BITS = 3 /* aux = bit matrix written by mask_out */ };
 enum { ASE_OK = 0, ASE_EINVAL = -1, ASE_ELAUNCH = -2, ASE_EUNSUPPORTED = -3 };
@@ -202,6 +204,10 @@ int ase_hip_reduce_sum(const float* x, int64_t n, int square, double* acc, int s
  *   mu_tanh: 1 -> mu_out = tanh(mu) precedes the losses (HRL high-level policy,
  *            learning/hrl_network_builder.py:26-29)
  *   acc[ASE_ACC_MASK_SUM] must already hold the GLOBAL mask sum.
+ *   grad_scale (all loss heads): the STORED head gradients d_* are multiplied by it (the bias gradients and the loss
+ *            scalars are not) - the static loss scale of ASE_F16 storage, whose back-propagated gradients would
+ *            otherwise fall into half's subnormal range; the weight-gradient launches undo it through their alpha.
+ *            The counterpart of the reference's GradScaler (learning/ase_agent.py:216,271-288).  1 for bf16 / f32.
  *   scratch: device f64[8192] workspace (per-workgroup partial sums, folded by a second tiny kernel). */
 int ase_hip_ppo_head(const float* mu, int64_t ld_mu, const float* value, int64_t ld_v,
                      const float* mb_actions, const float* mb_old_mu, const float* mb_old_sigma,
@@ -212,29 +218,31 @@ int ase_hip_ppo_head(const float* mu, int64_t ld_mu, const float* value, int64_t
                      float* db_mu, float* db_value, float* mu_out, double* acc, double* scratch,
                      int M, int m_global, int act_dim, int z_dim, int masked, int div_on, int mu_tanh,
                      int clip_value, float e_clip, float critic_coef, float bounds_coef,
-                     float div_coef, float div_tar, int dtype, void* stream);
+                     float div_coef, float div_tar, float grad_scale, int dtype, void* stream);
 
 /* Discriminator logit losses (learning/amp_agent.py:442-447,481-496): rows [0,2*amb) agent+replay
  * (target 0), rows [2*amb,3*amb) demo (target 1).  d_logit dtype [3*amb, ld_d] column 0. */
 int ase_hip_disc_head(const float* logit, int64_t ld_l, void* d_logit, int64_t ld_d, float* db_logit,
-                      double* acc, int amb, int amb_global, float disc_coef, int dtype, void* stream);
+                      double* acc, int amb, int amb_global, float disc_coef, float grad_scale, int dtype, void* stream);
 
 /* Encoder head (learning/ase_network_builder.py:217, learning/ase_agent.py:413-418,469-472):
  * e f32 [amb, ld_e] pre-normalisation output, z f32 [amb, z_dim]; d_e dtype [amb, ld_de].
  * enc_out (nullable) f32 [amb, z_dim] receives normalize(e). */
 int ase_hip_enc_head(const float* e, int64_t ld_e, const float* z, int64_t ld_z, void* d_e,
                      int64_t ld_de, float* db_enc, float* enc_out, double* acc, int amb, int amb_global,
-                     int z_dim, float enc_coef, int dtype, void* stream);
+                     int z_dim, float enc_coef, float grad_scale, int dtype, void* stream);
 
 /* Encoder gradient penalty (learning/ase_agent.py:431-441: mean_rows |d enc_err / d amp_obs|^2 with enc_err = -<normalize(e), z>),
  * the two per-row pieces around the GEMM chain.  e f32 [rows, ld_e] pre-normalisation encoder output, z f32 [rows, ld_z].
  *   seed: u[r, :] = scale * d enc_err / d e = -scale (z - eh <eh, z>) / |e|          (dtype [rows, ld_u]; eh = e / |e|)
- *   back: d_e[r, :] += J du[r, :],  J = d u / d e (unscaled), du f32 [rows, ld_du] = what the chain's backward returns at u;
+ *   back: d_e[r, :] += grad_scale * J du[r, :],  J = d u / d e (unscaled), du f32 [rows, ld_du] = what the chain's backward
+ *         returns at u (d_e carries the gradient scale of ase_hip_enc_head);
  *         db_enc (nullable, f32 [z_dim]) += column sums of the change of the stored d_e. */
 int ase_hip_enc_gp_seed(const float* e, int64_t ld_e, const float* z, int64_t ld_z, void* u, int64_t ld_u, int rows,
                         int z_dim, float scale, int dtype, void* stream);
 int ase_hip_enc_gp_back(const float* e, int64_t ld_e, const float* z, int64_t ld_z, const float* du, int64_t ld_du,
-                        void* d_e, int64_t ld_de, float* db_enc, int rows, int z_dim, int dtype, void* stream);
+                        void* d_e, int64_t ld_de, float* db_enc, int rows, int z_dim, float grad_scale, int dtype,
+                        void* stream);
 
 /* Gradient-penalty seed: g[r,j] = (h[r,j] > 0) ? scale * w[j] : 0  (d logit / d last hidden, ReLU). */
 int ase_hip_gp_seed(const void* h, int64_t ld_h, const float* w, void* g, int64_t ld_g, int rows,

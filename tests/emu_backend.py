@@ -23,6 +23,13 @@ def _rows(idx, remap, M):
     return p
 
 
+def _store(v, dtype):
+    """f32 -> storage type as the kernels convert: round to nearest even; half saturates at its largest finite value."""
+    if dtype == torch.float16:
+        v = v.clamp(-65504.0, 65504.0)
+    return v.to(dtype)
+
+
 class EmuBackend:
     name = "emu"
 
@@ -68,7 +75,7 @@ class EmuBackend:
         elif aux_mode == L.AUX_TANH_GRAD:
             x = aux[:M, :N].float()
             v = v * (1 - x * x)
-        out = v.to(Cm.dtype)
+        out = _store(v, Cm.dtype)
         Cm[:M, :N] = out
         if mask_out is not None:
             assert N % 32 == 0
@@ -192,8 +199,8 @@ class EmuBackend:
 
     def ppo_head(self, mu, value, mb, new_z, logstd, d_mu, d_value, db_mu, db_value, acc, M, m_global, act_dim,
                  z_dim, masked, div_on, mu_tanh, clip_value, e_clip, critic_coef, bounds_coef, div_coef, div_tar,
-                 mu_out=None):
-        D = act_dim
+                 mu_out=None, grad_scale=1.0):
+        D, gs = act_dim, float(grad_scale)
         raw = mu[:M, :D]
         m = torch.tanh(raw) if mu_tanh else raw
         a, omu, osg = mb['actions'], mb['mu'], mb['sigma']
@@ -235,13 +242,13 @@ class EmuBackend:
                 gm2 = gm2 * (1 - m2 * m2)
         if mu_tanh:
             gm = gm * (1 - m * m)
-        o1 = gm.to(d_mu.dtype)
+        o1 = _store(gs * gm, d_mu.dtype)
         d_mu[:M, :D] = o1
-        dbm = o1.float().sum(0)
+        dbm = o1.float().sum(0) / gs
         if div_on:
-            o2 = gm2.to(d_mu.dtype)
+            o2 = _store(gs * gm2, d_mu.dtype)
             d_mu[M:2 * M, :D] = o2
-            dbm = dbm + o2.float().sum(0)
+            dbm = dbm + o2.float().sum(0) / gs
         v = value[:M, 0]
         R = mb['returns'].view(-1)
         if clip_value:
@@ -255,12 +262,12 @@ class EmuBackend:
         else:
             c = (R - v) ** 2
             dv = 2 * (v - R)
-        ov_ = (critic_coef * dv / m_global).to(d_value.dtype)
+        ov_ = _store(gs * (critic_coef * dv / m_global), d_value.dtype)
         d_value[:M, 0] = ov_
         if db_mu is not None:
             db_mu[:D] += dbm
             if db_value is not None:
-                db_value[0] += ov_.float().sum()
+                db_value[0] += ov_.float().sum() / gs
         if mu_out is not None:
             mu_out[:M, :D] = m
         acc[L.ACC_A_LOSS] += (mk * a_loss).double().sum()
@@ -272,7 +279,7 @@ class EmuBackend:
         if div_on:
             acc[L.ACC_DIV] += (mk * div_row).double().sum()
 
-    def disc_head(self, logit, d_logit, db_logit, acc, amb, amb_global, disc_coef):
+    def disc_head(self, logit, d_logit, db_logit, acc, amb, amb_global, disc_coef, grad_scale=1.0):
         l = logit[:3 * amb, 0]
         la, ld = l[:2 * amb], l[2 * amb:]
         sp = lambda x: torch.clamp_min(x, 0) + torch.log1p(torch.exp(-x.abs()))
@@ -282,20 +289,20 @@ class EmuBackend:
         acc[L.ACC_DEMO_ACC] += (ld > 0).double().sum()
         ga = disc_coef * 0.5 * torch.sigmoid(la) / (2.0 * amb_global)
         gd = -disc_coef * 0.5 * torch.sigmoid(-ld) / amb_global
-        o = torch.cat([ga, gd]).to(d_logit.dtype)
+        o = _store(grad_scale * torch.cat([ga, gd]), d_logit.dtype)
         d_logit[:3 * amb, 0] = o
         if db_logit is not None:
-            db_logit[0] += o.float().sum()
+            db_logit[0] += o.float().sum() / grad_scale
 
-    def enc_head(self, e, z, d_e, db_enc, enc_out, acc, amb, amb_global, z_dim, enc_coef):
+    def enc_head(self, e, z, d_e, db_enc, enc_out, acc, amb, amb_global, z_dim, enc_coef, grad_scale=1.0):
         ev, zv = e[:amb, :z_dim], z[:amb, :z_dim]
         nrm = ev.norm(dim=-1, keepdim=True).clamp_min(1e-12)
         h = ev / nrm
         dot = (h * zv).sum(-1, keepdim=True)
-        o = (-(enc_coef / amb_global) * (zv - h * dot) / nrm).to(d_e.dtype)
+        o = _store(grad_scale * (-(enc_coef / amb_global) * (zv - h * dot) / nrm), d_e.dtype)
         d_e[:amb, :z_dim] = o
         if db_enc is not None:
-            db_enc[:z_dim] += o.float().sum(0)
+            db_enc[:z_dim] += o.float().sum(0) / grad_scale
         if enc_out is not None:
             enc_out[:amb, :z_dim] = h
         acc[L.ACC_ENC] += (-dot).double().sum()
@@ -307,7 +314,7 @@ class EmuBackend:
         a = (h * zv).sum(-1, keepdim=True)
         u[:rows, :z_dim] = (-scale * (zv - h * a) / nrm).to(u.dtype)
 
-    def enc_gp_back(self, e, z, du, d_e, db_enc, rows, z_dim):
+    def enc_gp_back(self, e, z, du, d_e, db_enc, rows, z_dim, grad_scale=1.0):
         ev, zv, r = e[:rows, :z_dim], z[:rows, :z_dim], du[:rows, :z_dim]
         nrm = ev.norm(dim=-1, keepdim=True).clamp_min(1e-12)
         h = ev / nrm
@@ -315,10 +322,10 @@ class EmuBackend:
         hr, zr = (h * r).sum(-1, keepdim=True), (zv * r).sum(-1, keepdim=True)
         jr = (zv * hr + h * zr + a * r - 3 * a * h * hr) / (nrm * nrm)
         old = d_e[:rows, :z_dim].float().clone()
-        new = (old + jr).to(d_e.dtype)
+        new = _store(old + grad_scale * jr, d_e.dtype)
         d_e[:rows, :z_dim] = new
         if db_enc is not None:
-            db_enc[:z_dim] += (new.float() - old).sum(0)
+            db_enc[:z_dim] += (new.float() - old).sum(0) / grad_scale
 
     def gp_seed(self, h, w, g, rows, width, scale=1.0):
         g[:rows, :width] = torch.where(h[:rows, :width].float() > 0, (scale * w[:width]).expand(rows, width),

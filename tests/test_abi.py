@@ -25,7 +25,7 @@ def _header_decls():
 def test_library_is_built_and_loads():
     assert os.path.exists(L.LIB_PATH), "run __graft_entry__.build() first"
     lib = L.load()
-    assert lib.ase_hip_abi_version() == 1
+    assert lib.ase_hip_abi_version() == L.ABI_VERSION
     assert lib.ase_hip_last_error() is not None
 
 

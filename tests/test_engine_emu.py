@@ -15,13 +15,13 @@ from tests.helpers import build_net, close, get_rms, set_rms
 CASES = ['ase_tiny', 'amp_tiny', 'ppo_tiny', 'ase_sep_tiny', 'ase_gp_tiny', 'ase_sep_gp_tiny']
 
 
-def first_step(G, be, dtype, device='cpu'):
+def first_step(G, be, dtype, device='cpu', grad_scale=None):
     kind, cfg, E = G['kind'], G['cfg'], G['epochs'][0]
     net = build_net(G, device)
     mb = {k: v.to(device) for k, v in E['first_minibatch'].items()}
     M = mb['obs'].shape[0]
     amb = cfg.get('amp_minibatch_size', 0) if kind != 'ppo' else 0
-    eng = UpdateEngine(kind, net, cfg, be, minibatch=M, amp_minibatch=amb, dtype=dtype)
+    eng = UpdateEngine(kind, net, cfg, be, minibatch=M, amp_minibatch=amb, dtype=dtype, grad_scale=grad_scale)
     set_rms(eng.obs_state, E['rms_step0_before']['obs'])
     if kind != 'ppo':
         set_rms(eng.amp_state, E['rms_step0_before']['amp'])
@@ -64,6 +64,37 @@ def test_first_step_f32_emulated(name, golden_dir):
     net, eng = first_step(G, EmuBackend(), torch.float32)
     lr = G['cfg']['learning_rate']
     check_first_step(G, net, eng, rtol=2e-5, gtol=2e-4, wtol=lr * 0.05)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_gradient_scale_is_transparent(name, golden_dir):
+    """The static gradient scale of half storage (engine.gs; the GradScaler's place, learning/ase_agent.py:216,271-288): the
+    loss heads store S * gradient, the data-gradient chains and both gradient-penalty chains carry S, the weight-gradient
+    launches and the bias gradients undo it.  With f32 storage a power-of-two S changes nothing but exponents: the golden
+    step of the reference is reproduced at the same tolerances with S = 4096 (every net kind, both penalty variants)."""
+    G = torch.load(os.path.join(golden_dir, name + '.pt'), weights_only=False)
+    net, eng = first_step(G, EmuBackend(), torch.float32, grad_scale=4096.0)
+    assert eng.gs == 4096.0
+    check_first_step(G, net, eng, rtol=2e-5, gtol=2e-4, wtol=G['cfg']['learning_rate'] * 0.05)
+
+
+@pytest.mark.parametrize('name', ['ase_tiny', 'amp_tiny', 'ppo_tiny', 'ase_gp_tiny'])
+def test_first_step_f16_emulated(name, golden_dir):
+    """Half storage (the reference's mixed_precision arithmetic): 11 significant bits on activations, shadow weights and
+    back-propagated gradients, f32 accumulation.  On the stress minibatches of the goldens (clip fraction 0.93): losses
+    within 1e-2 of the reference, every gradient tensor within 6 % relative L2 (bf16: 8e-2 / 30 %)."""
+    G = torch.load(os.path.join(golden_dir, name + '.pt'), weights_only=False)
+    net, eng = first_step(G, EmuBackend(), torch.float16)
+    assert eng.gs > 1.0
+    E = G['epochs'][0]
+    res, ref = eng.results(), E['steps'][0]
+    for k in ('actor_loss', 'b_loss', 'disc_loss', 'disc_grad_penalty', 'enc_loss', 'amp_diversity_loss', 'kl', 'enc_grad_penalty'):
+        if k in ref:
+            close(res[k], ref[k], 1e-2, 3e-3, k)
+    grads = eng.export_grads()
+    for k, g in E['first_grads'].items():
+        rel = float((grads[k].double() - g.double()).norm() / (g.double().norm() + 1e-30))
+        assert rel < 0.06, ('grad ' + k, rel)
 
 
 @pytest.mark.parametrize('early', [False, True])

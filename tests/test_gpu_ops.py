@@ -1,8 +1,8 @@
 """GPU parity tests, op level: every C-ABI entry point of libase_hip.so against the CPU emulation of the
 same op (tests/emu_backend.py) on identical seeded inputs.  Shapes include the odd sizes of the real
 nets (K = 253+64 -> 320 padded concat, 1400 -> 1408, N = 31 / 1 heads, ragged M).
-f32 storage = exact-f32 MFMA: tolerance is summation-order noise; bf16 storage: inputs are rounded to
-bf16 on both sides, products accumulate in f32, so only the output rounding (2^-8 relative) remains."""
+f32 storage = exact-f32 MFMA: tolerance is summation-order noise; bf16 / f16 storage: inputs are rounded to
+the storage type on both sides, products accumulate in f32, so only the output rounding (2^-8 relative) remains."""
 import math
 
 import pytest
@@ -14,7 +14,7 @@ from tests.helpers import close
 
 pytestmark = pytest.mark.gpu
 
-DT = [torch.float32, torch.bfloat16]
+DT = [torch.float32, torch.bfloat16, torch.float16]
 
 
 @pytest.fixture(scope='module')
@@ -28,7 +28,7 @@ def _pair(t):
 
 
 def _tol(dt):
-    return (2e-5, 2e-5) if dt == torch.float32 else (1.2e-2, 2e-3)
+    return (2e-5, 2e-5) if dt == torch.float32 else ((1.2e-2, 2e-3) if dt == torch.bfloat16 else (1.5e-3, 3e-4))
 
 
 @pytest.mark.parametrize('dt', DT)
@@ -461,8 +461,8 @@ def test_stacked_rows_aux_wrap_and_bias_rows(be, dt):
         outs.append((C.float().cpu(), G.cpu(), gb.cpu()))
     rt, at = _tol(dt)
     close(outs[0][0], outs[1][0], rt, at * 2, 'C')
-    close(outs[0][1], outs[1][1], 1e-3 if dt == torch.bfloat16 else 3e-5, 2e-3, 'G')
-    close(outs[0][2], outs[1][2], 1e-3 if dt == torch.bfloat16 else 3e-5, 2e-3, 'gbias')
+    close(outs[0][1], outs[1][1], 1e-3 if dt != torch.float32 else 3e-5, 2e-3, 'G')
+    close(outs[0][2], outs[1][2], 1e-3 if dt != torch.float32 else 3e-5, 2e-3, 'gbias')
 
 
 @pytest.mark.parametrize('M,N,K', [(513, 320, 1408), (1024, 1024, 1024), (77, 64, 128), (2048, 1024, 320)])
@@ -520,10 +520,10 @@ def test_gemm_nt_relu_bit_mask(be, dt, M, N, K):
     assert float(d1.float().abs().max()) > 0
 
 
-def test_gemm_tn_grouped_matches_per_layer(be):
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+def test_gemm_tn_grouped_matches_per_layer(be, dt):
     """One grouped launch over several layers (different row counts, widths, concat column maps, bias row limits)
     against the per-layer kernel and the emulation."""
-    dt = torch.bfloat16
     g = torch.Generator().manual_seed(21)
     shapes = [(2048, 512, 1024, 512, 1024, 1024, 1024, 0), (4096, 1024, 320, 1024, 317, 253, 256, 0),
               (1024, 256, 1408, 200, 1400, 1400, 1400, 768), (2048, 1024, 1024, 1024, 1024, 1024, 1024, 1536)]
@@ -545,10 +545,10 @@ def test_gemm_tn_grouped_matches_per_layer(be):
         close(gb, bc, 3e-5, 3e-5 * math.sqrt(M), 'grouped tn bias')
 
 
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('M,N,K', [(16384, 1024, 1024), (8192, 512, 1408), (16000, 1000, 192), (32768, 256, 64)])
-def test_gemm_nt_phased_tile(be, M, N, K):
+def test_gemm_nt_phased_tile(be, dt, M, N, K):
     """Shapes that take the phased 256 x 256 kernel (whole rounds of tiles) incl. ragged edges and 1-3 K-tiles."""
-    dt = torch.bfloat16
     g = torch.Generator().manual_seed(K)
     A = (torch.randn(M, K, generator=g) * 0.5).to(dt)
     B = (torch.randn(N, K, generator=g) * 0.1).to(dt)
