@@ -55,9 +55,43 @@ CFG_ASE = {
 }
 
 
+def _yaml(name):
+    import yaml
+    with open(os.path.join(ref_runner.REFERENCE_ROOT, 'ase', 'data', 'cfg', 'train', 'rlg', name)) as f:
+        return yaml.safe_load(f)['params']
+
+
 def _case(kind):
     net = copy.deepcopy(NET_ASE)
     cfg = copy.deepcopy(CFG_ASE)
+    if kind == 'ase_cfg2':
+        # BASELINE.json configs[1] / SURVEY 8d 'Config 2' at the REAL layer widths: network and hyper-parameters of
+        # ase/data/cfg/train/rlg/ase_humanoid.yaml:9-46,53-114 VERBATIM (read from the reference tree), with only the batch
+        # geometry reduced so that the unmodified reference finishes in seconds on the host: 64 envs x horizon 32 = 2048
+        # samples, minibatch 512 / amp minibatch 128, 2 mini-epochs = 8 optimisation steps; rings 1024 / 4096 rows (their
+        # size only enters through the recorded sampling indices).
+        y = _yaml('ase_humanoid.yaml')
+        n, c = y['network'], y['config']
+        c.update(minibatch_size=512, amp_minibatch_size=128, mini_epochs=2, amp_batch_size=128,
+                 amp_obs_demo_buffer_size=1024, amp_replay_buffer_size=4096)
+        return n, c
+    if kind == 'ase_swish':
+        # row X1: a non-ReLU activation (rl_games activations_factory 'swish' = SiLU, learning/ase_network_builder.py:162) in the
+        # policy MLPs AND the discriminator / encoder trunk: the gradient penalty's double backward (learning/amp_agent.py:453-459)
+        # then has a second-derivative term
+        n, c = _case('ase')
+        n['mlp']['activation'] = 'swish'
+        n['disc']['activation'] = 'swish'
+        n['enc']['activation'] = 'swish'
+        return n, c
+    if kind == 'hrl_cfg4':
+        # BASELINE.json configs[3]: the HRL high-level policy's PPO update at its real shape 258 -> [1024, 512] -> 64 with
+        # tanh(mu) (learning/hrl_network_builder.py:26-29), ase/data/cfg/train/rlg/hrl_humanoid.yaml:9-39,45-77 verbatim
+        # but for the batch geometry (64 envs x 32, minibatch 512, 2 mini-epochs)
+        y = _yaml('hrl_humanoid.yaml')
+        n, c = y['network'], y['config']
+        c.update(minibatch_size=512, mini_epochs=2)
+        return n, c
     if kind == 'amp_cfg1':
         # BASELINE.json configs[0]: AMP agent, 64 envs x horizon 16, obs 253 / act 31, 2-layer [256, 128] MLPs, the other
         # hyper-parameters of ase/data/cfg/train/rlg/amp_humanoid.yaml (SURVEY §8d 'Config 1': minibatch 256, amp minibatch 64,
@@ -142,11 +176,13 @@ def _rms_state(m):
     return {'mean': m.running_mean.clone(), 'var': m.running_var.clone(), 'count': m.count.clone()}
 
 
-def make_case(name, kind, seed, num_envs=16, obs_size=37, act_size=7, amp_size=44, epochs=2, slim=False, regen=False):
+def make_case(name, kind, seed, num_envs=16, obs_size=37, act_size=7, amp_size=44, epochs=2, slim=False, regen=False,
+              seeded=False, sample=0):
     """slim: leave out what only the single-step tests read (first-step gradients / weights, the checkpoint dictionary);
     regen: leave out every tensor the test can regenerate from the seeded synthetic source (observations, AMP observations,
     demo stream - tests/test_agent_emu.py:regenerate) and the duplicated dataset rows."""
-    akind = {'ase_sep': 'ase', 'amp_cfg1': 'amp', 'ase_gp': 'ase', 'ase_sep_gp': 'ase'}.get(kind, kind)
+    akind = {'ase_sep': 'ase', 'amp_cfg1': 'amp', 'ase_gp': 'ase', 'ase_sep_gp': 'ase', 'ase_cfg2': 'ase', 'ase_swish': 'ase',
+             'hrl_cfg4': 'ppo'}.get(kind, kind)
     net, cfg = _case(kind)
     akind_kind = kind
     spec = EnvSpec(num_envs=num_envs, horizon=cfg['horizon_length'], obs_size=obs_size, act_size=act_size,
@@ -164,9 +200,23 @@ def make_case(name, kind, seed, num_envs=16, obs_size=37, act_size=7, amp_size=4
     torch.manual_seed(seed)
     A = ref_runner.build_ref_agent(akind, net, cfg, num_envs=num_envs, obs_size=obs_size, act_size=act_size,
                                    amp_obs_size=amp_size if akind != 'ppo' else None, demo_fetch=demo_fetch, seed=seed)
+    init_sd = {k.replace('a2c_network.', '', 1): v.detach().clone() for k, v in A.model.state_dict().items()}
+    if seeded:
+        # seeded=True (real widths): the initial weights are a function of (shapes, the reference initialiser's own
+        # bounds, seed) - tests/helpers.seeded_init - loaded into the reference agent here and regenerated by the tests
+        from tests.helpers import seeded_init
+        shapes = {k: tuple(v.shape) for k, v in init_sd.items()}
+        bounds = {}
+        for k, v in init_sd.items():
+            if v.numel() == 0 or float(v.abs().max()) == float(v.abs().min()):
+                bounds[k] = {'const': float(v.reshape(-1)[0]) if v.numel() else 0.0}
+            else:
+                bounds[k] = float('%.4g' % (float(v.abs().max()) * 1.0001))
+        init_sd = seeded_init(shapes, bounds, seed)
+        A.model.load_state_dict({'a2c_network.' + k: v for k, v in init_sd.items()})
     G = {'kind': akind, 'net': net, 'cfg': cfg, 'seed': seed,
          'spec': dict(num_envs=num_envs, obs_size=obs_size, act_size=act_size, amp_obs_size=amp_size),
-         'init_sd': {k.replace('a2c_network.', '', 1): v.detach().clone() for k, v in A.model.state_dict().items()},
+         'init_sd': init_sd,
          'trainable': [k.replace('a2c_network.', '', 1) for k, p in A.model.named_parameters() if p.requires_grad],
          'epochs': []}
     if akind != 'ppo':
@@ -218,7 +268,7 @@ def make_case(name, kind, seed, num_envs=16, obs_size=37, act_size=7, amp_size=4
             steps.append({k: (v.detach().clone() if torch.is_tensor(v) else torch.tensor(float(v)))
                           for k, v in A.train_result.items()})
         A.calc_gradients = calc
-        A.play_steps = lambda: _tail(A, akind if kind == 'amp_cfg1' else kind)
+        A.play_steps = lambda: _tail(A, akind if kind in ('amp_cfg1', 'ase_cfg2', 'ase_swish', 'hrl_cfg4') else kind)
         if akind != 'ppo':
             E['replay_total_before'] = A._amp_replay_buffer.get_total_count()
             E['replay_head_before'] = A._amp_replay_buffer._head
@@ -256,7 +306,7 @@ def make_case(name, kind, seed, num_envs=16, obs_size=37, act_size=7, amp_size=4
     import copy
     if not slim:
         G['ckpt_after'] = copy.deepcopy(A.get_full_state_weights())
-    if slim:
+    if slim and not sample:
         for E in G['epochs']:
             for k in ('sd_after_step0', 'first_grads'):
                 E.pop(k, None)
@@ -269,6 +319,16 @@ def make_case(name, kind, seed, num_envs=16, obs_size=37, act_size=7, amp_size=4
             for k in ('dataset', 'first_minibatch', 'demo_fetched', 'replay_data_after'):
                 E.pop(k, None)
 
+    if seeded:
+        del G['init_sd']
+        G.update(init_shapes=shapes, init_bounds=bounds, init_seed=seed)
+    if sample:
+        from tests.helpers import pack_sampled
+        G['sample'] = {'n': sample, 'seed': seed}
+        for E in G['epochs']:
+            for key in ('first_grads', 'sd_after_step0', 'sd_after'):
+                if key in E:
+                    E[key] = {k: (pack_sampled(k, v, sample, seed) if v.numel() > sample else v) for k, v in E[key].items()}
     os.makedirs(OUT, exist_ok=True)
     path = os.path.join(OUT, name + '.pt')
     torch.save(G, path)
@@ -277,6 +337,17 @@ def make_case(name, kind, seed, num_envs=16, obs_size=37, act_size=7, amp_size=4
 
 if __name__ == '__main__':
     torch.set_num_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == 'real':           # real layer widths from the reference's yaml files (compact fixtures)
+        torch.set_num_threads(16)
+        for s_ in (0, 1, 2):
+            make_case('ase_cfg2_small' + ('' if s_ == 0 else f'_s{s_}'), 'ase_cfg2', seed=30 + s_, num_envs=64, obs_size=253,
+                      act_size=31, amp_size=1400, epochs=1, regen=True, seeded=True, sample=4096, slim=True)
+        make_case('hrl_cfg4_small', 'hrl_cfg4', seed=40, num_envs=64, obs_size=258, act_size=64, amp_size=0, epochs=1,
+                  regen=True, seeded=True, sample=4096, slim=True)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'swish':
+        make_case('ase_swish_tiny', 'ase_swish', seed=7, epochs=1)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'encgp':          # only the N4 cases (the others are unchanged)
         make_case('ase_gp_tiny', 'ase_gp', seed=5, epochs=1)
         make_case('ase_sep_gp_tiny', 'ase_sep_gp', seed=6, epochs=1)

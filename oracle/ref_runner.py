@@ -51,6 +51,7 @@ def load_reference():
         sys.modules["utils.torch_utils"] = tu
     import contextlib
     import io
+    sys.dont_write_bytecode = True          # /root/reference is read-only material: no __pycache__ next to its sources
     with contextlib.redirect_stdout(io.StringIO()):
         from learning import (amp_agent, amp_datasets, amp_models, amp_network_builder, ase_agent,
                               ase_models, ase_network_builder, common_agent, hrl_models,

@@ -6,7 +6,7 @@ import os
 import pytest
 import torch
 
-from tests.test_agent_emu import make_agent, replay_epochs
+from tests.test_agent_emu import REAL_WIDTH, check_real_width, make_agent, replay_epochs
 
 pytestmark = pytest.mark.gpu
 
@@ -23,6 +23,34 @@ def test_two_epochs_f32(be, name, golden_dir):
     G = torch.load(os.path.join(golden_dir, name + '.pt'), weights_only=False)
     ag = make_agent(G, be, device='cuda', precision='f32')
     replay_epochs(G, ag, rtol=3e-4, wtol=G['cfg']['learning_rate'] * 0.25)
+
+
+@pytest.mark.parametrize('name', REAL_WIDTH)
+def test_real_width_reference_goldens_f32(be, name, golden_dir):
+    """The UNMODIFIED reference at the real layer widths (ase_humanoid.yaml / hrl_humanoid.yaml nets verbatim; rows a9 / a22):
+    first-step losses + sampled gradients / post-Adam weights at BASELINE's 1e-4, then all 8 steps of the update."""
+    G = torch.load(os.path.join(golden_dir, name + '.pt'), weights_only=False)
+    lr = float(G['cfg']['learning_rate'])        # (PyYAML reads the yaml's '2e-5' as a string)
+    check_real_width(G, lambda: make_agent(G, be, device='cuda', precision='f32'), rtol=1e-4, gtol=3e-4, wtol=lr * 0.25,
+                     traj_rtol=3e-4)
+
+
+@pytest.mark.parametrize('precision,loss_tol', [('f16', 2e-3), ('bf16', 2e-2)])
+@pytest.mark.parametrize('name', ['ase_cfg2_small', 'hrl_cfg4_small'])
+def test_real_width_reference_goldens_16bit(be, name, precision, loss_tol, golden_dir):
+    """The 16-bit storage modes against the same reference goldens (foreign old log-probabilities: the reference's f32
+    rollout feeds the 16-bit update, so an error d in mu is amplified by |a - mu| / sigma^2 - the hard case; bench.py
+    measures the self-consistent one): every step's loss scalars within the stated bound relative to their scale."""
+    G = torch.load(os.path.join(golden_dir, name + '.pt'), weights_only=False)
+    ag = make_agent(G, be, device='cuda', precision=precision)
+    infos = replay_epochs(G, ag, rtol=0, wtol=0, check=False)
+    E = G['epochs'][0]
+    scale = {'actor_loss': 1.0, 'enc_loss': 1.0, 'kl': 0.1, 'b_loss': 1.0}
+    for i, ref in enumerate(E['steps']):
+        for k in ('actor_loss', 'critic_loss', 'kl', 'b_loss', 'disc_loss', 'disc_grad_penalty', 'enc_loss', 'amp_diversity_loss'):
+            if k in ref:
+                a, b = float(infos[0][k][i]), float(ref[k].mean())
+                assert a == a and abs(a - b) <= loss_tol * max(abs(b), scale.get(k, 0.0)), (precision, k, i, a, b)
 
 
 @pytest.mark.parametrize('name', ['amp_tiny', 'ppo_tiny'])

@@ -153,7 +153,7 @@ def test_rms_pipeline(be, dt, D, W, gathered):
 
 def test_rms_eval_and_unnorm(be):
     D = 17
-    st = torch.rand(2 * D + 1, dtype=torch.float64) + 0.5
+    st = torch.rand(2 * D + 1, dtype=torch.float64, generator=torch.Generator().manual_seed(3)) + 0.5
     outs = []
     for dev in ('cuda', 'cpu'):
         b = be if dev == 'cuda' else EmuBackend()
@@ -164,7 +164,7 @@ def test_rms_eval_and_unnorm(be):
         b.rms_unnormalize(st[[0, D, 2 * D]].contiguous().to(dev), x, y)
         outs.append((mean.cpu(), std.cpu(), y.cpu()))
     for a, c in zip(*outs):
-        close(a, c, 1e-6, 1e-7)
+        close(a, c, 3e-7, 1e-7)        # (sqrtf on the device is within 1 ulp, not correctly rounded)
 
 
 def test_gather_rows(be):
