@@ -268,7 +268,14 @@ class UpdateEngine:
             self.new_z = zt(M, self.z, f32)
             # Philox stream of the latent draws {seed, offset}: seeded by the run, advanced on device, part of the
             # checkpoint (CommonAgent.get_full_state_weights)
-            self.rng_state = torch.tensor([int(self.cfg.get('seed', 0)) ^ 0x5EED, 0], dtype=torch.int64, device=dev)
+            # Two streams: the ROLLOUT's latents (sample_latents(n) of the network, read-then-advance) and the in-step
+            # DIVERSITY draw (advanced by begin_step, read without advancing) never share a (seed, offset) pair - with one
+            # stream the first rollout draw after an update repeated the last diversity draw.  Horovod mode: rank-distinct
+            # seeds (independent streams per rank, like the reference's ranks); sharded mode: one stream indexed by the
+            # global row, identical on every rank.
+            seed = int(self.cfg.get('seed', 0)) + (0 if self.shard else 7919 * self.rank)
+            self.rng_state = torch.tensor([seed ^ 0x5EED, 0], dtype=torch.int64, device=dev)
+            self.div_rng = torch.tensor([seed ^ 0xD1755EED, 0], dtype=torch.int64, device=dev)
         if self.has_disc:
             Rd = 3 * AMB
             # Rows [0, 3 AMB) = agent | replay | demo.  A 4th block of AMB rows carries the gradient-penalty chain of
@@ -521,8 +528,8 @@ class UpdateEngine:
         bufs = [self.params, self.adam_m, self.adam_v, self.opt_state, self.obs_state, self.val_state]
         if self.has_disc:
             bufs.append(self.amp_state)
-        if self.style:
-            bufs.append(self.rng_state)
+        if self.style and self.shard:        # (Horovod mode: every rank keeps its own latent streams)
+            bufs += [self.rng_state, self.div_rng]
         for t in bufs:
             if t.is_cuda and dist.get_backend() == 'gloo':
                 h = t.cpu()
@@ -560,7 +567,7 @@ class UpdateEngine:
         else:
             # element index = GLOBAL minibatch row: rank r of a sharded step draws rows [r M, (r + 1) M); the kernel
             # also writes the compute-dtype copy the style MLP reads
-            be.sample_latents(self.new_z, M, self.z, self.rng_state,
+            be.sample_latents(self.new_z, M, self.z, self.div_rng,
                               row_offset=self.rank * M if (self.shard and self.R > 1) else 0, advance=False,
                               z2=self.Zs[M:])
 
@@ -569,7 +576,7 @@ class UpdateEngine:
         # one launch: Adam step counter / bias corrections (advance=False - calc_gradients-style calls - leaves them),
         # loss accumulators and per-step partial statistics zeroed, position of the diversity-latent stream advanced
         be.begin_step(self.opt_state if advance else None, self.acc, zero2=self.stats_flat,
-                      rng_bump=self.rng_state if self.div_on else None)
+                      rng_bump=self.div_rng if self.div_on else None)
         self._prep = None
         if self._short_prologue and self._amp_stats_in_branch():
             # Short prologue (single GPU, streams): the actor chain - the critical path - keeps only the observation chain

@@ -239,10 +239,20 @@ class CommonAgent:
                 'device': self.ppo_device}
 
     # ------------------------------------------------------------------ buffers
+    def _drop_graphs(self):
+        """Recorded launch programs / captured graphs have the addresses of the experience and dataset buffers baked in:
+        whenever those are re-allocated the recordings go (and the library-side programs are freed)."""
+        for g in getattr(self, '_graphs', {}).values():
+            if not g['hipgraph']:
+                for prog in g['graphs']:
+                    self.backend.prog_destroy(prog)
+        self._graphs = {}
+
     def init_tensors(self):
         H, N, dev = self.horizon_length, self.num_actors * self.num_agents, self.ppo_device
         f32 = dict(dtype=torch.float32, device=dev)
         A = self.actions_num
+        self._drop_graphs()
         self.experience = {            # rl_games ExperienceBuffer.tensor_dict layout (time-major)
             'obses': torch.zeros(H, N, *self.obs_shape, **f32), 'rewards': torch.zeros(H, N, 1, **f32),
             'values': torch.zeros(H, N, 1, **f32), 'neglogpacs': torch.zeros(H, N, **f32),
@@ -338,6 +348,7 @@ class CommonAgent:
         state['env_state'] = None
         # extra key (ignored by the reference's loader): position of the device-side latent / action streams
         state['hip_rng_state'] = {'latents': self.engine.rng_state.cpu().clone() if self.engine.style else None,
+                                  'diversity': self.engine.div_rng.cpu().clone() if self.engine.style else None,
                                   'actions': self.action_rng.cpu().clone()}
         return state
 
@@ -351,6 +362,8 @@ class CommonAgent:
         if rs is not None:
             if rs.get('latents') is not None and self.engine.style:
                 self.engine.rng_state.copy_(rs['latents'])
+                if rs.get('diversity') is not None:
+                    self.engine.div_rng.copy_(rs['diversity'])
             self.action_rng.copy_(rs['actions'])
         if self.world_size > 1:
             self._sync_initial_state()
@@ -605,7 +618,10 @@ class CommonAgent:
 
     def _collect_result(self):
         eng = self.engine
-        side = eng._side(1) if (eng.multi_stream and self._snapshot_aside) else None
+        # (a captured hipGraph replays on the main stream only: nothing would order its next replay behind a side-stream
+        #  snapshot, so that mode snapshots in stream order)
+        hipgraph = self.use_graph and self.config.get('graph_capture') == 'hipgraph'
+        side = eng._side(1) if (eng.multi_stream and self._snapshot_aside and not hipgraph) else None
         if side is not None:
             # the two small snapshot copies (scalar vector, logit column) leave the main stream: they used to sit between
             # one step's last kernel and the next step's first (13 us per step).  They run on the discriminator's stream -

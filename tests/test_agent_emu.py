@@ -204,6 +204,28 @@ def test_real_width_reference_goldens_emulated(name, golden_dir):
     check_real_width(G, lambda: make_agent(G, EmuBackend()), rtol=2e-4, gtol=3e-4, wtol=lr * 0.1)
 
 
+def test_diversity_and_rollout_latents_use_different_streams(golden_dir):
+    """The in-step diversity draw (learning/ase_agent.py:451) and the rollout's latent draws (sample_latents(n) of the network,
+    learning/ase_agent.py:366-383) come from two Philox streams: the first rollout draw after an update must not repeat the
+    last diversity draw (with one shared stream it did)."""
+    G = torch.load(os.path.join(golden_dir, 'ase_tiny.pt'), weights_only=False)
+    ag = make_agent(G, EmuBackend())
+    E = regenerate(G)['epochs'][0]
+    ag.vec_env.q.append(G['demo_init'].clone())
+    for k, v in E['exp'].items():
+        if k in ag.experience:
+            ag.experience[k].copy_(v)
+    batch = ag._play_steps_tail()
+    ag.vec_env.q.append(E['demo_fetched'].clone())
+    ag.update(batch, perms=E['dataset_perms'])            # latents drawn by the engine
+    div = ag.engine.new_z[:4].clone()
+    z1 = ag.model.a2c_network.sample_latents(4).clone()
+    z2 = ag.model.a2c_network.sample_latents(4).clone()
+    assert float(div.abs().sum()) > 0 and not torch.allclose(z1, div) and not torch.allclose(z2, div) and not torch.allclose(z1, z2)
+    st = ag.get_full_state_weights()['hip_rng_state']
+    assert int(st['diversity'][1]) > 0 and int(st['latents'][1]) == 2 and int(st['diversity'][0]) != int(st['latents'][0])
+
+
 def test_checkpoint_keys_match_reference(golden_dir):
     """get_full_state_weights() has the reference's keys (rl_games A2CBase + learning/amp_agent.py:47-52); the model
     state_dict has the reference's names / shapes / dtypes including the shared-trunk aliases."""

@@ -82,7 +82,7 @@ def test_graph_and_eager_agree_ase(be, golden_dir):
     res = []
     for graph in (False, True):
         ag = make_agent(G, be, device='cuda', precision='f32', graph_capture=graph)
-        ag.engine.rng_state[0] = 777
+        ag.engine.div_rng[0] = 777
         E = G['epochs'][0]
         ag.vec_env.q.append(G['demo_init'].clone())
         for k, v in E['exp'].items():
