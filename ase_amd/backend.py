@@ -37,12 +37,13 @@ class HipBackend:
     def __init__(self, device=None, x3=False):
         # x3: f32-stored GEMM operands are multiplied as three bf16 MFMAs on a hi/lo split (ASE_F32X3)
         self.x3 = bool(x3)
+        self.tn_workspace = True     # grouped weight gradients: partial tiles + reduce kernel (False: f32 atomics into G)
         if not torch.cuda.is_available():
             raise L.AseHipError("HipBackend needs a ROCm GPU (torch.cuda.is_available() is False); "
                                 "the update path has no CPU fallback")
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.lib = L.get()
-        self._head_scratch = torch.zeros(8192, dtype=torch.float64, device=self.device)
+        self._head_scratch = torch.zeros(L.PPO_SCRATCH, dtype=torch.float64, device=self.device)   # (zeroed: it ends in a ticket word)
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
@@ -100,7 +101,8 @@ class HipBackend:
             assert aux.dtype == torch.int32
         else:
             assert aux is None or aux.dtype == A.dtype
-        assert mask_out is None or mask_out.dtype == torch.int32
+        # twin output: the ReLU bit matrix (int32 words), or for the smooth activations the pre-activation in the storage type
+        assert mask_out is None or mask_out.dtype == (A.dtype if act >= L.ACT_SILU else torch.int32)
         out_f32 = int(Cm.dtype == torch.float32 and A.dtype != torch.float32)
         L.check(self.lib.ase_hip_gemm_nt(_ptr(A), _ld(A), _ptr(B), _ld(B), _ptr(Cm), _ld(Cm), _ptr(bias), _ptr(aux),
                                          _ld(aux), int(aux_split), int(aux_delta), _ptr(colsum), int(colsum_n),
@@ -139,17 +141,23 @@ class HipBackend:
                 tab[16 * i + j] = int(v)
         max_work = 8192
         work = (C.c_int32 * (4 * max_work))()
-        n_work = C.c_int(0)
-        L.check(self.lib.ase_hip_gemm_tn_grouped_plan(tab, n, int(target_wg), work, max_work, C.byref(n_work)),
-                "gemm_tn_grouped_plan")
-        nw = n_work.value
+        red = (C.c_int32 * (4 * max_work))()
+        n_work, n_red = C.c_int(0), C.c_int(0)
+        L.check(self.lib.ase_hip_gemm_tn_grouped_plan(tab, n, int(target_wg), work, max_work, C.byref(n_work), red, max_work,
+                                                      C.byref(n_red)), "gemm_tn_grouped_plan")
+        nw, nr = n_work.value, n_red.value
         dev_tab = torch.tensor(list(tab), dtype=torch.int64, device=self.device)
         dev_work = torch.tensor(list(work[:4 * nw]), dtype=torch.int32, device=self.device)
-        return {'problems': dev_tab, 'work': dev_work, 'n_work': nw, 'keep': problems, 'dtype': _code(problems[0][0].dtype)}
+        dev_red = torch.tensor(list(red[:4 * nr]), dtype=torch.int32, device=self.device)
+        # partial-sum workspace of this launch (plans of different branches run side by side: one each)
+        ws = torch.empty(nw * L.TN_SLAB, dtype=torch.float32, device=self.device) if self.tn_workspace else None
+        return {'problems': dev_tab, 'work': dev_work, 'n_work': nw, 'red': dev_red, 'n_red': nr, 'ws': ws, 'keep': problems,
+                'dtype': _code(problems[0][0].dtype)}
 
     def gemm_tn_grouped(self, plan):
-        L.check(self.lib.ase_hip_gemm_tn_grouped(_ptr(plan['problems']), _ptr(plan['work']), plan['n_work'], plan['dtype'],
-                                                 self._stream()), "gemm_tn_grouped")
+        L.check(self.lib.ase_hip_gemm_tn_grouped(_ptr(plan['problems']), _ptr(plan['work']), plan['n_work'], _ptr(plan['red']),
+                                                 plan['n_red'], _ptr(plan['ws']), plan['dtype'], self._stream()),
+                "gemm_tn_grouped")
 
     def refresh_shadow(self, W, Ws, Wts, split_src, split_dst):
         n, k = W.shape
@@ -292,9 +300,14 @@ class HipBackend:
                                              _ptr(db_enc), rows, z_dim, float(grad_scale), _code(d_e.dtype), self._stream()),
                 "enc_gp_back")
 
-    def gp_seed(self, h, w, g, rows, width, scale=1.0):
-        L.check(self.lib.ase_hip_gp_seed(_ptr(h), _ld(h), _ptr(w), _ptr(g), _ld(g), rows, width, float(scale), _code(h.dtype),
-                                         self._stream()), "gp_seed")
+    def gp_seed(self, h, w, g, rows, width, scale=1.0, act=L.ACT_RELU):
+        L.check(self.lib.ase_hip_gp_seed(_ptr(h), _ld(h), _ptr(w), _ptr(g), _ld(g), rows, width, float(scale), int(act),
+                                         _code(h.dtype), self._stream()), "gp_seed")
+
+    def gp_second(self, twin, g, dg, dz, rows, width, act):
+        """dz += act'' / act'^2 * g * dg (second-order term of the gradient penalty's backward, smooth activations)."""
+        L.check(self.lib.ase_hip_gp_second(_ptr(twin), _ld(twin), _ptr(g), _ld(g), _ptr(dg), _ld(dg), _ptr(dz), _ld(dz), rows,
+                                           width, int(act), _code(dz.dtype), self._stream()), "gp_second")
 
     def sqnorm(self, x, rows, cols, acc, slot, scale=1.0):
         L.check(self.lib.ase_hip_sqnorm(_ptr(x), _ld(x), rows, cols, _ptr(acc), slot, float(scale), _code(x.dtype),

@@ -15,6 +15,7 @@
 //   TN kernels: gemm_tn_kernel (128 x 128, register-staged, transposed LDS reads) and the phased gemm_tn8 kernels
 //       (256 x 256, DMA-staged), single problem or grouped (all weight gradients of a step in one grid).
 #include "common.h"
+#include "act.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -158,6 +159,7 @@ struct NTParams {
     int aux_split, aux_delta;       // rows m >= aux_split read aux row m - aux_delta (stacked row blocks sharing a mask)
     float* colsum; int colsum_n;
     uint32_t* mask_out; int64_t ldmask;   // nullable: bit (m, n) = stored value > 0, 32 columns per word, ldmask in words
+    char* pre_out; int64_t ldpre;         // nullable (smooth activations): the pre-activation z in the storage type, ldpre in bytes
     int M, N, K;                    // K in elements (multiple of 128/sizeof(T))
     int act, aux_mode, out_f32;
     float alpha;
@@ -274,6 +276,20 @@ __device__ __forceinline__ void nt_epilogue_impl(const NTParams& p, f32x16 (&acc
                 const int m = mrow0 + ic * 32 + row;
                 if (m >= p.M) continue;
                 f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * WCOLS + c4 * 4);
+                if (p.act >= ASE_ACT_SILU) {            // smooth activations: the slab holds z; keep it (twin), then activate
+                    if (p.pre_out) {
+                        if constexpr (sizeof(T) == 2) {
+                            typename V16<T>::x4 zt;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) zt[q] = from_f32<T>(v[q]);
+                            *reinterpret_cast<typename V16<T>::x4*>(p.pre_out + (int64_t)m * p.ldpre + (int64_t)n0 * 2) = zt;
+                        } else {
+                            *reinterpret_cast<f32x4*>(p.pre_out + (int64_t)m * p.ldpre + (int64_t)n0 * 4) = v;
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = act_apply(p.act, v[q]);
+                }
                 if constexpr (AUXK == 2) {
                     const uint32_t nib = cur[it].v >> (n0 & 31);
 #pragma unroll
@@ -282,7 +298,9 @@ __device__ __forceinline__ void nt_epilogue_impl(const NTParams& p, f32x16 (&acc
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float a = (float)cur[it].v[q];
-                        v[q] = (p.aux_mode == ASE_AUX_RELU_MASK) ? (a > 0.f ? v[q] : 0.f) : v[q] * (1.f - a * a);
+                        if (p.aux_mode == ASE_AUX_RELU_MASK) v[q] = a > 0.f ? v[q] : 0.f;
+                        else if (p.aux_mode == ASE_AUX_TANH_GRAD) v[q] = v[q] * (1.f - a * a);
+                        else v[q] = v[q] * act_grad(p.aux_mode >> 8, a);          // ASE_AUX_PREACT | (activation << 8)
                     }
                 }
                 if (p.out_f32 || sizeof(T) == 4) {
@@ -993,7 +1011,7 @@ int nt_choice(int M, int N, int K, int es, bool b16) {
 // mask operand absent or a bit matrix
 static bool rows_epi(const NTParams& p, int wave_cols) {
     static const int on = lab_knob("ASE_NT_ROWS", 1);
-    return on && !p.out_f32 && p.N % wave_cols == 0 && p.colsum == nullptr && p.act != ASE_ACT_TANH &&
+    return on && !p.out_f32 && p.N % wave_cols == 0 && p.colsum == nullptr && p.act <= ASE_ACT_RELU &&
            (p.aux_mode == ASE_AUX_NONE || p.aux_mode == ASE_AUX_RELU_BITS);
 }
 
@@ -1019,6 +1037,11 @@ template <typename T> int dispatch_nt(const NTParams& p, hipStream_t s) {
             case 21: if (k128) return launch_nt<T, 2, 2, 2, 1, 128, 2, 2>(p, s); break;   // 128 x 64 tile
             case 22: if (k128) return launch_nt<T, 2, 2, 1, 2, 128, 3, 2>(p, s); break;   // 64 x 128, 3 stages
             case 23: if (k128) return launch_nt<T, 2, 2, 1, 1, 128, 4, 2>(p, s); break;   // 64 x 64, 128-byte rows, 4 stages
+            // skinny outputs (N <= 64: heads, style columns): HBM-bound streams of A - taller tiles, deeper rings
+            case 50: if (k128) return launch_nt<T, 4, 2, 2, 1, 128, 2, 1>(p, s); break;   // 256 x 64, 8 waves, 2 stages (80 KB)
+            case 51: if (k128) return launch_nt<T, 4, 1, 2, 2, 128, 3, 1>(p, s); break;   // 256 x 64, 4 waves (64 x 64 each), 3 stages (120 KB)
+            case 52: if (k128) return launch_nt<T, 2, 2, 2, 1, 128, 4, 1>(p, s); break;   // 128 x 64, 4 waves, 4 stages (96 KB)
+            case 53: if (k128) return launch_nt<T, 2, 2, 2, 1, 128, 3, 2>(p, s); break;   // 128 x 64, 3 stages (72 KB, two per CU)
             default: break;
         }
     }
@@ -1316,6 +1339,8 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(TNParams p) {
 // out as ONE grid whose work items {problem, tile, m range} are sized so that ~256 workgroups each run a long
 // contraction (100+ K-tiles): the same 256 x 256 KB of partial sums are then paid once per step, not once per layer.
 // ------------------------------------------------------------------------------------------------
+constexpr int kTnSlab = 65536 + 256;       // floats per work item in the partial-sum workspace: 256 x 256 tile + 256 bias sums
+
 struct TN8Lane {
     const char* src[4][2];     // per-lane DMA source of unit kind (B-lo, A-lo, B-hi, A-hi) x piece, at K-tile 0
     int dst[4][2];             // wave-uniform LDS byte offset of the piece inside a K-tile buffer
@@ -1443,9 +1468,12 @@ __device__ __forceinline__ void tn8_ktile(int t, int nk, const TN8Lane& L, char*
 }
 
 // one work item: output tile (bn0, bk0) of problem p over the K-tiles [m_begin, m_begin + 64 nk)
+// ws / wsb (grouped launch): the work item's slab of the partial-sum workspace - the raw accumulator image (64 K floats,
+// chunk ((wave * 8 + i * 2 + j) * 4 + g) x 64 lanes x f32x4: every store instruction writes one contiguous KiB) and 256
+// bias partial sums - which tn_reduce_kernel folds into the gradient; null: f32 atomics straight into G.
 template <typename T, int V>
 __device__ __forceinline__ void tn8_body(const TNParams& p, char* smem, int bn0, int bk0, int m_begin, int nk,
-                                         unsigned long long* prof) {
+                                         unsigned long long* prof, float* ws = nullptr, float* wsb = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
@@ -1525,6 +1553,28 @@ __device__ __forceinline__ void tn8_body(const TNParams& p, char* smem, int bn0,
     if (prof && tid == 0) prof[2] = wall_clock64();
 
     const int col_in = lane & 31, row_hi = (lane >> 5) * 4;
+    if (ws) {
+        f32x4* o = reinterpret_cast<f32x4*>(ws) + lane;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    o[((wid * 8 + i * 2 + j) * 4 + g) * 64] =
+                        f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        if (do_bias && col_in == 0) {              // (zeros when no K-tile of this item lies below bias_rows)
+            const int nl = (wr * 4 + wc) * 32 + row_hi;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) wsb[nl + (e & 3) + 8 * (e >> 2)] = bacc[e];
+        }
+        if (prof) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) prof[3] = wall_clock64();
+        }
+        return;
+    }
     if (bias_tiles > 0 && col_in == 0) {           // every column of bacc holds the sums: column 0 writes them
         const int nbase = bn0 + (wr * 4 + wc) * 32 + row_hi;
 #pragma unroll
@@ -1576,7 +1626,7 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(TNParams p) {
 template <typename T, int V>
 __global__ __launch_bounds__(512) void gemm_tn8g_kernel(const int64_t* __restrict__ problems,
                                                         const int32_t* __restrict__ work, int n_work,
-                                                        unsigned long long* prof) {
+                                                        unsigned long long* prof, float* __restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int item = xcd_remap(blockIdx.x, n_work);             // neighbours in the work list share operand panels
     const int32_t* w = work + 4 * item;
@@ -1590,9 +1640,61 @@ __global__ __launch_bounds__(512) void gemm_tn8g_kernel(const int64_t* __restric
     p.bias_rows = (int)d[6]; p.M = (int)d[7]; p.N = (int)d[8]; p.K = (int)d[9];
     p.n_real = (int)d[10]; p.k_real = (int)d[11]; p.split_src = (int)d[12]; p.split_dst = (int)d[13];
     p.alpha = __builtin_bit_cast(float, (int)d[14]);
-    p.tiles_k = (int)d[15];
+    p.tiles_k = (int)(d[15] & 0xFFFF);
     tn8_body<T, V>(p, smem, (tile / p.tiles_k) * 256, (tile % p.tiles_k) * 256, m_begin, nk,
-                prof ? prof + blockIdx.x * 4 : nullptr);
+                   prof ? prof + blockIdx.x * 4 : nullptr, ws ? ws + (int64_t)item * kTnSlab : nullptr,
+                   ws ? ws + (int64_t)item * kTnSlab + 65536 : nullptr);
+}
+
+// Second kernel of the grouped launch: G += alpha * (sum of the work items' partial tiles), gbias likewise.  One workgroup
+// per (reduce entry, quarter tile); red[r] = {problem, tile, first item, splits}, split s of a tile sits `tiles of the
+// problem` items further (ase_hip_gemm_tn_grouped_plan's order).  Plain read-modify-write: every (n, k) of a problem has
+// exactly one owner; problems that share a gradient buffer with another one (field 15 bit 30 set by the planner: the
+// gradient-penalty terms of the encoder land on the discriminator's weights) use atomics.
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const int64_t* __restrict__ problems, const int32_t* __restrict__ red,
+                                                        const float* __restrict__ ws) {
+    const int32_t* r = red + 4 * blockIdx.x;
+    const int pi = r[0], tile = r[1], first = r[2], splits = r[3], q = blockIdx.y;
+    const int64_t* d = problems + 16 * pi;
+    float* G = reinterpret_cast<float*>(d[4]);
+    float* gbias = reinterpret_cast<float*>(d[5]);
+    const int n_real = (int)d[10], k_real = (int)d[11], split_src = (int)d[12], gap = (int)d[13] - (int)d[12];
+    const float alpha = __builtin_bit_cast(float, (int)d[14]);
+    const int tiles_k = (int)(d[15] & 0xFFFF), shared = (int)((d[15] >> 30) & 1);
+    const int stride = ((n_real + 255) / 256) * tiles_k;
+    const int bn0 = (tile / tiles_k) * 256, bk0 = (tile % tiles_k) * 256;
+    const float* base = ws + (int64_t)first * kTnSlab;
+    for (int c = q * 4096 + threadIdx.x; c < (q + 1) * 4096; c += 256) {
+        const int lane = c & 63, cc = c >> 6, g = cc & 3, j = (cc >> 2) & 1, i = (cc >> 3) & 3, wid = cc >> 5;
+        const int k = bk0 + ((wid & 3) * 2 + j) * 32 + (lane & 31);
+        int kk = -1;
+        if (k < split_src) kk = k;
+        else if (k >= split_src + gap && k - gap < k_real) kk = k - gap;
+        const int n0 = bn0 + ((wid >> 2) * 4 + i) * 32 + (lane >> 5) * 4 + 8 * g;
+        if (kk < 0 || n0 >= n_real) continue;
+        f32x4 sum = *reinterpret_cast<const f32x4*>(base + (int64_t)c * 4);
+        for (int s2 = 1; s2 < splits; ++s2) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(base + (int64_t)s2 * stride * kTnSlab + (int64_t)c * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum[e] += v[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (n0 + e >= n_real) break;
+            float* dst = G + (int64_t)(n0 + e) * k_real + kk;
+            if (shared) atomic_add_f32(dst, alpha * sum[e]);
+            else *dst += alpha * sum[e];
+        }
+    }
+    if (q == 0 && gbias && bk0 == 0) {
+        const int n = bn0 + threadIdx.x;
+        if (n < n_real) {
+            float t = 0.f;
+            for (int s2 = 0; s2 < splits; ++s2) t += base[(int64_t)s2 * stride * kTnSlab + 65536 + threadIdx.x];
+            if (shared) atomic_add_f32(gbias + n, alpha * t);
+            else gbias[n] += alpha * t;
+        }
+    }
 }
 
 template <typename T, int V> int launch_tn8(TNParams p, hipStream_t stream) {
@@ -1625,7 +1727,8 @@ template <typename T, int V> int launch_tn8(TNParams p, hipStream_t stream) {
     return ASE_OK;
 }
 
-template <typename T, int V> int launch_tn8g(const int64_t* problems, const int32_t* work, int n_work, hipStream_t stream) {
+template <typename T, int V> int launch_tn8g(const int64_t* problems, const int32_t* work, int n_work, const int32_t* red,
+                                             int n_red, float* ws, hipStream_t stream) {
     constexpr int lds = 2 * 65536;
     static bool attr_done = false;
     auto kern = gemm_tn8g_kernel<T, V>;
@@ -1638,7 +1741,8 @@ template <typename T, int V> int launch_tn8g(const int64_t* problems, const int3
         }
         attr_done = true;
     }
-    ASE_LAUNCH(kern, dim3(n_work), dim3(512), lds, stream, problems, work, n_work, g_nt_prof);
+    ASE_LAUNCH(kern, dim3(n_work), dim3(512), lds, stream, problems, work, n_work, g_nt_prof, ws);
+    if (ws) ASE_LAUNCH(tn_reduce_kernel, dim3(n_red, 4), dim3(256), 0, stream, problems, red, (const float*)ws);
     ASE_CHECK_LAUNCH("gemm_tn_grouped");
     return ASE_OK;
 }
@@ -1797,13 +1901,20 @@ extern "C" int ase_hip_gemm_nt(const void* A, int64_t lda, const void* B, int64_
                       (aux == nullptr || bits || (((uintptr_t)aux % 8) == 0 && (ldaux * es) % 8 == 0)),
                   "gemm_nt: C / aux must allow 8/16-byte row-vector access (N %% 4 == 0, aligned pitches)");
     ASE_CHECK_ARG(!bits || (((uintptr_t)aux % 4) == 0 && ldaux * 32 >= N), "gemm_nt: bit mask needs ldaux >= N / 32 words");
-    ASE_CHECK_ARG(mask_out == nullptr || (N % 32 == 0 && ((uintptr_t)mask_out % 4) == 0 && ldmask * 32 >= N),
+    const bool smooth = act >= ASE_ACT_SILU;
+    ASE_CHECK_ARG(act >= ASE_ACT_NONE && act <= ASE_ACT_SOFTPLUS, "gemm_nt: unknown activation %d", act);
+    ASE_CHECK_ARG((aux_mode & 0xFF) <= ASE_AUX_PREACT && ((aux_mode & 0xFF) == ASE_AUX_PREACT || (aux_mode >> 8) == 0) &&
+                      (aux_mode >> 8) <= ASE_ACT_SOFTPLUS, "gemm_nt: bad aux_mode 0x%x", aux_mode);
+    ASE_CHECK_ARG(mask_out == nullptr || smooth || (N % 32 == 0 && ((uintptr_t)mask_out % 4) == 0 && ldmask * 32 >= N),
                   "gemm_nt: mask_out needs N %% 32 == 0 and ldmask >= N / 32 words");
+    ASE_CHECK_ARG(mask_out == nullptr || !smooth || (ldmask >= N && ((uintptr_t)mask_out % 16) == 0 && (ldmask * es) % 8 == 0),
+                  "gemm_nt: the pre-activation twin needs ldmask >= N elements, 16-byte alignment");
     NTParams p;
     p.A = (const char*)A; p.lda = lda * es;
     p.B = (const char*)B; p.ldb = ldb * es;
     p.C = (char*)C; p.ldc = ldc * (out_f32 ? 4 : es);
-    p.mask_out = (uint32_t*)mask_out; p.ldmask = ldmask;
+    p.mask_out = smooth ? nullptr : (uint32_t*)mask_out; p.ldmask = ldmask;
+    p.pre_out = smooth ? (char*)mask_out : nullptr; p.ldpre = ldmask * es;
     p.bias = bias; p.aux = (const char*)aux; p.ldaux = bits ? ldaux * 4 : ldaux * es; p.aux_split = aux_split > 0 ? aux_split : M; p.aux_delta = aux_delta; p.colsum = colsum; p.colsum_n = colsum ? colsum_n : 0;
     p.M = M; p.N = N; p.K = K; p.act = act; p.aux_mode = aux_mode; p.out_f32 = out_f32; p.alpha = alpha;
     p.tiles_m = p.tiles_n = 0;
@@ -1860,8 +1971,9 @@ static int tn_problem_check(const int64_t* d, int i) {
 }
 
 extern "C" int ase_hip_gemm_tn_grouped_plan(int64_t* problems, int n_problems, int target_wg, int32_t* work, int max_work,
-                                            int* n_work) {
+                                            int* n_work, int32_t* red, int max_red, int* n_red) {
     ASE_CHECK_ARG(problems && work && n_work && n_problems > 0 && max_work > 0, "gemm_tn_grouped_plan: null/empty argument");
+    ASE_CHECK_ARG(red == nullptr || (n_red && max_red > 0), "gemm_tn_grouped_plan: reduce table without its size");
     if (target_wg <= 0) target_wg = lab_knob("ASE_TN_GROUP_WG", 256);      // one 8-wave workgroup per CU
     int64_t max_kt = 1;
     for (int i = 0; i < n_problems; ++i) {
@@ -1869,7 +1981,10 @@ extern "C" int ase_hip_gemm_tn_grouped_plan(int64_t* problems, int n_problems, i
         const int rc = tn_problem_check(d, i);
         if (rc != ASE_OK) return rc;
         if (d[6] <= 0) d[6] = d[7];                          // bias_rows: all rows
-        d[15] = (d[9] + 255) / 256;                          // tiles_k
+        d[15] = (d[9] + 255) / 256;                          // tiles_k (bits 0-15)
+        ASE_CHECK_ARG(d[15] < 65536, "gemm_tn_grouped_plan: problem %d: K too wide", i);
+        for (int j = 0; j < n_problems; ++j)                 // bit 30: another problem adds to the same gradient / bias buffer
+            if (j != i && (problems[16 * j + 4] == d[4] || (d[5] && problems[16 * j + 5] == d[5]))) d[15] |= (int64_t)1 << 30;
         if (d[7] / 64 > max_kt) max_kt = d[7] / 64;
     }
     // Contraction length c (K-tiles per work item): all tiles of a problem are cut at the same rows (workgroups on the
@@ -1880,7 +1995,7 @@ extern "C" int ase_hip_gemm_tn_grouped_plan(int64_t* problems, int n_problems, i
         int64_t tot = 0;
         for (int i = 0; i < n_problems; ++i) {
             const int64_t* d = problems + 16 * i;
-            const int64_t tiles = ((d[10] + 255) / 256) * d[15], kt = d[7] / 64;
+            const int64_t tiles = ((d[10] + 255) / 256) * (d[15] & 0xFFFF), kt = d[7] / 64;
             tot += tiles * ((kt + c - 1) / c);
         }
         return tot;
@@ -1892,11 +2007,20 @@ extern "C" int ase_hip_gemm_tn_grouped_plan(int64_t* problems, int n_problems, i
         const int64_t cost = rounds * (cc + 8);
         if (best < 0 || cost < best) { best = cost; c = cc; }
     }
-    int nw = 0;
+    int nw = 0, nr = 0;
     for (int i = 0; i < n_problems; ++i) {
         const int64_t* d = problems + 16 * i;
-        const int tiles = (int)(((d[10] + 255) / 256) * d[15]);
+        const int tiles = (int)(((d[10] + 255) / 256) * (d[15] & 0xFFFF));
         const int64_t kt = d[7] / 64, splits = (kt + c - 1) / c, chunk = (kt + splits - 1) / splits;
+        int live = 0;                                        // splits that hold rows (the last ones may be empty)
+        for (int64_t s = 0; s < splits; ++s) live += (s * chunk < kt);
+        if (red) {
+            for (int t = 0; t < tiles; ++t) {
+                ASE_CHECK_ARG(nr < max_red, "gemm_tn_grouped_plan: more than %d reduce entries", max_red);
+                red[4 * nr + 0] = i; red[4 * nr + 1] = t; red[4 * nr + 2] = nw + t; red[4 * nr + 3] = live;
+                ++nr;
+            }
+        }
         for (int64_t s = 0; s < splits; ++s) {
             const int64_t k0 = s * chunk, nk = (k0 + chunk <= kt) ? chunk : kt - k0;
             if (nk <= 0) continue;
@@ -1908,14 +2032,18 @@ extern "C" int ase_hip_gemm_tn_grouped_plan(int64_t* problems, int n_problems, i
         }
     }
     *n_work = nw;
+    if (n_red) *n_red = nr;
     return ASE_OK;
 }
 
-extern "C" int ase_hip_gemm_tn_grouped(const int64_t* problems, const int32_t* work, int n_work, int dtype, void* stream) {
+extern "C" int ase_hip_gemm_tn_grouped(const int64_t* problems, const int32_t* work, int n_work, const int32_t* red, int n_red,
+                                       float* workspace, int dtype, void* stream) {
     ASE_CHECK_ARG(problems && work && n_work > 0, "gemm_tn_grouped: null/empty argument");
     ASE_CHECK_ARG(dtype == ASE_BF16 || dtype == ASE_F16, "gemm_tn_grouped: 16-bit storage types only (dtype %d)", dtype);
-    if (dtype == ASE_F16) return launch_tn8g<f16_t, 0>(problems, work, n_work, (hipStream_t)stream);
-    return launch_tn8g<bf16_t, 0>(problems, work, n_work, (hipStream_t)stream);
+    ASE_CHECK_ARG(workspace == nullptr || (red && n_red > 0 && ((uintptr_t)workspace % 16) == 0),
+                  "gemm_tn_grouped: a workspace needs the reduce table of the plan (and 16-byte alignment)");
+    if (dtype == ASE_F16) return launch_tn8g<f16_t, 0>(problems, work, n_work, red, n_red, workspace, (hipStream_t)stream);
+    return launch_tn8g<bf16_t, 0>(problems, work, n_work, red, n_red, workspace, (hipStream_t)stream);
 }
 
 extern "C" int ase_hip_refresh_shadow(const float* W, int n_real, int k_real, void* Ws, int64_t ldws, void* Wts,

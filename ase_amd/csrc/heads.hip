@@ -1,6 +1,7 @@
 // Loss heads of the ASE/AMP/PPO update: forward value and analytic input-gradient in one pass,
 // f32 math (as the reference), f64 accumulators for the reported scalars.
 #include "common.h"
+#include "act.h"
 
 namespace {
 
@@ -26,11 +27,14 @@ struct PpoArgs {
     void* d_value; int64_t ld_dv;
     float *db_mu, *db_value, *mu_out;
     double* acc;
-    double* scratch;              // [gridDim.x][8] per-workgroup partial sums (no contended atomics)
+    double* scratch;              // ticket word, then [gridDim.x][kPpoSlots] per-workgroup partial sums (no contended atomics)
     int M, m_global, act_dim, z_dim, masked, div_on, mu_tanh, clip_value;
     float e_clip, critic_coef, bounds_coef, div_coef, div_tar;
     float gs, inv_gs;             // the stored head gradients carry the static gradient scale (f16 storage), the bias gradients do not
 };
+
+// per-workgroup partials: 7 loss sums, then 64 + 1 head-bias column sums (mu columns, value)
+constexpr int kPpoSlots = 72;
 
 // LPR lanes per row (act_dim <= LPR: 32 for the humanoid's 28 / 31 actions, 64 for the HRL high-level policy whose action
 // is the 64-d latent), 256 / LPR rows per 256-thread block.
@@ -158,43 +162,58 @@ __global__ __launch_bounds__(256) void ppo_head_kernel(PpoArgs p) {
             part[6] += (double)(mk * div_row);
         }
     }
-    if (p.db_mu) {  // head bias gradients: column sums over this block's 8 rows, one atomic per column
-        sdb[rib][lane] = gm_out + gm2_out;
-        if (lane == 0) sdb[rib][LPR] = dv_out;
-        __syncthreads();
-        if (threadIdx.x < LPR + 1) {
-            float t = 0.f;
+    // Every workgroup leaves its partial sums (7 loss sums in f64, the head-bias column sums of its rows) in its scratch
+    // slab - 1024 workgroups adding to the same 40 addresses with atomics cost ~20 us of this kernel - and takes a ticket;
+    // the LAST workgroup to arrive folds all slabs into the accumulators / bias gradients and resets the ticket.
+    double* const slabs = p.scratch + 8;               // (the first word of the workspace is the ticket)
+    double* mine = slabs + (int64_t)blockIdx.x * kPpoSlots;
+    sdb[rib][lane] = gm_out + gm2_out;
+    if (lane == 0) sdb[rib][LPR] = dv_out;
+    __syncthreads();
+    if (threadIdx.x < LPR + 1) {
+        float t = 0.f;
 #pragma unroll
-            for (int q = 0; q < ROWS; ++q) t += sdb[q][threadIdx.x];
-            if (threadIdx.x < p.act_dim) atomic_add_f32(p.db_mu + threadIdx.x, t);
-            else if (threadIdx.x == LPR && p.db_value) atomic_add_f32(p.db_value, t);
+        for (int q = 0; q < ROWS; ++q) t += sdb[q][threadIdx.x];
+        mine[7 + (threadIdx.x < LPR ? threadIdx.x : 64)] = (double)t;
+    }
+    block_sum<7>(part, sm);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) mine[k] = part[k];
+    }
+    __shared__ int last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned int* ticket = reinterpret_cast<unsigned int*>(p.scratch);
+        last = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1 : 0;
+        if (last) *ticket = 0;                           // the next launch starts from 0 (stream order)
+    }
+    __syncthreads();
+    if (!last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    // fold: thread (c, g) sums slot c over the workgroups b = g, g + 4, ...; the four groups meet in LDS
+    __shared__ double fold[4][kPpoSlots];
+    const int c = threadIdx.x & 63, g4 = threadIdx.x >> 6;
+    for (int cc = c; cc < kPpoSlots; cc += 64) {
+        double t = 0.0;
+        for (int b = g4; b < (int)gridDim.x; b += 4) t += slabs[(int64_t)b * kPpoSlots + cc];
+        fold[g4][cc] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < kPpoSlots) {
+        const int cc = threadIdx.x;
+        const double t = fold[0][cc] + fold[1][cc] + fold[2][cc] + fold[3][cc];
+        if (cc < 7) {
+            const int slot[7] = {ASE_ACC_A_LOSS, ASE_ACC_B_LOSS, ASE_ACC_ENTROPY, ASE_ACC_CLIPPED, ASE_ACC_C_LOSS, ASE_ACC_KL, ASE_ACC_DIV};
+            if (cc < 6 || p.div_on) p.acc[slot[cc]] += t;
+        } else if (p.db_mu) {
+            const int j = cc - 7;
+            if (j < p.act_dim) atomic_add_f32(p.db_mu + j, (float)t);
+            else if (j == 64 && p.db_value) atomic_add_f32(p.db_value, (float)t);
         }
-    }
-    block_sum<7>(part, sm);
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int k = 0; k < 7; ++k) p.scratch[(int64_t)blockIdx.x * 8 + k] = part[k];
-    }
-}
-
-// second stage: one workgroup folds the per-workgroup partials into the accumulators
-__global__ __launch_bounds__(256) void ppo_head_fold_kernel(const double* __restrict__ scratch, int nblocks,
-                                                            double* __restrict__ acc, int div_on) {
-    __shared__ double sm[7 * 16];
-    double part[7] = {0, 0, 0, 0, 0, 0, 0};
-    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
-#pragma unroll
-        for (int k = 0; k < 7; ++k) part[k] += scratch[(int64_t)b * 8 + k];
-    }
-    block_sum<7>(part, sm);
-    if (threadIdx.x == 0) {
-        acc[ASE_ACC_A_LOSS] += part[0];
-        acc[ASE_ACC_B_LOSS] += part[1];
-        acc[ASE_ACC_ENTROPY] += part[2];
-        acc[ASE_ACC_CLIPPED] += part[3];
-        acc[ASE_ACC_C_LOSS] += part[4];
-        acc[ASE_ACC_KL] += part[5];
-        if (div_on) acc[ASE_ACC_DIV] += part[6];
     }
 }
 
@@ -350,14 +369,46 @@ __global__ __launch_bounds__(256) void enc_gp_kernel(const float* __restrict__ e
     }
 }
 
+// derivative factors of the gradient-penalty chain from a layer's twin t: the activation OUTPUT for ReLU / tanh (both
+// derivatives are functions of it), the PRE-activation for the smooth activations
+__device__ __forceinline__ float twin_grad(int act, float t) {
+    if (act == ASE_ACT_RELU) return t > 0.f ? 1.f : 0.f;
+    if (act == ASE_ACT_TANH) return 1.f - t * t;
+    return act_grad(act, t);
+}
+// act'' / act'^2 (0 where act' vanishes: the chain value it multiplies is 0 there too)
+__device__ __forceinline__ float twin_curv(int act, float t) {
+    float d1, d2;
+    if (act == ASE_ACT_RELU || act == ASE_ACT_NONE) return 0.f;
+    if (act == ASE_ACT_TANH) { d1 = 1.f - t * t; d2 = -2.f * t * d1; }
+    else { d1 = act_grad(act, t); d2 = act_grad2(act, t); }
+    return d1 != 0.f ? d2 / (d1 * d1) : 0.f;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gp_seed_kernel(const T* __restrict__ h, int64_t ld_h, const float* __restrict__ w,
-                                                      T* __restrict__ g, int64_t ld_g, int rows, int width, float scale) {
+                                                      T* __restrict__ g, int64_t ld_g, int rows, int width, float scale, int act) {
     const int64_t n = (int64_t)rows * width;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / width), j = (int)(i - (int64_t)r * width);
         const float hv = to_f32(h[(int64_t)r * ld_h + j]);
-        g[(int64_t)r * ld_g + j] = from_f32<T>(hv > 0.f ? scale * w[j] : 0.f);
+        g[(int64_t)r * ld_g + j] = from_f32<T>(scale * w[j] * twin_grad(act, hv));
+    }
+}
+
+// second-order term of the gradient penalty's backward: dz[r, j] += act''(z) / act'(z)^2 * g[r, j] * dg[r, j]
+// (g = act' u the chain value, dg = act' r the masked backward-of-chain value: the product is act'' u r)
+template <typename T>
+__global__ __launch_bounds__(256) void gp_second_kernel(const T* __restrict__ t, int64_t ld_t, const T* __restrict__ g, int64_t ld_g,
+                                                        const T* __restrict__ dg, int64_t ld_dg, T* __restrict__ dz, int64_t ld_dz,
+                                                        int rows, int width, int act) {
+    const int64_t n = (int64_t)rows * width;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / width), j = (int)(i - (int64_t)r * width);
+        const float c = twin_curv(act, to_f32(t[(int64_t)r * ld_t + j]));
+        const float e = c * to_f32(g[(int64_t)r * ld_g + j]) * to_f32(dg[(int64_t)r * ld_dg + j]);
+        T* o = dz + (int64_t)r * ld_dz + j;
+        *o = from_f32<T>(to_f32(*o) + e);
     }
 }
 
@@ -483,7 +534,7 @@ extern "C" int ase_hip_ppo_head(const float* mu, int64_t ld_mu, const float* val
     p.div_on = div_on; p.mu_tanh = mu_tanh; p.clip_value = clip_value; p.e_clip = e_clip; p.critic_coef = critic_coef;
     p.bounds_coef = bounds_coef; p.div_coef = div_coef; p.div_tar = div_tar; p.gs = grad_scale; p.inv_gs = 1.f / grad_scale;
     const int rows = act_dim <= 32 ? 8 : 4;         // rows per workgroup (32 / 64 lanes per row)
-    const dim3 grid(min((M + rows - 1) / rows, 1024));       // scratch holds 1024 x 8 doubles
+    const dim3 grid(min((M + rows - 1) / rows, 1024));       // scratch: (1024 x 72 + 1) doubles, the ticket word zero between launches
     const int rc = ase_dispatch_storage(dtype, [&](auto tag) {
         typedef typename decltype(tag)::type T;
         if (act_dim <= 32) ASE_LAUNCH((ppo_head_kernel<T, 32>), grid, dim3(256), 0, (hipStream_t)stream, p);
@@ -491,7 +542,6 @@ extern "C" int ase_hip_ppo_head(const float* mu, int64_t ld_mu, const float* val
         return ASE_OK;
     });
     ASE_CHECK_ARG(rc == ASE_OK, "ppo_head: bad dtype %d", dtype);
-    ASE_LAUNCH(ppo_head_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, (int)grid.x, acc, div_on);
     ASE_CHECK_LAUNCH("ppo_head");
     return ASE_OK;
 }
@@ -563,16 +613,34 @@ extern "C" int ase_hip_enc_gp_back(const float* e, int64_t ld_e, const float* z,
 }
 
 extern "C" int ase_hip_gp_seed(const void* h, int64_t ld_h, const float* w, void* g, int64_t ld_g, int rows, int width,
-                               float scale, int dtype, void* stream) {
+                               float scale, int act, int dtype, void* stream) {
     ASE_CHECK_ARG(h && w && g && rows > 0 && width > 0, "gp_seed: null/empty operand");
+    ASE_CHECK_ARG(act >= ASE_ACT_RELU && act <= ASE_ACT_SOFTPLUS, "gp_seed: activation %d", act);
     const dim3 grid(grid_for((int64_t)rows * width));
     const int rc = ase_dispatch_storage(dtype, [&](auto tag) {
         typedef typename decltype(tag)::type T;
-        ASE_LAUNCH(gp_seed_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)h, ld_h, w, (T*)g, ld_g, rows, width, scale);
+        ASE_LAUNCH(gp_seed_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)h, ld_h, w, (T*)g, ld_g, rows, width, scale,
+                   act);
         return ASE_OK;
     });
     ASE_CHECK_ARG(rc == ASE_OK, "gp_seed: bad dtype %d", dtype);
     ASE_CHECK_LAUNCH("gp_seed");
+    return ASE_OK;
+}
+
+extern "C" int ase_hip_gp_second(const void* twin, int64_t ld_t, const void* g, int64_t ld_g, const void* dg, int64_t ld_dg,
+                                 void* dz, int64_t ld_dz, int rows, int width, int act, int dtype, void* stream) {
+    ASE_CHECK_ARG(twin && g && dg && dz && rows > 0 && width > 0, "gp_second: null/empty operand");
+    ASE_CHECK_ARG(act >= ASE_ACT_RELU && act <= ASE_ACT_SOFTPLUS, "gp_second: activation %d", act);
+    const dim3 grid(grid_for((int64_t)rows * width));
+    const int rc = ase_dispatch_storage(dtype, [&](auto tag) {
+        typedef typename decltype(tag)::type T;
+        ASE_LAUNCH(gp_second_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)twin, ld_t, (const T*)g, ld_g, (const T*)dg,
+                   ld_dg, (T*)dz, ld_dz, rows, width, act);
+        return ASE_OK;
+    });
+    ASE_CHECK_ARG(rc == ASE_OK, "gp_second: bad dtype %d", dtype);
+    ASE_CHECK_LAUNCH("gp_second");
     return ASE_OK;
 }
 

@@ -33,8 +33,14 @@ def P(x, m=64):
     return (int(x) + m - 1) // m * m
 
 
-_ACT = {'relu': L.ACT_RELU, 'tanh': L.ACT_TANH, 'None': L.ACT_NONE, 'none': L.ACT_NONE, None: L.ACT_NONE}
+# rl_games activations_factory names (learning/ase_network_builder.py:162) -> epilogue codes; 'swish' is SiLU
+_ACT = {'relu': L.ACT_RELU, 'tanh': L.ACT_TANH, 'None': L.ACT_NONE, 'none': L.ACT_NONE, None: L.ACT_NONE,
+        'swish': L.ACT_SILU, 'silu': L.ACT_SILU, 'elu': L.ACT_ELU, 'gelu': L.ACT_GELU, 'sigmoid': L.ACT_SIGMOID,
+        'selu': L.ACT_SELU, 'softplus': L.ACT_SOFTPLUS}
+# what the data-gradient epilogue multiplies by: ReLU - the activation's sign (bit-mask twin), tanh - 1 - y^2 of the output
+# itself, the smooth activations - act'(z) of the pre-activation the forward launch kept in the layer's twin buffer
 _AUX = {L.ACT_RELU: L.AUX_RELU_MASK, L.ACT_TANH: L.AUX_TANH_GRAD, L.ACT_NONE: L.AUX_NONE}
+_AUX.update({a: L.AUX_PREACT | (a << 8) for a in range(L.ACT_SILU, L.ACT_SOFTPLUS + 1)})
 
 
 class Dense:
@@ -242,11 +248,15 @@ class UpdateEngine:
         self._bits = {}      # activation buffer (storage pointer) -> (buffer, bit-mask twin [rows, n_pad / 32] int32)
 
         def with_bits(h, d):
-            """ReLU activations get a bit-mask twin: the forward epilogue writes it (mask_out), the data-gradient
-            epilogue reads 1 bit instead of 2-4 bytes per element (ASE_AUX_RELU_BITS)."""
+            """Twin of an activation buffer, written by the forward epilogue (mask_out) and read by the data-gradient
+            launch of the same activation: ReLU - a bit mask (1 bit instead of 2-4 bytes per element, ASE_AUX_RELU_BITS);
+            smooth activations (SiLU, ELU, GELU, ...) - the pre-activation z (ASE_AUX_PREACT: act'(z) is not a function of
+            the output)."""
             if d.act == L.ACT_RELU and self._use_bits:
                 self._bits[h.untyped_storage().data_ptr()] = (h, torch.zeros(h.shape[0], h.shape[1] // 32, dtype=torch.int32,
                                                                                 device=dev))
+            elif d.act >= L.ACT_SILU:
+                self._bits[h.untyped_storage().data_ptr()] = (h, torch.zeros_like(h))
             return h
 
         def chain_bufs(chain, rows):
@@ -416,7 +426,7 @@ class UpdateEngine:
     def _fwd(self, d, X, Y, rows, act=None):
         act = d.act if act is None else act
         self.be.gemm_nt(X, d.Ws, Y, rows, d.n_pad, d.k_pad, bias=d.bs, act=act,
-                        mask_out=self._mask_of(Y) if act == L.ACT_RELU else None)
+                        mask_out=self._mask_of(Y) if (act == L.ACT_RELU or act >= L.ACT_SILU) else None)
 
     def _aux(self, aux, mode):
         """(aux tensor, aux mode) of a data-gradient launch: the bit-mask twin replaces a ReLU activation."""
@@ -424,6 +434,10 @@ class UpdateEngine:
             bits = self._mask_of(aux)
             if bits is not None:
                 return bits, L.AUX_RELU_BITS
+        elif (mode & 0xFF) == L.AUX_PREACT:
+            pre = self._mask_of(aux)
+            assert pre is not None, "a smooth activation's data gradient needs the pre-activation twin of its buffer"
+            return pre, mode
         return (aux if mode else None), mode
 
     def _mask_of(self, h):
@@ -437,6 +451,15 @@ class UpdateEngine:
         if c0 != 0 or h.shape[1] != base.shape[1]:
             return None
         return bits[r0:r0 + h.shape[0]]
+
+    def _twin(self, h, d):
+        """Twin of activation buffer h of layer d as the gradient-penalty kernels read it (ase_hip_gp_seed / gp_second): the
+        output itself for ReLU / tanh, the stored pre-activation for the smooth activations."""
+        if d.act >= L.ACT_SILU:
+            t = self._mask_of(h)
+            assert t is not None
+            return t
+        return h
 
     def _fwd_chain(self, chain, X, H, rows):
         for d, h in zip(chain, H):
@@ -949,8 +972,8 @@ class UpdateEngine:
             be.zero_(self.G0)     # keeps the reported penalty at 0 without the chain
             self._bwd_chain(self.disc, self.Xd, self.Hd, self.dZd, Rd)
             return
-        for d in self.disc:
-            assert d.act == L.ACT_RELU, "analytic gradient penalty needs ReLU discriminator layers"
+        if any(d.act != L.ACT_RELU for d in self.disc):
+            return self._disc_backward_curved(gp_coef)
         assert nl >= 2, "gradient penalty with a single discriminator layer is not implemented"
         cg = gp_coef * 2.0 / self.AMBg
         s = math.sqrt(cg)
@@ -984,6 +1007,56 @@ class UpdateEngine:
             X = self.Xd4 if l == 0 else self.Hd4[l - 1]
             self._tn(self.dZd4[l], X, d.gW[0], 4 * AMB, d.n_pad, d.k_pad, d.N, d.K, d.split_src, d.split_dst,
                      gbias=d.gb[0], bias_rows=Rd)
+
+    def _disc_backward_curved(self, gp_coef):
+        """Discriminator backward with the gradient penalty for activations with curvature (anything but ReLU; SURVEY 8 row
+        X1, learning/amp_agent.py:453-459 with create_graph=True).  Per demo row, with z_l the pre-activations, a'_l = act'(z_l):
+            chain      g_L = a'_L * w_logit,  u_{l-1} = W_l^T g_l,  g_{l-1} = a'_{l-1} * u_{l-1},  g_in = W_1^T g_1
+            penalty    J = c / AMB  sum |g_in|^2
+            its backward: r_0 = W_1 (dJ/dg_in);  dJ/du_l = a'_l * r_l (stored dGp[l]);  r_{l+1} = W_{l+1} (dJ/du_l)
+            weights    dJ/dW_l = g_l (dJ/du_{l-1})^T  (the stacked weight-gradient launches, as in the ReLU form)
+            NEW        dJ/dz_l += a''_l * u_l * r_l = (a''_l / a'_l^2) * g_l * dGp[l]      (ase_hip_gp_second)
+        The last line is the path through a'(z) that vanishes for ReLU; it joins the demo rows of the ordinary backward
+        (dZ_l) BEFORE that layer's data- and weight-gradient launches, so the penalty chain (which needs nothing of the loss
+        backward) runs first here instead of riding on the discriminator's data-gradient launches.  Scales as in
+        _disc_backward: chain values carry s = sqrt(2 c / AMB), the r side also the gradient scale S."""
+        be, c, AMB = self.be, self.cfg, self.AMB
+        Rd, nl, S = 3 * AMB, len(self.disc), self.gs
+        cg = gp_coef * 2.0 / self.AMBg
+        s = math.sqrt(cg)
+        demo = slice(2 * AMB, 3 * AMB)
+        top = self.disc[-1]
+        # ---- the chain on the demo rows (AMB-row launches into the 4th row block of dZd4)
+        be.gp_seed(self._twin(self.Hd[-1][demo], top), self.disc_head.W[0].view(-1), self.Gp[-1], AMB, top.N, scale=s, act=top.act)
+        for l in range(nl - 1, 0, -1):
+            d, pl = self.disc[l], self.disc[l - 1]
+            aux, mode = self._aux(self.Hd[l - 1][demo], _AUX[pl.act])
+            be.gemm_nt(self.Gp[l], d.Wts, self.Gp[l - 1], AMB, d.k_pad, d.n_pad, aux=aux, aux_mode=mode)
+        d0 = self.disc[0]
+        be.gemm_nt(self.Gp[0], d0.Wts, self.G0, AMB, d0.k_pad, d0.n_pad, alpha=S)        # S s * g_in
+        be.sqnorm(self.G0, AMB, d0.k_pad, self.acc, L.ACC_GP, scale=1.0 / (cg * S * S))
+        # ---- its backward: dGp[l] = a'_l * (dGp[l-1] @ W_l^T), the last one only for the logit weights' gradient
+        x = self.G0
+        for l in range(nl):
+            d = self.disc[l]
+            last = l == nl - 1
+            aux, mode = self._aux(self.Hd[l][demo], _AUX[d.act])
+            be.gemm_nt(x, d.Ws, self.GpTop if last else self.dGp[l], AMB, d.n_pad, d.k_pad, aux=aux, aux_mode=mode,
+                       alpha=s / S if last else 1.0, colsum=self.disc_head.gW[0].view(-1) if last else None,
+                       colsum_n=d.N if last else 0)
+            if last:     # the top layer's dGp in storage type and S scale, for the second-order term below
+                be.gemm_nt(x, d.Ws, self.dGp[l], AMB, d.n_pad, d.k_pad, aux=aux, aux_mode=mode)
+            x = self.dGp[l]
+        # ---- ordinary backward, the second-order terms joining the demo rows layer by layer
+        for l in range(nl - 1, -1, -1):
+            d = self.disc[l]
+            be.gp_second(self._twin(self.Hd[l][demo], d), self.Gp[l], self.dGp[l], self.dZd[l][demo], AMB, d.N, d.act)
+            X = self.Xd4 if l == 0 else self.Hd4[l - 1]
+            self._tn(self.dZd4[l], X, d.gW[0], 4 * AMB, d.n_pad, d.k_pad, d.N, d.K, d.split_src, d.split_dst,
+                     gbias=d.gb[0], bias_rows=Rd)
+            if l > 0:
+                pl = self.disc[l - 1]
+                self._dgrad(d, self.dZd[l], self.dZd[l - 1], Rd, self.Hd[l - 1], pl.act)
 
     # ------------------------------------------------------------------ collectives (single rank: no-ops)
     def _ar(self, t):

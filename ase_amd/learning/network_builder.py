@@ -70,7 +70,11 @@ class A2CNetwork(nn.Module):
         assert params.get('separate', False), "reference configs use separate actor / critic trunks"
         self.units = list(params['mlp']['units'])
         self.activation = params['mlp']['activation']
-        assert self.activation in ('relu', 'tanh'), "HIP epilogues: relu / tanh / identity"
+        # rl_games activations_factory names with a HIP epilogue (csrc/act.h): value + first / second derivative
+        SUPPORTED = ('relu', 'tanh', 'sigmoid', 'elu', 'selu', 'swish', 'gelu', 'softplus')
+        for blk in ('mlp', 'disc', 'enc'):
+            if blk in params:
+                assert params[blk]['activation'] in SUPPORTED, f"{blk}.activation {params[blk]['activation']!r}: one of {SUPPORTED}"
         self.mu_tanh = kind == 'ppo'
         self.latent_dim = int(ase_latent_shape[-1]) if kind == 'ase' else 0
         self.style_units = list(STYLE_UNITS)

@@ -10,9 +10,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libase_hip.so")
 
 ABI_VERSION = 2
+PPO_SCRATCH = 1024 * 72 + 8       # ASE_PPO_SCRATCH: doubles of ase_hip_ppo_head's workspace
+TN_SLAB = 65536 + 256        # ASE_TN_SLAB: floats per work item in the grouped weight-gradient launch's workspace
 F32, BF16, F32X3, F16 = 0, 1, 2, 3
-ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
-AUX_NONE, AUX_RELU_MASK, AUX_TANH_GRAD, AUX_RELU_BITS = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_SILU, ACT_ELU, ACT_GELU, ACT_SIGMOID, ACT_SELU, ACT_SOFTPLUS = range(9)
+AUX_NONE, AUX_RELU_MASK, AUX_TANH_GRAD, AUX_RELU_BITS, AUX_PREACT = 0, 1, 2, 3, 4
 
 # accumulator slots (ASE_ACC_*)
 (ACC_MASK_SUM, ACC_A_LOSS, ACC_B_LOSS, ACC_ENTROPY, ACC_CLIPPED, ACC_C_LOSS, ACC_KL, ACC_DIV, ACC_BCE_AGENT,
@@ -44,7 +46,8 @@ SIGNATURES = {
     "ase_hip_ppo_head": [_p, _i64, _p, _i64] + [_p] * 11 + [_p, _i64, _p, _i64, _p, _p, _p, _p, _p] + [_i] * 8 + [_f] * 6 + [_i, _p],
     "ase_hip_disc_head": [_p, _i64, _p, _i64, _p, _p, _i, _i, _f, _f, _i, _p],
     "ase_hip_enc_head": [_p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _i, _i, _i, _f, _f, _i, _p],
-    "ase_hip_gp_seed": [_p, _i64, _p, _p, _i64, _i, _i, _f, _i, _p],
+    "ase_hip_gp_seed": [_p, _i64, _p, _p, _i64, _i, _i, _f, _i, _i, _p],
+    "ase_hip_gp_second": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i, _i, _i, _i, _p],
     "ase_hip_sqnorm": [_p, _i64, _i, _i, _p, _i, _d, _i, _p],
     "ase_hip_finalize_scalars": [_p, _p, _i, _i, _i, _i, _i, _i] + [_f] * 11 + [_p],
     "ase_hip_enc_gp_seed": [_p, _i64, _p, _i64, _p, _i64, _i, _i, _f, _i, _p],
@@ -68,7 +71,7 @@ SIGNATURES = {
     "ase_hip_build_amp_obs": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _i, _i, _i, _p, _i, _i, _p],
     "ase_hip_gemm_nt_kernel_id": [_i, _i, _i, _i],
     "ase_hip_apply_multi": [_p, _i, _p, _p, _i, _p],
-    "ase_hip_gemm_tn_grouped_plan": [_p, _i, _i, _p, _i, _p],
+    "ase_hip_gemm_tn_grouped_plan": [_p, _i, _i, _p, _i, _p, _p, _i, _p],
     "ase_hip_prog_create": [_p],
     "ase_hip_prog_destroy": [_p],
     "ase_hip_prog_begin": [_p],
@@ -79,7 +82,7 @@ SIGNATURES = {
     "ase_hip_wait": [_p, _i],
     "ase_hip_memset": [_p, _i, _i64, _p],
     "ase_hip_memcpy": [_p, _p, _i64, _p],
-    "ase_hip_gemm_tn_grouped": [_p, _p, _i, _i, _p],
+    "ase_hip_gemm_tn_grouped": [_p, _p, _i, _p, _i, _p, _i, _p],
 }
 
 

@@ -112,7 +112,9 @@ class SyntheticSource:
         nlp = 0.5 * (((actions - mu) / sigma) ** 2).sum(-1) + 0.5 * math.log(2 * math.pi) * s.act_size + logstd.sum(-1)
         mask = torch.bernoulli(self.probs.expand(H, N), generator=g)
         det = (mask == 0.0).reshape(H * N)
-        actions[det] = mu[det]                         # learning/ase_agent.py:143-146
+        if with_amp:                                   # eps-greedy belongs to the AMP / ASE agents (learning/ase_agent.py:143-146:
+            actions[det] = mu[det]                     # the mean action, the SAMPLE's neglogp, and the row masked out of the
+                                                       # actor loss); a plain PPO rollout always acts on its samples
         dones = (torch.rand(H, N, generator=g) < 1.0 / s.episode_length)
         terminate = dones & (torch.rand(H, N, generator=g) < 0.5)
         exp['actions'] = actions.view(H, N, -1)

@@ -36,8 +36,12 @@ extern "C" {
 enum { ASE_F32 = 0, ASE_BF16 = 1, ASE_F32X3 = 2 /* f32 storage, products as 3 bf16 MFMAs on a hi/lo split (GEMMs only) */,
        ASE_F16 = 3 /* IEEE half storage + v_mfma_f32_32x32x16_f16, f32 accumulate: what the reference's mixed_precision flag
                       (torch.cuda.amp autocast + GradScaler, learning/ase_agent.py:216,271-288) computes in; conversions saturate */ };
-enum { ASE_ACT_NONE = 0, ASE_ACT_RELU = 1, ASE_ACT_TANH = 2 };
-enum { ASE_AUX_NONE = 0, ASE_AUX_RELU_MASK = 1, ASE_AUX_TANH_GRAD = 2, ASE_AUX_RELU_BITS = 3 /* aux = bit matrix written by mask_out */ };
+/* activations: the names of rl_games' activations_factory (learning/ase_network_builder.py:162); swish = SiLU */
+enum { ASE_ACT_NONE = 0, ASE_ACT_RELU = 1, ASE_ACT_TANH = 2, ASE_ACT_SILU = 3, ASE_ACT_ELU = 4, ASE_ACT_GELU = 5,
+       ASE_ACT_SIGMOID = 6, ASE_ACT_SELU = 7, ASE_ACT_SOFTPLUS = 8 };
+enum { ASE_AUX_NONE = 0, ASE_AUX_RELU_MASK = 1, ASE_AUX_TANH_GRAD = 2, ASE_AUX_RELU_BITS = 3 /* aux = bit matrix written by mask_out */,
+       ASE_AUX_PREACT = 4 /* aux = the layer's PRE-activation z (dtype, written by the forward launch as its twin): multiply by
+                             act'(z); the activation id rides in bits 8+ of aux_mode: ASE_AUX_PREACT | (ASE_ACT_x << 8) */ };
 enum { ASE_OK = 0, ASE_EINVAL = -1, ASE_ELAUNCH = -2, ASE_EUNSUPPORTED = -3 };
 
 int ase_hip_abi_version(void);
@@ -62,9 +66,12 @@ int ase_hip_debug_nt_profile(void* buf);
  *   the gradient-penalty chain rides on the discriminator's data-gradient launches).
  *   colsum (nullable, f32[colsum_n]) += column sums of the stored values for n < colsum_n (atomic):
  *   the bias gradient of the producing layer.
- *   mask_out (nullable, uint32 [M, ldmask], N % 32 == 0): bit n % 32 of word [m, n / 32] = (stored C[m,n] > 0).  A forward
- *   ReLU layer writes it; the data-gradient launch of the same activation reads it as aux with ASE_AUX_RELU_BITS
- *   (ldaux in words) - 1/16 of the bytes of re-reading the bf16 activation in the store-bound epilogue.
+ *   mask_out (nullable) = the layer's TWIN output, what the data-gradient launch of the same activation will read as aux:
+ *   act NONE / RELU / TANH: uint32 [M, ldmask], N % 32 == 0: bit n % 32 of word [m, n / 32] = (stored C[m,n] > 0) - read back
+ *     with ASE_AUX_RELU_BITS (ldaux in words): 1/16 of the bytes of re-reading the 16-bit activation in the store-bound epilogue;
+ *   act >= ASE_ACT_SILU: dtype [M, ldmask] (ldmask in ELEMENTS), the pre-activation z = alpha * A.B^T + bias - read back with
+ *     ASE_AUX_PREACT (the derivative of a non-monotonic activation is not a function of its output; tanh keeps
+ *     ASE_AUX_TANH_GRAD on the output itself).
  * Replaces: nn.Linear + activation forward  (learning/ase_network_builder.py:255-259,305-324,
  *   learning/amp_network_builder.py:81-84), and autograd's data-gradient of the same layers
  *   (B = the transposed weight shadow; mask = derivative of the previous activation), and the
@@ -88,20 +95,27 @@ int ase_hip_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, floa
                     int bias_rows, int M, int N, int K, int n_real, int k_real, int split_src, int split_dst,
                     float alpha, int dtype, void* stream);
 
-/* All weight gradients of one optimisation step in ONE launch (bf16).  They only depend on buffers the data-gradient
- * chain has already written, and one grid of ~256 long contractions pays the split-M reduction (f32 atomics, memory-side
- * on this chip) once per step instead of once per layer.
+/* All weight gradients of one branch of an optimisation step in ONE grouped launch (16-bit storage).  They only depend on
+ * buffers the data-gradient chain has already written, and one grid of ~256 long contractions pays the split-M reduction once
+ * per step instead of once per layer.
  *   problems: int64[n][16] = {A, lda, B, ldb, G, gbias (or 0), bias_rows (0 = all), M, N, K, n_real, k_real, split_src,
  *             split_dst, alpha (f32 bit pattern), 0}, fields as in ase_hip_gemm_tn, leading dimensions in elements;
  *             M and bias_rows multiples of 64.
- *   ase_hip_gemm_tn_grouped_plan (host only, no GPU needed): validates the HOST copy of the table, fills field 15 and
- *             writes the work list int32[n_work][4] = {problem, 256 x 256 output tile, first row, 64-row K-tiles};
- *             target_wg <= 0: one workgroup per CU.
- *   ase_hip_gemm_tn_grouped: launch with DEVICE copies of the planned table and work list.
+ *   ase_hip_gemm_tn_grouped_plan (host only, no GPU needed): validates the HOST copy of the table, fills field 15 (tiles
+ *             along k; bit 30: the gradient buffer is shared with another problem of the launch) and writes the work list
+ *             int32[n_work][4] = {problem, 256 x 256 output tile, first row, 64-row K-tiles} and (red non-null) the reduce
+ *             list int32[n_red][4] = {problem, tile, first work item, splits}; target_wg <= 0: one workgroup per CU.
+ *   ase_hip_gemm_tn_grouped: launch with DEVICE copies of the planned tables.  workspace (device f32, 16-byte aligned,
+ *             n_work * ASE_TN_SLAB floats, private to the launch until it completes): every work item stores its partial
+ *             tile there with plain 16-byte stores and a second kernel adds the sums into G / gbias (deterministic, no
+ *             atomics: memory-side f32 atomics run at ~1.4 TB/s on this chip, 64 MB of them per launch).  workspace NULL:
+ *             the work items add into G with f32 atomics directly.
  * Replaces: loss.backward()'s weight / bias gradients of every nn.Linear (learning/ase_agent.py:271). */
+#define ASE_TN_SLAB (65536 + 256)
 int ase_hip_gemm_tn_grouped_plan(int64_t* problems, int n_problems, int target_wg, int32_t* work, int max_work,
-                                 int* n_work);
-int ase_hip_gemm_tn_grouped(const int64_t* problems, const int32_t* work, int n_work, int dtype, void* stream);
+                                 int* n_work, int32_t* red, int max_red, int* n_red);
+int ase_hip_gemm_tn_grouped(const int64_t* problems, const int32_t* work, int n_work, const int32_t* red, int n_red,
+                            float* workspace, int dtype, void* stream);
 
 /* Shadow copies of one weight matrix for the matrix cores: W_s [n_pad,k_pad] and its transpose
  * Wt_s [k_pad,n_pad] (both dtype, zero padded, concat columns moved to split_dst).  Run after
@@ -208,7 +222,10 @@ int ase_hip_reduce_sum(const float* x, int64_t n, int square, double* acc, int s
  *            scalars are not) - the static loss scale of ASE_F16 storage, whose back-propagated gradients would
  *            otherwise fall into half's subnormal range; the weight-gradient launches undo it through their alpha.
  *            The counterpart of the reference's GradScaler (learning/ase_agent.py:216,271-288).  1 for bf16 / f32.
- *   scratch: device f64[8192] workspace (per-workgroup partial sums, folded by a second tiny kernel). */
+ *   scratch: device f64[ASE_PPO_SCRATCH] workspace, ZEROED once by the caller and private to one launch at a time:
+ *            per-workgroup partial sums (loss scalars, head-bias column sums) + a ticket word; the last workgroup to arrive
+ *            folds them into acc / db_* (no contended atomics, no second launch) and resets the ticket. */
+#define ASE_PPO_SCRATCH (1024 * 72 + 8)
 int ase_hip_ppo_head(const float* mu, int64_t ld_mu, const float* value, int64_t ld_v,
                      const float* mb_actions, const float* mb_old_mu, const float* mb_old_sigma,
                      const float* mb_old_logp, const float* mb_adv, const float* mb_old_value,
@@ -244,9 +261,17 @@ int ase_hip_enc_gp_back(const float* e, int64_t ld_e, const float* z, int64_t ld
                         void* d_e, int64_t ld_de, float* db_enc, int rows, int z_dim, float grad_scale, int dtype,
                         void* stream);
 
-/* Gradient-penalty seed: g[r,j] = (h[r,j] > 0) ? scale * w[j] : 0  (d logit / d last hidden, ReLU). */
+/* Gradient-penalty seed (learning/amp_agent.py:453-459): g[r,j] = scale * w[j] * act'  (d logit / d pre-activation of the last
+ * hidden layer).  h = that layer's TWIN: its output for ReLU (act' = [h > 0]) and tanh (1 - h^2), its pre-activation z for
+ * the smooth activations (act >= ASE_ACT_SILU). */
 int ase_hip_gp_seed(const void* h, int64_t ld_h, const float* w, void* g, int64_t ld_g, int rows,
-                    int width, float scale, int dtype, void* stream);
+                    int width, float scale, int act, int dtype, void* stream);
+
+/* Second-order term of the penalty's double backward for activations with curvature: with g = act'(z) u the chain value at a
+ * layer and dg = act'(z) r the (masked) gradient of the penalty w.r.t. u,  dz[r,j] += act''(z) u r = act'' / act'^2 * g * dg
+ * - the path through act'(z) that autograd's create_graph=True adds for anything but ReLU.  twin as in ase_hip_gp_seed. */
+int ase_hip_gp_second(const void* twin, int64_t ld_t, const void* g, int64_t ld_g, const void* dg, int64_t ld_dg,
+                      void* dz, int64_t ld_dz, int rows, int width, int act, int dtype, void* stream);
 
 /* acc[slot] += scale * sum_{r,j} x[r,j]^2 over a dtype matrix [rows, cols]. */
 int ase_hip_sqnorm(const void* x, int64_t ld, int rows, int cols, double* acc, int slot, double scale,

@@ -177,7 +177,7 @@ def _rms_state(m):
 
 
 def make_case(name, kind, seed, num_envs=16, obs_size=37, act_size=7, amp_size=44, epochs=2, slim=False, regen=False,
-              seeded=False, sample=0):
+              seeded=False, sample=0, warm=0):
     """slim: leave out what only the single-step tests read (first-step gradients / weights, the checkpoint dictionary);
     regen: leave out every tensor the test can regenerate from the seeded synthetic source (observations, AMP observations,
     demo stream - tests/test_agent_emu.py:regenerate) and the duplicated dataset rows."""
@@ -219,6 +219,19 @@ def make_case(name, kind, seed, num_envs=16, obs_size=37, act_size=7, amp_size=4
          'init_sd': init_sd,
          'trainable': [k.replace('a2c_network.', '', 1) for k, p in A.model.named_parameters() if p.requires_grad],
          'epochs': []}
+    if warm:
+        # warm=n: the reference's own RunningMeanStd modules see n batches of 4096 observations (drawn from the synthetic
+        # feature distributions with a SEPARATE generator) before the recorded epoch - the regime of real training, where one
+        # more minibatch barely moves the statistics and the first step's importance ratio is ~1.  Cold statistics (count 1)
+        # make the first minibatch re-normalise everything: clip fraction ~0.98, ratios of e^10 (kept as the stress seed).
+        g2 = torch.Generator().manual_seed(seed * 31 + 4242)
+        A.set_train()
+        with torch.no_grad():
+            for _ in range(warm):
+                A.running_mean_std(src.obs_fs.draw(4096, g2))
+                if akind != 'ppo':
+                    A._amp_input_mean_std(src.amp_fs.draw(4096, g2))
+        G['warm'] = warm
     if akind != 'ppo':
         A._init_amp_demo_buf()        # learning/amp_agent.py:520-528 (reference code, calls demo_fetch)
         G['demo_init'] = torch.cat(demo_log, 0)
@@ -339,11 +352,11 @@ if __name__ == '__main__':
     torch.set_num_threads(4)
     if len(sys.argv) > 1 and sys.argv[1] == 'real':           # real layer widths from the reference's yaml files (compact fixtures)
         torch.set_num_threads(16)
-        for s_ in (0, 1, 2):
+        for s_ in (0, 1, 2):      # seeds 0, 1: warmed statistics (ratio ~ 1); seed 2: cold statistics (the stress regime)
             make_case('ase_cfg2_small' + ('' if s_ == 0 else f'_s{s_}'), 'ase_cfg2', seed=30 + s_, num_envs=64, obs_size=253,
-                      act_size=31, amp_size=1400, epochs=1, regen=True, seeded=True, sample=4096, slim=True)
+                      act_size=31, amp_size=1400, epochs=1, regen=True, seeded=True, sample=4096, slim=True, warm=0 if s_ == 2 else 16)
         make_case('hrl_cfg4_small', 'hrl_cfg4', seed=40, num_envs=64, obs_size=258, act_size=64, amp_size=0, epochs=1,
-                  regen=True, seeded=True, sample=4096, slim=True)
+                  regen=True, seeded=True, sample=4096, slim=True, warm=16)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'swish':
         make_case('ase_swish_tiny', 'ase_swish', seed=7, epochs=1)

@@ -115,14 +115,18 @@ static int run_grouped(int reps) {
         const float one = 1.0f; int bits; memcpy(&bits, &one, 4); d[14] = bits;
         flops += 2.0 * h.M * h.N * h.K;
     }
-    std::vector<int32_t> work(4 * 4096); int nw = 0;
-    if (ase_hip_gemm_tn_grouped_plan(prob.data(), P, 0, work.data(), 4096, &nw)) { printf("plan failed: %s\n", ase_hip_last_error()); return 3; }
+    std::vector<int32_t> work(4 * 4096), red(4 * 4096); int nw = 0, nr = 0;
+    if (ase_hip_gemm_tn_grouped_plan(prob.data(), P, 0, work.data(), 4096, &nw, red.data(), 4096, &nr)) { printf("plan failed: %s\n", ase_hip_last_error()); return 3; }
     int mn = 1 << 30, mx = 0; for (int i = 0; i < nw; ++i) { mn = std::min(mn, work[4 * i + 3]); mx = std::max(mx, work[4 * i + 3]); }
     printf("grouped plan: %d problems -> %d work items, K-tiles per item %d..%d\n", P, nw, mn, mx);
-    int64_t* dprob; int32_t* dwork;
-    CK(hipMalloc(&dprob, prob.size() * 8)); CK(hipMalloc(&dwork, (size_t)nw * 16));
+    int64_t* dprob; int32_t *dwork, *dred; float* ws = nullptr;
+    CK(hipMalloc(&dprob, prob.size() * 8)); CK(hipMalloc(&dwork, (size_t)nw * 16)); CK(hipMalloc(&dred, (size_t)nr * 16));
     CK(hipMemcpy(dprob, prob.data(), prob.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dwork, work.data(), (size_t)nw * 16, hipMemcpyHostToDevice));
-    auto grouped = [&]() { if (ase_hip_gemm_tn_grouped(dprob, dwork, nw, ASE_BF16, st)) { printf("grouped failed: %s\n", ase_hip_last_error()); exit(3); } };
+    CK(hipMemcpy(dred, red.data(), (size_t)nr * 16, hipMemcpyHostToDevice));
+    // LAB_TNG_WS=0: f32 atomics into G; default: partial tiles in a workspace + the reduce kernel
+    if (!getenv("LAB_TNG_WS") || atoi(getenv("LAB_TNG_WS"))) CK(hipMalloc(&ws, (size_t)nw * ASE_TN_SLAB * 4));
+    printf("reduce entries %d, workspace %s\n", nr, ws ? "on" : "off (atomics)");
+    auto grouped = [&]() { if (ase_hip_gemm_tn_grouped(dprob, dwork, nw, dred, nr, ws, ASE_BF16, st)) { printf("grouped failed: %s\n", ase_hip_last_error()); exit(3); } };
     auto single = [&]() {
         for (int i = 0; i < P; ++i) {
             const Shape& h = shapes[i];

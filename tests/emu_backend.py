@@ -30,6 +30,41 @@ def _store(v, dtype):
     return v.to(dtype)
 
 
+def _act_fns(act):
+    """(f, f', f'') of an activation as functions of the pre-activation (csrc/act.h)."""
+    import torch.nn.functional as F
+    sg = torch.sigmoid
+    phi = lambda z: torch.exp(-0.5 * z * z) * 0.3989422804014327
+    Phi = lambda z: 0.5 * (1 + torch.erf(z * 0.7071067811865476))
+    lam, al = 1.0507009873554805, 1.6732632423543772
+    return {
+        L.ACT_NONE: (lambda z: z, lambda z: torch.ones_like(z), lambda z: torch.zeros_like(z)),
+        L.ACT_RELU: (torch.relu, lambda z: (z > 0).to(z.dtype), lambda z: torch.zeros_like(z)),
+        L.ACT_TANH: (torch.tanh, lambda z: 1 - torch.tanh(z) ** 2, lambda z: -2 * torch.tanh(z) * (1 - torch.tanh(z) ** 2)),
+        L.ACT_SILU: (F.silu, lambda z: sg(z) * (1 + z * (1 - sg(z))), lambda z: sg(z) * (1 - sg(z)) * (2 + z * (1 - 2 * sg(z)))),
+        L.ACT_ELU: (F.elu, lambda z: torch.where(z > 0, torch.ones_like(z), torch.exp(z)),
+                    lambda z: torch.where(z > 0, torch.zeros_like(z), torch.exp(z))),
+        L.ACT_GELU: (F.gelu, lambda z: Phi(z) + z * phi(z), lambda z: phi(z) * (2 - z * z)),
+        L.ACT_SIGMOID: (sg, lambda z: sg(z) * (1 - sg(z)), lambda z: sg(z) * (1 - sg(z)) * (1 - 2 * sg(z))),
+        L.ACT_SELU: (F.selu, lambda z: lam * torch.where(z > 0, torch.ones_like(z), al * torch.exp(z)),
+                     lambda z: lam * torch.where(z > 0, torch.zeros_like(z), al * torch.exp(z))),
+        L.ACT_SOFTPLUS: (F.softplus, sg, lambda z: sg(z) * (1 - sg(z))),
+    }[act]
+
+
+def _twin_factors(act, t):
+    """(act', act'' / act'^2) from a layer's twin: its output for ReLU / tanh, its pre-activation otherwise."""
+    if act == L.ACT_RELU:
+        return (t > 0).float(), torch.zeros_like(t)
+    if act == L.ACT_TANH:
+        d1 = 1 - t * t
+        d2 = -2 * t * d1
+    else:
+        _, f1, f2 = _act_fns(act)
+        d1, d2 = f1(t), f2(t)
+    return d1, torch.where(d1 != 0, d2 / (d1 * d1), torch.zeros_like(d1))
+
+
 class EmuBackend:
     name = "emu"
 
@@ -62,11 +97,16 @@ class EmuBackend:
         v = alpha * (a @ b.t())
         if bias is not None:
             v = v + bias[:N]
+        z_pre = v
         if act == L.ACT_RELU:
             v = torch.relu(v)
         elif act == L.ACT_TANH:
             v = torch.tanh(v)
-        if aux_mode == L.AUX_RELU_MASK:
+        elif act != L.ACT_NONE:
+            v = _act_fns(act)[0](v)
+        if (aux_mode & 0xFF) == L.AUX_PREACT:
+            v = v * _act_fns(aux_mode >> 8)[1](aux[:M, :N].float())
+        elif aux_mode == L.AUX_RELU_MASK:
             v = v * (aux[:M, :N].float() > 0)
         elif aux_mode == L.AUX_RELU_BITS:         # uint32 words, 32 columns each (stored as int32)
             w = aux[:M, :(N + 31) // 32].to(torch.int64) & 0xFFFFFFFF
@@ -77,7 +117,9 @@ class EmuBackend:
             v = v * (1 - x * x)
         out = _store(v, Cm.dtype)
         Cm[:M, :N] = out
-        if mask_out is not None:
+        if mask_out is not None and act >= L.ACT_SILU:        # twin of a smooth activation: the pre-activation itself
+            mask_out[:M, :N] = _store(z_pre, mask_out.dtype)
+        elif mask_out is not None:
             assert N % 32 == 0
             b = (out.float() > 0).to(torch.int64).reshape(M, N // 32, 32)
             w = (b << torch.arange(32)).sum(-1)
@@ -327,9 +369,13 @@ class EmuBackend:
         if db_enc is not None:
             db_enc[:z_dim] += (new.float() - old).sum(0) / grad_scale
 
-    def gp_seed(self, h, w, g, rows, width, scale=1.0):
-        g[:rows, :width] = torch.where(h[:rows, :width].float() > 0, (scale * w[:width]).expand(rows, width),
-                                       torch.zeros(rows, width)).to(g.dtype)
+    def gp_seed(self, h, w, g, rows, width, scale=1.0, act=L.ACT_RELU):
+        d1, _ = _twin_factors(act, h[:rows, :width].float())
+        g[:rows, :width] = _store(scale * w[:width] * d1, g.dtype)
+
+    def gp_second(self, twin, g, dg, dz, rows, width, act):
+        _, c = _twin_factors(act, twin[:rows, :width].float())
+        dz[:rows, :width] = _store(dz[:rows, :width].float() + c * g[:rows, :width].float() * dg[:rows, :width].float(), dz.dtype)
 
     def sqnorm(self, x, rows, cols, acc, slot, scale=1.0):
         acc[slot] += scale * (x[:rows, :cols].double() ** 2).sum()

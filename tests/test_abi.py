@@ -72,8 +72,20 @@ def _plan(problems, target=256):
             tab[16 * i + j] = v
     work = (ctypes.c_int32 * (4 * 8192))()
     nw = ctypes.c_int(0)
-    rc = lib.ase_hip_gemm_tn_grouped_plan(tab, n, target, work, 8192, ctypes.byref(nw))
+    red = (ctypes.c_int32 * (4 * 8192))()
+    nr = ctypes.c_int(0)
+    rc = lib.ase_hip_gemm_tn_grouped_plan(tab, n, target, work, 8192, ctypes.byref(nw), red, 8192, ctypes.byref(nr))
     items = [tuple(work[4 * i:4 * i + 4]) for i in range(nw.value)]
+    if rc == 0:
+        # reduce list: one entry per (problem, tile); split s of the tile is work item first + s * tiles(problem)
+        ents = [tuple(red[4 * i:4 * i + 4]) for i in range(nr.value)]
+        tiles_of = {}
+        for (p_, t_, m0, nk) in items:
+            tiles_of[p_] = max(tiles_of.get(p_, 0), t_ + 1)
+        assert sorted((p_, t_) for p_, t_, _, _ in ents) == sorted({(p_, t_) for p_, t_, _, _ in items})
+        for p_, t_, first, splits in ents:
+            own = [i for i, it in enumerate(items) if it[0] == p_ and it[1] == t_]
+            assert own == [first + s_ * tiles_of[p_] for s_ in range(splits)], (p_, t_, first, splits, own)
     return rc, items, tab
 
 
@@ -94,7 +106,7 @@ def test_grouped_weight_gradient_plan_covers_every_tile_once():
         cover.setdefault((p, t), []).append((m0, m0 + 64 * nk))
     for p, (M, N, K, nr, kr, br) in enumerate(probs):
         tiles = ((nr + 255) // 256) * ((K + 255) // 256)
-        assert tab[16 * p + 15] == (K + 255) // 256 and tab[16 * p + 6] == (br or M)
+        assert (tab[16 * p + 15] & 0xFFFF) == (K + 255) // 256 and tab[16 * p + 6] == (br or M)
         for t in range(tiles):
             segs = sorted(cover[(p, t)])
             assert segs[0][0] == 0 and segs[-1][1] == M

@@ -84,6 +84,12 @@ def replay_epochs(G, ag, rtol, wtol, check=True, max_steps=None):
         ag.vec_env.q.append(G['demo_init'].clone())
         ag._amp_obs_demo_buffer._sample_idx = G['demo_sample_perm0'].to(dev)
         ag._amp_replay_buffer._sample_idx = G['replay_sample_perm0'].to(dev)
+    if G.get('warm'):                   # goldens recorded with warmed-up running statistics (make_golden.py warm=n): start there
+        from tests.helpers import set_rms
+        E0 = G['epochs'][0]['rms_before']
+        set_rms(ag.engine.obs_state, E0['obs'])
+        if kind != 'ppo':
+            set_rms(ag.engine.amp_state, E0['amp'])
     all_info = []
     for E in G['epochs']:
         ag.update_epoch()               # the train loop's epoch counter (rl_games A2CBase.train / make_golden.py)
@@ -140,7 +146,7 @@ def replay_epochs(G, ag, rtol, wtol, check=True, max_steps=None):
 
 
 @pytest.mark.parametrize('name', ['ase_tiny', 'amp_tiny', 'ppo_tiny', 'ase_sep_tiny', 'ase_tiny_s1', 'ase_tiny_s2', 'amp_cfg1', 'ase_gp_tiny',
-                                  'ase_sep_gp_tiny'])
+                                  'ase_sep_gp_tiny', 'ase_swish_tiny'])
 def test_two_epochs_emulated(name, golden_dir):
     G = torch.load(os.path.join(golden_dir, name + '.pt'), weights_only=False)
     ag = make_agent(G, EmuBackend())

@@ -12,7 +12,8 @@ from ase_amd.engine import UpdateEngine
 from tests.emu_backend import EmuBackend
 from tests.helpers import build_net, close, get_rms, set_rms
 
-CASES = ['ase_tiny', 'amp_tiny', 'ppo_tiny', 'ase_sep_tiny', 'ase_gp_tiny', 'ase_sep_gp_tiny']
+CASES = ['ase_tiny', 'amp_tiny', 'ppo_tiny', 'ase_sep_tiny', 'ase_gp_tiny', 'ase_sep_gp_tiny',
+         'ase_swish_tiny']       # swish (SiLU) in the policy MLPs, the discriminator and the encoder: the curved gradient penalty
 
 
 def first_step(G, be, dtype, device='cpu', grad_scale=None):

@@ -77,6 +77,37 @@ def test_gemm_nt_epilogues(be, dt, act, aux_mode):
 
 
 @pytest.mark.parametrize('dt', DT)
+@pytest.mark.parametrize('act', [L.ACT_SILU, L.ACT_ELU, L.ACT_GELU, L.ACT_SIGMOID, L.ACT_SELU, L.ACT_SOFTPLUS])
+def test_gemm_nt_smooth_activations(be, dt, act):
+    """Row X1: the rl_games activations beyond relu / tanh (swish = SiLU, elu, gelu, sigmoid, selu, softplus): the forward
+    epilogue stores act(z) and keeps the pre-activation z as the layer's twin; the data-gradient epilogue multiplies by
+    act'(z) read back from that twin (ASE_AUX_PREACT); the gradient-penalty kernels use act''(z) / act'(z)^2."""
+    M, N, K = 300, 192, 256
+    g = torch.Generator().manual_seed(100 + act)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(dt)
+    B = (torch.randn(N, K, generator=g) * 0.15).to(dt)
+    bias = torch.randn(N, generator=g) * 0.5
+    dY = (torch.randn(M, N, generator=g) * 0.3).to(dt)
+    W2 = (torch.randn(N, N, generator=g) * 0.1).to(dt)
+    wl = torch.randn(N, generator=g)
+    outs = []
+    for dev in ('cuda', 'cpu'):
+        b = be if dev == 'cuda' else EmuBackend()
+        H, Z = torch.zeros(M, N, dtype=dt, device=dev), torch.zeros(M, N, dtype=dt, device=dev)
+        b.gemm_nt(A.to(dev), B.to(dev), H, M, N, K, bias=bias.to(dev), act=act, mask_out=Z)
+        dX = torch.zeros(M, N, dtype=dt, device=dev)
+        b.gemm_nt(dY.to(dev), W2.to(dev), dX, M, N, N, aux=Z, aux_mode=L.AUX_PREACT | (act << 8))
+        gs = torch.zeros(M, N, dtype=dt, device=dev)
+        b.gp_seed(Z, wl.to(dev), gs, M, N, scale=0.7, act=act)
+        dz = dY.to(dev).clone()
+        b.gp_second(Z, gs, dX, dz, M, N, act)
+        outs.append([t.float().cpu() for t in (H, Z, dX, gs, dz)])
+    rt, at = _tol(dt)
+    for name, a, c in zip(('act(z)', 'z twin', 'dX = (dY W) act\'(z)', 'gp seed', 'gp second'), *outs):
+        close(a, c, rt * 2, at * 4, name)
+
+
+@pytest.mark.parametrize('dt', DT)
 def test_gemm_nt_f32_out(be, dt):
     M, N, K = 257, 64, 512
     g = torch.Generator().manual_seed(5)

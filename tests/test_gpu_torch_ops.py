@@ -130,4 +130,4 @@ def test_small_ops():
     z = torch.ops.ase_hip.sample_latents(1000, 64, st)
     assert int(st[1]) == 1 and torch.allclose(z.norm(dim=-1), torch.ones(1000, device=DEV), atol=1e-5)
     with pytest.raises(RuntimeError):
-        torch.ops.ase_hip.linear_act(torch.zeros(4, 8, device=DEV, dtype=torch.float16), torch.zeros(3, 8, device=DEV), torch.zeros(3, device=DEV), 'relu')
+        torch.ops.ase_hip.linear_act(torch.zeros(4, 8, device=DEV, dtype=torch.float64), torch.zeros(3, 8, device=DEV), torch.zeros(3, device=DEV), 'relu')
