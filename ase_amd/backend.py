@@ -13,6 +13,9 @@ import torch
 from . import lib as L
 
 
+_HOSTFN = C.CFUNCTYPE(None, C.c_void_p)
+
+
 def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -37,6 +40,7 @@ class HipBackend:
     def __init__(self, device=None, x3=False):
         # x3: f32-stored GEMM operands are multiplied as three bf16 MFMAs on a hi/lo split (ASE_F32X3)
         self.x3 = bool(x3)
+        self._recording, self._host_keep, self._host_error = None, {}, None
         self.tn_workspace = True     # grouped weight gradients: partial tiles + reduce kernel (False: f32 atomics into G)
         if not torch.cuda.is_available():
             raise L.AseHipError("HipBackend needs a ROCm GPU (torch.cuda.is_available() is False); "
@@ -75,18 +79,41 @@ class HipBackend:
 
     def prog_begin(self, prog):
         L.check(self.lib.ase_hip_prog_begin(prog), "prog_begin")
+        self._recording = prog.value
+        self._host_keep.setdefault(prog.value, [])
 
     def prog_end(self, prog):
+        self._recording = None
         L.check(self.lib.ase_hip_prog_end(prog), "prog_end")
+
+    def host_call(self, fn):
+        """A host-side operation at this position of the launch sequence (a collective, a torch op between kernels): run
+        now, or - while a launch program records - on every replay (ase_hip_prog_host).  fn enqueues its own GPU work."""
+        if self._recording is None:
+            fn()
+            return
+
+        def trampoline(_arg, fn=fn):
+            try:
+                fn()
+            except BaseException as e:           # an exception cannot cross the C frame: keep it for the caller of prog_launch
+                self._host_error = e
+        cb = _HOSTFN(trampoline)
+        self._host_keep[self._recording].append(cb)          # the program calls through this object on every replay
+        L.check(self.lib.ase_hip_prog_host(C.cast(cb, C.c_void_p), None), "prog_host")
 
     def prog_launch(self, prog):
         L.check(self.lib.ase_hip_prog_launch(prog), "prog_launch")
+        if self._host_error is not None:
+            e, self._host_error = self._host_error, None
+            raise e
 
     def prog_size(self, prog):
         return self.lib.ase_hip_prog_size(prog)
 
     def prog_destroy(self, prog):
         self.lib.ase_hip_prog_destroy(prog)
+        self._host_keep.pop(prog.value, None)
 
     def _gemm_code(self, dtype):
         c = _code(dtype)
@@ -158,6 +185,18 @@ class HipBackend:
         L.check(self.lib.ase_hip_gemm_tn_grouped(_ptr(plan['problems']), _ptr(plan['work']), plan['n_work'], _ptr(plan['red']),
                                                  plan['n_red'], _ptr(plan['ws']), plan['dtype'], self._stream()),
                 "gemm_tn_grouped")
+
+    # packed MFMA-fragment copies of weight matrices (the phased NT kernel reads them straight into registers)
+    @staticmethod
+    def packed_bytes(N, K):
+        return ((N + 255) // 256 * 8) * (K // 16) * 1024
+
+    def pack_b_multi(self, desc, dtype):
+        """desc: device int64 [n, 6] = {B, ldb, N, K, Bp, 0} (ase_hip.h)."""
+        L.check(self.lib.ase_hip_pack_b_multi(_ptr(desc), desc.shape[0], _code(dtype), self._stream()), "pack_b_multi")
+
+    def pack_register(self, B, Bp):
+        L.check(self.lib.ase_hip_pack_register(_ptr(B), _ld(B), _ptr(Bp)), "pack_register")
 
     def refresh_shadow(self, W, Ws, Wts, split_src, split_dst):
         n, k = W.shape

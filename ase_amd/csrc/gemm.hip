@@ -14,10 +14,10 @@
 //       see the comment blocks in front of each; nt_choice() picks per shape.  One epilogue (nt_epilogue) for all.
 //   TN kernels: gemm_tn_kernel (128 x 128, register-staged, transposed LDS reads) and the phased gemm_tn8 kernels
 //       (256 x 256, DMA-staged), single problem or grouped (all weight gradients of a step in one grid).
-#include "common.h"
-#include "act.h"
+#include "gemm_nt.h"
 #include <stdlib.h>
-#include <type_traits>
+
+using namespace ase_nt;
 
 namespace {
 
@@ -25,20 +25,8 @@ unsigned long long* g_nt_prof = nullptr;      // tuning aid, see ase_hip_debug_n
 
 constexpr int kThreads = 256;
 
-// Bijective XCD-aware remap: workgroup b runs on XCD b % 8; give each XCD a contiguous tile range.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
-    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + loc;
-}
-
 template <typename T> struct Mma;
 
-// LDS rows are RB = 64 or 128 bytes, unpadded; chunk c (16 B) of row r lives at slot c ^ swz(r):
-//   RB = 128: swz = (r >> 1) & 7   (a 256-byte bank window holds 2 rows x 8 slots)
-//   RB =  64: swz = (r >> 2) & 3   (4 rows x 4 slots)
-// either way the 16 rows (distinct mod 16) of a ds_read_b128 lane group land on 16 distinct slots.
-template <int RB> __device__ __forceinline__ int lds_swz(int r) { return RB == 128 ? ((r >> 1) & 7) : ((r >> 2) & 3); }
 
 template <typename T> struct Mma16 {
     typedef typename V16<T>::x8 x8;
@@ -140,33 +128,12 @@ template <> struct Mma<f32s_t> {
 // HBM -> LDS DMA of one operand tile: pass i moves rows [RPP i, RPP i + RPP) (RPP = 8 rows per wave); wave w of the
 // pass owns the 8 rows RPP i + 8 w .. + 7 = one 1-KiB lane-linear LDS piece (M0 = wave-uniform base, lane l lands at
 // base + 16 l).
-typedef __attribute__((address_space(1))) const void gptr_t;
-typedef __attribute__((address_space(3))) void lptr_t;
 template <int PASSES, int RPP, int RB>
 __device__ __forceinline__ void nt_stage(const char* const (&src)[PASSES], int64_t koff, char* lds_wave_base) {
 #pragma unroll
     for (int i = 0; i < PASSES; ++i)
         __builtin_amdgcn_global_load_lds((gptr_t*)(src[i] + koff), (lptr_t*)(lds_wave_base + i * RPP * RB), 16, 0, 0);
 }
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-struct NTParams {
-    const char* A; int64_t lda;     // leading dims in BYTES
-    const char* B; int64_t ldb;
-    char* C; int64_t ldc;           // bytes
-    const float* bias;
-    const char* aux; int64_t ldaux; // bytes
-    int aux_split, aux_delta;       // rows m >= aux_split read aux row m - aux_delta (stacked row blocks sharing a mask)
-    float* colsum; int colsum_n;
-    uint32_t* mask_out; int64_t ldmask;   // nullable: bit (m, n) = stored value > 0, 32 columns per word, ldmask in words
-    char* pre_out; int64_t ldpre;         // nullable (smooth activations): the pre-activation z in the storage type, ldpre in bytes
-    int M, N, K;                    // K in elements (multiple of 128/sizeof(T))
-    int act, aux_mode, out_f32;
-    float alpha;
-    int tiles_m, tiles_n;
-    unsigned long long* prof;       // debug: per-workgroup phase timestamps (ase_hip_debug_nt_profile), else null
-};
-
 // ---- epilogue of the NT kernels.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (e&3) + 8*(e>>2) + 4*(lane>>5),
 // i.e. a lane owns ONE column: storing from registers would be 2-byte scattered stores.  Phase 1 applies bias +
 // activation (per-column bias = per-lane scalar) and transposes FMC x FNC fragments of the wave's sub-tile through a
@@ -553,7 +520,6 @@ int launch_nt(const NTParams& p0, hipStream_t stream) {
 //   previous occupant (K-tile t - 2) was last read >= 2 phases earlier (the WAR distance two staggered groups need);
 //   a unit is read one phase after the counted wait + barrier that retires it (RAW across the stagger).
 // ------------------------------------------------------------------------------------------------
-typedef __attribute__((ext_vector_type(4))) int i32x4;
 
 template <int UNITS> __device__ __forceinline__ void wait_dma_units() { wait_vmcnt<2 * UNITS>(); }
 __device__ __forceinline__ void wait_dma_units_rt(int units) {      // wave-uniform runtime count (loop tail)
@@ -587,16 +553,6 @@ __device__ __forceinline__ void nt8_read(i32x4 (&f)[4], const char* base, const 
     if constexpr (!LIVE) { asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3])); return; }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) f[ks] = *reinterpret_cast<const i32x4*>(base + L.roff[ks]);
-}
-
-// SW: operands swapped in the MFMA (D = B-fragment x A-fragment): the accumulator then holds the TRANSPOSED 32 x 32
-// block - a lane owns one output ROW and 4 x 4 consecutive columns - which nt8_epilogue_rows stores straight from
-// registers (no LDS transposition).
-template <typename T, bool SW>
-__device__ __forceinline__ f32x16 nt8_mfma(const i32x4& a, const i32x4& b, const f32x16& c) {
-    typedef typename V16<T>::x8 x8;
-    if constexpr (SW) return mfma16<T>(__builtin_bit_cast(x8, b), __builtin_bit_cast(x8, a), c);
-    else return mfma16<T>(__builtin_bit_cast(x8, a), __builtin_bit_cast(x8, b), c);
 }
 
 template <typename T, bool LIVE = true, bool SW = false>
@@ -638,13 +594,6 @@ __device__ __forceinline__ void nt8_mma_issue(f32x16& c0, f32x16& c1, const i32x
     }
 }
 
-#define NT8_BARRIER()                        \
-    do {                                     \
-        __builtin_amdgcn_sched_barrier(0);   \
-        __builtin_amdgcn_s_barrier();        \
-        __builtin_amdgcn_sched_barrier(0);   \
-    } while (0)
-
 // schedule variants (bit mask V): 1 = retire the LDS reads BEFORE the first barrier; 2 = no s_setprio around the MFMAs.
 // (The DMA is always issued AFTER the phase's fragment reads: hipcc puts a vmcnt(0) in front of any LDS read that
 // follows a global_load_lds without a barrier in between.)
@@ -673,19 +622,20 @@ __device__ __forceinline__ void nt8_ktile_m(int t, int nk, const NT8Lane& L, cha
                                             i32x4 (&b1)[4]) {
     constexpr int RB = 128;
     constexpr bool DM = !(V & 4), RD = !(V & 8), MM = !(V & 16);
+    constexpr bool BF = (V & 256) != 0;       // lab ablation (timing only): the B operand costs nothing - no B DMA, no B fragment reads
     const int U = 4 * nk;
     const bool l1 = !TAIL || t + 1 < nk, l2 = !TAIL || t + 2 < nk;
     // ---- phase 0
-    nt8_read<RD>(b0, bP, L);
+    nt8_read<RD && !BF>(b0, bP, L);
     nt8_read<RD>(a0, aP, L);
     nt8_read<RD>(a1, aP + 32 * RB, L);
     if (!TAIL) wait_dma_units<3>();
     else wait_dma_units_rt(min(U, 4 * t + 6) - (4 * t + 3));
     nt8_sync_in<V>();
-    nt8_mma_issue<T, 2, DM, MM, SW>(acc[0][0], acc[1][0], a0, a1, b0, L, smem, t + 1, l1);
+    nt8_mma_issue<T, 2, DM && !BF, MM, SW>(acc[0][0], acc[1][0], a0, a1, b0, L, smem, t + 1, l1);
     nt8_sync_out<V>();
     // ---- phase 1
-    nt8_read<RD>(b1, bP + 32 * RB, L);
+    nt8_read<RD && !BF>(b1, bP + 32 * RB, L);
     if (!TAIL) wait_dma_units<3>();
     else wait_dma_units_rt(min(U, 4 * t + 7) - (4 * t + 4));
     nt8_sync_in<V>();
@@ -701,7 +651,7 @@ __device__ __forceinline__ void nt8_ktile_m(int t, int nk, const NT8Lane& L, cha
     if (!TAIL) wait_dma_units<3>();
     else if (t + 1 < nk) wait_dma_units_rt(min(U, 4 * t + 9) - (4 * t + 6));
     nt8_sync_in<V>();
-    nt8_mma_issue<T, 1, DM, MM, SW>(acc[2][0], acc[3][0], a0, a1, b0, L, smem, t + 2, l2);
+    nt8_mma_issue<T, 1, DM && !BF, MM, SW>(acc[2][0], acc[3][0], a0, a1, b0, L, smem, t + 2, l2);
     nt8_sync_out<V>();
 }
 
@@ -750,74 +700,6 @@ __device__ __forceinline__ void nt8_ktile(int t, int nk, const NT8Lane& L, char*
     nt8_sync_out<V>();
 }
 
-
-// ---- epilogue of the phased kernel with swapped MFMA operands.  acc[i][j] holds the transposed 32 x 32 block: lane
-// (r = lane & 31, h = lane >> 5) owns output row i*32 + r and the columns j*32 + 8 g + 4 h + q (g = e >> 2, q = e & 3):
-// four runs of 4 consecutive columns.  bias + activation + mask in registers, bf16 packing, then v_permlane32_swap
-// between the column groups (g, g + 1) of the two half-waves gives every lane 8 consecutive columns = ONE 16-byte store
-// (lanes 0-31: columns 8 g .., lanes 32-63: columns 8 (g + 1) ..): 16 global_store_dwordx4 per wave for its 128 x 64
-// outputs instead of 256 ds_write_b32 + 64 ds_read_b128 + 64 global_store_dwordx2 through an LDS slab (the epilogue was
-// bound by store ISSUE, not by bandwidth).  Mask words: one 32-bit word per (row, 32-column fragment) per lane - all 8 of
-// a wave tile are fetched before the main loop (bits[]); the forward's mask_out word is assembled from the two
-// half-waves' 16 bits each with one more swap.  Needs whole 64-column wave tiles (N % 64 == 0) and a bf16 output.
-template <typename T, int AUXK>
-__device__ __forceinline__ void nt8_epilogue_rows(const NTParams& p, f32x16 (&acc)[4][2], int lane, int mrow0, int ncol0,
-                                                  const uint32_t (&bits)[4][2]) {
-    if (ncol0 >= p.N) return;                                   // wave-uniform: N is a multiple of 64
-    const int r = lane & 31, h = lane >> 5;
-    f32x4 bias[2][4];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (p.bias) bias[j][g] = *reinterpret_cast<const f32x4*>(p.bias + ncol0 + j * 32 + 8 * g + 4 * h);
-            else bias[j][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = mrow0 + i * 32 + r;
-        const bool row_ok = m < p.M;
-        char* crow = p.C + (int64_t)m * p.ldc + (int64_t)ncol0 * 2 + h * 16;
-        uint32_t mword[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            uint32_t pk[4][2];
-            uint32_t mb = 0;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                T o[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float v = p.alpha * acc[i][j][g * 4 + q] + bias[j][g][q];
-                    if (p.act == ASE_ACT_RELU) v = fmaxf(v, 0.f);
-                    if constexpr (AUXK == 2) v = ((bits[i][j] >> (8 * g + 4 * h + q)) & 1u) ? v : 0.f;
-                    o[q] = from_f32<T>(v);
-                    mb |= ((float)o[q] > 0.f ? 1u : 0u) << (8 * g + 4 * h + q);
-                }
-                pk[g][0] = (uint32_t)__builtin_bit_cast(uint16_t, o[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, o[1]) << 16);
-                pk[g][1] = (uint32_t)__builtin_bit_cast(uint16_t, o[2]) | ((uint32_t)__builtin_bit_cast(uint16_t, o[3]) << 16);
-            }
-#pragma unroll
-            for (int g = 0; g < 4; g += 2) {
-                const auto s0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
-                const auto s1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
-                // lanes 0-31: [own g | upper's g] = columns 8 g .. 8 g + 7; lanes 32-63: [lower's g + 1 | own g + 1]
-                if (row_ok) {
-                    const uint4 out = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-                    *reinterpret_cast<uint4*>(crow + (j * 32 + 8 * g) * 2) = out;
-                }
-            }
-            mword[j] = mb;
-        }
-        if (p.mask_out) {
-            // word j of this row = own 16 bits | the other half-wave's 16 bits
-            const auto w = __builtin_amdgcn_permlane32_swap(mword[0], mword[1], false, false);
-            // after the swap: lanes 0-31 hold (own word 0 bits, upper's word 0 bits); lanes 32-63 (lower's word 1, own word 1)
-            const uint32_t full = w[0] | w[1];
-            if (row_ok) p.mask_out[(int64_t)m * p.ldmask + (ncol0 >> 5) + h] = full;
-        }
-    }
-}
 
 template <typename T, int V, bool SW>
 __global__ __launch_bounds__(512) void gemm_nt8_kernel(NTParams p) {
@@ -1018,7 +900,7 @@ static bool rows_epi(const NTParams& p, int wave_cols) {
 template <typename T> int dispatch_nt(const NTParams& p, hipStream_t s) {
     const bool k128 = (p.K * (int)sizeof(T)) % 128 == 0;       // 128-byte staged rows need K in whole 128-byte steps
 #ifdef ASE_LAB
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (std::is_same<T, bf16_t>::value) {      // (bf16 only: every variant is another kernel instantiation)
         // tuning aid: force one of the co-resident tilings (<= 80 KB of LDS => two workgroups per CU)
         static const int variant = lab_knob("ASE_NT_VARIANT", 0);
         switch (variant) {
@@ -1054,24 +936,31 @@ template <typename T> int dispatch_nt(const NTParams& p, hipStream_t s) {
                 // mask operand absent or a bit matrix; otherwise the LDS-slab epilogue.  DMA issued inside the MFMA block (V = 64).
                 const bool rows_ok = rows_epi(p, 64);
 #ifdef ASE_LAB
-                static const int v8 = lab_knob("ASE_NT8_V", -2);   // ablation builds of the phased kernel (timing only)
-                if (rows_ok && v8 == 128) return launch_nt8<T, 0, true>(p, s);
-                switch (v8) {
-                    case 4: return launch_nt8<T, 4>(p, s);
-                    case 8: return launch_nt8<T, 8>(p, s);
-                    case 12: return launch_nt8<T, 12>(p, s);
-                    case 16: return launch_nt8<T, 16>(p, s);
-                    case 28: return launch_nt8<T, 28>(p, s);
-                    case 32: return launch_nt8<T, 32>(p, s);
-                    case 2: return launch_nt8<T, 2>(p, s);
-                    case 1: return launch_nt8<T, 1>(p, s);
-                    case 66: return launch_nt8<T, 66>(p, s);
-                    case 72: return launch_nt8<T, 72>(p, s);
-                    case 80: return launch_nt8<T, 80>(p, s);
-                    case 0: return launch_nt8<T, 0>(p, s);
-                    default: break;
+                if constexpr (std::is_same<T, bf16_t>::value) {      // ablation builds of the phased kernel (timing only)
+                    static const int v8 = lab_knob("ASE_NT8_V", -2);
+                    if (rows_ok && v8 == 128) return launch_nt8<T, 0, true>(p, s);
+                    switch (v8) {
+                        case 4: return launch_nt8<T, 4>(p, s);
+                        case 8: return launch_nt8<T, 8>(p, s);
+                        case 12: return launch_nt8<T, 12>(p, s);
+                        case 16: return launch_nt8<T, 16>(p, s);
+                        case 28: return launch_nt8<T, 28>(p, s);
+                        case 32: return launch_nt8<T, 32>(p, s);
+                        case 2: return launch_nt8<T, 2>(p, s);
+                        case 1: return launch_nt8<T, 1>(p, s);
+                        case 66: return launch_nt8<T, 66>(p, s);
+                        case 72: return launch_nt8<T, 72>(p, s);
+                        case 80: return launch_nt8<T, 80>(p, s);
+                        case 0: return launch_nt8<T, 0>(p, s);
+                        case 320: return launch_nt8<T, 320, true>(p, s);     // "B operand for free" bound (wrong results)
+                        case 328: return launch_nt8<T, 328, true>(p, s);     // ... and no A fragment reads either
+                        default: break;
+                    }
                 }
 #endif
+                static const int use_packed = lab_knob("ASE_NT_PACKED", 1);
+                if (rows_ok && p.Bp && use_packed && p.M % 256 == 0)
+                    return ase_nt8p_launch(p, std::is_same<T, bf16_t>::value ? ASE_BF16 : ASE_F16, g_nt_prof, s);     // weights from their packed copy, straight into registers
                 if (rows_ok) return launch_nt8<T, 64, true>(p, s);
                 return launch_nt8<T, 64>(p, s);
             }
@@ -1661,36 +1550,62 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const int64_t* __restric
     const int n_real = (int)d[10], k_real = (int)d[11], split_src = (int)d[12], gap = (int)d[13] - (int)d[12];
     const float alpha = __builtin_bit_cast(float, (int)d[14]);
     const int tiles_k = (int)(d[15] & 0xFFFF), shared = (int)((d[15] >> 30) & 1);
-    const int stride = ((n_real + 255) / 256) * tiles_k;
+    const int64_t stride = (int64_t)(((n_real + 255) / 256) * tiles_k) * kTnSlab;
     const int bn0 = (tile / tiles_k) * 256, bk0 = (tile % tiles_k) * 256;
     const float* base = ws + (int64_t)first * kTnSlab;
-    for (int c = q * 4096 + threadIdx.x; c < (q + 1) * 4096; c += 256) {
+    // a workgroup owns 1024 consecutive 16-byte chunks of the tile image (gridDim.y = 16); a thread 4 of them, with the
+    // loads of all four chunks (and of the gradient words they update) in flight together: the kernel is a pure stream of
+    // (splits x 256 KB + 2 x gradient tile) per entry and must not serialise on one load latency per chunk
+    int cidx[4], kk[4], n0[4];
+    bool live[4];
+    f32x4 sum[4];
+    float gold[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c = q * 1024 + u * 256 + threadIdx.x;
         const int lane = c & 63, cc = c >> 6, g = cc & 3, j = (cc >> 2) & 1, i = (cc >> 3) & 3, wid = cc >> 5;
         const int k = bk0 + ((wid & 3) * 2 + j) * 32 + (lane & 31);
-        int kk = -1;
-        if (k < split_src) kk = k;
-        else if (k >= split_src + gap && k - gap < k_real) kk = k - gap;
-        const int n0 = bn0 + ((wid >> 2) * 4 + i) * 32 + (lane >> 5) * 4 + 8 * g;
-        if (kk < 0 || n0 >= n_real) continue;
-        f32x4 sum = *reinterpret_cast<const f32x4*>(base + (int64_t)c * 4);
-        for (int s2 = 1; s2 < splits; ++s2) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(base + (int64_t)s2 * stride * kTnSlab + (int64_t)c * 4);
+        kk[u] = -1;
+        if (k < split_src) kk[u] = k;
+        else if (k >= split_src + gap && k - gap < k_real) kk[u] = k - gap;
+        n0[u] = bn0 + ((wid >> 2) * 4 + i) * 32 + (lane >> 5) * 4 + 8 * g;
+        cidx[u] = c;
+        live[u] = kk[u] >= 0 && n0[u] < n_real;
+        sum[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (live[u]) {
+            sum[u] = *reinterpret_cast<const f32x4*>(base + (int64_t)c * 4);
+            if (!shared) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) sum[e] += v[e];
+                for (int e = 0; e < 4; ++e) gold[u][e] = (n0[u] + e < n_real) ? G[(int64_t)(n0[u] + e) * k_real + kk[u]] : 0.f;
+            }
         }
+    }
+    for (int s2 = 1; s2 < splits; ++s2) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            v[u] = live[u] ? *reinterpret_cast<const f32x4*>(base + s2 * stride + (int64_t)cidx[u] * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum[u][e] += v[u][e];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (!live[u]) continue;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            if (n0 + e >= n_real) break;
-            float* dst = G + (int64_t)(n0 + e) * k_real + kk;
-            if (shared) atomic_add_f32(dst, alpha * sum[e]);
-            else *dst += alpha * sum[e];
+            if (n0[u] + e >= n_real) break;
+            float* dst = G + (int64_t)(n0[u] + e) * k_real + kk[u];
+            if (shared) atomic_add_f32(dst, alpha * sum[u][e]);
+            else *dst = gold[u][e] + alpha * sum[u][e];
         }
     }
     if (q == 0 && gbias && bk0 == 0) {
         const int n = bn0 + threadIdx.x;
         if (n < n_real) {
             float t = 0.f;
-            for (int s2 = 0; s2 < splits; ++s2) t += base[(int64_t)s2 * stride * kTnSlab + 65536 + threadIdx.x];
+            for (int s2 = 0; s2 < splits; ++s2) t += base[s2 * stride + 65536 + threadIdx.x];
             if (shared) atomic_add_f32(gbias + n, alpha * t);
             else gbias[n] += alpha * t;
         }
@@ -1742,7 +1657,7 @@ template <typename T, int V> int launch_tn8g(const int64_t* problems, const int3
         attr_done = true;
     }
     ASE_LAUNCH(kern, dim3(n_work), dim3(512), lds, stream, problems, work, n_work, g_nt_prof, ws);
-    if (ws) ASE_LAUNCH(tn_reduce_kernel, dim3(n_red, 4), dim3(256), 0, stream, problems, red, (const float*)ws);
+    if (ws) ASE_LAUNCH(tn_reduce_kernel, dim3(n_red, 16), dim3(256), 0, stream, problems, red, (const float*)ws);
     ASE_CHECK_LAUNCH("gemm_tn_grouped");
     return ASE_OK;
 }
@@ -1919,6 +1834,10 @@ extern "C" int ase_hip_gemm_nt(const void* A, int64_t lda, const void* B, int64_
     p.M = M; p.N = N; p.K = K; p.act = act; p.aux_mode = aux_mode; p.out_f32 = out_f32; p.alpha = alpha;
     p.tiles_m = p.tiles_n = 0;
     p.prof = nullptr;
+    p.Bp = nullptr;
+    if (es == 2 && K % 64 == 0) {          // a registered packed copy of exactly this matrix (same base, same pitch)
+        p.Bp = ase_packed_lookup(B, ldb);
+    }
     if (dtype == ASE_BF16) return dispatch_nt<bf16_t>(p, (hipStream_t)stream);
     if (dtype == ASE_F16) return dispatch_nt<f16_t>(p, (hipStream_t)stream);
     if (dtype == ASE_F32X3) return dispatch_nt<f32s_t>(p, (hipStream_t)stream);

@@ -1,0 +1,143 @@
+// Pieces of the NT matrix-core kernels shared by gemm.hip and gemm_nt8p.hip (gfx950): tile order, LDS swizzle, launch
+// parameters, the MFMA wrapper with swapped operands and the row-per-lane epilogue of the phased kernels.
+#pragma once
+#include "common.h"
+#include "act.h"
+#include <type_traits>
+
+namespace ase_nt {
+
+
+// Bijective XCD-aware remap: workgroup b runs on XCD b % 8; give each XCD a contiguous tile range.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + loc;
+}
+
+
+// LDS rows are RB = 64 or 128 bytes, unpadded; chunk c (16 B) of row r lives at slot c ^ swz(r):
+//   RB = 128: swz = (r >> 1) & 7   (a 256-byte bank window holds 2 rows x 8 slots)
+//   RB =  64: swz = (r >> 2) & 3   (4 rows x 4 slots)
+// either way the 16 rows (distinct mod 16) of a ds_read_b128 lane group land on 16 distinct slots.
+template <int RB> __device__ __forceinline__ int lds_swz(int r) { return RB == 128 ? ((r >> 1) & 7) : ((r >> 2) & 3); }
+
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+struct NTParams {
+    const char* A; int64_t lda;     // leading dims in BYTES
+    const char* B; int64_t ldb;
+    char* C; int64_t ldc;           // bytes
+    const float* bias;
+    const char* aux; int64_t ldaux; // bytes
+    int aux_split, aux_delta;       // rows m >= aux_split read aux row m - aux_delta (stacked row blocks sharing a mask)
+    float* colsum; int colsum_n;
+    uint32_t* mask_out; int64_t ldmask;   // nullable: bit (m, n) = stored value > 0, 32 columns per word, ldmask in words
+    char* pre_out; int64_t ldpre;         // nullable (smooth activations): the pre-activation z in the storage type, ldpre in bytes
+    int M, N, K;                    // K in elements (multiple of 128/sizeof(T))
+    int act, aux_mode, out_f32;
+    float alpha;
+    int tiles_m, tiles_n;
+    unsigned long long* prof;       // debug: per-workgroup phase timestamps (ase_hip_debug_nt_profile), else null
+    const char* Bp;                 // nullable: B in the packed fragment layout (ase_hip_pack_b), registered for this B
+};
+
+
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+// SW: operands swapped in the MFMA (D = B-fragment x A-fragment): the accumulator then holds the TRANSPOSED 32 x 32
+// block - a lane owns one output ROW and 4 x 4 consecutive columns - which nt8_epilogue_rows stores straight from
+// registers (no LDS transposition).
+template <typename T, bool SW>
+__device__ __forceinline__ f32x16 nt8_mfma(const i32x4& a, const i32x4& b, const f32x16& c) {
+    typedef typename V16<T>::x8 x8;
+    if constexpr (SW) return mfma16<T>(__builtin_bit_cast(x8, b), __builtin_bit_cast(x8, a), c);
+    else return mfma16<T>(__builtin_bit_cast(x8, a), __builtin_bit_cast(x8, b), c);
+}
+
+
+#define NT8_BARRIER()                        \
+    do {                                     \
+        __builtin_amdgcn_sched_barrier(0);   \
+        __builtin_amdgcn_s_barrier();        \
+        __builtin_amdgcn_sched_barrier(0);   \
+    } while (0)
+
+
+// ---- epilogue of the phased kernel with swapped MFMA operands.  acc[i][j] holds the transposed 32 x 32 block: lane
+// (r = lane & 31, h = lane >> 5) owns output row i*32 + r and the columns j*32 + 8 g + 4 h + q (g = e >> 2, q = e & 3):
+// four runs of 4 consecutive columns.  bias + activation + mask in registers, bf16 packing, then v_permlane32_swap
+// between the column groups (g, g + 1) of the two half-waves gives every lane 8 consecutive columns = ONE 16-byte store
+// (lanes 0-31: columns 8 g .., lanes 32-63: columns 8 (g + 1) ..): 16 global_store_dwordx4 per wave for its 128 x 64
+// outputs instead of 256 ds_write_b32 + 64 ds_read_b128 + 64 global_store_dwordx2 through an LDS slab (the epilogue was
+// bound by store ISSUE, not by bandwidth).  Mask words: one 32-bit word per (row, 32-column fragment) per lane - all 8 of
+// a wave tile are fetched before the main loop (bits[]); the forward's mask_out word is assembled from the two
+// half-waves' 16 bits each with one more swap.  Needs whole 64-column wave tiles (N % 64 == 0) and a bf16 output.
+template <typename T, int AUXK>
+__device__ __forceinline__ void nt8_epilogue_rows(const NTParams& p, f32x16 (&acc)[4][2], int lane, int mrow0, int ncol0,
+                                                  const uint32_t (&bits)[4][2]) {
+    if (ncol0 >= p.N) return;                                   // wave-uniform: N is a multiple of 64
+    const int r = lane & 31, h = lane >> 5;
+    f32x4 bias[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (p.bias) bias[j][g] = *reinterpret_cast<const f32x4*>(p.bias + ncol0 + j * 32 + 8 * g + 4 * h);
+            else bias[j][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = mrow0 + i * 32 + r;
+        const bool row_ok = m < p.M;
+        char* crow = p.C + (int64_t)m * p.ldc + (int64_t)ncol0 * 2 + h * 16;
+        uint32_t mword[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            uint32_t pk[4][2];
+            uint32_t mb = 0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                T o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v = p.alpha * acc[i][j][g * 4 + q] + bias[j][g][q];
+                    if (p.act == ASE_ACT_RELU) v = fmaxf(v, 0.f);
+                    if constexpr (AUXK == 2) v = ((bits[i][j] >> (8 * g + 4 * h + q)) & 1u) ? v : 0.f;
+                    o[q] = from_f32<T>(v);
+                    mb |= ((float)o[q] > 0.f ? 1u : 0u) << (8 * g + 4 * h + q);
+                }
+                pk[g][0] = (uint32_t)__builtin_bit_cast(uint16_t, o[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, o[1]) << 16);
+                pk[g][1] = (uint32_t)__builtin_bit_cast(uint16_t, o[2]) | ((uint32_t)__builtin_bit_cast(uint16_t, o[3]) << 16);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                const auto s0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
+                // lanes 0-31: [own g | upper's g] = columns 8 g .. 8 g + 7; lanes 32-63: [lower's g + 1 | own g + 1]
+                if (row_ok) {
+                    const uint4 out = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                    *reinterpret_cast<uint4*>(crow + (j * 32 + 8 * g) * 2) = out;
+                }
+            }
+            mword[j] = mb;
+        }
+        if (p.mask_out) {
+            // word j of this row = own 16 bits | the other half-wave's 16 bits
+            const auto w = __builtin_amdgcn_permlane32_swap(mword[0], mword[1], false, false);
+            // after the swap: lanes 0-31 hold (own word 0 bits, upper's word 0 bits); lanes 32-63 (lower's word 1, own word 1)
+            const uint32_t full = w[0] | w[1];
+            if (row_ok) p.mask_out[(int64_t)m * p.ldmask + (ncol0 >> 5) + h] = full;
+        }
+    }
+}
+
+
+}  // namespace ase_nt
+
+// gemm_nt8p.hip: the phased kernel with packed weights (dtype ASE_BF16 / ASE_F16; p.Bp set), and the registry of packed copies
+int ase_nt8p_launch(const ase_nt::NTParams& p, int dtype, unsigned long long* prof, hipStream_t stream);
+const char* ase_packed_lookup(const void* B, int64_t ldb);

@@ -27,7 +27,7 @@ struct PpoArgs {
     void* d_value; int64_t ld_dv;
     float *db_mu, *db_value, *mu_out;
     double* acc;
-    double* scratch;              // ticket word, then [gridDim.x][kPpoSlots] per-workgroup partial sums (no contended atomics)
+    double* scratch;              // [8 spare] then [gridDim.x][kPpoSlots] per-workgroup partial sums (no contended atomics)
     int M, m_global, act_dim, z_dim, masked, div_on, mu_tanh, clip_value;
     float e_clip, critic_coef, bounds_coef, div_coef, div_tar;
     float gs, inv_gs;             // the stored head gradients carry the static gradient scale (f16 storage), the bias gradients do not
@@ -163,9 +163,9 @@ __global__ __launch_bounds__(256) void ppo_head_kernel(PpoArgs p) {
         }
     }
     // Every workgroup leaves its partial sums (7 loss sums in f64, the head-bias column sums of its rows) in its scratch
-    // slab - 1024 workgroups adding to the same 40 addresses with atomics cost ~20 us of this kernel - and takes a ticket;
-    // the LAST workgroup to arrive folds all slabs into the accumulators / bias gradients and resets the ticket.
-    double* const slabs = p.scratch + 8;               // (the first word of the workspace is the ticket)
+    // slab - 1024 workgroups adding to the same 40 addresses with atomics cost ~20 us of this kernel; ppo_head_fold_kernel
+    // folds the slabs.
+    double* const slabs = p.scratch + 8;
     double* mine = slabs + (int64_t)blockIdx.x * kPpoSlots;
     sdb[rib][lane] = gm_out + gm2_out;
     if (lane == 0) sdb[rib][LPR] = dv_out;
@@ -181,25 +181,19 @@ __global__ __launch_bounds__(256) void ppo_head_kernel(PpoArgs p) {
 #pragma unroll
         for (int k = 0; k < 7; ++k) mine[k] = part[k];
     }
-    __shared__ int last;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned int* ticket = reinterpret_cast<unsigned int*>(p.scratch);
-        last = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1 : 0;
-        if (last) *ticket = 0;                           // the next launch starts from 0 (stream order)
-    }
-    __syncthreads();
-    if (!last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();
-    // fold: thread (c, g) sums slot c over the workgroups b = g, g + 4, ...; the four groups meet in LDS
+}
+
+// second stage (a kernel boundary is the cheapest agent-scope release / acquire there is: a per-workgroup release fence
+// - one L2 write-back each - made the 1024-workgroup kernel 6x slower): ONE workgroup folds the slabs into the accumulators
+// and the head-bias gradients.  Thread (c, g) sums slot c over the workgroups b = g, g + 4, ...; the four groups meet in LDS.
+__global__ __launch_bounds__(256) void ppo_head_fold_kernel(const double* __restrict__ slabs, int nblocks, double* __restrict__ acc,
+                                                            float* __restrict__ db_mu, float* __restrict__ db_value, int act_dim,
+                                                            int div_on) {
     __shared__ double fold[4][kPpoSlots];
     const int c = threadIdx.x & 63, g4 = threadIdx.x >> 6;
     for (int cc = c; cc < kPpoSlots; cc += 64) {
         double t = 0.0;
-        for (int b = g4; b < (int)gridDim.x; b += 4) t += slabs[(int64_t)b * kPpoSlots + cc];
+        for (int b = g4; b < nblocks; b += 4) t += slabs[(int64_t)b * kPpoSlots + cc];
         fold[g4][cc] = t;
     }
     __syncthreads();
@@ -208,11 +202,11 @@ __global__ __launch_bounds__(256) void ppo_head_kernel(PpoArgs p) {
         const double t = fold[0][cc] + fold[1][cc] + fold[2][cc] + fold[3][cc];
         if (cc < 7) {
             const int slot[7] = {ASE_ACC_A_LOSS, ASE_ACC_B_LOSS, ASE_ACC_ENTROPY, ASE_ACC_CLIPPED, ASE_ACC_C_LOSS, ASE_ACC_KL, ASE_ACC_DIV};
-            if (cc < 6 || p.div_on) p.acc[slot[cc]] += t;
-        } else if (p.db_mu) {
+            if (cc < 6 || div_on) acc[slot[cc]] += t;
+        } else if (db_mu) {
             const int j = cc - 7;
-            if (j < p.act_dim) atomic_add_f32(p.db_mu + j, (float)t);
-            else if (j == 64 && p.db_value) atomic_add_f32(p.db_value, (float)t);
+            if (j < act_dim) atomic_add_f32(db_mu + j, (float)t);
+            else if (j == 64 && db_value) atomic_add_f32(db_value, (float)t);
         }
     }
 }
@@ -542,6 +536,8 @@ extern "C" int ase_hip_ppo_head(const float* mu, int64_t ld_mu, const float* val
         return ASE_OK;
     });
     ASE_CHECK_ARG(rc == ASE_OK, "ppo_head: bad dtype %d", dtype);
+    ASE_LAUNCH(ppo_head_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)(scratch + 8), (int)grid.x, acc, db_mu,
+               db_value, act_dim, div_on);
     ASE_CHECK_LAUNCH("ppo_head");
     return ASE_OK;
 }

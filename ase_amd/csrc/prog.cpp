@@ -7,7 +7,7 @@ void ase_set_error(const char* fmt, ...);
 
 struct AseProgram {
     struct Entry {
-        int kind;                // 0 launch closure, 1 record event, 2 wait event
+        int kind;                // 0 launch closure, 1 record event, 2 wait event, 3 host callback
         hipStream_t stream;
         int ev;
         std::function<void(hipStream_t)> fn;
@@ -78,7 +78,7 @@ extern "C" int ase_hip_prog_launch(void* prog) {
     AseProgram* pg = static_cast<AseProgram*>(prog);
     if (!pg || g_recording == pg) { ase_set_error("prog_launch: null program or still recording"); return ASE_EINVAL; }
     for (auto& e : pg->entries) {
-        if (e.kind == 0) e.fn(e.stream);
+        if (e.kind == 0 || e.kind == 3) e.fn(e.stream);
         else if (e.kind == 1) (void)hipEventRecord(pg->events[e.ev], e.stream);
         else (void)hipStreamWaitEvent(e.stream, pg->events[e.ev], 0);
     }
@@ -112,6 +112,16 @@ extern "C" int ase_hip_wait(void* stream, int id) {
     }
     if (id < 0 || id >= kPool || !g_pool_ready) { ase_set_error("wait: bad event id %d", id); return ASE_EINVAL; }
     if (hipStreamWaitEvent((hipStream_t)stream, g_pool[id], 0) != hipSuccess) { ase_set_error("wait: hipStreamWaitEvent failed"); return ASE_ELAUNCH; }
+    return ASE_OK;
+}
+
+extern "C" int ase_hip_prog_host(void (*fn)(void*), void* arg) {
+    if (!fn) { ase_set_error("prog_host: null callback"); return ASE_EINVAL; }
+    if (AseProgram* pg = g_recording) {
+        pg->entries.push_back({3, nullptr, -1, [=](hipStream_t) { fn(arg); }});
+        return ASE_OK;
+    }
+    fn(arg);
     return ASE_OK;
 }
 

@@ -217,6 +217,22 @@ class UpdateEngine:
                 ob, _ = net.param_slices[name + '.bias']
                 d.b.append(self.params[ob:ob + nr])
                 d.gb.append(self.grads[ob:ob + nr])
+        # Packed MFMA-fragment copies of the 16-bit shadows (ase_hip_pack_b): launches that take the phased 256 x 256 kernel
+        # read the weights from them straight into registers (no LDS round trip for B).  Registered once with the library
+        # (same base pointer + pitch => ase_hip_gemm_nt may use the packed copy), re-packed behind every optimizer launch.
+        self._packed = T in (torch.bfloat16, torch.float16) and hasattr(self.be, 'pack_b_multi') and self.cfg.get('packed_weights', True)
+        self._pack_rows = {}
+        if self._packed:
+            for d in self.layers:
+                rows = []
+                for B in (d.Ws, d.Wts):
+                    N, K = B.shape
+                    if N >= 256 and K % 64 == 0:
+                        Bp = torch.zeros(self.be.packed_bytes(N, K), dtype=torch.uint8, device=dev)
+                        self.be.pack_register(B, Bp)
+                        rows.append([B.data_ptr(), B.stride(0), N, K, Bp.data_ptr(), 0])
+                        d.__dict__.setdefault('packed', []).append((B, Bp))
+                self._pack_rows[id(d)] = rows
         o, shp = net.param_slices['sigma']
         self.logstd = self.params[o:o + shp[0]]
         # weight-only loss terms (learning/amp_agent.py:449-466, learning/ase_agent.py:420-425): ranges of the flat buffer
@@ -361,6 +377,35 @@ class UpdateEngine:
             self._refresh_desc = torch.tensor(rows, dtype=torch.int64, device=self.dev)
             self._refresh_items = items
         self.be.refresh_shadow_multi(self._refresh_desc, self._refresh_items, self.dtype)
+        self._pack(None)
+
+    def close(self):
+        """Forget the packed-copy registrations of this engine's shadows (the library keys them by address: a later tensor
+        at a recycled address must not inherit them)."""
+        if getattr(self, '_packed', False):
+            for d in self.layers:
+                for B, Bp in d.__dict__.get('packed', []):
+                    try:
+                        self.be.pack_register(B, None)
+                    except Exception:
+                        pass
+            self._packed = False
+
+    def __del__(self):
+        self.close()
+
+    def _pack(self, group):
+        """Re-pack the fragment copies of a parameter group's shadows (None: all layers) - one launch."""
+        if not self._packed:
+            return
+        if not hasattr(self, '_pack_desc'):
+            pol = self.style + self.actor + [self.mu_head] + self.critic + [self.value_head]
+            mk = lambda ls: (torch.tensor([r for d in ls for r in self._pack_rows[id(d)]], dtype=torch.int64, device=self.dev)
+                             if any(self._pack_rows[id(d)] for d in ls) else None)
+            self._pack_desc = {None: mk(self.layers), 'policy': mk(pol), 'disc': mk([d for d in self.layers if d not in pol])}
+        desc = self._pack_desc[group]
+        if desc is not None:
+            self.be.pack_b_multi(desc, self.dtype)
 
     def _build_apply_desc(self):
         """Pointer table of ase_hip_apply_multi: per weight matrix its parameter / gradient / Adam-moment slices, the
@@ -699,8 +744,9 @@ class UpdateEngine:
             if self._dist_on():
                 self._ar(self.grads[lo:hi])
                 if not self.shard:
-                    self.grads[lo:hi].mul_(1.0 / self.R)
+                    self._host(lambda: self.grads[lo:hi].mul_(1.0 / self.R))
             self.be.apply_multi(self._apply_desc[a:b], self._apply_items[a:b], self.dtype, self.opt_state, self.acc)
+            self._pack(group)
 
     # ---- phase B: normalise, forward, loss heads, backward -----------------------------------------
     def phase_main(self, ds, idx, remap, amp_streams=None, new_z=None, inline_apply=False):
@@ -868,6 +914,7 @@ class UpdateEngine:
             # weight-only loss terms + their reported norms + Adam + shadow refresh of every layer: ONE launch
             self._build_apply_desc()
             be.apply_multi(self._apply_desc, self._apply_items, self.dtype, self.opt_state, self.acc)
+            self._pack(None)
         else:
             if self.has_disc:
                 # weight-only loss terms, added once after the gradient reduction
@@ -1059,17 +1106,35 @@ class UpdateEngine:
                 self._dgrad(d, self.dZd[l], self.dZd[l - 1], Rd, self.Hd[l - 1], pl.act)
 
     # ------------------------------------------------------------------ collectives (single rank: no-ops)
+    def _host(self, fn):
+        """A torch-level operation INSIDE the step (the collectives of the exchange points and the few tensor operations
+        around them): executed now on the current stream, or - while the backend records a launch program - recorded as a
+        host callback at this position of the sequence and executed on every replay, on the stream that is current NOW
+        (kernel launches are not the only things a replay must repeat: a program that dropped them would exchange nothing)."""
+        if self.dev.type != 'cuda':
+            self.be.host_call(fn)
+            return
+        s = torch.cuda.current_stream(self.dev)
+
+        def run():
+            with torch.cuda.stream(s):
+                fn()
+        self.be.host_call(run)
+
     def _ar(self, t):
         """SUM all-reduce of a device tensor over the data-parallel group: RCCL over xGMI in production (backend
         'nccl').  With the 'gloo' backend (CPU test rigs, or several ranks sharing one GPU) device tensors are staged
         through the host."""
         import torch.distributed as dist
-        if t.is_cuda and dist.get_backend() == 'gloo':
-            h = t.cpu()
-            dist.all_reduce(h)
-            t.copy_(h)
-        else:
-            dist.all_reduce(t)
+
+        def run():
+            if t.is_cuda and dist.get_backend() == 'gloo':
+                h = t.cpu()
+                dist.all_reduce(h)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t)
+        self._host(run)
 
     def _dist_on(self):
         return self.R > 1 or self.force_dist
@@ -1077,10 +1142,10 @@ class UpdateEngine:
     def _allreduce_stats(self):
         if self._dist_on() and self.shard:
             if self.masked:
-                self.stats_flat[-1:].copy_(self.acc[L.ACC_MASK_SUM:L.ACC_MASK_SUM + 1])
+                self.be.copy_(self.stats_flat[-1:], self.acc[L.ACC_MASK_SUM:L.ACC_MASK_SUM + 1])
             self._ar(self.stats_flat)
             if self.masked:
-                self.acc[L.ACC_MASK_SUM:L.ACC_MASK_SUM + 1].copy_(self.stats_flat[-1:])
+                self.be.copy_(self.acc[L.ACC_MASK_SUM:L.ACC_MASK_SUM + 1], self.stats_flat[-1:])
 
     def _allreduce_grads(self):
         if self._dist_on():
@@ -1089,11 +1154,10 @@ class UpdateEngine:
                 self._ar(self.acc[1:])              # slot 0 (mask sum) is already global
             else:
                 # Horovod semantics: every rank's loss is complete on its own minibatch; the optimizer sees the AVERAGE
-                self.grads[:self.n_train].mul_(1.0 / self.R)
+                self._host(lambda: self.grads[:self.n_train].mul_(1.0 / self.R))
 
     def _identity_stats(self, mean, std):
-        mean.zero_()
-        std.fill_(1.0)
+        self._host(lambda: (mean.zero_(), std.fill_(1.0)))
 
     # ------------------------------------------------------------------ results
     def results(self, snapshot=False):

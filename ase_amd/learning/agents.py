@@ -552,15 +552,18 @@ class CommonAgent:
                             the engine's three streams, replayed with ~1 us of host work per launch, branch -> stream mapping
                             fixed by us;
           'hipgraph'        a captured hipGraph (torch.cuda.CUDAGraph): the runtime chooses how its branches map to queues.
-        Single GPU: one program for the whole step.  Data parallel: three (local statistics | forward-backward | optimizer)
-        with the RCCL all-reduces issued between them.  One program (set) per minibatch position: the index tensors are
+        Launch programs: ONE program for the whole step, data parallel included - the collectives are host-callback entries
+        of the program (ase_hip_prog_host) at the positions the eager step issues them, so the discriminator bucket's
+        all-reduce overlaps the policy branch's backward exactly as in eager mode.  Captured hipGraphs cannot hold a
+        collective of another library: data parallel = three graphs (local statistics | forward-backward | optimizer) with
+        the all-reduces between them.  One program (set) per minibatch position: the index tensors are
         slices of persistent per-mini-epoch buffers (permutation, composed demo / replay indices), so a replay needs no
         copies."""
         eng = self.engine
         key = (int(idx.data_ptr()),) + (tuple((int(s[0].data_ptr()), int(s[1].data_ptr())) for s in streams) if streams else ())
         g = self._graphs.get(key)
         hipgraph = self.config.get('graph_capture') == 'hipgraph'
-        single = self.world_size == 1 and not eng.force_dist
+        single = (self.world_size == 1 and not eng.force_dist) or not hipgraph
         if g is None:
             eng.step(self._ds, idx, self._remap, streams)                # this call's real step; also warms up lazies
             torch.cuda.synchronize()

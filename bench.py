@@ -12,8 +12,11 @@ One "step" = one whole update of one rollout batch = everything ``train_epoch`` 
 loop: AMP/encoder rewards, GAE, advantage + value normalisation, demo/replay sampling, 48 minibatch
 optimisation steps (normalisers, 4 MLPs forward/backward, losses incl. gradient penalty + diversity, Adam),
 replay store.  Inputs (the synthetic experience buffer) are resident in HBM before the timed
-region.  With N > 1 every minibatch is row-sharded over the ranks (strong scaling, BASELINE config 3) and the
-flat gradient buffer is all-reduced over RCCL/xGMI each optimisation step.
+region.  With N > 1 (one process per GPU) the default is the reference's own multi-GPU semantics (rl_games HorovodWrapper,
+learning/common_agent.py:94-107): every rank owns 4096 environments and draws its own 16384-row minibatches, the gradient
+buckets are averaged by RCCL all-reduces over xGMI (the discriminator bucket while the policy branch is still in its
+backward) - weak scaling, `value` = all ranks' samples / max-over-ranks time.  `--dp-mode shard` row-shards every minibatch
+of the SAME 4096 environments over the ranks instead (the R-rank update equals the 1-rank update; strong scaling).
 
 Prints ONE JSON line on rank 0.
 """
@@ -183,7 +186,7 @@ def algorithmic_flops_per_step(eng):
     return f
 
 
-def make_agent(device, precision, use_graph, world, rank, seed=0, force_dist=False, multi_stream=True):
+def make_agent(device, precision, use_graph, world, rank, seed=0, force_dist=False, multi_stream=True, dp_mode='horovod'):
     from ase_amd.learning import agents, models
     from ase_amd.learning.network_builder import ASEBuilder
     from ase_amd.synthetic import EnvSpec, SyntheticSource
@@ -196,11 +199,12 @@ def make_agent(device, precision, use_graph, world, rank, seed=0, force_dist=Fal
     b = ASEBuilder()
     b.load(net_p)
     sp = lambda n: types.SimpleNamespace(shape=(n,))
-    src = SyntheticSource(spec, seed=1234 + 2)
+    # 'horovod' (weak scaling): every rank owns its own 4096 environments - a different synthetic stream per rank
+    src = SyntheticSource(spec, seed=1234 + 2 + (0 if dp_mode == 'shard' else 1009 * rank))
     cfg = dict(cfg)
     cfg.update(network=models.ModelASEContinuous(b), num_actors=spec.num_envs, device=device, precision=precision,
                graph_capture=use_graph, world_size=world, rank=rank, vec_env=src, force_dist=force_dist,
-               multi_stream=multi_stream,
+               multi_stream=multi_stream, dp_mode=dp_mode,
                env_info={'observation_space': sp(253), 'action_space': sp(31), 'amp_observation_space': sp(1400)})
     return agents.ASEAgent('bench', cfg), cfg, spec
 
@@ -398,6 +402,11 @@ def main():
                     'state) and throughput are reported beside the headline (comma list of bf16,f16,f32,bf16x3; "" = headline only)')
     ap.add_argument('--no-parity-mode', action='store_true', help='same as --modes ""')
     ap.add_argument('--force-dist', action='store_true', help='run the collectives even with one rank (RCCL smoke)')
+    ap.add_argument('--dp-mode', default='horovod', choices=['horovod', 'shard'],
+                    help='N > 1: horovod = the reference\'s own multi-GPU semantics (rl_games HorovodWrapper, learning/common_agent.py:'
+                         '94-107): every rank owns 4096 environments and its own 16384-row minibatches, gradients averaged by one RCCL '
+                         'all-reduce per branch and step - WEAK scaling, per-GPU work fixed; shard = the same 4096 environments with '
+                         'every minibatch row-sharded over the ranks (the R-rank update equals the 1-rank update) - STRONG scaling')
     ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'])
     ap.add_argument('--breakdown', action='store_true', help='per-shape GEMM time table on stderr')
     ap.add_argument('--verbose', action='store_true', help='per-update times on stderr')
@@ -425,8 +434,10 @@ def main():
     t_setup = time.time()
     _dbg('init done')
     agent, cfg, spec = make_agent(device, args.precision, use_graph, world, rank, force_dist=args.force_dist,
-                                   multi_stream=not args.no_multi_stream)
-    B = agent.batch_size
+                                   multi_stream=not args.no_multi_stream, dp_mode=args.dp_mode)
+    weak = world > 1 and args.dp_mode == 'horovod'
+    Bl = agent.batch_size                                    # this rank's samples per update
+    B = Bl * (world if weak else 1)                          # samples of one update over ALL ranks
     _dbg('agent built')
 
     # ---- untimed: synthetic rollout into HBM (the policy outputs come from the engine's own inference path)
@@ -500,9 +511,9 @@ def main():
         eng.be = tb._be
         eng.multi_stream = ms_flag
         agent.use_graph = use_graph
-        n_opt = cfg['mini_epochs'] * (B // cfg['minibatch_size'])
-        alg = algorithmic_flops_per_step(eng) * n_opt + 2.0 * B * sum(d.N * d.K for d in eng.disc) \
-            + 2.0 * B * (1 + eng.z) * eng.disc_head.K
+        n_opt = cfg['mini_epochs'] * (Bl // cfg['minibatch_size'])
+        alg = algorithmic_flops_per_step(eng) * n_opt + 2.0 * Bl * sum(d.N * d.K for d in eng.disc) \
+            + 2.0 * Bl * (1 + eng.z) * eng.disc_head.K
         gemm_ms = sum(v['ms'] for v in summ.values())
         launches = sum(v['launches'] for v in summ.values())
         peak = MFMA_PEAK_TFLOPS[args.precision]
@@ -583,15 +594,18 @@ def main():
     if rank == 0:
         out = {'metric': 'ASE PPO-update samples/sec (4096 envs x horizon 32)', 'value': round(value, 1),
                'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-               'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'strong',
+               'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'strong' if (world > 1 and not weak) else 'weak',
                'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
                'config': {'workload': 'BASELINE configs[1]: ASE agent, 4096 envs x horizon 32, obs 253 / act 31 / amp obs '
                                       '1400 / latent 64, [1024,1024,512] MLPs + disc + shared-trunk encoder, minibatch 16384 '
                                       '(amp 4096) x 6 mini-epochs = 48 optimisation steps per update; random-init weights',
-                          'samples_per_step': B, 'optimisation_steps_per_step': cfg['mini_epochs'] * (B // cfg['minibatch_size']),
+                          'samples_per_step': B, 'optimisation_steps_per_step': cfg['mini_epochs'] * (Bl // cfg['minibatch_size']),
                           'ms_epoch_tail': round(ms_tail, 3), 'ms_optimisation_steps_only': round(ms_per_step - ms_tail, 3),
-                          'replay': use_graph if use_graph else 'eager', 'parallelism': f'dp{world} (minibatch rows sharded, RCCL grad all-reduce)'
-                          if world > 1 else 'single GPU'},
+                          'replay': use_graph if use_graph else 'eager',
+                          'parallelism': 'single GPU' if world == 1 else
+                          (f'dp{world}, the reference\'s Horovod semantics: 4096 environments and a 16384-row minibatch per GPU, gradients '
+                           'averaged by RCCL all-reduce (one bucket per branch, overlapped with the other branches\' backward)' if weak else
+                           f'dp{world}, every 16384-row minibatch row-sharded over the ranks, RCCL gradient all-reduce (sum)')},
                'roofline': roof, 'cpu_baseline': cpu, 'qualifying_mode': qualifying, 'modes': modes,
                'parity': (modes.get(args.precision) or {}).get('parity'),
                'last_train_result': {k: round(v, 6) for k, v in last.items()}}

@@ -117,6 +117,19 @@ int ase_hip_gemm_tn_grouped_plan(int64_t* problems, int n_problems, int target_w
 int ase_hip_gemm_tn_grouped(const int64_t* problems, const int32_t* work, int n_work, const int32_t* red, int n_red,
                             float* workspace, int dtype, void* stream);
 
+/* Packed copy of a weight matrix for the phased NT kernel: B [N, K] (16-bit, K % 64 == 0) as 1-KiB chunks
+ * [8 ceil(N / 256)][K / 16][64 lanes][8 k-values] - chunk (nt, kc), lane (r = l & 31, h = l >> 5) = B[32 nt + r][16 kc + 8 h ..]:
+ * what one lane of a 32 x 32 x 16 MFMA operand holds, so a fragment is ONE coalesced 16-byte load per lane from L2 into
+ * registers and the weights never touch the LDS (which then carries the activations only, prefetched three K-tiles deep).
+ * Bp needs ASE_PACKED_BYTES(N, K) bytes (n-tiles up to a whole 256-row tile); rows >= N are zero.  ase_hip_pack_register(B, ldb, Bp) tells ase_hip_gemm_nt that
+ * launches with exactly this B (base pointer and pitch) may read the packed copy instead (Bp NULL: forget B); the OWNER of
+ * the weights re-packs after every change (the engine: right behind the optimizer launch).  desc of the multi form:
+ * DEVICE int64[n][6] = {B, ldb, N, K, Bp, 0}.  (No reference counterpart.) */
+#define ASE_PACKED_BYTES(N, K) ((int64_t)(((N) + 255) / 256 * 8) * ((K) / 16) * 1024)
+int ase_hip_pack_b(const void* B, int64_t ldb, int N, int K, void* Bp, int dtype, void* stream);
+int ase_hip_pack_b_multi(const int64_t* desc, int n, int dtype, void* stream);
+int ase_hip_pack_register(const void* B, int64_t ldb, const void* Bp);
+
 /* Shadow copies of one weight matrix for the matrix cores: W_s [n_pad,k_pad] and its transpose
  * Wt_s [k_pad,n_pad] (both dtype, zero padded, concat columns moved to split_dst).  Run after
  * every optimizer step.  (No reference counterpart: the reference multiplies f32 masters.) */
@@ -222,9 +235,9 @@ int ase_hip_reduce_sum(const float* x, int64_t n, int square, double* acc, int s
  *            scalars are not) - the static loss scale of ASE_F16 storage, whose back-propagated gradients would
  *            otherwise fall into half's subnormal range; the weight-gradient launches undo it through their alpha.
  *            The counterpart of the reference's GradScaler (learning/ase_agent.py:216,271-288).  1 for bf16 / f32.
- *   scratch: device f64[ASE_PPO_SCRATCH] workspace, ZEROED once by the caller and private to one launch at a time:
- *            per-workgroup partial sums (loss scalars, head-bias column sums) + a ticket word; the last workgroup to arrive
- *            folds them into acc / db_* (no contended atomics, no second launch) and resets the ticket. */
+ *   scratch: device f64[ASE_PPO_SCRATCH] workspace, private to one launch at a time: per-workgroup partial sums (loss
+ *            scalars, head-bias column sums), folded into acc / db_* by a second one-workgroup kernel of the same call (no
+ *            contended atomics; a kernel boundary instead of per-workgroup fences). */
 #define ASE_PPO_SCRATCH (1024 * 72 + 8)
 int ase_hip_ppo_head(const float* mu, int64_t ld_mu, const float* value, int64_t ld_v,
                      const float* mb_actions, const float* mb_old_mu, const float* mb_old_sigma,
@@ -412,6 +425,12 @@ int ase_hip_prog_begin(void* prog);
 int ase_hip_prog_end(void* prog);
 int ase_hip_prog_size(void* prog);          /* entries recorded (launches + fork / join points); < 0: null program */
 int ase_hip_prog_launch(void* prog);
+/* A HOST callback at this position of the sequence: called immediately outside a recording, on every replay inside one.
+ * This is how the exchange points of the data-parallel update (the RCCL all-reduce of a branch's gradient bucket, issued while
+ * the other branches' backward launches are still being replayed - learning/common_agent.py:94-107, the Horovod optimizer's
+ * gradient hooks) live inside ONE launch program; fn runs on the replaying thread and must enqueue its work on a stream
+ * itself. */
+int ase_hip_prog_host(void (*fn)(void*), void* arg);
 int ase_hip_mark(void* stream, int* id);
 int ase_hip_wait(void* stream, int id);
 int ase_hip_memset(void* dst, int value, int64_t bytes, void* stream);

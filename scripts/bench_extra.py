@@ -7,6 +7,9 @@ rollout-time inference path.  One JSON line per measurement on stdout.
   hrl   : config 4's high-level PPO update (obs 258, action 64, [1024, 512]), 4096 x 32 batch
   ase16k: config 5's batch (16384 envs x 32 = 524288 samples, 192 optimisation steps), ASE nets
   ase-f32 / ase-bf16x3: config 2 in the parity / split precision modes
+  shard : ONE rank's share of the sharded data-parallel update (BASELINE configs[2]) on one GPU, for R = 2, 4, 8 ranks: the
+          48 optimisation steps of an update at minibatch 16384 / R, amp minibatch 4096 / R (--shard-of R[,R...]); no collectives
+          - the compute side of the scaling curve the driver's 8-GPU run would take, and the launch count it has to hide
   infer : get_action_values (eval-mode normalisation + actor + critic forward + sample) on 4096 observations
 """
 import argparse
@@ -22,7 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def build(kind, num_envs, precision, graph=True):
+def build(kind, num_envs, precision, graph=True, overrides=None):
     from ase_amd import cfg as defaults
     from ase_amd.learning import agents, models
     from ase_amd.learning.network_builder import AMPBuilder, ASEBuilder, HRLBuilder
@@ -40,6 +43,7 @@ def build(kind, num_envs, precision, graph=True):
     b.load(net_p)
     sp = lambda n: types.SimpleNamespace(shape=(n,))
     cfg = dict(cfg)
+    cfg.update(overrides or {})
     info = {'observation_space': sp(obs), 'action_space': sp(act)}
     if amp:
         info['amp_observation_space'] = sp(amp)
@@ -75,7 +79,34 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--updates', type=int, default=4)
     ap.add_argument('--only', default='')
+    ap.add_argument('--shard-of', default='', help='comma list of rank counts R: time one rank\'s share of the sharded update')
+    ap.add_argument('--precision', default='bf16')
     args = ap.parse_args()
+    if args.shard_of:
+        for R in [int(x) for x in args.shard_of.split(',')]:
+            ag, cfg, spec = build('ase', 4096, args.precision, overrides={'minibatch_size': 16384 // R, 'amp_minibatch_size': 4096 // R})
+
+            def one():
+                return ag.update(ag._play_steps_tail(), max_steps=48)
+            for _ in range(3):
+                one()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.updates):
+                one()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / args.updates
+            progs = [g for g in ag._graphs.values() if not g['hipgraph']]
+            entries = max((sum(ag.backend.prog_size(p) for p in g['graphs']) for g in progs), default=0)
+            print(json.dumps({'measurement': f'shard-of-{R}', 'what': 'one rank\'s compute of the sharded data-parallel update: 48 '
+                              f'optimisation steps at minibatch {16384 // R} / amp {4096 // R} rows + the epoch tail (whole batch: the tail '
+                              'is sharded too in the real run), no collectives', 'ranks': R, 'ms_per_update': round(dt * 1e3, 3),
+                              'us_per_step': round(dt * 1e6 / 48, 1), 'program_entries_per_step': entries, 'precision': args.precision,
+                              'allreduce_bytes_per_step': int(ag.model.a2c_network.trainable_numel) * 4,
+                              'ideal_us_per_step_from_1gpu': None}), flush=True)
+            del ag
+            torch.cuda.empty_cache()
+        return
     runs = [('amp', 'amp', 4096, 'bf16'), ('hrl', 'hrl', 4096, 'bf16'), ('ase16k', 'ase', 16384, 'bf16'),
             ('ase-f32', 'ase', 4096, 'f32'), ('ase-bf16x3', 'ase', 4096, 'bf16x3')]
     for name, kind, envs, prec in runs:
