@@ -186,18 +186,6 @@ class HipBackend:
                                                  plan['n_red'], _ptr(plan['ws']), plan['dtype'], self._stream()),
                 "gemm_tn_grouped")
 
-    # packed MFMA-fragment copies of weight matrices (the phased NT kernel reads them straight into registers)
-    @staticmethod
-    def packed_bytes(N, K):
-        return ((N + 255) // 256 * 8) * (K // 16) * 1024
-
-    def pack_b_multi(self, desc, dtype):
-        """desc: device int64 [n, 6] = {B, ldb, N, K, Bp, 0} (ase_hip.h)."""
-        L.check(self.lib.ase_hip_pack_b_multi(_ptr(desc), desc.shape[0], _code(dtype), self._stream()), "pack_b_multi")
-
-    def pack_register(self, B, Bp):
-        L.check(self.lib.ase_hip_pack_register(_ptr(B), _ld(B), _ptr(Bp)), "pack_register")
-
     def refresh_shadow(self, W, Ws, Wts, split_src, split_dst):
         n, k = W.shape
         ref = Ws if Ws is not None else Wts

@@ -958,9 +958,6 @@ template <typename T> int dispatch_nt(const NTParams& p, hipStream_t s) {
                     }
                 }
 #endif
-                static const int use_packed = lab_knob("ASE_NT_PACKED", 1);
-                if (rows_ok && p.Bp && use_packed && p.M % 256 == 0)
-                    return ase_nt8p_launch(p, std::is_same<T, bf16_t>::value ? ASE_BF16 : ASE_F16, g_nt_prof, s);     // weights from their packed copy, straight into registers
                 if (rows_ok) return launch_nt8<T, 64, true>(p, s);
                 return launch_nt8<T, 64>(p, s);
             }
@@ -1834,10 +1831,6 @@ extern "C" int ase_hip_gemm_nt(const void* A, int64_t lda, const void* B, int64_
     p.M = M; p.N = N; p.K = K; p.act = act; p.aux_mode = aux_mode; p.out_f32 = out_f32; p.alpha = alpha;
     p.tiles_m = p.tiles_n = 0;
     p.prof = nullptr;
-    p.Bp = nullptr;
-    if (es == 2 && K % 64 == 0) {          // a registered packed copy of exactly this matrix (same base, same pitch)
-        p.Bp = ase_packed_lookup(B, ldb);
-    }
     if (dtype == ASE_BF16) return dispatch_nt<bf16_t>(p, (hipStream_t)stream);
     if (dtype == ASE_F16) return dispatch_nt<f16_t>(p, (hipStream_t)stream);
     if (dtype == ASE_F32X3) return dispatch_nt<f32s_t>(p, (hipStream_t)stream);

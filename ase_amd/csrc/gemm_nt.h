@@ -1,4 +1,4 @@
-// Pieces of the NT matrix-core kernels shared by gemm.hip and gemm_nt8p.hip (gfx950): tile order, LDS swizzle, launch
+// Pieces of the NT matrix-core kernels (gfx950) kept in a header: tile order, LDS swizzle, launch
 // parameters, the MFMA wrapper with swapped operands and the row-per-lane epilogue of the phased kernels.
 #pragma once
 #include "common.h"
@@ -42,7 +42,6 @@ struct NTParams {
     float alpha;
     int tiles_m, tiles_n;
     unsigned long long* prof;       // debug: per-workgroup phase timestamps (ase_hip_debug_nt_profile), else null
-    const char* Bp;                 // nullable: B in the packed fragment layout (ase_hip_pack_b), registered for this B
 };
 
 
@@ -137,7 +136,3 @@ __device__ __forceinline__ void nt8_epilogue_rows(const NTParams& p, f32x16 (&ac
 
 
 }  // namespace ase_nt
-
-// gemm_nt8p.hip: the phased kernel with packed weights (dtype ASE_BF16 / ASE_F16; p.Bp set), and the registry of packed copies
-int ase_nt8p_launch(const ase_nt::NTParams& p, int dtype, unsigned long long* prof, hipStream_t stream);
-const char* ase_packed_lookup(const void* B, int64_t ldb);

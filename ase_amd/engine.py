@@ -217,22 +217,6 @@ class UpdateEngine:
                 ob, _ = net.param_slices[name + '.bias']
                 d.b.append(self.params[ob:ob + nr])
                 d.gb.append(self.grads[ob:ob + nr])
-        # Packed MFMA-fragment copies of the 16-bit shadows (ase_hip_pack_b): launches that take the phased 256 x 256 kernel
-        # read the weights from them straight into registers (no LDS round trip for B).  Registered once with the library
-        # (same base pointer + pitch => ase_hip_gemm_nt may use the packed copy), re-packed behind every optimizer launch.
-        self._packed = T in (torch.bfloat16, torch.float16) and hasattr(self.be, 'pack_b_multi') and self.cfg.get('packed_weights', True)
-        self._pack_rows = {}
-        if self._packed:
-            for d in self.layers:
-                rows = []
-                for B in (d.Ws, d.Wts):
-                    N, K = B.shape
-                    if N >= 256 and K % 64 == 0:
-                        Bp = torch.zeros(self.be.packed_bytes(N, K), dtype=torch.uint8, device=dev)
-                        self.be.pack_register(B, Bp)
-                        rows.append([B.data_ptr(), B.stride(0), N, K, Bp.data_ptr(), 0])
-                        d.__dict__.setdefault('packed', []).append((B, Bp))
-                self._pack_rows[id(d)] = rows
         o, shp = net.param_slices['sigma']
         self.logstd = self.params[o:o + shp[0]]
         # weight-only loss terms (learning/amp_agent.py:449-466, learning/ase_agent.py:420-425): ranges of the flat buffer
@@ -377,35 +361,6 @@ class UpdateEngine:
             self._refresh_desc = torch.tensor(rows, dtype=torch.int64, device=self.dev)
             self._refresh_items = items
         self.be.refresh_shadow_multi(self._refresh_desc, self._refresh_items, self.dtype)
-        self._pack(None)
-
-    def close(self):
-        """Forget the packed-copy registrations of this engine's shadows (the library keys them by address: a later tensor
-        at a recycled address must not inherit them)."""
-        if getattr(self, '_packed', False):
-            for d in self.layers:
-                for B, Bp in d.__dict__.get('packed', []):
-                    try:
-                        self.be.pack_register(B, None)
-                    except Exception:
-                        pass
-            self._packed = False
-
-    def __del__(self):
-        self.close()
-
-    def _pack(self, group):
-        """Re-pack the fragment copies of a parameter group's shadows (None: all layers) - one launch."""
-        if not self._packed:
-            return
-        if not hasattr(self, '_pack_desc'):
-            pol = self.style + self.actor + [self.mu_head] + self.critic + [self.value_head]
-            mk = lambda ls: (torch.tensor([r for d in ls for r in self._pack_rows[id(d)]], dtype=torch.int64, device=self.dev)
-                             if any(self._pack_rows[id(d)] for d in ls) else None)
-            self._pack_desc = {None: mk(self.layers), 'policy': mk(pol), 'disc': mk([d for d in self.layers if d not in pol])}
-        desc = self._pack_desc[group]
-        if desc is not None:
-            self.be.pack_b_multi(desc, self.dtype)
 
     def _build_apply_desc(self):
         """Pointer table of ase_hip_apply_multi: per weight matrix its parameter / gradient / Adam-moment slices, the
@@ -746,7 +701,6 @@ class UpdateEngine:
                 if not self.shard:
                     self._host(lambda: self.grads[lo:hi].mul_(1.0 / self.R))
             self.be.apply_multi(self._apply_desc[a:b], self._apply_items[a:b], self.dtype, self.opt_state, self.acc)
-            self._pack(group)
 
     # ---- phase B: normalise, forward, loss heads, backward -----------------------------------------
     def phase_main(self, ds, idx, remap, amp_streams=None, new_z=None, inline_apply=False):
@@ -914,7 +868,6 @@ class UpdateEngine:
             # weight-only loss terms + their reported norms + Adam + shadow refresh of every layer: ONE launch
             self._build_apply_desc()
             be.apply_multi(self._apply_desc, self._apply_items, self.dtype, self.opt_state, self.acc)
-            self._pack(None)
         else:
             if self.has_disc:
                 # weight-only loss terms, added once after the gradient reduction

@@ -34,9 +34,6 @@ _p, _i, _i64, _f, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 SIGNATURES = {
     "ase_hip_gemm_nt": [_p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _i, _i, _p, _i, _p, _i64, _i, _i, _i, _i, _i, _i, _f, _i, _p],
     "ase_hip_gemm_tn": [_p, _i64, _p, _i64, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
-    "ase_hip_pack_b": [_p, _i64, _i, _i, _p, _i, _p],
-    "ase_hip_pack_b_multi": [_p, _i, _i, _p],
-    "ase_hip_pack_register": [_p, _i64, _p],
     "ase_hip_refresh_shadow": [_p, _i, _i, _p, _i64, _p, _i64, _i, _i, _i, _p],
     "ase_hip_refresh_shadow_multi": [_p, _i, _i, _p],
     "ase_hip_gather_multi": [_p, _i, _p, _i, _i, _i, _p],

@@ -117,19 +117,6 @@ int ase_hip_gemm_tn_grouped_plan(int64_t* problems, int n_problems, int target_w
 int ase_hip_gemm_tn_grouped(const int64_t* problems, const int32_t* work, int n_work, const int32_t* red, int n_red,
                             float* workspace, int dtype, void* stream);
 
-/* Packed copy of a weight matrix for the phased NT kernel: B [N, K] (16-bit, K % 64 == 0) as 1-KiB chunks
- * [8 ceil(N / 256)][K / 16][64 lanes][8 k-values] - chunk (nt, kc), lane (r = l & 31, h = l >> 5) = B[32 nt + r][16 kc + 8 h ..]:
- * what one lane of a 32 x 32 x 16 MFMA operand holds, so a fragment is ONE coalesced 16-byte load per lane from L2 into
- * registers and the weights never touch the LDS (which then carries the activations only, prefetched three K-tiles deep).
- * Bp needs ASE_PACKED_BYTES(N, K) bytes (n-tiles up to a whole 256-row tile); rows >= N are zero.  ase_hip_pack_register(B, ldb, Bp) tells ase_hip_gemm_nt that
- * launches with exactly this B (base pointer and pitch) may read the packed copy instead (Bp NULL: forget B); the OWNER of
- * the weights re-packs after every change (the engine: right behind the optimizer launch).  desc of the multi form:
- * DEVICE int64[n][6] = {B, ldb, N, K, Bp, 0}.  (No reference counterpart.) */
-#define ASE_PACKED_BYTES(N, K) ((int64_t)(((N) + 255) / 256 * 8) * ((K) / 16) * 1024)
-int ase_hip_pack_b(const void* B, int64_t ldb, int N, int K, void* Bp, int dtype, void* stream);
-int ase_hip_pack_b_multi(const int64_t* desc, int n, int dtype, void* stream);
-int ase_hip_pack_register(const void* B, int64_t ldb, const void* Bp);
-
 /* Shadow copies of one weight matrix for the matrix cores: W_s [n_pad,k_pad] and its transpose
  * Wt_s [k_pad,n_pad] (both dtype, zero padded, concat columns moved to split_dst).  Run after
  * every optimizer step.  (No reference counterpart: the reference multiplies f32 masters.) */

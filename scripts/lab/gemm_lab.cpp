@@ -211,10 +211,6 @@ int main(int argc, char** argv) {
         if (use_aux) { CK(hipMalloc(&aux, (int64_t)M * N * 2)); fill_kernel<<<1024, 256, 0, st>>>(aux, (int64_t)M * N, 4, 1.0f); }
         if (use_aux == 2) pack_bits_kernel<<<4096, 256, 0, st>>>(aux, bitsbuf, M, N);
         CK(hipMemsetAsync(C, 0xff, (int64_t)M * N * 2, st));
-        if (getenv("LAB_PACK") && atoi(getenv("LAB_PACK"))) {       // packed copy of B for the nt8p kernel
-            void* Bp; CK(hipMalloc(&Bp, ASE_PACKED_BYTES(N, K)));
-            if (ase_hip_pack_b(B, K, N, K, Bp, ASE_BF16, st) || ase_hip_pack_register(B, K, Bp)) { printf("pack failed: %s\n", ase_hip_last_error()); return 3; }
-        }
         auto run = [&]() {
             int rc = ase_hip_gemm_nt(A, K, B, K, C, N, bias, use_aux == 2 ? (void*)bitsbuf : (void*)aux, use_aux == 2 ? (N + 31) / 32 : N, 0, 0, nullptr, 0,
                                      use_aux == 3 ? bitsbuf : nullptr, (N + 31) / 32, M, N, K, relu ? ASE_ACT_RELU : ASE_ACT_NONE,

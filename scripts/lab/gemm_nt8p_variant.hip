@@ -1,3 +1,9 @@
+// LAB VARIANT, NOT BUILT (round 3): the phased NT kernel with the WEIGHTS read from a packed MFMA-fragment copy straight into
+// registers (no LDS for B, four-tile A ring, one barrier per K-tile).  Measured (gpurun r3e, scripts/lab/r3e.sh):
+// 16384 x 1024 x 1024 41.4 us against 38.4 us of gemm_nt8_kernel (main loop 29.3 vs 25.7 us), 8192^3 942 vs 1135 TF/s - the
+// 8 direct fragment loads per wave and K-tile cost more than the LDS round trip they replace - and its hand-counted vmcnt
+// scheme still had a race (intermittent wrong tiles).  The bound it chased: with B costing NOTHING (ASE_NT8_V=320 ablation)
+// the kernel runs 33.5 us, i.e. at most 13 % at K = 1024.  Dropped; kept for the record (it needs csrc/gemm_nt.h).
 // The phased NT kernel with the weights read from their packed copy (see the comment block below) + the pack kernels.
 #include "gemm_nt.h"
 

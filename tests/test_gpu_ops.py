@@ -591,56 +591,6 @@ def test_gemm_nt_phased_tile(be, dt, M, N, K):
     close(Cg.float(), Cc.float(), rt, at * math.sqrt(K / 64), f'nt phased {M}x{N}x{K}')
 
 
-@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize('M,N,K', [(16384, 1024, 1024), (12288, 1024, 1408), (32768, 512, 64), (16000, 1024, 192)])
-def test_gemm_nt_packed_weights(be, dt, M, N, K):
-    """The phased kernel with the weights read from their packed MFMA-fragment copy (ase_hip_pack_b + ase_hip_pack_register:
-    B never touches the LDS) - forward form (bias + ReLU + bit-mask twin) and data-gradient form (bit-mask operand) - equals
-    the emulation AND the same launches without the packed copy, bit for bit (same products, same f32 summation order per
-    output: the K-loop order is identical)."""
-    import ctypes as C
-    from ase_amd import lib as LL
-    g = torch.Generator().manual_seed(M + K)
-    A = (torch.randn(M, K, generator=g) * 0.5).to(dt).cuda()
-    B = (torch.randn(N, K, generator=g) * 0.1).to(dt).cuda()
-    bias = torch.randn(N, generator=g).cuda()
-    dY = (torch.randn(M, N, generator=g) * 0.3).to(dt).cuda()
-    Bt = (torch.randn(K, N, generator=g) * 0.1).to(dt).cuda() if K % 64 == 0 and K >= 256 else None
-
-    def run():
-        H, bits = torch.zeros(M, N, dtype=dt).cuda(), torch.zeros(M, N // 32, dtype=torch.int32).cuda()
-        be.gemm_nt(A, B, H, M, N, K, bias=bias, act=L.ACT_RELU, mask_out=bits)
-        dX = None
-        if Bt is not None:          # data-gradient form: dX = (dY @ Bt^T) masked by the bits of an activation of width K
-            dX = torch.zeros(M, K, dtype=dt).cuda()
-            be.gemm_nt(dY, Bt, dX, M, K, N, aux=kb_fixed, aux_mode=L.AUX_RELU_BITS)
-        return H, bits, dX
-    kb_fixed = torch.randint(-2 ** 31, 2 ** 31 - 1, (M, max(K // 32, 1)), dtype=torch.int32, generator=g).cuda()
-    plain = run()
-    keep = []
-    for mat in (B, Bt):
-        if mat is None:
-            continue
-        n, k = mat.shape
-        Bp = torch.zeros(be.packed_bytes(n, k), dtype=torch.uint8).cuda()
-        LL.check(be.lib.ase_hip_pack_b(C.c_void_p(mat.data_ptr()), k, n, k, C.c_void_p(Bp.data_ptr()), LL.BF16 if dt == torch.bfloat16 else LL.F16,
-                                       be._stream()), 'pack_b')
-        be.pack_register(mat, Bp)
-        keep.append((mat, Bp))
-    try:
-        packed = run()
-    finally:
-        for mat, _ in keep:
-            be.pack_register(mat, None)
-    for a, b, name in zip(plain, packed, ('H', 'mask bits', 'dX')):
-        if a is not None:
-            assert torch.equal(a, b), name + ': packed-B launch differs from the LDS-staged one'
-    Hc, bc = torch.zeros(M, N, dtype=dt), torch.zeros(M, N // 32, dtype=torch.int32)
-    EmuBackend().gemm_nt(A.cpu(), B.cpu(), Hc, M, N, K, bias=bias.cpu(), act=L.ACT_RELU, mask_out=bc)
-    rt, at = _tol(dt)
-    close(packed[0].float(), Hc.float(), rt, at * math.sqrt(K / 64), 'packed H vs emulation')
-
-
 @pytest.mark.parametrize('dt', DT)
 def test_apply_multi_fused_optimizer_step(be, dt):
     """ase_hip_apply_multi = weight-only gradient terms + their norms + Adam + shadow refresh, against the separate ops
