@@ -336,18 +336,22 @@ class HipBackend:
         L.check(self.lib.ase_hip_gp_second(_ptr(twin), _ld(twin), _ptr(g), _ld(g), _ptr(dg), _ld(dg), _ptr(dz), _ld(dz), rows,
                                            width, int(act), _code(dz.dtype), self._stream()), "gp_second")
 
+    def colsum(self, x, rows, cols, out, scale=1.0):
+        assert x.dtype == torch.float32 and out.dtype == torch.float32
+        L.check(self.lib.ase_hip_colsum(_ptr(x), _ld(x), rows, cols, float(scale), _ptr(out), self._stream()), "colsum")
+
     def sqnorm(self, x, rows, cols, acc, slot, scale=1.0):
         L.check(self.lib.ase_hip_sqnorm(_ptr(x), _ld(x), rows, cols, _ptr(acc), slot, float(scale), _code(x.dtype),
                                         self._stream()),
                 "sqnorm")
 
-    def finalize_scalars(self, acc, out, m_global, amb_global, masked, has_disc, has_enc, has_div, c):
+    def finalize_scalars(self, acc, out, m_global, amb_global, masked, has_disc, has_enc, has_div, c, opt_state=None, kl_threshold=0.0):
         L.check(self.lib.ase_hip_finalize_scalars(
             _ptr(acc), _ptr(out), m_global, amb_global, int(masked), int(has_disc), int(has_enc), int(has_div),
             float(c['critic_coef']), float(c['entropy_coef']), float(c.get('bounds_loss_coef') or 0.0), float(c.get('disc_coef', 0)),
             float(c.get('disc_logit_reg', 0)), float(c.get('disc_grad_penalty', 0)), float(c.get('disc_weight_decay', 0)),
             float(c.get('enc_coef', 0)), float(c.get('enc_weight_decay', 0)), float(c.get('amp_diversity_bonus', 0)),
-            float(c.get('enc_grad_penalty', 0)), self._stream()), "finalize_scalars")
+            float(c.get('enc_grad_penalty', 0)), _ptr(opt_state), float(kl_threshold), self._stream()), "finalize_scalars")
 
     # ------------------------------------------------------------------ optimizer
     def begin_step(self, opt_state, acc, zero2=None, rng_bump=None):

@@ -184,17 +184,25 @@ __global__ __launch_bounds__(256) void ppo_head_kernel(PpoArgs p) {
 }
 
 // second stage (a kernel boundary is the cheapest agent-scope release / acquire there is: a per-workgroup release fence
-// - one L2 write-back each - made the 1024-workgroup kernel 6x slower): ONE workgroup folds the slabs into the accumulators
-// and the head-bias gradients.  Thread (c, g) sums slot c over the workgroups b = g, g + 4, ...; the four groups meet in LDS.
+// - one L2 write-back each - made the 1024-workgroup kernel 6x slower): a few workgroups fold the slabs into the accumulators
+// and the head-bias gradients.  Thread (c, g) sums slot c over the slabs b = lo + g, lo + g + 4, ...; the four groups meet in LDS.
 __global__ __launch_bounds__(256) void ppo_head_fold_kernel(const double* __restrict__ slabs, int nblocks, double* __restrict__ acc,
                                                             float* __restrict__ db_mu, float* __restrict__ db_value, int act_dim,
                                                             int div_on) {
+    // gridDim.x workgroups share the slabs; 8 independent loads in flight per thread (a single chain of dependent loads over
+    // 1024 slabs took 129 us)
     __shared__ double fold[4][kPpoSlots];
     const int c = threadIdx.x & 63, g4 = threadIdx.x >> 6;
+    const int per = (nblocks + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = min(nblocks, lo + per);
     for (int cc = c; cc < kPpoSlots; cc += 64) {
-        double t = 0.0;
-        for (int b = g4; b < nblocks; b += 4) t += slabs[(int64_t)b * kPpoSlots + cc];
-        fold[g4][cc] = t;
+        double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int b = lo + g4;
+        for (; b + 28 < hi; b += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] += slabs[(int64_t)(b + 4 * u) * kPpoSlots + cc];
+        }
+        for (; b < hi; b += 4) t[0] += slabs[(int64_t)b * kPpoSlots + cc];
+        fold[g4][cc] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
     }
     __syncthreads();
     if (threadIdx.x < kPpoSlots) {
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(256) void ppo_head_fold_kernel(const double* __rest
         const double t = fold[0][cc] + fold[1][cc] + fold[2][cc] + fold[3][cc];
         if (cc < 7) {
             const int slot[7] = {ASE_ACC_A_LOSS, ASE_ACC_B_LOSS, ASE_ACC_ENTROPY, ASE_ACC_CLIPPED, ASE_ACC_C_LOSS, ASE_ACC_KL, ASE_ACC_DIV};
-            if (cc < 6 || div_on) acc[slot[cc]] += t;
+            if (cc < 6 || div_on) atomic_add_f64(acc + slot[cc], t);
         } else if (db_mu) {
             const int j = cc - 7;
             if (j < act_dim) atomic_add_f32(db_mu + j, (float)t);
@@ -437,8 +445,32 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const T* __restrict__ x, in
     if (threadIdx.x == 0) atomic_add_f64(acc, v[0] * scale);
 }
 
+// out[j] += scale * sum_r x[r, j] (f32 matrix, row pitch ld): 64 columns x 4 row groups per workgroup, grid-stride over
+// row chunks, one atomic per column and workgroup
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ld, int rows, int cols, float scale,
+                                                     float* __restrict__ out, int rows_per_block) {
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + tx;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (j < cols) {
+        int r = r0 + ty;
+        for (; r + 12 < r1; r += 16) {
+            s0 += x[(int64_t)r * ld + j]; s1 += x[(int64_t)(r + 4) * ld + j];
+            s2 += x[(int64_t)(r + 8) * ld + j]; s3 += x[(int64_t)(r + 12) * ld + j];
+        }
+        for (; r < r1; r += 4) s0 += x[(int64_t)r * ld + j];
+    }
+    red[ty][tx] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (ty == 0 && j < cols) atomic_add_f32(out + j, scale * (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]));
+}
+
 struct FinArgs {
     int m_global, amb_global, masked, has_disc, has_enc, has_div;
+    double* opt_state;        // nullable: adaptive learning rate (rl_games AdaptiveScheduler) - opt_state[1] is the lr
+    float kl_threshold;
     float critic_coef, entropy_coef, bounds_coef, disc_coef, disc_logit_reg, disc_grad_penalty, disc_weight_decay,
         enc_coef, enc_weight_decay, div_coef, enc_grad_penalty;
 };
@@ -486,6 +518,15 @@ __global__ void finalize_scalars_kernel(const double* __restrict__ acc, float* _
         out[ASE_RES_DIV_LOSS] = (float)dv;
     }
     out[ASE_RES_LOSS] = (float)loss;
+    if (a.opt_state) {
+        // rl_games schedulers.AdaptiveScheduler.update (min_lr 1e-6, max_lr 1e-2), 'legacy' schedule: after every optimisation
+        // step, from that step's kl (learning/common_agent.py:204-208)
+        double lr = a.opt_state[1];
+        const double cur = lr;
+        if (kl > 2.0 * (double)a.kl_threshold) lr = fmax(cur / 1.5, 1e-6);
+        if (kl < 0.5 * (double)a.kl_threshold) lr = fmin(cur * 1.5, 1e-2);
+        a.opt_state[1] = lr;
+    }
 }
 
 inline int grid_for(int64_t n, int block = 256, int cap = 2048) {
@@ -536,7 +577,7 @@ extern "C" int ase_hip_ppo_head(const float* mu, int64_t ld_mu, const float* val
         return ASE_OK;
     });
     ASE_CHECK_ARG(rc == ASE_OK, "ppo_head: bad dtype %d", dtype);
-    ASE_LAUNCH(ppo_head_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)(scratch + 8), (int)grid.x, acc, db_mu,
+    ASE_LAUNCH(ppo_head_fold_kernel, dim3(grid.x >= 64 ? 8 : 1), dim3(256), 0, (hipStream_t)stream, (const double*)(scratch + 8), (int)grid.x, acc, db_mu,
                db_value, act_dim, div_on);
     ASE_CHECK_LAUNCH("ppo_head");
     return ASE_OK;
@@ -658,18 +699,29 @@ extern "C" int ase_hip_sqnorm(const void* x, int64_t ld, int rows, int cols, dou
     return ASE_OK;
 }
 
+extern "C" int ase_hip_colsum(const float* x, int64_t ld, int rows, int cols, float scale, float* out, void* stream) {
+    ASE_CHECK_ARG(x && out && rows > 0 && cols > 0 && ld >= cols, "colsum: null/empty operand");
+    const int rpb = 128;
+    ASE_LAUNCH(colsum_kernel, dim3((cols + 63) / 64, (rows + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, x, ld, rows, cols, scale,
+               out, rpb);
+    ASE_CHECK_LAUNCH("colsum");
+    return ASE_OK;
+}
+
 extern "C" int ase_hip_finalize_scalars(const double* acc, float* out, int m_global, int amb_global, int masked,
                                         int has_disc, int has_enc, int has_div, float critic_coef, float entropy_coef,
                                         float bounds_coef, float disc_coef, float disc_logit_reg,
                                         float disc_grad_penalty, float disc_weight_decay, float enc_coef,
-                                        float enc_weight_decay, float div_coef, float enc_grad_penalty, void* stream) {
+                                        float enc_weight_decay, float div_coef, float enc_grad_penalty, double* opt_state_lr,
+                                        float kl_threshold, void* stream) {
     ASE_CHECK_ARG(acc && out && m_global > 0, "finalize_scalars: null/empty operand");
+    ASE_CHECK_ARG(opt_state_lr == nullptr || kl_threshold > 0.f, "finalize_scalars: adaptive lr needs a positive kl threshold");
     FinArgs a;
     a.m_global = m_global; a.amb_global = amb_global; a.masked = masked; a.has_disc = has_disc; a.has_enc = has_enc;
     a.has_div = has_div; a.critic_coef = critic_coef; a.entropy_coef = entropy_coef; a.bounds_coef = bounds_coef;
     a.disc_coef = disc_coef; a.disc_logit_reg = disc_logit_reg; a.disc_grad_penalty = disc_grad_penalty;
     a.disc_weight_decay = disc_weight_decay; a.enc_coef = enc_coef; a.enc_weight_decay = enc_weight_decay;
-    a.div_coef = div_coef; a.enc_grad_penalty = enc_grad_penalty;
+    a.div_coef = div_coef; a.enc_grad_penalty = enc_grad_penalty; a.opt_state = opt_state_lr; a.kl_threshold = kl_threshold;
     ASE_LAUNCH(finalize_scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, acc, out, a);
     ASE_CHECK_LAUNCH("finalize_scalars");
     return ASE_OK;

@@ -102,6 +102,10 @@ class UpdateEngine:
         self.grad_norm = float(cfg.get('grad_norm', 1.0))
         self.norm_value = bool(cfg.get('normalize_value', False))
         self.bounds_coef = float(cfg.get('bounds_loss_coef') or 0.0)
+        # lr_schedule: adaptive (rl_games AdaptiveScheduler under the default 'legacy' schedule_type): the learning rate follows
+        # every step's kl - on the device, inside the launch that forms the reported scalars
+        self.adaptive_lr = cfg.get('lr_schedule', 'constant') == 'adaptive'
+        self.kl_threshold = float(cfg.get('kl_threshold', 0.008))
         self.obs, self.act = net.obs_size, net.actions_num
         self.z = net.latent_dim if kind == 'ase' else 0
         self.amp = net.amp_obs_size if kind in ('amp', 'ase') else 0
@@ -571,6 +575,7 @@ class UpdateEngine:
         its bucket, optimizer step of its parameters - so the discriminator's tail overlaps the policy's backward."""
         self.phase_stats(ds, idx, remap, amp_streams, advance=apply, new_z=new_z)
         self._allreduce_stats()
+        self._lr_live = apply          # (calc_gradients-style calls without the optimizer step leave the learning rate alone)
         inline = apply and self._fused_apply and not self.truncate
         self.phase_main(ds, idx, remap, amp_streams, new_z, inline_apply=inline)
         if inline:
@@ -859,7 +864,8 @@ class UpdateEngine:
         if self._dist_on() and self.shard:
             self._ar(self.acc[1:L.ACC_LOGIT_W2])
         self.be.finalize_scalars(self.acc, self.res, self.Mg if self.shard else self.M, self.AMBg if self.shard else self.AMB,
-                                 self.masked, self.has_disc, self.has_enc, self.div_on, c)
+                                 self.masked, self.has_disc, self.has_enc, self.div_on, c,
+                                 opt_state=self.opt_state if (self.adaptive_lr and self._lr_live) else None, kl_threshold=self.kl_threshold)
 
     # ---- phase C (end-of-step form): weight-only loss terms, optimizer, shadows, reported scalars ------
     def phase_apply(self, apply=True):
@@ -893,7 +899,8 @@ class UpdateEngine:
                         self.adam_v[:self.n_train], self.opt_state)
                 self.refresh_shadows()
         be.finalize_scalars(self.acc, self.res, self.Mg if self.shard else self.M, self.AMBg if self.shard else self.AMB,
-                            self.masked, self.has_disc, self.has_enc, self.div_on, c)
+                            self.masked, self.has_disc, self.has_enc, self.div_on, c,
+                            opt_state=self.opt_state if (self.adaptive_lr and apply) else None, kl_threshold=self.kl_threshold)
 
     def _enc_grad_penalty(self, h_top):
         """Encoder gradient penalty  c * mean_rows |d err / d x|^2,  err = -<normalize(e), z>  (learning/ase_agent.py:431-441,
@@ -999,8 +1006,9 @@ class UpdateEngine:
             last = l == nl - 1
             aux, mode = self._aux(self.Hd[l][2 * AMB:], L.AUX_RELU_MASK)
             be.gemm_nt(self.dGp[l - 1], d.Ws, self.GpTop if last else self.dGp[l], AMB, d.n_pad, d.k_pad, aux=aux,
-                       aux_mode=mode, alpha=s / S if last else 1.0,
-                       colsum=self.disc_head.gW[0].view(-1) if last else None, colsum_n=d.N if last else 0)
+                       aux_mode=mode, alpha=s / S if last else 1.0)
+            if last:      # the penalty's gradient w.r.t. the logit weights: column sums of the top launch (f32, true scale)
+                be.colsum(self.GpTop, AMB, d.N, self.disc_head.gW[0].view(-1))
         # weight (+ bias) gradients: one launch per layer over the stacked rows
         for l in range(nl):
             d = self.disc[l]
@@ -1042,8 +1050,9 @@ class UpdateEngine:
             last = l == nl - 1
             aux, mode = self._aux(self.Hd[l][demo], _AUX[d.act])
             be.gemm_nt(x, d.Ws, self.GpTop if last else self.dGp[l], AMB, d.n_pad, d.k_pad, aux=aux, aux_mode=mode,
-                       alpha=s / S if last else 1.0, colsum=self.disc_head.gW[0].view(-1) if last else None,
-                       colsum_n=d.N if last else 0)
+                       alpha=s / S if last else 1.0)
+            if last:
+                be.colsum(self.GpTop, AMB, d.N, self.disc_head.gW[0].view(-1))
             if last:     # the top layer's dGp in storage type and S scale, for the second-order term below
                 be.gemm_nt(x, d.Ws, self.dGp[l], AMB, d.n_pad, d.k_pad, aux=aux, aux_mode=mode)
             x = self.dGp[l]

@@ -124,7 +124,10 @@ class CommonAgent:
         self.grad_norm = config.get('grad_norm', 1.0)
         # mixed_precision (rl_games: torch.cuda.amp autocast = half arithmetic + GradScaler, learning/ase_agent.py:216,271-288)
         # selects the half-storage mode: 'f16' below, with a static power-of-two gradient scale in the GradScaler's place
-        assert config.get('lr_schedule', 'constant') in ('constant', None)
+        # lr_schedule: constant | adaptive (rl_games AdaptiveScheduler on every step's kl, schedule_type 'legacy' - the default;
+        # learning/common_agent.py:204-208).  The per-mini-epoch / per-epoch variants ('standard', 'standard_epoch') are not built.
+        assert config.get('lr_schedule', 'constant') in ('constant', 'adaptive', None)
+        assert config.get('lr_schedule', 'constant') != 'adaptive' or config.get('schedule_type', 'legacy') == 'legacy'
         self.multi_gpu = config.get('multi_gpu', False)
         self.world_size, self.rank = config.get('world_size', 1), config.get('rank', 0)
         # 'shard' (strong scaling: the R-rank update equals the 1-rank update) | 'horovod' (the reference's semantics:
@@ -635,7 +638,7 @@ class CommonAgent:
             self._snapshot_stream = side
         else:
             r = dict(eng.results(snapshot=True))
-        r['last_lr'] = self.last_lr
+        r['last_lr'] = self.engine.opt_state[1].clone() if self.engine.adaptive_lr else self.last_lr
         r['lr_mul'] = 1.0
         return r
 
@@ -776,6 +779,8 @@ class CommonAgent:
             torch.cuda.current_stream().wait_stream(self._snapshot_stream)
             self._snapshot_stream = None
         self._post_update(batch_dict)
+        if self.engine.adaptive_lr:            # host mirror of the device-side schedule (checkpoints, logs): once per update
+            self.last_lr = float(self.engine.opt_state[1])
         return train_info
 
 

@@ -48,8 +48,9 @@ SIGNATURES = {
     "ase_hip_enc_head": [_p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _i, _i, _i, _f, _f, _i, _p],
     "ase_hip_gp_seed": [_p, _i64, _p, _p, _i64, _i, _i, _f, _i, _i, _p],
     "ase_hip_gp_second": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i, _i, _i, _i, _p],
+    "ase_hip_colsum": [_p, _i64, _i, _i, _f, _p, _p],
     "ase_hip_sqnorm": [_p, _i64, _i, _i, _p, _i, _d, _i, _p],
-    "ase_hip_finalize_scalars": [_p, _p, _i, _i, _i, _i, _i, _i] + [_f] * 11 + [_p],
+    "ase_hip_finalize_scalars": [_p, _p, _i, _i, _i, _i, _i, _i] + [_f] * 11 + [_p, _f, _p],
     "ase_hip_enc_gp_seed": [_p, _i64, _p, _i64, _p, _i64, _i, _i, _f, _i, _p],
     "ase_hip_enc_gp_back": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i, _i, _f, _i, _p],
     "ase_hip_clip_scale": [_p, _i64, _p, _f, _p],

@@ -273,12 +273,20 @@ int ase_hip_gp_seed(const void* h, int64_t ld_h, const float* w, void* g, int64_
 int ase_hip_gp_second(const void* twin, int64_t ld_t, const void* g, int64_t ld_g, const void* dg, int64_t ld_dg,
                       void* dz, int64_t ld_dz, int rows, int width, int act, int dtype, void* stream);
 
+/* out[j] += scale * sum_r x[r, j] over an f32 matrix [rows, cols] (row pitch ld): the gradient of the logit weights from the
+ * gradient penalty = column sums of the last launch of the chain's backward (learning/amp_agent.py:453-459) - a 3 us
+ * stream instead of column sums inside that launch's store-bound epilogue. */
+int ase_hip_colsum(const float* x, int64_t ld, int rows, int cols, float scale, float* out, void* stream);
+
 /* acc[slot] += scale * sum_{r,j} x[r,j]^2 over a dtype matrix [rows, cols]. */
 int ase_hip_sqnorm(const void* x, int64_t ld, int rows, int cols, double* acc, int slot, double scale,
                    int dtype, void* stream);
 
 /* train_result scalars from the accumulators (same keys as learning/ase_agent.py:296-306).
- * out f32[ASE_RES_COUNT]. */
+ * out f32[ASE_RES_COUNT].  opt_state_lr (nullable: constant lr): the optimizer state of ase_hip_begin_step - the learning rate
+ * opt_state[1] is then adapted from this step's kl as rl_games' AdaptiveScheduler does under the 'legacy' schedule after every
+ * minibatch (learning/common_agent.py:204-208; lr_schedule: adaptive, kl_threshold): kl > 2 thr: lr / 1.5 (>= 1e-6),
+ * kl < thr / 2: lr * 1.5 (<= 1e-2) - on the device, no .item() per step. */
 enum {
     ASE_RES_A_LOSS = 0, ASE_RES_C_LOSS, ASE_RES_B_LOSS, ASE_RES_ENTROPY, ASE_RES_CLIP_FRAC, ASE_RES_KL,
     ASE_RES_DISC_LOSS, ASE_RES_DISC_GP, ASE_RES_DISC_LOGIT_LOSS, ASE_RES_DISC_AGENT_ACC,
@@ -289,7 +297,8 @@ int ase_hip_finalize_scalars(const double* acc, float* out, int m_global, int am
                              int has_disc, int has_enc, int has_div, float critic_coef,
                              float entropy_coef, float bounds_coef, float disc_coef, float disc_logit_reg,
                              float disc_grad_penalty, float disc_weight_decay, float enc_coef,
-                             float enc_weight_decay, float div_coef, float enc_grad_penalty, void* stream);
+                             float enc_weight_decay, float div_coef, float enc_grad_penalty, double* opt_state_lr,
+                             float kl_threshold, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Optimizer (torch.optim.Adam(lr, eps=1e-8, weight_decay=0): learning/common_agent.py:45,

@@ -380,15 +380,25 @@ class EmuBackend:
         _, c = _twin_factors(act, twin[:rows, :width].float())
         dz[:rows, :width] = _store(dz[:rows, :width].float() + c * g[:rows, :width].float() * dg[:rows, :width].float(), dz.dtype)
 
+    def colsum(self, x, rows, cols, out, scale=1.0):
+        out[:cols] += scale * x[:rows, :cols].float().sum(0)
+
     def sqnorm(self, x, rows, cols, acc, slot, scale=1.0):
         acc[slot] += scale * (x[:rows, :cols].double() ** 2).sum()
 
-    def finalize_scalars(self, acc, out, m_global, amb_global, masked, has_disc, has_enc, has_div, c):
+    def finalize_scalars(self, acc, out, m_global, amb_global, masked, has_disc, has_enc, has_div, c, opt_state=None, kl_threshold=0.0):
         a = acc.tolist()
         S = a[L.ACC_MASK_SUM]
         den = S if masked else float(m_global)
         al, bl, ent, cf = a[L.ACC_A_LOSS] / den, a[L.ACC_B_LOSS] / den, a[L.ACC_ENTROPY] / den, a[L.ACC_CLIPPED] / den
         cl, kl = a[L.ACC_C_LOSS] / m_global, a[L.ACC_KL] / m_global
+        if opt_state is not None:                 # rl_games AdaptiveScheduler (schedulers.py), 'legacy' schedule
+            lr = cur = float(opt_state[1])
+            if kl > 2.0 * kl_threshold:
+                lr = max(cur / 1.5, 1e-6)
+            if kl < 0.5 * kl_threshold:
+                lr = min(cur * 1.5, 1e-2)
+            opt_state[1] = lr
         loss = al + c['critic_coef'] * cl - c['entropy_coef'] * ent + float(c.get('bounds_loss_coef') or 0.0) * bl
         out.zero_()
         out[L.RES_A_LOSS], out[L.RES_C_LOSS], out[L.RES_B_LOSS] = al, cl, bl

@@ -232,6 +232,29 @@ def test_diversity_and_rollout_latents_use_different_streams(golden_dir):
     assert int(st['diversity'][1]) > 0 and int(st['latents'][1]) == 2 and int(st['diversity'][0]) != int(st['latents'][0])
 
 
+def test_adaptive_lr_schedule_follows_every_steps_kl(golden_dir):
+    """lr_schedule: adaptive (N4): rl_games' AdaptiveScheduler under the default 'legacy' schedule - after EVERY optimisation step
+    lr <- lr / 1.5 if that step's kl > 2 thr, lr * 1.5 if kl < thr / 2 (clamped to [1e-6, 1e-2]), restated here from
+    rl_games/common/schedulers.py; the engine applies it on the device inside the launch that forms the reported scalars."""
+    import copy
+    G = copy.deepcopy(torch.load(os.path.join(golden_dir, 'ppo_tiny.pt'), weights_only=False))
+    G['cfg'].update(lr_schedule='adaptive', kl_threshold=0.5)
+    ag = make_agent(G, EmuBackend())
+    lr0 = float(G['cfg']['learning_rate'])
+    infos = replay_epochs(G, ag, rtol=0, wtol=0, check=False)
+    lr, seen = lr0, []
+    for info in infos:
+        for i in range(len(info['kl'])):
+            kl = float(info['kl'][i])
+            if kl > 2.0 * 0.5:
+                lr = max(lr / 1.5, 1e-6)
+            elif kl < 0.5 * 0.5:
+                lr = min(lr * 1.5, 1e-2)
+            seen.append(lr)
+            assert abs(float(info['last_lr'][i]) - lr) <= 1e-12 * lr, (i, float(info['last_lr'][i]), lr, kl)
+    assert len(set(seen)) > 2 and abs(ag.last_lr - lr) <= 1e-12 * lr          # the schedule actually moved
+
+
 def test_checkpoint_keys_match_reference(golden_dir):
     """get_full_state_weights() has the reference's keys (rl_games A2CBase + learning/amp_agent.py:47-52); the model
     state_dict has the reference's names / shapes / dtypes including the shared-trunk aliases."""

@@ -198,6 +198,17 @@ def test_rms_eval_and_unnorm(be):
         close(a, c, 3e-7, 1e-7)        # (sqrtf on the device is within 1 ulp, not correctly rounded)
 
 
+def test_colsum(be):
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(4096, 576, generator=g)
+    out0 = torch.randn(512, generator=g)
+    og, oc = out0.clone().cuda(), out0.clone()
+    be.colsum(x.cuda()[:, :512], 4096, 500, og, scale=0.25)          # row pitch 576, 500 of 512 columns
+    EmuBackend().colsum(x[:, :512], 4096, 500, oc, scale=0.25)
+    close(og, oc, 1e-5, 1e-4, 'colsum')
+    assert torch.equal(og[500:].cpu(), out0[500:])
+
+
 def test_gather_rows(be):
     src = torch.randn(640, 31)
     idx = torch.randperm(640)[:200].to(torch.int32)
