@@ -4,30 +4,38 @@ Hardware queues.  The update engine runs the three network branches of an optimi
 discriminator) on three HIP streams.  How many streams the runtime lets execute side by side is its hardware-queue
 count, ``GPU_MAX_HW_QUEUES``, which libamdhip64 reads ONCE when it initialises (the first HIP call of the process, not
 ``import torch``).  Measured on MI355X with the launch programs of this package: 75.9 ms per update with 4 queues,
-78.5 ms with 3 (the null stream's work shares a queue with one branch), 80.5 ms with 6.  Importing this package sets the
-variable to 4 unless the user set it; if HIP is already initialised by then the setting cannot take effect any more and
-``hw_queue_note`` says so.  Nothing depends on the value for correctness: with fewer queues than streams the branches
-simply serialise (the fork / join points are events, replayed by the library itself - no hipGraph involved).
+78.5 ms with 3 (the null stream's work shares a queue with one branch), 80.5 ms with 6.
+
+Importing this package changes NOTHING in the process.  A launcher that wants the measured overlap calls
+``ase_amd.configure()`` before its first GPU call (bench.py does); the call reports whether the setting could still take
+effect (``ase_amd.hw_queue_note``) and the bench line carries that note.  Nothing depends on the value for correctness: with
+fewer queues than streams the branches simply serialise (the fork / join points are events, replayed by the library itself -
+no hipGraph involved).
 """
 import os
 import sys
 
 HW_QUEUES_DEFAULT = '4'
-hw_queue_note = None
+hw_queue_note = 'ase_amd.configure() was not called: GPU_MAX_HW_QUEUES keeps the runtime default'
+hw_queues_applied = False
 
 
-def _configure_hw_queues():
-    global hw_queue_note
+def configure(hw_queues=HW_QUEUES_DEFAULT):
+    """Process-level runtime settings for the measured stream overlap; call BEFORE the first HIP call of the process.
+    Returns True if the setting is in effect (set here, or already exported by the user), False if HIP was initialised
+    earlier (then only a warning note is left)."""
+    global hw_queue_note, hw_queues_applied
     if 'GPU_MAX_HW_QUEUES' in os.environ:
         hw_queue_note = f"GPU_MAX_HW_QUEUES={os.environ['GPU_MAX_HW_QUEUES']} (set by the user)"
-        return
+        hw_queues_applied = True
+        return True
     t = sys.modules.get('torch')
     if t is not None and getattr(t, 'cuda', None) is not None and t.cuda.is_initialized():
-        hw_queue_note = ("HIP was initialised before `import ase_amd`: GPU_MAX_HW_QUEUES keeps the runtime default; import "
-                         "ase_amd (or export GPU_MAX_HW_QUEUES=4) before the first GPU call for the measured stream overlap")
-        return
-    os.environ['GPU_MAX_HW_QUEUES'] = HW_QUEUES_DEFAULT
-    hw_queue_note = f"GPU_MAX_HW_QUEUES={HW_QUEUES_DEFAULT} (set by ase_amd)"
-
-
-_configure_hw_queues()
+        hw_queue_note = ("WARNING: HIP was initialised before ase_amd.configure(): GPU_MAX_HW_QUEUES keeps the runtime default "
+                         "(call configure() or export GPU_MAX_HW_QUEUES=4 before the first GPU call for the measured stream overlap)")
+        hw_queues_applied = False
+        return False
+    os.environ['GPU_MAX_HW_QUEUES'] = str(hw_queues)
+    hw_queue_note = f"GPU_MAX_HW_QUEUES={hw_queues} (set by ase_amd.configure())"
+    hw_queues_applied = True
+    return True

@@ -146,13 +146,11 @@ class HipBackend:
         """Problems the phased bf16 kernel takes: whole 64-row K-tiles.  Narrow outputs (heads, style MLP: N or K <= 64)
         waste most of a 256 x 256 tile's MFMAs, but a work item costs its HBM traffic either way: measured (scripts/lab,
         LAB_TNG_N) the six narrow problems of a step add 67 us to the grouped launch against 156 us as seven launches of the
-        128 x 128 kernel.  ASE_TN_GROUP_ALL=0 restores the round-1 rule (wide outputs only)."""
-        import os
-        if dtype not in (torch.bfloat16, torch.float16) or M % 64 != 0 or bias_rows % 64 != 0:
-            return False
-        if os.environ.get('ASE_TN_GROUP_ALL', '1') != '0':
-            return True
-        return n_real >= 128 and K >= 128 and n_real * K >= 512 * 512
+        128 x 128 kernel."""
+        # (every problem: narrow outputs - heads, style MLP, N or K <= 64 - waste most of a 256 x 256 tile's MFMAs, but a work
+        #  item costs its HBM traffic either way; measured: the six narrow problems of a step add 67 us to the grouped launch
+        #  against 156 us as seven launches of the 128 x 128 kernel)
+        return dtype in (torch.bfloat16, torch.float16) and M % 64 == 0 and bias_rows % 64 == 0
 
     def make_tn_plan(self, problems, target_wg=0):
         """problems: [(A, B, G, gbias|None, bias_rows, M, N, K, n_real, k_real, split_src, split_dst, alpha)] -> plan

@@ -22,7 +22,6 @@ Data layout in HBM
     kernels, so neither swap_and_flatten01 nor the dataset gather materialise anything.
 """
 import math
-import os
 
 import torch
 
@@ -119,27 +118,36 @@ class UpdateEngine:
         self._scratch = {}
         self.multi_stream = bool(cfg.get('multi_stream', True)) and getattr(backend, 'name', '') == 'hip'
         self._side_streams = None
-        self._tn_defer = bool(getattr(backend, 'grouped_tn_ok', None)) and os.environ.get('ASE_TN_GROUPED', '1') != '0'
+        # Scheduling options (cfg['engine_opts'], a dict; every default is the measured best of its A/B on MI355X):
+        #   tn_grouped      weight gradients of a branch queued and launched as ONE grouped grid (else one launch per layer)
+        #   tn_wg_side      workgroups the planner sizes a SIDE branch's grouped launch for (it runs beside other branches)
+        #   tn_early        policy weight gradients as soon as the actor's data-gradient chain is through, beside the style-MLP
+        #                   tail (else ONE policy launch as the last kernel of the step; 70.4 ms either way)
+        #   disc_early      head of the discriminator branch submitted at the top of the step, into the ~80 us of prologue kernels
+        #   short_prologue  only the observation chain in front of the actor chain; latent copies / gathers on side streams
+        #   style_early     style MLP beside the observation chain (69.3 vs 68.9 ms: the window is not idle)
+        #   relu_bits       bit-mask twins of ReLU activations for the data-gradient epilogues
+        #   fused_apply     weight-only loss terms + Adam + shadow refresh in one launch per branch (apply_wide: its 16-byte path)
+        #   side_streams    2 = critic and discriminator on their own streams, 1 = they share one
+        o = dict(tn_grouped=True, tn_wg_side=64, tn_early=False, disc_early=True, short_prologue=True, style_early=False,
+                 relu_bits=True, fused_apply=True, apply_wide=True, side_streams=2)
+        unknown = set(cfg.get('engine_opts', {}) or {}) - set(o)
+        assert not unknown, f"unknown engine_opts {sorted(unknown)}"
+        o.update(cfg.get('engine_opts', {}) or {})
+        self._tn_defer = bool(getattr(backend, 'grouped_tn_ok', None)) and bool(o['tn_grouped'])
         self._tn_queue, self._tn_plans = [], {}          # weight gradients queued by the CURRENT branch (see _flush_tn)
-        self._tn_wg_side = int(os.environ.get('ASE_TN_WG_SIDE', '64'))
-        # policy weight gradients as soon as the actor's data-gradient chain is through (beside the style-MLP tail,
-        # ASE_TN_EARLY=1) or as the last launch of the step (default: ONE policy launch that also holds the style MLP's and
-        # the heads' narrow gradients - measured 70.4 ms either way, 96 instead of 432 weight-gradient launches per update)
-        self._tn_early = os.environ.get('ASE_TN_EARLY', '0') != '0'
-        # head of the discriminator branch (moments, normalisation, forward) submitted at the top of the step, into the
-        # ~80 us in which the main stream runs its chain of small prologue kernels (ASE_DISC_EARLY=0: where the branch
-        # used to start, behind the actor's and the critic's forward launches in submission order)
-        self._disc_early = os.environ.get('ASE_DISC_EARLY', '1') != '0'
+        self._tn_wg_side = int(o['tn_wg_side'])
+        self._tn_early = bool(o['tn_early'])
+        self._disc_early = bool(o['disc_early'])
         self._early_fork = None
-        self._short_prologue = os.environ.get('ASE_SHORT_PROLOGUE', '1') != '0'
+        self._short_prologue = bool(o['short_prologue'])
         self._prep = self._lat_ready = self._fill_done = None
-        # (measured: 69.3 ms with the style chain beside the observation chain, 68.9 ms behind it - the window is not idle,
-        #  the discriminator branch's head already fills it; kept as a switch)
-        self._style_early = os.environ.get('ASE_STYLE_EARLY', '0') != '0'
+        self._style_early = bool(o['style_early'])
+        self._n_side = max(1, min(int(o['side_streams']), 2))
         self._apply_groups = None
-        self._use_bits = os.environ.get('ASE_RELU_BITS', '1') != '0'
-        self._fused_apply = hasattr(backend, 'apply_multi') and os.environ.get('ASE_FUSED_APPLY', '1') != '0'
-        self._apply_wide = os.environ.get('ASE_APPLY_WIDE', '1') != '0'
+        self._use_bits = bool(o['relu_bits'])
+        self._fused_apply = hasattr(backend, 'apply_multi') and bool(o['fused_apply'])
+        self._apply_wide = bool(o['apply_wide'])
         self._apply_desc = self._apply_items = None
         self.force_dist = bool(cfg.get('force_dist', False))   # exercise the collectives with a 1-rank group
         self._refresh_desc = None
@@ -609,7 +617,7 @@ class UpdateEngine:
         if self._short_prologue and self._amp_stats_in_branch():
             # Short prologue (single GPU, streams): the actor chain - the critical path - keeps only the observation chain
             # (moments -> finalise -> normalise) in front of it on the main stream.  The latent copies and the diversity draw
-            # (ASE_STYLE_EARLY=1: the style MLP's three small matrix kernels too) run beside it on the critic's stream,
+            # (engine_opts style_early: the style MLP's three small matrix kernels too) run beside it on the critic's stream,
             # followed by the gather of the loss-head fields and the mask sum (first needed ~300 us later); zeroing the
             # gradients goes to the discriminator's stream (that branch is their first user).
             m0 = self._mark()
@@ -661,8 +669,7 @@ class UpdateEngine:
         if not self.multi_stream:
             return None
         if self._side_streams is None:
-            n = int(os.environ.get('ASE_SIDE_STREAMS', '2'))        # 1: critic and discriminator share one side stream
-            self._side_streams = [torch.cuda.Stream(device=self.dev) for _ in range(max(1, min(n, 2)))]
+            self._side_streams = [torch.cuda.Stream(device=self.dev) for _ in range(self._n_side)]
         return self._side_streams[k % len(self._side_streams)]
 
     class _Branch:

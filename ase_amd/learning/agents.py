@@ -181,7 +181,7 @@ class CommonAgent:
                                    grad_scale=config.get('grad_scale', None))
         self.model.a2c_network.infer = InferenceEngine(self.model.a2c_network, self.engine)
         self.use_graph = bool(config.get('graph_capture', False))
-        self._snapshot_aside = os.environ.get('ASE_SNAPSHOT_ASIDE', '1') != '0'
+        self._snapshot_aside = bool(config.get('snapshot_aside', True))     # per-step result snapshots on a side stream
         self._snapshot_stream = None
         self._graphs = {}
         self._train_mode = True

@@ -30,7 +30,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import ase_amd          # noqa: E402  (first: it settles the runtime's hardware-queue count before HIP initialises, see its docstring)
+import ase_amd          # noqa: E402
+ase_amd.configure()     # the runtime's hardware-queue count, before HIP initialises (ase_amd/__init__.py); reported on the JSON line
 import torch            # noqa: E402
 
 MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f16': 2500.0, 'f32': 157.3, 'bf16x3': 2500.0 / 3}   # x3: three bf16 MFMAs per product        # /opt/skills/guides/MI355X_MICROARCH.md (dense)
@@ -606,6 +607,7 @@ def main():
                           (f'dp{world}, the reference\'s Horovod semantics: 4096 environments and a 16384-row minibatch per GPU, gradients '
                            'averaged by RCCL all-reduce (one bucket per branch, overlapped with the other branches\' backward)' if weak else
                            f'dp{world}, every 16384-row minibatch row-sharded over the ranks, RCCL gradient all-reduce (sum)')},
+               'runtime': ase_amd.hw_queue_note,
                'roofline': roof, 'cpu_baseline': cpu, 'qualifying_mode': qualifying, 'modes': modes,
                'parity': (modes.get(args.precision) or {}).get('parity'),
                'last_train_result': {k: round(v, 6) for k, v in last.items()}}

@@ -16,8 +16,10 @@ CASES = ['ase_tiny', 'amp_tiny', 'ppo_tiny', 'ase_sep_tiny', 'ase_gp_tiny', 'ase
          'ase_swish_tiny']       # swish (SiLU) in the policy MLPs, the discriminator and the encoder: the curved gradient penalty
 
 
-def first_step(G, be, dtype, device='cpu', grad_scale=None):
-    kind, cfg, E = G['kind'], G['cfg'], G['epochs'][0]
+def first_step(G, be, dtype, device='cpu', grad_scale=None, engine_opts=None):
+    kind, cfg, E = G['kind'], dict(G['cfg']), G['epochs'][0]
+    if engine_opts:
+        cfg['engine_opts'] = engine_opts
     net = build_net(G, device)
     mb = {k: v.to(device) for k, v in E['first_minibatch'].items()}
     M = mb['obs'].shape[0]
@@ -100,15 +102,14 @@ def test_first_step_f16_emulated(name, golden_dir):
 
 @pytest.mark.parametrize('early', [False, True])
 @pytest.mark.parametrize('name', CASES)
-def test_deferred_weight_gradients(name, early, golden_dir, monkeypatch):
+def test_deferred_weight_gradients(name, early, golden_dir):
     """The grouped weight-gradient launches (all layers of a branch queued during its backward, ONE launch per branch
     group - discriminator | policy - at the end of the branch) read nothing the data-gradient chain overwrites: same
     golden result with every layer deferred."""
     G = torch.load(os.path.join(golden_dir, name + '.pt'), weights_only=False)
-    monkeypatch.setenv('ASE_TN_EARLY', '1' if early else '0')
     be = EmuBackend(group_all=True)
-    net, eng = first_step(G, be, torch.float32)
-    # discriminator branch | actor + critic + style MLP as the last launch of the step; with ASE_TN_EARLY the actor +
+    net, eng = first_step(G, be, torch.float32, engine_opts={'tn_early': early})
+    # discriminator branch | actor + critic + style MLP as the last launch of the step; with engine_opts tn_early the actor +
     # critic layers go beside the style-MLP backward and what the style MLP queued after that is a third launch
     assert be.grouped_launches == {'ppo': 1, 'amp': 2, 'ase': 3 if early else 2}[G['kind']] and not eng._tn_queue
     lr = G['cfg']['learning_rate']
