@@ -16,6 +16,8 @@
 //       (256 x 256, DMA-staged), single problem or grouped (all weight gradients of a step in one grid).
 #include "gemm_nt.h"
 #include <stdlib.h>
+#include <algorithm>
+#include <vector>
 
 using namespace ase_nt;
 
@@ -935,6 +937,9 @@ template <typename T> int dispatch_nt(const NTParams& p, hipStream_t s) {
                 // row-per-lane epilogue (swapped MFMA operands): 16-bit output in whole 64-column wave tiles, no column sums,
                 // mask operand absent or a bit matrix; otherwise the LDS-slab epilogue.  DMA issued inside the MFMA block (V = 64).
                 const bool rows_ok = rows_epi(p, 64);
+                // four waves, register-staged operands (gemm_nt4.hip): whole 128-column wave tiles with the row-per-lane epilogue
+                static const int nt4r = lab_knob("ASE_NT4R", 1);
+                if (nt4r && rows_epi(p, 128) && p.pre_out == nullptr) return launch_nt4r<T>(p, g_nt_prof, s);
 #ifdef ASE_LAB
                 if constexpr (std::is_same<T, bf16_t>::value) {      // ablation builds of the phased kernel (timing only)
                     static const int v8 = lab_knob("ASE_NT8_V", -2);
@@ -1508,7 +1513,7 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(TNParams p) {
 
 // Grouped launch.  problems: device int64[n][16] = {A, lda, B, ldb, G, gbias, bias_rows, M, N, K, n_real, k_real,
 // split_src, split_dst, alpha (f32 bits), tiles_k}, leading dimensions in ELEMENTS; work: device int32[n_work][4] =
-// {problem, tile, m_begin, nk} (ase_hip_gemm_tn_grouped_plan).
+// {problem, tile, m_begin, nk | slab << 16} (ase_hip_gemm_tn_grouped_plan).
 template <typename T, int V>
 __global__ __launch_bounds__(512) void gemm_tn8g_kernel(const int64_t* __restrict__ problems,
                                                         const int32_t* __restrict__ work, int n_work,
@@ -1517,7 +1522,9 @@ __global__ __launch_bounds__(512) void gemm_tn8g_kernel(const int64_t* __restric
     const int item = xcd_remap(blockIdx.x, n_work);             // neighbours in the work list share operand panels
     const int32_t* w = work + 4 * item;
     const int pi = __builtin_amdgcn_readfirstlane(w[0]), tile = __builtin_amdgcn_readfirstlane(w[1]);
-    const int m_begin = __builtin_amdgcn_readfirstlane(w[2]), nk = __builtin_amdgcn_readfirstlane(w[3]);
+    const int m_begin = __builtin_amdgcn_readfirstlane(w[2]), w3 = __builtin_amdgcn_readfirstlane(w[3]);
+    const int nk = w3 & 0xFFFF, slab = w3 >> 16;               // slab: the item's place in the workspace (reduce table order)
+    if (nk == 0) return;                                        // padding of an XCD's position range
     const int64_t* d = problems + 16 * pi;
     TNParams p;
     p.A = reinterpret_cast<const char*>(d[0]); p.lda = d[1] * 2;
@@ -1528,8 +1535,8 @@ __global__ __launch_bounds__(512) void gemm_tn8g_kernel(const int64_t* __restric
     p.alpha = __builtin_bit_cast(float, (int)d[14]);
     p.tiles_k = (int)(d[15] & 0xFFFF);
     tn8_body<T, V>(p, smem, (tile / p.tiles_k) * 256, (tile % p.tiles_k) * 256, m_begin, nk,
-                   prof ? prof + blockIdx.x * 4 : nullptr, ws ? ws + (int64_t)item * kTnSlab : nullptr,
-                   ws ? ws + (int64_t)item * kTnSlab + 65536 : nullptr);
+                   prof ? prof + blockIdx.x * 4 : nullptr, ws ? ws + (int64_t)slab * kTnSlab : nullptr,
+                   ws ? ws + (int64_t)slab * kTnSlab + 65536 : nullptr);
 }
 
 // Second kernel of the grouped launch: G += alpha * (sum of the work items' partial tiles), gbias likewise.  One workgroup
@@ -1919,6 +1926,10 @@ extern "C" int ase_hip_gemm_tn_grouped_plan(int64_t* problems, int n_problems, i
         const int64_t cost = rounds * (cc + 8);
         if (best < 0 || cost < best) { best = cost; c = cc; }
     }
+    // Canonical numbering (the partial-tile slab an item writes; the reduce table refers to it): problem-major, then split,
+    // then tile - split s of a tile sits `tiles of the problem` slabs further.
+    struct Group { int prob, t0, nt, m_begin, nk, slab0; };
+    std::vector<Group> groups;
     int nw = 0, nr = 0;
     for (int i = 0; i < n_problems; ++i) {
         const int64_t* d = problems + 16 * i;
@@ -1936,13 +1947,69 @@ extern "C" int ase_hip_gemm_tn_grouped_plan(int64_t* problems, int n_problems, i
         for (int64_t s = 0; s < splits; ++s) {
             const int64_t k0 = s * chunk, nk = (k0 + chunk <= kt) ? chunk : kt - k0;
             if (nk <= 0) continue;
-            for (int t = 0; t < tiles; ++t) {
-                ASE_CHECK_ARG(nw < max_work, "gemm_tn_grouped_plan: more than %d work items", max_work);
-                work[4 * nw + 0] = i; work[4 * nw + 1] = t; work[4 * nw + 2] = (int)(k0 * 64); work[4 * nw + 3] = (int)nk;
-                ++nw;
-            }
+            ASE_CHECK_ARG(nk < 65536 && nw + tiles < 32768, "gemm_tn_grouped_plan: work item out of the packed range");
+            groups.push_back(Group{i, 0, tiles, (int)(k0 * 64), (int)nk, nw});
+            nw += tiles;
         }
     }
+    ASE_CHECK_ARG(nw <= max_work, "gemm_tn_grouped_plan: more than %d work items", max_work);
+    // Launch order.  Workgroup b runs on XCD b mod 8 and the kernel maps it to list position (b mod 8) * cap + b / 8, so
+    // positions [x cap, (x + 1) cap) are XCD x's.  The tiles of one (problem, row range) read the same operand panels - 4 x 4
+    // tiles of a 1024 x 1024 layer: 8 distinct panels for 32 panel reads - but only through ONE XCD's L2: a group that
+    // straddles two XCDs is fetched twice.  So the groups are bin-packed (first fit, largest first) into the 8 position
+    // ranges, whole, and the ranges are padded with empty items (nk = 0: the workgroup returns at once) to a common length.
+    const int per_round = (target_wg + 7) / 8;
+    const int rounds = (nw + target_wg - 1) / target_wg;
+    int cap = (nw + 7) / 8;
+    const int cap_max = (rounds * per_round > cap) ? rounds * per_round : cap;
+    std::vector<Group> parts;                                // groups wider than a range: cut at multiples of cap_max
+    for (const Group& g : groups)
+        for (int t = 0; t < g.nt; t += cap_max)
+            parts.push_back(Group{g.prob, g.t0 + t, (g.nt - t < cap_max) ? g.nt - t : cap_max, g.m_begin, g.nk, g.slab0});
+    std::stable_sort(parts.begin(), parts.end(), [](const Group& a, const Group& b) { return a.nt > b.nt; });
+    std::vector<int> bin_of(parts.size());
+    for (;; ++cap) {
+        int fill[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        bool ok = true;
+        for (size_t g = 0; g < parts.size() && ok; ++g) {
+            int x = 0;
+            while (x < 8 && fill[x] + parts[g].nt > cap) ++x;
+            if (x == 8) { ok = false; break; }
+            bin_of[g] = x;
+            fill[x] += parts[g].nt;
+        }
+        if (ok) break;
+        if (cap >= cap_max) {                                // no whole-group packing within the rounds: fill in order
+            int x = 0, used = 0;
+            std::vector<Group> cut;
+            std::vector<int> cut_bin;
+            for (const Group& g : parts) {
+                int t = 0;
+                while (t < g.nt) {
+                    if (used == cap) { ++x; used = 0; }
+                    const int n = (g.nt - t < cap - used) ? g.nt - t : cap - used;
+                    cut.push_back(Group{g.prob, g.t0 + t, n, g.m_begin, g.nk, g.slab0});
+                    cut_bin.push_back(x);
+                    t += n; used += n;
+                }
+            }
+            parts.swap(cut);
+            bin_of.swap(cut_bin);
+            break;
+        }
+    }
+    ASE_CHECK_ARG(8 * cap <= max_work, "gemm_tn_grouped_plan: more than %d work items (%d with the XCD padding)", max_work, 8 * cap);
+    for (int i = 0; i < 8 * cap * 4; ++i) work[i] = 0;
+    int at[8];
+    for (int x = 0; x < 8; ++x) at[x] = x * cap;
+    for (size_t g = 0; g < parts.size(); ++g) {
+        const Group& q = parts[g];
+        for (int t = 0; t < q.nt; ++t) {
+            int32_t* w = work + 4 * at[bin_of[g]]++;
+            w[0] = q.prob; w[1] = q.t0 + t; w[2] = q.m_begin; w[3] = q.nk | ((q.slab0 + q.t0 + t) << 16);
+        }
+    }
+    nw = 8 * cap;
     *n_work = nw;
     if (n_red) *n_red = nr;
     return ASE_OK;

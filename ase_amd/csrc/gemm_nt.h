@@ -75,14 +75,15 @@ __device__ __forceinline__ f32x16 nt8_mfma(const i32x4& a, const i32x4& b, const
 // bound by store ISSUE, not by bandwidth).  Mask words: one 32-bit word per (row, 32-column fragment) per lane - all 8 of
 // a wave tile are fetched before the main loop (bits[]); the forward's mask_out word is assembled from the two
 // half-waves' 16 bits each with one more swap.  Needs whole 64-column wave tiles (N % 64 == 0) and a bf16 output.
-template <typename T, int AUXK>
-__device__ __forceinline__ void nt8_epilogue_rows(const NTParams& p, f32x16 (&acc)[4][2], int lane, int mrow0, int ncol0,
-                                                  const uint32_t (&bits)[4][2]) {
-    if (ncol0 >= p.N) return;                                   // wave-uniform: N is a multiple of 64
+// NJ: 32-column fragments of the wave tile (2: the 8-wave kernel's 128 x 64, 4: the 4-wave kernel's 128 x 128).
+template <typename T, int AUXK, int NJ = 2>
+__device__ __forceinline__ void nt8_epilogue_rows(const NTParams& p, f32x16 (&acc)[4][NJ], int lane, int mrow0, int ncol0,
+                                                  const uint32_t (&bits)[4][NJ]) {
+    if (ncol0 >= p.N) return;                                   // wave-uniform: N is a multiple of the wave tile's width
     const int r = lane & 31, h = lane >> 5;
-    f32x4 bias[2][4];
+    f32x4 bias[NJ][4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             if (p.bias) bias[j][g] = *reinterpret_cast<const f32x4*>(p.bias + ncol0 + j * 32 + 8 * g + 4 * h);
@@ -93,9 +94,9 @@ __device__ __forceinline__ void nt8_epilogue_rows(const NTParams& p, f32x16 (&ac
         const int m = mrow0 + i * 32 + r;
         const bool row_ok = m < p.M;
         char* crow = p.C + (int64_t)m * p.ldc + (int64_t)ncol0 * 2 + h * 16;
-        uint32_t mword[2];
+        uint32_t mword[NJ];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             uint32_t pk[4][2];
             uint32_t mb = 0;
 #pragma unroll
@@ -125,14 +126,20 @@ __device__ __forceinline__ void nt8_epilogue_rows(const NTParams& p, f32x16 (&ac
             mword[j] = mb;
         }
         if (p.mask_out) {
-            // word j of this row = own 16 bits | the other half-wave's 16 bits
-            const auto w = __builtin_amdgcn_permlane32_swap(mword[0], mword[1], false, false);
-            // after the swap: lanes 0-31 hold (own word 0 bits, upper's word 0 bits); lanes 32-63 (lower's word 1, own word 1)
-            const uint32_t full = w[0] | w[1];
-            if (row_ok) p.mask_out[(int64_t)m * p.ldmask + (ncol0 >> 5) + h] = full;
+#pragma unroll
+            for (int jp = 0; jp < NJ; jp += 2) {
+                // word j of this row = own 16 bits | the other half-wave's 16 bits
+                const auto w = __builtin_amdgcn_permlane32_swap(mword[jp], mword[jp + 1], false, false);
+                // after the swap: lanes 0-31 hold (own word jp bits, upper's word jp bits); lanes 32-63 (lower's word jp + 1, own)
+                const uint32_t full = w[0] | w[1];
+                if (row_ok) p.mask_out[(int64_t)m * p.ldmask + (ncol0 >> 5) + jp + h] = full;
+            }
         }
     }
 }
 
+
+// the 4-wave register-staged 256 x 256 kernel (gemm_nt4.hip); prof: debug stamps or null
+template <typename T> int launch_nt4r(const NTParams& p, unsigned long long* prof, hipStream_t stream);
 
 }  // namespace ase_nt

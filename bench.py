@@ -71,7 +71,8 @@ class TimedBackend:
         s.record()
         fn(*a, **kw)
         e.record()
-        self.records.append((kind, flops, s, e, self._shape))
+        self.records.append((kind, flops, s, e, self._shape, getattr(self, '_nbytes', 0.0)))
+        self._nbytes = 0.0
 
     def gemm_nt(self, A, B, Cm, M, N, K, **kw):
         from ase_amd import lib as L
@@ -84,6 +85,7 @@ class TimedBackend:
         kid = self._be.lib.ase_hip_gemm_nt_kernel_id(M, N, K, self._be._gemm_code(A.dtype))
         kind = 'nt8' if kid == 2 else 'nt'
         self.bytes[kind] = self.bytes.get(kind, 0.0) + nbytes
+        self._nbytes = float(nbytes)
         self._timed(kind, 2.0 * M * N * K, self._be.gemm_nt, A, B, Cm, M, N, K, **kw)
 
     def gemm_tn(self, A, B, G, M, N, K, n_real, k_real, split_src, split_dst, **kw):
@@ -94,6 +96,8 @@ class TimedBackend:
     def gemm_tn_grouped(self, plan):
         flops = sum(2.0 * M * nr * kr for (A, B, G, gb, br, M, N, K, nr, kr, ss, sd, al) in plan['keep'])
         self._shape = (0, len(plan['keep']), plan['n_work'])       # grouped: N = problems, K = work items
+        es = plan['keep'][0][0].element_size()        # both operands once + the f32 gradient read-modify-write
+        self._nbytes = float(sum(M * (N + K) * es + 8 * nr * kr for (A, B, G, gb, br, M, N, K, nr, kr, ss, sd, al) in plan['keep']))
         self._timed('tn', flops, self._be.gemm_tn_grouped, plan)
 
     # ---- HBM-bound kernels: algorithmic bytes per launch, HIP events around the launch
@@ -152,17 +156,27 @@ class TimedBackend:
                 out[kind] = {'launches': len(rs), 'ms': ms, 'flops': sum(r[1] for r in rs)}
         return out
 
-    def breakdown(self):
+    def breakdown(self, peak_tflops=2500.0, peak_gbps=8000.0):
+        """Per-shape table: HIP-event time, TF/s, and the shape's own roofline - floor = max(flop / MFMA peak, algorithmic
+        operand bytes / 8 TB/s); `of floor` = floor / measured (event brackets include ~4-8 us of launch gap)."""
         torch.cuda.synchronize()
         agg = {}
-        for kind, flops, s, e, shape in self.records:
-            a = agg.setdefault((kind,) + shape, [0, 0.0, 0.0])
+        for kind, flops, s, e, shape, nb in self.records:
+            a = agg.setdefault((kind,) + shape, [0, 0.0, 0.0, 0.0])
             a[0] += 1
             a[1] += s.elapsed_time(e)
             a[2] += flops
+            a[3] += nb
         rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
-        return [f'{k[0]} M={k[1]:6d} N={k[2]:5d} K={k[3]:5d}  n={v[0]:4d}  {v[1]:8.2f} ms  {v[2] / (v[1] * 1e-3) / 1e12:7.1f} TF/s'
-                for k, v in rows]
+        out = []
+        for k, v in rows:
+            us = v[1] * 1e3 / v[0]
+            t_m, t_h = v[2] / v[0] / (peak_tflops * 1e12) * 1e6, v[3] / v[0] / (peak_gbps * 1e9) * 1e6
+            bound = 'hbm ' if t_h > t_m else 'mfma'
+            roof = f'  {v[3] / v[0] / 1e6:7.1f} MB  floor {max(t_m, t_h):6.1f} us ({bound})  {max(t_m, t_h) / us:5.2f} of floor' if v[3] else ''
+            out.append(f'{k[0]} M={k[1]:6d} N={k[2]:5d} K={k[3]:5d}  n={v[0]:4d}  {v[1]:8.2f} ms  {us:7.1f} us  '
+                       f'{v[2] / (v[1] * 1e-3) / 1e12:7.1f} TF/s{roof}')
+        return out
 
 
 def algorithmic_flops_per_step(eng):
@@ -508,7 +522,7 @@ def main():
         one_update()
         summ = tb.summary()
         if args.breakdown:
-            print('\n'.join(tb.breakdown()), file=sys.stderr)
+            print('\n'.join(tb.breakdown(peak_tflops=MFMA_PEAK_TFLOPS[args.precision])), file=sys.stderr)
         eng.be = tb._be
         eng.multi_stream = ms_flag
         agent.use_graph = use_graph

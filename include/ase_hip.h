@@ -103,8 +103,12 @@ int ase_hip_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, floa
  *             M and bias_rows multiples of 64.
  *   ase_hip_gemm_tn_grouped_plan (host only, no GPU needed): validates the HOST copy of the table, fills field 15 (tiles
  *             along k; bit 30: the gradient buffer is shared with another problem of the launch) and writes the work list
- *             int32[n_work][4] = {problem, 256 x 256 output tile, first row, 64-row K-tiles} and (red non-null) the reduce
- *             list int32[n_red][4] = {problem, tile, first work item, splits}; target_wg <= 0: one workgroup per CU.
+ *             int32[n_work][4] = {problem, 256 x 256 output tile, first row, 64-row K-tiles | workspace slab << 16} in LAUNCH
+ *             order - positions [x n_work/8, (x+1) n_work/8) run on XCD x: the tiles of one (problem, row range) share their
+ *             operand panels through that XCD's L2, so such groups are bin-packed whole into the 8 ranges and the ranges
+ *             padded with empty items (K-tiles = 0; n_work is a multiple of 8) - and (red non-null) the reduce list
+ *             int32[n_red][4] = {problem, tile, first slab, splits} (split s of a tile: slab first + s * tiles of the problem);
+ *             target_wg <= 0: one workgroup per CU.
  *   ase_hip_gemm_tn_grouped: launch with DEVICE copies of the planned tables.  workspace (device f32, 16-byte aligned,
  *             n_work * ASE_TN_SLAB floats, private to the launch until it completes): every work item stores its partial
  *             tile there with plain 16-byte stores and a second kernel adds the sums into G / gbias (deterministic, no

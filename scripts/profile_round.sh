@@ -26,3 +26,5 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM
 done
 grep -h "^{\"metric\"" $OUT/bench_replay.log > $OUT/bench_replay.json
 grep -h "^{\"metric\"" $OUT/bench_serial.log > $OUT/bench_serial.json
+# the per-launch HBM traffic file bench.py quotes (copy to profiles/rNN_pmc.json together with the summaries)
+python scripts/make_pmc_json.py $OUT/pmc_summary.txt $OUT/pmc.json $OUT/kernel_stats_serial.txt > $OUT/pmc_json.log 2>&1

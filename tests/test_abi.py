@@ -75,17 +75,29 @@ def _plan(problems, target=256):
     red = (ctypes.c_int32 * (4 * 8192))()
     nr = ctypes.c_int(0)
     rc = lib.ase_hip_gemm_tn_grouped_plan(tab, n, target, work, 8192, ctypes.byref(nw), red, 8192, ctypes.byref(nr))
-    items = [tuple(work[4 * i:4 * i + 4]) for i in range(nw.value)]
+    raw = [tuple(work[4 * i:4 * i + 4]) for i in range(nw.value)]
+    # launch order, padded per XCD range with empty items (K-tiles = 0); field 3 = K-tiles | workspace slab << 16
+    items = [(p_, t_, m0, w3 & 0xFFFF) for (p_, t_, m0, w3) in raw if w3 & 0xFFFF]
+    slabs = [w3 >> 16 for (p_, t_, m0, w3) in raw if w3 & 0xFFFF]
     if rc == 0:
-        # reduce list: one entry per (problem, tile); split s of the tile is work item first + s * tiles(problem)
+        assert nw.value % 8 == 0 and sorted(slabs) == list(range(len(slabs)))          # every slab exactly once
+        # reduce list: one entry per (problem, tile); split s of the tile wrote slab first + s * tiles(problem)
         ents = [tuple(red[4 * i:4 * i + 4]) for i in range(nr.value)]
         tiles_of = {}
         for (p_, t_, m0, nk) in items:
             tiles_of[p_] = max(tiles_of.get(p_, 0), t_ + 1)
         assert sorted((p_, t_) for p_, t_, _, _ in ents) == sorted({(p_, t_) for p_, t_, _, _ in items})
         for p_, t_, first, splits in ents:
-            own = [i for i, it in enumerate(items) if it[0] == p_ and it[1] == t_]
+            own = sorted(sl for sl, it in zip(slabs, items) if it[0] == p_ and it[1] == t_)
             assert own == [first + s_ * tiles_of[p_] for s_ in range(splits)], (p_, t_, first, splits, own)
+        # whole sharing groups per XCD range where the packing allows it: the tiles of one (problem, row range) of a power-of-
+        # two tile count never straddle two ranges when everything fits one round
+        cap = nw.value // 8
+        where = {}
+        for pos, (p_, t_, m0, w3) in enumerate(raw):
+            if w3 & 0xFFFF:
+                where.setdefault((p_, m0), set()).add(pos // cap)
+        _plan.straddlers = sum(len(v) > 1 for v in where.values())
     return rc, items, tab
 
 
@@ -97,7 +109,7 @@ def test_grouped_weight_gradient_plan_covers_every_tile_once():
              (16384, 1024, 1408, 1024, 1400, 12288), (16384, 1024, 1024, 1024, 1024, 12288), (16384, 512, 1024, 512, 1024, 12288)]
     rc, items, tab = _plan(probs)
     assert rc == 0
-    assert len(items) == 256
+    assert len(items) == 256 and _plan.straddlers == 0       # one workgroup per CU, no operand panel fetched by two XCDs
     cover = {}
     for p, t, m0, nk in items:
         M, N, K, nr, kr, br = probs[p]
