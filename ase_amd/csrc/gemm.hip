@@ -24,6 +24,7 @@ using namespace ase_nt;
 namespace {
 
 unsigned long long* g_nt_prof = nullptr;      // tuning aid, see ase_hip_debug_nt_profile
+int g_nt_prof_clk = 0;                        // ... stamps 1, 2 in shader clocks (ase_hip_debug_nt_profile_clock)
 
 constexpr int kThreads = 256;
 
@@ -793,7 +794,7 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(NTParams p) {
         if (mask_dma) wait_vmcnt<4 + 4>(); else wait_dma_units<2>();
     }
     NT8_BARRIER();
-    if (p.prof && tid == 0) p.prof[blockIdx.x * 4 + 1] = wall_clock64();
+    if (p.prof && tid == 0) p.prof[blockIdx.x * 4 + 1] = p.prof_clk ? (unsigned long long)clock64() : wall_clock64();
     if (wr == 1) NT8_BARRIER();                  // the second wave group runs one barrier behind
 
     i32x4 a0[4], a1[4], b0[4], b1[4];
@@ -811,7 +812,7 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(NTParams p) {
     }
     if (wr == 0) NT8_BARRIER();
     __syncthreads();                             // the ring becomes the epilogue slab
-    if (p.prof && tid == 0) p.prof[blockIdx.x * 4 + 2] = wall_clock64();
+    if (p.prof && tid == 0) p.prof[blockIdx.x * 4 + 2] = p.prof_clk ? (unsigned long long)clock64() : wall_clock64();
 
     float* slab = reinterpret_cast<float*>(smem) + wid * (64 * 64);
     if ((V & 32) && p.alpha != 12345.f) return;      // ablation: no epilogue (the guard keeps the accumulators live)
@@ -851,6 +852,7 @@ template <typename T, int V, bool SW = false> int launch_nt8(const NTParams& p0,
     }
     NTParams p = p0;
     p.prof = g_nt_prof;
+    p.prof_clk = g_nt_prof_clk;
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = (p.N + 255) / 256;
     ASE_LAUNCH(kern, dim3(p.tiles_m * p.tiles_n), dim3(512), lds, stream, p);
@@ -937,9 +939,11 @@ template <typename T> int dispatch_nt(const NTParams& p, hipStream_t s) {
                 // row-per-lane epilogue (swapped MFMA operands): 16-bit output in whole 64-column wave tiles, no column sums,
                 // mask operand absent or a bit matrix; otherwise the LDS-slab epilogue.  DMA issued inside the MFMA block (V = 64).
                 const bool rows_ok = rows_epi(p, 64);
-                // four waves, register-staged operands (gemm_nt4.hip): whole 128-column wave tiles with the row-per-lane epilogue
-                static const int nt4r = lab_knob("ASE_NT4R", 1);
+#ifdef ASE_LAB
+                // lab variant: four waves, register-staged operands (scripts/lab/gemm_nt4r_variant.hip)
+                static const int nt4r = lab_knob("ASE_NT4R", 0);
                 if (nt4r && rows_epi(p, 128) && p.pre_out == nullptr) return launch_nt4r<T>(p, g_nt_prof, s);
+#endif
 #ifdef ASE_LAB
                 if constexpr (std::is_same<T, bf16_t>::value) {      // ablation builds of the phased kernel (timing only)
                     static const int v8 = lab_knob("ASE_NT8_V", -2);
@@ -1796,6 +1800,11 @@ extern "C" int ase_hip_refresh_shadow_multi(const int64_t* desc, int n_layers, i
 
 extern "C" int ase_hip_debug_nt_profile(void* buf) {
     g_nt_prof = reinterpret_cast<unsigned long long*>(buf);
+    return ASE_OK;
+}
+
+extern "C" int ase_hip_debug_nt_profile_clock(int shader_clock) {
+    g_nt_prof_clk = shader_clock ? 1 : 0;
     return ASE_OK;
 }
 

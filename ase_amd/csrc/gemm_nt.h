@@ -42,6 +42,7 @@ struct NTParams {
     float alpha;
     int tiles_m, tiles_n;
     unsigned long long* prof;       // debug: per-workgroup phase timestamps (ase_hip_debug_nt_profile), else null
+    int prof_clk;                   // debug: stamps 1 and 2 (main loop) in shader clocks instead of the 100 MHz clock
 };
 
 
@@ -139,7 +140,9 @@ __device__ __forceinline__ void nt8_epilogue_rows(const NTParams& p, f32x16 (&ac
 }
 
 
-// the 4-wave register-staged 256 x 256 kernel (gemm_nt4.hip); prof: debug stamps or null
+#ifdef ASE_LAB
+// lab variant: the 4-wave register-staged 256 x 256 kernel (scripts/lab/gemm_nt4r_variant.hip); prof: debug stamps or null
 template <typename T> int launch_nt4r(const NTParams& p, unsigned long long* prof, hipStream_t stream);
+#endif
 
 }  // namespace ase_nt

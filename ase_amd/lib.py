@@ -68,6 +68,7 @@ SIGNATURES = {
     "ase_hip_normalize_rows": [_p, _i64, _p, _i64, _i, _i, _p],
     "ase_hip_sample_actions": [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "ase_hip_debug_nt_profile": [_p],
+    "ase_hip_debug_nt_profile_clock": [_i],
     "ase_hip_motion_state": [_p] * 6 + [_i] + [_p] * 6 + [_i, _p, _p, _i, _p, _i] + [_p] * 8,
     "ase_hip_build_amp_obs": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _i, _i, _i, _p, _i, _i, _p],
     "ase_hip_gemm_nt_kernel_id": [_i, _i, _i, _i],

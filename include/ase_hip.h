@@ -54,6 +54,10 @@ int ase_hip_gemm_nt_kernel_id(int M, int N, int K, int dtype);
 /* Kernel-tuning aid (scripts/lab): when buf is a device uint64[4 * workgroups] array, the phased NT kernel stamps
  * {entry, first tile landed, main loop done, stores retired} per workgroup (100 MHz clock); NULL switches it off. */
 int ase_hip_debug_nt_profile(void* buf);
+/* ... shader_clock != 0: the two main-loop stamps (1, 2) of the phased kernel count SHADER clocks (s_memtime) instead of the
+ * 100 MHz clock - two profiled launches of one shape give the clock frequency the chip actually sustains under that kernel
+ * (bench.py `roofline.sustained_clock_mhz`: MI355X does not hold its 2.4 GHz boost under dense MFMA load). */
+int ase_hip_debug_nt_profile_clock(int shader_clock);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense layers (matrix cores).

@@ -22,7 +22,21 @@
 // phase ends with lgkmcnt(0) (its reads feed the next phase, its writes must be done before the next barrier); vmcnt is
 // counted by the compiler (the loads are builtins, only the LDS instructions are inline asm so that nothing reorders them).
 // Registers: 256 accumulators + 4 fragment sets (128) + 4 staging sets (64) + addresses.
-#include "gemm_nt.h"
+//
+// LAB VARIANT, NOT part of the product build (scripts/lab/Makefile links it into libase_hip_lab.so; ASE_NT4R=1 dispatches it,
+// ASE_NT4R_ABL selects a timing ablation).  MEASURED (round 3, scripts/lab/r3i.sh / r3k.sh, profiles/r03_lab_nt4r.log):
+// correct on every shape and in the product's whole GPU test-suite (193 tests with it dispatched), and NOT faster than the
+// 8-wave phased kernel: main loop of the 16384 x 1024 x 1024 layer 24.9 us (8-wave: 25.4), 32768 x 1024 x 1024 69.1 vs 69.6 us
+// per launch, 8192^3 1045 vs 962 us, launches with a mask operand 1-2 us slower (the mask words are ordinary loads here).
+// Ablations on the 16384 x 1024 x 1024 layer (loop us): full 24.9 | no global loads 23.1 | no loads, no LDS writes 21.2 | no
+// fragment reads 20.9 | MFMAs + barriers only 17.8 - the costs are ADDITIVE here too (~18 cycles of matrix-pipe time per
+// memory instruction issued between two MFMAs of the only wave of a SIMD).  Shader clocks of the loop (s_memtime against the
+// 100 MHz s_memrealtime): 39.85 k cycles in 25.0 us = 1.59 GHz for the full kernel, 34.3 k in 17.95 us = 1.91 GHz MFMA-only,
+// 8192^3 1.73 / 2.05 GHz: the chip does not hold its 2.4 GHz boost under dense MFMA load on random operands.  In CYCLES the
+// loop keeps the matrix pipe busy 82 % of the time (2048 of 2490 per K-tile); the rest of the gap to the 2.5 PF dense peak is
+// frequency.  That - not the staging mechanism - is what both 256 x 256 kernels are up against.
+#include "../../ase_amd/csrc/gemm_nt.h"
+#include <stdlib.h>
 
 using namespace ase_nt;
 
@@ -58,7 +72,8 @@ __device__ constexpr bool nt4_kind_is_b(int kind) { return kind == 1 || kind == 
 // one phase: c{ij} += a[i] x b[j] over the 4 k-steps.
 //   SUB: the fragment set read for the next phase = 64-row half SUB of the wave's A or B rows, at LDS addresses rd[ks]
 //   KIND: the unit kind written (K-tile image `wimg`, if wr_live) and loaded (K-tile `ltile`, if ld_live) - staging set st
-template <typename T, int SUB, int KIND>
+// ABL (lab builds only, timing ablations with wrong results): 1 no global loads, 2 no LDS writes, 4 no fragment reads
+template <typename T, int SUB, int KIND, int ABL>
 __device__ __forceinline__ void nt4_phase(f32x16& c00, f32x16& c10, f32x16& c01, f32x16& c11, const i32x4 (&a)[2][4],
                                           const i32x4 (&b)[2][4], i32x4 (&nx)[2][4], const uint32_t (&rd)[4], bool rd_live,
                                           const NT4Lane& L, i32x4 (&st)[4], uint32_t wbase, bool wr_live,
@@ -68,16 +83,16 @@ __device__ __forceinline__ void nt4_phase(f32x16& c00, f32x16& c10, f32x16& c01,
         constexpr int n = decltype(nc)::value;
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (n < 8) {                                   // fragment reads first: the next phase starts with them
-            if (rd_live) {
+            if (!(ABL & 4) && rd_live) {
                 constexpr int ks = n & 3, off = SUB * 8192 + (n >> 2) * 4096;
                 nt4_read1<off>(nx[n >> 2][ks], rd[ks]);
             }
         } else if constexpr (n < 12) {
             constexpr int g = n - 8;
-            if (wr_live) nt4_write1<(isB ? 32768 : 0) + nt4_piece_row(KIND, g) * 128>(wbase, st[g]);
+            if (!(ABL & 2) && wr_live) nt4_write1<(isB ? 32768 : 0) + nt4_piece_row(KIND, g) * 128>(wbase, st[g]);
         } else {
             constexpr int g = n - 12;
-            if (ld_live) {
+            if (!(ABL & 1) && ld_live) {
                 const uint32_t soff = (uint32_t)(nt4_piece_row(KIND, g) * ld) + (uint32_t)ltile * 128u;
                 st[g] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
             }
@@ -113,7 +128,7 @@ __device__ __forceinline__ void nt4_phase(f32x16& c00, f32x16& c10, f32x16& c01,
 
 // one K-tile.  On entry X = A01(t), Bp = B01(t) are in registers; on exit X = A01(t + 1), Bq = B01(t + 1).
 // TAIL: one of the last two K-tiles (reads / writes / loads of K-tiles past the end are switched off).
-template <typename T, bool TAIL>
+template <typename T, bool TAIL, int ABL>
 __device__ __forceinline__ void nt4_ktile(int t, int nk, const NT4Lane& L, f32x16 (&acc)[4][4], i32x4 (&X)[2][4],
                                           i32x4 (&Y)[2][4], i32x4 (&Bp)[2][4], i32x4 (&Bq)[2][4], i32x4 (&S)[4][4],
                                           __amdgpu_buffer_rsrc_t rsA, __amdgpu_buffer_rsrc_t rsB, int64_t lda, int64_t ldb) {
@@ -127,9 +142,9 @@ __device__ __forceinline__ void nt4_ktile(int t, int nk, const NT4Lane& L, f32x1
         rb[ks] = L.adB[ks] + cur;
     }
     NT8_BARRIER();
-    nt4_phase<T, 1, 0>(acc[0][0], acc[1][0], acc[0][1], acc[1][1], X, Bp, Bq, rb, true, L, S[0], wb, more, rsA, L.voffA, lda,
+    nt4_phase<T, 1, 0, ABL>(acc[0][0], acc[1][0], acc[0][1], acc[1][1], X, Bp, Bq, rb, true, L, S[0], wb, more, rsA, L.voffA, lda,
                        t + 2, ld);                                                   // reads B23(t); writes A0(t+1); loads A0(t+2)
-    nt4_phase<T, 1, 1>(acc[0][2], acc[1][2], acc[0][3], acc[1][3], X, Bq, Y, ra, true, L, S[1], wb, more, rsB, L.voffB, ldb,
+    nt4_phase<T, 1, 1, ABL>(acc[0][2], acc[1][2], acc[0][3], acc[1][3], X, Bq, Y, ra, true, L, S[1], wb, more, rsB, L.voffB, ldb,
                        t + 2, ld);                                                   // reads A23(t); writes B0(t+1); loads B0(t+2)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -137,13 +152,13 @@ __device__ __forceinline__ void nt4_ktile(int t, int nk, const NT4Lane& L, f32x1
         rb[ks] = L.adB[ks] + nxt;
     }
     NT8_BARRIER();
-    nt4_phase<T, 0, 2>(acc[2][2], acc[3][2], acc[2][3], acc[3][3], Y, Bq, X, ra, more, L, S[2], wb, more, rsB, L.voffB, ldb,
+    nt4_phase<T, 0, 2, ABL>(acc[2][2], acc[3][2], acc[2][3], acc[3][3], Y, Bq, X, ra, more, L, S[2], wb, more, rsB, L.voffB, ldb,
                        t + 2, ld);                                                   // reads A01(t+1); writes B1(t+1); loads B1(t+2)
-    nt4_phase<T, 0, 3>(acc[2][0], acc[3][0], acc[2][1], acc[3][1], Y, Bp, Bq, rb, more, L, S[3], wb, more, rsA, L.voffA, lda,
+    nt4_phase<T, 0, 3, ABL>(acc[2][0], acc[3][0], acc[2][1], acc[3][1], Y, Bp, Bq, rb, more, L, S[3], wb, more, rsA, L.voffA, lda,
                        t + 2, ld);                                                   // reads B01(t+1); writes A1(t+1); loads A1(t+2)
 }
 
-template <typename T>
+template <typename T, int ABL>
 __global__ __launch_bounds__(256) void gemm_nt4r_kernel(NTParams p) {
     static_assert(sizeof(T) == 2, "16-bit storage only");
     constexpr int RB = 128, BM = 256, BK = 64;
@@ -237,10 +252,12 @@ __global__ __launch_bounds__(256) void gemm_nt4r_kernel(NTParams p) {
     nt4_retire(X);
     nt4_retire(P);
 
+    long long clk0 = 0;
+    if constexpr (ABL & 8) clk0 = clock64();                 // lab: shader clocks of the main loop (actual frequency under load)
     int t = 0;
     for (; t + 3 < nk; t += 2) {
-        nt4_ktile<T, false>(t, nk, L, acc, X, Y, P, Q, S, rsA, rsB, p.lda, p.ldb);
-        nt4_ktile<T, false>(t + 1, nk, L, acc, X, Y, Q, P, S, rsA, rsB, p.lda, p.ldb);
+        nt4_ktile<T, false, ABL>(t, nk, L, acc, X, Y, P, Q, S, rsA, rsB, p.lda, p.ldb);
+        nt4_ktile<T, false, ABL>(t + 1, nk, L, acc, X, Y, Q, P, S, rsA, rsB, p.lda, p.ldb);
     }
     // mask words of the wave tile (data-gradient launches: 128 rows x 4 words, one 16-byte load per row block and lane),
     // fetched while the last K-tiles multiply - the staging registers are free by then
@@ -255,9 +272,11 @@ __global__ __launch_bounds__(256) void gemm_nt4r_kernel(NTParams p) {
         }
     }
     for (; t < nk; t += 2) {                         // t is even here: B01(t) sits in P
-        nt4_ktile<T, true>(t, nk, L, acc, X, Y, P, Q, S, rsA, rsB, p.lda, p.ldb);
-        if (t + 1 < nk) nt4_ktile<T, true>(t + 1, nk, L, acc, X, Y, Q, P, S, rsA, rsB, p.lda, p.ldb);
+        nt4_ktile<T, true, ABL>(t, nk, L, acc, X, Y, P, Q, S, rsA, rsB, p.lda, p.ldb);
+        if (t + 1 < nk) nt4_ktile<T, true, ABL>(t + 1, nk, L, acc, X, Y, Q, P, S, rsA, rsB, p.lda, p.ldb);
     }
+    long long clk1 = 0;
+    if constexpr (ABL & 8) clk1 = clock64();
     if (p.prof && tid == 0) p.prof[blockIdx.x * 4 + 2] = wall_clock64();
     uint32_t row_bits[4][4];
     if (masked) {
@@ -272,6 +291,9 @@ __global__ __launch_bounds__(256) void gemm_nt4r_kernel(NTParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) p.prof[blockIdx.x * 4 + 3] = wall_clock64();
+        if constexpr (ABL & 8) {          // "epilogue+drain" column of the lab print x 1000 = shader clocks of the main loop
+            if (tid == 0) p.prof[blockIdx.x * 4 + 3] = p.prof[blockIdx.x * 4 + 2] + (unsigned long long)(clk1 - clk0) / 10;
+        }
     }
 }
 
@@ -282,7 +304,16 @@ namespace ase_nt {
 template <typename T> int launch_nt4r(const NTParams& p0, unsigned long long* prof, hipStream_t stream) {
     constexpr int lds = 2 * 512 * 128;
     static bool attr_done = false;
-    auto kern = gemm_nt4r_kernel<T>;
+    auto kern = gemm_nt4r_kernel<T, 0>;
+#ifdef ASE_LAB
+    static const int abl = getenv("ASE_NT4R_ABL") ? atoi(getenv("ASE_NT4R_ABL")) : 0;
+    if (abl == 1) kern = gemm_nt4r_kernel<T, 1>;
+    if (abl == 3) kern = gemm_nt4r_kernel<T, 3>;
+    if (abl == 4) kern = gemm_nt4r_kernel<T, 4>;
+    if (abl == 7) kern = gemm_nt4r_kernel<T, 7>;
+    if (abl == 8) kern = gemm_nt4r_kernel<T, 8>;
+    if (abl == 15) kern = gemm_nt4r_kernel<T, 15>;
+#endif
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) {
