@@ -969,6 +969,12 @@ class UpdateEngine:
                 self._tn(self.Ue[:, poff:], self.Qe[-1], gW, AMB, P(nr), head.k_pad, nr, head.K, head.split_src, head.split_dst)
         be.enc_gp_back(e, self.enc_z, self.DUe[:, off:], d_e, db, AMB, self.z, grad_scale=S)
 
+    def _gp_scales(self):
+        """(Sc, Sr): the gradient scale S = engine.gs (a power of two) split as evenly as powers of two allow."""
+        e = int(round(math.log2(self.gs)))
+        sc = 2.0 ** ((e + 1) // 2)
+        return sc, self.gs / sc
+
     def _disc_backward(self):
         """Discriminator trunk backward with the gradient penalty riding on the same launches.
 
@@ -992,7 +998,11 @@ class UpdateEngine:
         cg = gp_coef * 2.0 / self.AMBg
         s = math.sqrt(cg)
         top = self.disc[-1]
-        be.gp_seed(self.Hd[-1][2 * AMB:], self.disc_head.W[0].view(-1), self.Gp[-1], AMB, top.N, scale=s)
+        # the gradient scale S is split between the two factors of the penalty's weight-gradient products: the chain g_l carries
+        # Sc, the dJ/dU side Sr (Sc Sr = S, powers of two).  Both are O(1e-4) quantities - unscaled, the chain sat in half's
+        # subnormal range (< 6.1e-5) and the reported penalty came out 0.6-1.5e-4 off; bf16 / f32: S = Sc = Sr = 1.
+        Sc, Sr = self._gp_scales()
+        be.gp_seed(self.Hd[-1][2 * AMB:], self.disc_head.W[0].view(-1), self.Gp[-1], AMB, top.N, scale=s * Sc)
         # data-gradient chain on 4 AMB rows: [dZ_l ; s g_l] -> [dZ_{l-1} ; s g_{l-1}]
         for l in range(nl - 1, 0, -1):
             d, pl = self.disc[l], self.disc[l - 1]
@@ -1000,11 +1010,10 @@ class UpdateEngine:
             be.gemm_nt(self.dZd4[l], d.Wts, self.dZd4[l - 1], 4 * AMB, d.k_pad, d.n_pad, aux=aux, aux_mode=mode,
                        aux_split=Rd, aux_delta=AMB)
         d0 = self.disc[0]
-        # (the chain's second-operand side - G0 and the dJ/dU_l derived from it - carries the gradient scale S so that the
-        #  stacked weight-gradient launches undo it for both row blocks with one alpha)
-        S = self.gs
-        be.gemm_nt(self.Gp[0], d0.Wts, self.G0, AMB, d0.k_pad, d0.n_pad, alpha=S)        # S s * g_0
-        be.sqnorm(self.G0, AMB, d0.k_pad, self.acc, L.ACC_GP, scale=1.0 / (cg * S * S))
+        # (the chain's second-operand side - G0 and the dJ/dU_l derived from it - carries Sr so that the stacked
+        #  weight-gradient launches undo S = Sc Sr for both row blocks with one alpha)
+        be.gemm_nt(self.Gp[0], d0.Wts, self.G0, AMB, d0.k_pad, d0.n_pad, alpha=Sr / Sc)        # Sr s * g_0
+        be.sqnorm(self.G0, AMB, d0.k_pad, self.acc, L.ACC_GP, scale=1.0 / (cg * Sr * Sr))
         # backward of the chain (values scaled by s; see the docstring): dJ/dU_l, masked by the demo rows' ReLU masks
         aux, mode = self._aux(self.Hd[0][2 * AMB:], L.AUX_RELU_MASK)
         be.gemm_nt(self.G0, d0.Ws, self.dGp[0], AMB, d0.n_pad, d0.k_pad, aux=aux, aux_mode=mode)
@@ -1013,7 +1022,7 @@ class UpdateEngine:
             last = l == nl - 1
             aux, mode = self._aux(self.Hd[l][2 * AMB:], L.AUX_RELU_MASK)
             be.gemm_nt(self.dGp[l - 1], d.Ws, self.GpTop if last else self.dGp[l], AMB, d.n_pad, d.k_pad, aux=aux,
-                       aux_mode=mode, alpha=s / S if last else 1.0)
+                       aux_mode=mode, alpha=s / Sr if last else 1.0)
             if last:      # the penalty's gradient w.r.t. the logit weights: column sums of the top launch (f32, true scale)
                 be.colsum(self.GpTop, AMB, d.N, self.disc_head.gW[0].view(-1))
         # weight (+ bias) gradients: one launch per layer over the stacked rows
@@ -1034,7 +1043,7 @@ class UpdateEngine:
         The last line is the path through a'(z) that vanishes for ReLU; it joins the demo rows of the ordinary backward
         (dZ_l) BEFORE that layer's data- and weight-gradient launches, so the penalty chain (which needs nothing of the loss
         backward) runs first here instead of riding on the discriminator's data-gradient launches.  Scales as in
-        _disc_backward: chain values carry s = sqrt(2 c / AMB), the r side also the gradient scale S."""
+        _disc_backward: chain values carry s = sqrt(2 c / AMB) and Sc, the r side s and Sr (Sc Sr = the gradient scale S)."""
         be, c, AMB = self.be, self.cfg, self.AMB
         Rd, nl, S = 3 * AMB, len(self.disc), self.gs
         cg = gp_coef * 2.0 / self.AMBg
@@ -1042,14 +1051,16 @@ class UpdateEngine:
         demo = slice(2 * AMB, 3 * AMB)
         top = self.disc[-1]
         # ---- the chain on the demo rows (AMB-row launches into the 4th row block of dZd4)
-        be.gp_seed(self._twin(self.Hd[-1][demo], top), self.disc_head.W[0].view(-1), self.Gp[-1], AMB, top.N, scale=s, act=top.act)
+        Sc, Sr = self._gp_scales()               # chain side / dJ/dU side of the gradient scale, see _disc_backward
+        be.gp_seed(self._twin(self.Hd[-1][demo], top), self.disc_head.W[0].view(-1), self.Gp[-1], AMB, top.N, scale=s * Sc,
+                   act=top.act)
         for l in range(nl - 1, 0, -1):
             d, pl = self.disc[l], self.disc[l - 1]
             aux, mode = self._aux(self.Hd[l - 1][demo], _AUX[pl.act])
             be.gemm_nt(self.Gp[l], d.Wts, self.Gp[l - 1], AMB, d.k_pad, d.n_pad, aux=aux, aux_mode=mode)
         d0 = self.disc[0]
-        be.gemm_nt(self.Gp[0], d0.Wts, self.G0, AMB, d0.k_pad, d0.n_pad, alpha=S)        # S s * g_in
-        be.sqnorm(self.G0, AMB, d0.k_pad, self.acc, L.ACC_GP, scale=1.0 / (cg * S * S))
+        be.gemm_nt(self.Gp[0], d0.Wts, self.G0, AMB, d0.k_pad, d0.n_pad, alpha=Sr / Sc)        # Sr s * g_in
+        be.sqnorm(self.G0, AMB, d0.k_pad, self.acc, L.ACC_GP, scale=1.0 / (cg * Sr * Sr))
         # ---- its backward: dGp[l] = a'_l * (dGp[l-1] @ W_l^T), the last one only for the logit weights' gradient
         x = self.G0
         for l in range(nl):
@@ -1057,7 +1068,7 @@ class UpdateEngine:
             last = l == nl - 1
             aux, mode = self._aux(self.Hd[l][demo], _AUX[d.act])
             be.gemm_nt(x, d.Ws, self.GpTop if last else self.dGp[l], AMB, d.n_pad, d.k_pad, aux=aux, aux_mode=mode,
-                       alpha=s / S if last else 1.0)
+                       alpha=s / Sr if last else 1.0)
             if last:
                 be.colsum(self.GpTop, AMB, d.N, self.disc_head.gW[0].view(-1))
             if last:     # the top layer's dGp in storage type and S scale, for the second-order term below
