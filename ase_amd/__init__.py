@@ -20,11 +20,20 @@ hw_queue_note = 'ase_amd.configure() was not called: GPU_MAX_HW_QUEUES keeps the
 hw_queues_applied = False
 
 
-def configure(hw_queues=HW_QUEUES_DEFAULT):
+def configure(hw_queues=HW_QUEUES_DEFAULT, cpu_threads=None):
     """Process-level runtime settings for the measured stream overlap; call BEFORE the first HIP call of the process.
     Returns True if the setting is in effect (set here, or already exported by the user), False if HIP was initialised
-    earlier (then only a warning note is left)."""
+    earlier (then only a warning note is left).
+
+    cpu_threads: torch's intra-op CPU thread count (torch.set_num_threads).  The update keeps the host one step of work
+    ahead of the GPU at most; torch sizes its OpenMP pool by the machine (128 threads on a 256-core host) even inside a
+    container with a 16-core CPU quota, every small CPU tensor operation leaves those workers spinning, the cgroup throttles the
+    whole process for the rest of its 100 ms period, and the GPU idles: measured 2 updates in 20 at 1.2-2.3 x their 65 ms, none
+    in 120 with one thread (profiles/r03_update_time_spikes_threads.log).  bench.py passes 1; None leaves torch alone."""
     global hw_queue_note, hw_queues_applied
+    if cpu_threads is not None:
+        import torch
+        torch.set_num_threads(max(1, int(cpu_threads)))
     if 'GPU_MAX_HW_QUEUES' in os.environ:
         hw_queue_note = f"GPU_MAX_HW_QUEUES={os.environ['GPU_MAX_HW_QUEUES']} (set by the user)"
         hw_queues_applied = True

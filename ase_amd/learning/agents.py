@@ -679,9 +679,10 @@ class CommonAgent:
         if self.multi_gpu:
             self._sync_initial_state()
         self._init_train()
-        # config['manual_gc'] (off by default: it changes the process): the host only runs ~1000 launches ahead of the GPU, so
-        # a generation-2 pass of Python's cyclic collector inside an update (25-55 ms with torch imported) stalls the GPU -
-        # measured 2 updates in 20 at 92-130 ms instead of 65.5.  With the switch on, the collector runs between epochs only.
+        # config['manual_gc'] (off by default: it changes the process): the host is never more than one update ahead of the GPU
+        # (every update ends in a small read-back), so a long host pause inside an update is GPU idle time.  With the switch on,
+        # Python's cyclic collector runs between epochs only.  (The pauses actually measured on the benchmark boxes - 2 updates
+        # in 20 at 1.2-2.3 x - were CPU-quota throttling from torch's OpenMP workers, see ase_amd.configure(cpu_threads=...).)
         manual_gc = bool(self.config.get('manual_gc', False))
         if manual_gc:
             import gc
