@@ -418,6 +418,7 @@ def parity_both_states(agent, cfg, device, mode, steps_fresh, steps_stress, stal
 
 
 def time_updates(agent, n, prime):
+    torch.set_num_threads(1)          # (the oracle leg before this one raised it: see --host-threads)
     for _ in range(prime):
         agent.update(agent._play_steps_tail())
     torch.cuda.synchronize()
@@ -694,7 +695,8 @@ def main():
                           (f'dp{world}, the reference\'s Horovod semantics: 4096 environments and a 16384-row minibatch per GPU, gradients '
                            'averaged by RCCL all-reduce (one bucket per branch, overlapped with the other branches\' backward)' if weak else
                            f'dp{world}, every 16384-row minibatch row-sharded over the ranks, RCCL gradient all-reduce (sum)')},
-               'runtime': ase_amd.hw_queue_note + (('; Python cyclic GC frozen during the timed updates' if args.gc == 'freeze' else '') + f'; torch CPU threads {max(1, args.host_threads)} during the GPU-timed part',
+               'runtime': ase_amd.hw_queue_note + ('; Python cyclic GC frozen during the timed updates' if args.gc == 'freeze' else '')
+               + f'; torch CPU threads {max(1, args.host_threads)} during the GPU-timed part',
                'roofline': roof, 'cpu_baseline': cpu, 'qualifying_mode': qualifying, 'modes': modes,
                'parity': (modes.get(args.precision) or {}).get('parity'),
                'last_train_result': {k: round(v, 6) for k, v in last.items()}}
