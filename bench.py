@@ -418,15 +418,18 @@ def parity_both_states(agent, cfg, device, mode, steps_fresh, steps_stress, stal
 
 
 def time_updates(agent, n, prime):
+    """Median update time (HIP events) of n updates after `prime` untimed ones."""
     torch.set_num_threads(1)          # (the oracle leg before this one raised it: see --host-threads)
     for _ in range(prime):
         agent.update(agent._play_steps_tail())
     torch.cuda.synchronize()
-    t = time.perf_counter()
-    for _ in range(n):
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+    marks[0].record()
+    for i in range(n):
         agent.update(agent._play_steps_tail())
+        marks[i + 1].record()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t) / n * 1e3
+    return sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(n))[n // 2]
 
 
 def _dbg(msg):
@@ -642,13 +645,13 @@ def main():
                 ag, cfg_m, _ = make_agent(device, m, use_graph, world, rank)
                 fill_rollout(ag, device)
                 ag._init_amp_demo_buf()
-                ms_m = time_updates(ag, 2 if m in ('f32', 'bf16x3') else 4, prime=3)
+                ms_m = time_updates(ag, 3 if m in ('f32', 'bf16x3') else 7, prime=3)
             n_f = (args.cpu_steps + 2) // 2 if head else 3
             times, par = parity_both_states(ag, cfg_m, device, m, steps_fresh=n_f, steps_stress=(args.cpu_steps + 1 - n_f + 1) if head else 3)
             if head:
                 cpu = cpu_from_times(times, cfg, B_, MB_, AMB_, host_cores())
             modes[m] = {'value': round(B / (ms_m * 1e-3), 1), 'unit': 'samples/s', 'ms_per_step': round(ms_m, 3),
-                        'timed': f'{args.steps} updates (the headline)' if head else 'updates after 3 priming ones, same workload',
+                        'timed': f'{args.steps} updates (the headline)' if head else 'median of 7 (f32: 3) updates after 3 priming ones, same workload',
                         'grad_scale': ag.engine.gs, 'parity': par}
             if not head:
                 del ag

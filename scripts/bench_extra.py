@@ -19,10 +19,12 @@ import sys
 import time
 import types
 
-import torch
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+
+import ase_amd  # noqa: E402
+ase_amd.configure(cpu_threads=1)     # hardware queues before HIP initialises; one torch CPU thread
+import torch  # noqa: E402
 
 
 def build(kind, num_envs, precision, graph=True, overrides=None):
