@@ -129,11 +129,13 @@ class UpdateEngine:
         #   relu_bits       bit-mask twins of ReLU activations for the data-gradient epilogues
         #   fused_apply     weight-only loss terms + Adam + shadow refresh in one launch per branch (apply_wide: its 16-byte path)
         #   side_streams    2 = critic and discriminator on their own streams, 1 = they share one
+        #   gp_scale_split  f16 mode: the gradient scale split between the two factors of the penalty chain's products (_gp_scales)
         o = dict(tn_grouped=True, tn_wg_side=64, tn_early=False, disc_early=True, short_prologue=True, style_early=False,
-                 relu_bits=True, fused_apply=True, apply_wide=True, side_streams=2)
+                 relu_bits=True, fused_apply=True, apply_wide=True, side_streams=2, gp_scale_split=True)
         unknown = set(cfg.get('engine_opts', {}) or {}) - set(o)
         assert not unknown, f"unknown engine_opts {sorted(unknown)}"
         o.update(cfg.get('engine_opts', {}) or {})
+        self.engine_opts = o
         self._tn_defer = bool(getattr(backend, 'grouped_tn_ok', None)) and bool(o['tn_grouped'])
         self._tn_queue, self._tn_plans = [], {}          # weight gradients queued by the CURRENT branch (see _flush_tn)
         self._tn_wg_side = int(o['tn_wg_side'])
@@ -971,6 +973,8 @@ class UpdateEngine:
 
     def _gp_scales(self):
         """(Sc, Sr): the gradient scale S = engine.gs (a power of two) split as evenly as powers of two allow."""
+        if not self.engine_opts.get('gp_scale_split', True):
+            return 1.0, self.gs
         e = int(round(math.log2(self.gs)))
         sc = 2.0 ** ((e + 1) // 2)
         return sc, self.gs / sc
