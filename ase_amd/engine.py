@@ -115,6 +115,9 @@ class UpdateEngine:
         self.enc_sep = bool(getattr(net, 'enc_separate', False))
         self.enc_gp = kind == 'ase' and cfg.get('enc_grad_penalty', 0) != 0 and cfg.get('enc_coef', 0) != 0
         self.mu_tanh = kind == 'ppo' and getattr(net, 'mu_tanh', False)
+        # gp_f32: the gradient penalty's demo-row path in exact f32 inside a 16-bit engine (_gp_f32)
+        self.gp32 = bool(cfg.get('gp_f32', False)) and self.has_disc and dtype in (torch.float16, torch.bfloat16) and \
+            cfg.get('disc_coef', 0) * cfg.get('disc_grad_penalty', 0) != 0
         self._scratch = {}
         self.multi_stream = bool(cfg.get('multi_stream', True)) and getattr(backend, 'name', '') == 'hip'
         self._side_streams = None
@@ -319,6 +322,18 @@ class UpdateEngine:
             # last launch of the gradient-penalty chain's backward: only its column sums are used (the penalty's gradient
             # w.r.t. the logit weights), at true scale - f32 so that half storage cannot flush them
             self.GpTop = zt(AMB, self.disc[-1].n_pad, f32)
+            if self.gp32:
+                assert all(d.act == L.ACT_RELU for d in self.disc), "gp_f32 is built for ReLU discriminators"
+                import types
+                g = self._gp32 = types.SimpleNamespace()
+                g.X = zt(AMB, self.disc[0].k_pad, f32)                                  # normalised demo rows
+                g.Ws = [zt(d.n_pad, d.k_pad, f32) for d in self.disc]                   # f32 shadows of the trunk
+                g.Wts = [zt(d.k_pad, d.n_pad, f32) for d in self.disc]
+                g.H = [zt(AMB, d.n_pad, f32) for d in self.disc]
+                g.bits = [torch.zeros(AMB, d.n_pad // 32, dtype=torch.int32, device=dev) for d in self.disc]
+                g.Gp = [zt(AMB, d.n_pad, f32) for d in self.disc]                       # s * g_l
+                g.dGp = [zt(AMB, d.n_pad, f32) for d in self.disc[:-1]]                 # s * dJ/dU_l (masked)
+                g.G0 = zt(AMB, self.disc[0].k_pad, f32)                                 # s * g_0
             if self.enc_chain:
                 self.He, self.dZe = chain_bufs(self.enc_chain, AMB)
                 self.E = zt(AMB, self.enc_head.n_pad, f32)
@@ -743,6 +758,9 @@ class UpdateEngine:
             else:                          # rows that are not whole 16-byte chunks: one launch per stream
                 for s, (src, sidx, srm) in enumerate(amp_streams):
                     be.rms_normalize(src, self.amp, sidx, srm, AMB, self.amp_mean[s], self.amp_std[s], [xd[s]])
+            if self.gp32:                  # the demo stream once more, into the f32 input of the penalty path
+                src, sidx, srm = amp_streams[2]
+                be.rms_normalize(src, self.amp, sidx, srm, AMB, self.amp_mean[2], self.amp_std[2], [self._gp32.X])
             hd = self._fwd_chain(self.disc, self.Xd, self.Hd, Rd)
             self._fwd(self.disc_head, hd, self.HD, Rd)
             he = None
@@ -996,6 +1014,10 @@ class UpdateEngine:
             be.zero_(self.G0)     # keeps the reported penalty at 0 without the chain
             self._bwd_chain(self.disc, self.Xd, self.Hd, self.dZd, Rd)
             return
+        if self.gp32:
+            self._gp_f32(gp_coef)
+            self._bwd_chain(self.disc, self.Xd, self.Hd, self.dZd, Rd)
+            return
         if any(d.act != L.ACT_RELU for d in self.disc):
             return self._disc_backward_curved(gp_coef)
         assert nl >= 2, "gradient penalty with a single discriminator layer is not implemented"
@@ -1035,6 +1057,45 @@ class UpdateEngine:
             X = self.Xd4 if l == 0 else self.Hd4[l - 1]
             self._tn(self.dZd4[l], X, d.gW[0], 4 * AMB, d.n_pad, d.k_pad, d.N, d.K, d.split_src, d.split_dst,
                      gbias=d.gb[0], bias_rows=Rd)
+
+    def _gp_f32(self, gp_coef):
+        """The gradient penalty of the demo rows (learning/amp_agent.py:453-459) in exact f32 inside a 16-bit engine
+        (config gp_f32 / precision 'f16gp32').  The penalty is driven towards zero by training, i.e. d logit / d x becomes a
+        CANCELLING sum over the trunk's weights: its relative error in 16-bit storage grows as it shrinks (f16: 6e-5 at a
+        penalty of 0.047, 6.6e-4 at 0.0077 - weight rounding first, ReLU mask flips second).  So this path takes
+        nothing from the 16-bit launches: f32 shadows of the trunk, its own forward of the AMB demo rows (exact masks), the
+        chain, the penalty, the chain's backward and the penalty's weight-gradient terms (f32 launches straight into the
+        gradient buffer, ahead of the branch's grouped 16-bit launch on the same stream).  ~75 GFLOP per step for config 2."""
+        be, AMB, g = self.be, self.AMB, self._gp32
+        nl = len(self.disc)
+        cg = gp_coef * 2.0 / self.AMBg
+        s = math.sqrt(cg)
+        bits = L.AUX_RELU_BITS
+        for l, d in enumerate(self.disc):
+            be.refresh_shadow(d.W[0], g.Ws[l], g.Wts[l], d.split_src, d.split_dst)
+        x = g.X
+        for l, d in enumerate(self.disc):
+            be.gemm_nt(x, g.Ws[l], g.H[l], AMB, d.n_pad, d.k_pad, bias=d.bs, act=L.ACT_RELU, mask_out=g.bits[l])
+            x = g.H[l]
+        top = self.disc[-1]
+        be.gp_seed(g.H[-1], self.disc_head.W[0].view(-1), g.Gp[-1], AMB, top.N, scale=s)
+        for l in range(nl - 1, 0, -1):
+            d = self.disc[l]
+            be.gemm_nt(g.Gp[l], g.Wts[l], g.Gp[l - 1], AMB, d.k_pad, d.n_pad, aux=g.bits[l - 1], aux_mode=bits)
+        d0 = self.disc[0]
+        be.gemm_nt(g.Gp[0], g.Wts[0], g.G0, AMB, d0.k_pad, d0.n_pad)
+        be.sqnorm(g.G0, AMB, d0.k_pad, self.acc, L.ACC_GP, scale=1.0 / cg)
+        be.gemm_nt(g.G0, g.Ws[0], g.dGp[0], AMB, d0.n_pad, d0.k_pad, aux=g.bits[0], aux_mode=bits)
+        for l in range(1, nl):
+            d = self.disc[l]
+            last = l == nl - 1
+            be.gemm_nt(g.dGp[l - 1], g.Ws[l], self.GpTop if last else g.dGp[l], AMB, d.n_pad, d.k_pad, aux=g.bits[l],
+                       aux_mode=bits, alpha=s if last else 1.0)
+            if last:
+                be.colsum(self.GpTop, AMB, d.N, self.disc_head.gW[0].view(-1))
+        for l, d in enumerate(self.disc):
+            be.gemm_tn(g.Gp[l], g.G0 if l == 0 else g.dGp[l - 1], d.gW[0], AMB, d.n_pad, d.k_pad, d.N, d.K, d.split_src,
+                       d.split_dst, alpha=1.0)
 
     def _disc_backward_curved(self, gp_coef):
         """Discriminator backward with the gradient penalty for activations with curvature (anything but ReLU; SURVEY 8 row

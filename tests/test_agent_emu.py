@@ -362,3 +362,15 @@ def test_checkpoint_interop_with_reference(name, golden_dir):
     ag = make_agent(G, EmuBackend())
     replay_epochs(G, ag, rtol=2e-4, wtol=G['cfg']['learning_rate'] * 0.05, check=False)
     check_checkpoint_interop(G, ag, lambda: make_agent(G, EmuBackend()), wtol=G['cfg']['learning_rate'] * 0.05)
+
+
+def test_precision_f16gp32_selects_the_f32_penalty_path(golden_dir):
+    """precision 'f16gp32' = half storage + the gradient penalty's demo-row path in f32 (UpdateEngine._gp_f32): the agent maps
+    the name, the first step's reported penalty is the reference's, every step runs."""
+    G = torch.load(os.path.join(golden_dir, 'ase_tiny.pt'), weights_only=False)
+    ag = make_agent(G, EmuBackend(), precision='f16gp32')
+    assert ag.engine.gp32 and ag.engine.dtype == torch.float16
+    infos = replay_epochs(G, ag, rtol=0, wtol=0, check=False)
+    ref = G['epochs'][0]['steps'][0]
+    got = float(infos[0]['disc_grad_penalty'][0])
+    assert abs(got - float(ref['disc_grad_penalty'])) <= 1e-5 * abs(float(ref['disc_grad_penalty'])), (got, float(ref['disc_grad_penalty']))

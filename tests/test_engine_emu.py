@@ -16,10 +16,12 @@ CASES = ['ase_tiny', 'amp_tiny', 'ppo_tiny', 'ase_sep_tiny', 'ase_gp_tiny', 'ase
          'ase_swish_tiny']       # swish (SiLU) in the policy MLPs, the discriminator and the encoder: the curved gradient penalty
 
 
-def first_step(G, be, dtype, device='cpu', grad_scale=None, engine_opts=None):
+def first_step(G, be, dtype, device='cpu', grad_scale=None, engine_opts=None, gp_f32=False):
     kind, cfg, E = G['kind'], dict(G['cfg']), G['epochs'][0]
     if engine_opts:
         cfg['engine_opts'] = engine_opts
+    if gp_f32:
+        cfg['gp_f32'] = True
     net = build_net(G, device)
     mb = {k: v.to(device) for k, v in E['first_minibatch'].items()}
     M = mb['obs'].shape[0]
@@ -151,3 +153,27 @@ def test_truncate_grads_matches_clip_grad_norm(name, golden_dir):
     got = net.state_dict()
     for k in G['trainable']:
         close(got[k], sd[k].detach(), 1e-6, G['cfg']['learning_rate'] * 0.05, 'weight ' + k)
+
+
+@pytest.mark.parametrize('name', ['ase_tiny', 'amp_tiny', 'ase_sep_tiny'])
+def test_gradient_penalty_in_f32_inside_a_half_engine(name, golden_dir):
+    """config gp_f32 (precision 'f16gp32'): the penalty's demo-row path runs in exact f32 with its own forward, chain and
+    weight-gradient launches - the reported penalty matches the reference as the f32 engine does, the other scalars stay at
+    half's accuracy, and the discriminator trunk's gradients are at least as close to the reference as plain f16's."""
+    G = torch.load(os.path.join(golden_dir, name + '.pt'), weights_only=False)
+    ref = G['epochs'][0]['steps'][0]
+    _, e16 = first_step(G, EmuBackend(), torch.float16)
+    _, e32 = first_step(G, EmuBackend(), torch.float16, gp_f32=True)
+    r16, r32 = e16.results(), e32.results()
+    gp = float(ref['disc_grad_penalty'])
+    assert abs(float(r32['disc_grad_penalty']) - gp) <= 2e-6 * abs(gp), (float(r32['disc_grad_penalty']), gp)
+    for k in ('actor_loss', 'kl', 'critic_loss'):
+        assert abs(float(r32[k].mean()) - float(r16[k].mean())) <= 1e-6 * max(1.0, abs(float(r16[k].mean()))), k    # nothing else moved
+    if 'disc_loss' in ref:           # (the discriminator loss contains the penalty: it can only get closer)
+        assert abs(float(r32['disc_loss']) - float(ref['disc_loss'])) <= abs(float(r16['disc_loss']) - float(ref['disc_loss'])) + 1e-6
+    g16, g32, gref = e16.export_grads(), e32.export_grads(), G['epochs'][0]['first_grads']
+    for k, g in gref.items():
+        if '_disc_mlp' in k and k.endswith('weight'):
+            e_16 = float((g16[k] - g).norm() / g.norm())
+            e_32 = float((g32[k] - g).norm() / g.norm())
+            assert e_32 <= e_16 * 1.05 + 1e-6, (k, e_16, e_32)

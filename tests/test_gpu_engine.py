@@ -48,6 +48,31 @@ def test_first_step_vs_reference_golden_f16(be, name, golden_dir):
         assert rel < 0.08, ('grad ' + k, rel)
 
 
+@pytest.mark.parametrize('name', ['ase_tiny', 'amp_tiny', 'ase_sep_tiny'])
+def test_gradient_penalty_f32_path_in_half_engine(be, name, golden_dir):
+    """precision 'f16gp32' (config gp_f32): the penalty's demo-row path in exact f32 inside the half-storage engine - the
+    reported penalty matches the reference's golden like the f32 engine's (1e-5 relative), the discriminator trunk's gradients
+    are at least as close to the golden as plain f16's, the other scalars are those of the f16 engine."""
+    G = torch.load(os.path.join(golden_dir, name + '.pt'), weights_only=False)
+    _, e16 = first_step(G, be, torch.float16, device='cuda')
+    torch.cuda.synchronize()
+    r16, g16 = {k: v.clone() for k, v in e16.results().items()}, {k: v.cpu().clone() for k, v in e16.export_grads().items()}
+    _, e32 = first_step(G, be, torch.float16, device='cuda', gp_f32=True)
+    torch.cuda.synchronize()
+    assert e32.gp32
+    r32, g32 = e32.results(), {k: v.cpu() for k, v in e32.export_grads().items()}
+    E = G['epochs'][0]
+    gp = float(E['steps'][0]['disc_grad_penalty'])
+    assert abs(float(r32['disc_grad_penalty']) - gp) <= 1e-5 * abs(gp), (float(r32['disc_grad_penalty']), gp, float(r16['disc_grad_penalty']))
+    for k in ('actor_loss', 'kl'):
+        assert abs(float(r32[k]) - float(r16[k])) <= 1e-5 * max(1.0, abs(float(r16[k]))), k
+    for k, g in E['first_grads'].items():
+        if '_disc_mlp' in k and k.endswith('weight'):
+            e_16 = float((g16[k].double() - g.double()).norm() / g.double().norm())
+            e_32 = float((g32[k].double() - g.double()).norm() / g.double().norm())
+            assert e_32 <= e_16 * 1.1 + 1e-5, (k, e_16, e_32)
+
+
 @pytest.mark.parametrize('name', CASES)
 def test_first_step_vs_reference_golden_bf16(be, name, golden_dir):
     """bf16 storage / MFMA, f32 accumulate (8 mantissa bits on activations, shadow weights and
@@ -241,6 +266,7 @@ def test_epoch_tail_full_size_vs_oracle(precision):
 
 @pytest.mark.parametrize('mode,fresh_loss,fresh_grad,stress_loss,stress_grad', [
     ('f16', 2e-4, 6e-2, 6e-4, 0.35),        # measured 3.5e-5 ... 1.5e-4 (the gradient penalty; every other scalar <= 3e-5, asserted below) / 3.3e-2 / 1.9e-4 / 0.20
+    ('f16gp32', 1e-4, 6e-2, 3e-4, 0.35),    # f16 with the penalty's demo-row path in f32: 1e-4 on EVERY scalar of the fresh step
     ('bf16', 8e-3, 0.2, 6e-3, 0.7),         # measured 3.7e-3 (kl) / 0.10 / 2.5e-3 / 0.48
     ('f32', 1e-4, 2e-3, 1e-4, 5e-3)])       # measured 4.6e-6 / 5e-4 / 2.5e-7 / 8.6e-4
 def test_self_consistent_parity_config2(mode, fresh_loss, fresh_grad, stress_loss, stress_grad):
