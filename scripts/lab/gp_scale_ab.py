@@ -1,4 +1,4 @@
-"""Lab: f16 parity of the reported gradient penalty with the gradient scale split between the chain's two factors
+"""Lab (usage: gp_scale_ab.py [f16|f16gp32]): f16 parity of the reported gradient penalty with the gradient scale split between the chain's two factors
 (engine_opts['gp_scale_split'] = True) and with all of it on the dJ/dU side (False): same weights, statistics, minibatch -
 the running statistics are restored between the two engine steps, the f32 CPU oracle (oracle/restated.py) is evaluated once."""
 import os, sys
@@ -10,7 +10,8 @@ import bench
 from oracle import restated as R
 
 dev = 'cuda:0'
-agent, cfg, _ = bench.make_agent(dev, 'f16', 'program', 1, 0)
+MODE = sys.argv[1] if len(sys.argv) > 1 else 'f16'
+agent, cfg, _ = bench.make_agent(dev, MODE, 'program', 1, 0)
 bench.fill_rollout(agent, dev)
 agent._init_amp_demo_buf()
 eng = agent.engine
@@ -48,7 +49,7 @@ for rnd in range(4):
     keep = (eng.obs_state.clone(), eng.amp_state.clone())
     r = float(ref['disc_grad_penalty'].mean())
     out = []
-    for split in (True, False, True, False):
+    for split in ((True, False, True, False) if MODE == 'f16' else (True,)):
         eng.engine_opts['gp_scale_split'] = split
         eng.obs_state.copy_(keep[0]); eng.amp_state.copy_(keep[1])
         eng.step(agent._ds, idx_d, agent._remap, streams, new_z=z.to(dev), apply=False)
@@ -57,4 +58,4 @@ for rnd in range(4):
         out.append(f'split={split}: {(v - r) / r:+.2e}')
     eng.obs_state.copy_(keep[0]); eng.amp_state.copy_(keep[1])
     eng.engine_opts['gp_scale_split'] = True
-    print(f'after {7 * (rnd + 1)} updates: penalty {r:.5f} |', ' | '.join(out), flush=True)
+    print(f'[{MODE}] after {7 * (rnd + 1)} updates: penalty {r:.5f} |', ' | '.join(out), flush=True)
