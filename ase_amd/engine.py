@@ -332,8 +332,8 @@ class UpdateEngine:
                 g.H = [zt(AMB, d.n_pad, f32) for d in self.disc]
                 g.bits = [torch.zeros(AMB, d.n_pad // 32, dtype=torch.int32, device=dev) for d in self.disc]
                 g.Gp = [zt(AMB, d.n_pad, f32) for d in self.disc]                       # s * g_l
-                g.dGp = [zt(AMB, d.n_pad, f32) for d in self.disc[:-1]]                 # s * dJ/dU_l (masked)
-                g.G0 = zt(AMB, self.disc[0].k_pad, f32)                                 # s * g_0
+                g.G0 = zt(AMB, self.disc[0].k_pad, f32)                                 # S s * g_0
+                g.cast = None                                                           # (conversion table, built on first use)
             if self.enc_chain:
                 self.He, self.dZe = chain_bufs(self.enc_chain, AMB)
                 self.E = zt(AMB, self.enc_head.n_pad, f32)
@@ -1015,9 +1015,7 @@ class UpdateEngine:
             self._bwd_chain(self.disc, self.Xd, self.Hd, self.dZd, Rd)
             return
         if self.gp32:
-            self._gp_f32(gp_coef)
-            self._bwd_chain(self.disc, self.Xd, self.Hd, self.dZd, Rd)
-            return
+            return self._gp_f32(gp_coef)
         if any(d.act != L.ACT_RELU for d in self.disc):
             return self._disc_backward_curved(gp_coef)
         assert nl >= 2, "gradient penalty with a single discriminator layer is not implemented"
@@ -1059,15 +1057,18 @@ class UpdateEngine:
                      gbias=d.gb[0], bias_rows=Rd)
 
     def _gp_f32(self, gp_coef):
-        """The gradient penalty of the demo rows (learning/amp_agent.py:453-459) in exact f32 inside a 16-bit engine
-        (config gp_f32 / precision 'f16gp32').  The penalty is driven towards zero by training, i.e. d logit / d x becomes a
-        CANCELLING sum over the trunk's weights: its relative error in 16-bit storage grows as it shrinks (f16: 6e-5 at a
-        penalty of 0.047, 6.6e-4 at 0.0077 - weight rounding first, ReLU mask flips second).  So this path takes
-        nothing from the 16-bit launches: f32 shadows of the trunk, its own forward of the AMB demo rows (exact masks), the
-        chain, the penalty, the chain's backward and the penalty's weight-gradient terms (f32 launches straight into the
-        gradient buffer, ahead of the branch's grouped 16-bit launch on the same stream).  ~75 GFLOP per step for config 2."""
+        """The gradient penalty of the demo rows (learning/amp_agent.py:453-459) through an exact-f32 value path inside a
+        16-bit engine (config gp_f32 / precision 'f16gp32').  The penalty is driven towards zero by training, i.e.
+        d logit / d x becomes a CANCELLING sum over the trunk's weights: its relative error in 16-bit storage grows as it
+        shrinks (f16: 6e-5 at a penalty of 0.047, 6.6e-4 at 0.0077 - weight rounding first, ReLU mask flips second;
+        DESIGN 3.2).  So the VALUE takes nothing from the 16-bit launches: f32 shadows of the trunk, its own forward of the
+        AMB demo rows (exact masks), the chain g_l and |g_in|^2 as exact-f32 MFMA launches (6 launches, ~50 GFLOP per step for
+        config 2).  The chain is then handed to the 16-bit machinery - one conversion launch writes s g_l and S s g_0 into
+        the 4th row block of the discriminator's buffers - and the penalty's BACKWARD (dJ/dU_l through the exact masks, the
+        logit-weight term, the stacked weight-gradient problems) runs as in _disc_backward; the loss rows' data-gradient
+        launches shrink to 3 AMB rows."""
         be, AMB, g = self.be, self.AMB, self._gp32
-        nl = len(self.disc)
+        Rd, nl, S = 3 * AMB, len(self.disc), self.gs
         cg = gp_coef * 2.0 / self.AMBg
         s = math.sqrt(cg)
         bits = L.AUX_RELU_BITS
@@ -1083,19 +1084,32 @@ class UpdateEngine:
             d = self.disc[l]
             be.gemm_nt(g.Gp[l], g.Wts[l], g.Gp[l - 1], AMB, d.k_pad, d.n_pad, aux=g.bits[l - 1], aux_mode=bits)
         d0 = self.disc[0]
-        be.gemm_nt(g.Gp[0], g.Wts[0], g.G0, AMB, d0.k_pad, d0.n_pad)
-        be.sqnorm(g.G0, AMB, d0.k_pad, self.acc, L.ACC_GP, scale=1.0 / cg)
-        be.gemm_nt(g.G0, g.Ws[0], g.dGp[0], AMB, d0.n_pad, d0.k_pad, aux=g.bits[0], aux_mode=bits)
+        be.gemm_nt(g.Gp[0], g.Wts[0], g.G0, AMB, d0.k_pad, d0.n_pad, alpha=S)                    # S s * g_0, exact
+        be.sqnorm(g.G0, AMB, d0.k_pad, self.acc, L.ACC_GP, scale=1.0 / (cg * S * S))
+        # [dZ_l ; s g_l] and [X ; S s g_0]: the exact chain, rounded once, in the storage type
+        if g.cast is None:
+            code = {torch.bfloat16: L.BF16, torch.float16: L.F16}[self.dtype]
+            items = [(g.Gp[l], self.disc[l].n_pad, self.Gp[l]) for l in range(nl)] + [(g.G0, d0.k_pad, self.G0)]
+            rows = [[src.data_ptr(), src.stride(0), c, dst.data_ptr(), dst.stride(0), code] for src, c, dst in items]
+            g.cast = (torch.tensor(rows, dtype=torch.int64, device=self.dev), items)
+        be.gather_multi(g.cast[0], g.cast[1], None, (0, 0), AMB)
+        # the loss rows' data-gradient chain (3 AMB rows)
+        for l in range(nl - 1, 0, -1):
+            self._dgrad(self.disc[l], self.dZd[l], self.dZd[l - 1], Rd, self.Hd[l - 1], self.disc[l - 1].act)
+        # backward of the penalty chain (values carry s and the gradient scale S), through the EXACT masks
+        be.gemm_nt(self.G0, d0.Ws, self.dGp[0], AMB, d0.n_pad, d0.k_pad, aux=g.bits[0], aux_mode=bits)
         for l in range(1, nl):
             d = self.disc[l]
             last = l == nl - 1
-            be.gemm_nt(g.dGp[l - 1], g.Ws[l], self.GpTop if last else g.dGp[l], AMB, d.n_pad, d.k_pad, aux=g.bits[l],
-                       aux_mode=bits, alpha=s if last else 1.0)
+            be.gemm_nt(self.dGp[l - 1], d.Ws, self.GpTop if last else self.dGp[l], AMB, d.n_pad, d.k_pad, aux=g.bits[l],
+                       aux_mode=bits, alpha=s / S if last else 1.0)
             if last:
                 be.colsum(self.GpTop, AMB, d.N, self.disc_head.gW[0].view(-1))
-        for l, d in enumerate(self.disc):
-            be.gemm_tn(g.Gp[l], g.G0 if l == 0 else g.dGp[l - 1], d.gW[0], AMB, d.n_pad, d.k_pad, d.N, d.K, d.split_src,
-                       d.split_dst, alpha=1.0)
+        for l in range(nl):
+            d = self.disc[l]
+            X = self.Xd4 if l == 0 else self.Hd4[l - 1]
+            self._tn(self.dZd4[l], X, d.gW[0], 4 * AMB, d.n_pad, d.k_pad, d.N, d.K, d.split_src, d.split_dst,
+                     gbias=d.gb[0], bias_rows=Rd)
 
     def _disc_backward_curved(self, gp_coef):
         """Discriminator backward with the gradient penalty for activations with curvature (anything but ReLU; SURVEY 8 row
