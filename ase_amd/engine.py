@@ -115,7 +115,7 @@ class UpdateEngine:
         self.enc_sep = bool(getattr(net, 'enc_separate', False))
         self.enc_gp = kind == 'ase' and cfg.get('enc_grad_penalty', 0) != 0 and cfg.get('enc_coef', 0) != 0
         self.mu_tanh = kind == 'ppo' and getattr(net, 'mu_tanh', False)
-        # gp_f32: the gradient penalty's demo-row path in exact f32 inside a 16-bit engine (_gp_f32)
+        # gp_f32: the gradient penalty's value path (demo-row forward, chain) in exact f32 inside a 16-bit engine (_gp_f32)
         self.gp32 = bool(cfg.get('gp_f32', False)) and self.has_disc and dtype in (torch.float16, torch.bfloat16) and \
             cfg.get('disc_coef', 0) * cfg.get('disc_grad_penalty', 0) != 0
         self._scratch = {}

@@ -167,9 +167,9 @@ class CommonAgent:
         #            'bf16x3' (f32 storage, every product as three bf16 MFMAs on a hi/lo split: f32-grade results)
         #            'f16' (IEEE half storage + MFMA, f32 accumulate, static gradient scale: same rate as bf16, 3 more
         #                   mantissa bits - the reference's mixed_precision=True arithmetic)
-        #            'f16gp32' f16 with the gradient penalty's demo-row path (forward for the masks, chain, its weight-gradient
-        #                   terms) in exact f32: the penalty is a cancelling sum in the discriminator's weights and the one loss
-        #                   scalar half storage does not hold to 1e-4 at every training state
+        #            'f16gp32' f16 with the gradient penalty's VALUE path (demo-row forward for exact masks, chain) in exact f32:
+        #                   the penalty is a cancelling sum in the discriminator's weights and the one loss scalar half storage
+        #                   does not hold to 1e-4 at every training state; its backward stays in half
         precision = config.get('precision', 'f16' if config.get('mixed_precision', False) else 'bf16')
         dtype = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f16gp32': torch.float16, 'f32': torch.float32,
                  'bf16x3': torch.float32}[precision]
