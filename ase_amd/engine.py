@@ -1072,6 +1072,11 @@ class UpdateEngine:
         cg = gp_coef * 2.0 / self.AMBg
         s = math.sqrt(cg)
         bits = L.AUX_RELU_BITS
+        # gp_f32 = 'x3': the six f32-storage launches multiply as three bf16 MFMAs on hi / lo splits (unit roundoff ~2^-17)
+        # instead of the exact-f32 MFMA (1/16 of the 16-bit rate)
+        x3_prev = getattr(be, 'x3', None)
+        if self.cfg.get('gp_f32') == 'x3' and x3_prev is not None:
+            be.x3 = True
         for l, d in enumerate(self.disc):
             be.refresh_shadow(d.W[0], g.Ws[l], g.Wts[l], d.split_src, d.split_dst)
         x = g.X
@@ -1085,6 +1090,8 @@ class UpdateEngine:
             be.gemm_nt(g.Gp[l], g.Wts[l], g.Gp[l - 1], AMB, d.k_pad, d.n_pad, aux=g.bits[l - 1], aux_mode=bits)
         d0 = self.disc[0]
         be.gemm_nt(g.Gp[0], g.Wts[0], g.G0, AMB, d0.k_pad, d0.n_pad, alpha=S)                    # S s * g_0, exact
+        if x3_prev is not None:
+            be.x3 = x3_prev
         be.sqnorm(g.G0, AMB, d0.k_pad, self.acc, L.ACC_GP, scale=1.0 / (cg * S * S))
         # [dZ_l ; s g_l] and [X ; S s g_0]: the exact chain, rounded once, in the storage type
         if g.cast is None:

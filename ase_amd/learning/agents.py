@@ -171,10 +171,10 @@ class CommonAgent:
         #                   the penalty is a cancelling sum in the discriminator's weights and the one loss scalar half storage
         #                   does not hold to 1e-4 at every training state; its backward stays in half
         precision = config.get('precision', 'f16' if config.get('mixed_precision', False) else 'bf16')
-        dtype = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f16gp32': torch.float16, 'f32': torch.float32,
-                 'bf16x3': torch.float32}[precision]
-        if precision == 'f16gp32':
-            config = self.config = dict(config, gp_f32=True)
+        dtype = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f16gp32': torch.float16, 'f16gpx3': torch.float16,
+                 'f32': torch.float32, 'bf16x3': torch.float32}[precision]
+        if precision in ('f16gp32', 'f16gpx3'):      # (f16gpx3: the same path with three-bf16-MFMA products)
+            config = self.config = dict(config, gp_f32=True if precision == 'f16gp32' else 'x3')
         self.precision = precision
         backend = config.get('backend', None)
         if backend is None:

@@ -34,7 +34,7 @@ import ase_amd          # noqa: E402
 ase_amd.configure()     # the runtime's hardware-queue count, before HIP initialises (ase_amd/__init__.py); reported on the JSON line
 import torch            # noqa: E402
 
-MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f16': 2500.0, 'f16gp32': 2500.0, 'f32': 157.3, 'bf16x3': 2500.0 / 3}   # x3: three bf16 MFMAs per product        # /opt/skills/guides/MI355X_MICROARCH.md (dense)
+MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f16': 2500.0, 'f16gp32': 2500.0, 'f16gpx3': 2500.0, 'f32': 157.3, 'bf16x3': 2500.0 / 3}   # x3: three bf16 MFMAs per product        # /opt/skills/guides/MI355X_MICROARCH.md (dense)
 
 
 def load_cfg():
@@ -444,14 +444,14 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'f16', 'f16gp32', 'f32', 'bf16x3'])
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'f16', 'f16gp32', 'f16gpx3', 'f32', 'bf16x3'])
     ap.add_argument('--no-graph', action='store_true', help='eager launches from Python (no recorded launch program)')
     ap.add_argument('--hipgraph', action='store_true', help='replay captured hipGraphs instead of the library launch programs')
     ap.add_argument('--no-multi-stream', action='store_true', help='launch the three network branches on ONE stream')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=8)
-    ap.add_argument('--modes', default='bf16,f16,f16gp32,f32', help='precision modes whose parity (fresh rollout + stale-rollout stress '
-                    'state) and throughput are reported beside the headline (comma list of bf16,f16,f32,bf16x3; "" = headline only)')
+    ap.add_argument('--modes', default='bf16,f16,f16gpx3,f16gp32,f32', help='precision modes whose parity (fresh rollout + stale-rollout stress '
+                    'state) and throughput are reported beside the headline (comma list of bf16,f16,f16gpx3,f16gp32,f32,bf16x3; "" = headline only)')
     ap.add_argument('--no-parity-mode', action='store_true', help='same as --modes ""')
     ap.add_argument('--force-dist', action='store_true', help='run the collectives even with one rank (RCCL smoke)')
     ap.add_argument('--dp-mode', default='horovod', choices=['horovod', 'shard'],
@@ -604,7 +604,7 @@ def main():
         traffic, traffic_src = None, None
         pmc = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_pmc.json')) \
             if os.path.isdir(os.path.join(ROOT, 'profiles')) else []
-        if pmc and args.precision in ('bf16', 'f16', 'f16gp32'):
+        if pmc and args.precision in ('bf16', 'f16', 'f16gp32', 'f16gpx3'):
             j = json.load(open(os.path.join(ROOT, 'profiles', pmc[-1])))
             if j.get('kernel_class') == dom:
                 traffic, traffic_src = j['hbm_bytes_per_launch'], 'profiles/' + pmc[-1]
