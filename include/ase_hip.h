@@ -180,7 +180,9 @@ int ase_hip_rms_unnormalize(const double* state, const float* x, float* y, int64
 int ase_hip_gather_rows(const float* src, int64_t ld_src, int D, const int32_t* idx, int remap_h,
                         int remap_n, int M, void* dst, int64_t ld_dst, int dst_dtype, void* stream);
 
-/* Several fields by ONE launch.  desc: DEVICE int64[n_fields][6] = {src, ld_src, D, dst, ld_dst, dst_dtype}. */
+/* Several fields by ONE launch.  desc: DEVICE int64[n_fields][6] = {src, ld_src, D, dst, ld_dst, dst_dtype}.  idx may be NULL
+ * (identity row map): the launch is then a multi-tensor f32 -> storage-type conversion (the exact gradient-penalty chain handed
+ * to the 16-bit launches, UpdateEngine._gp_f32). */
 int ase_hip_gather_multi(const int64_t* desc, int n_fields, const int32_t* idx, int remap_h, int remap_n,
                          int M, void* stream);
 

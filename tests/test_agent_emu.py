@@ -368,6 +368,8 @@ def test_precision_f16gp32_selects_the_f32_penalty_path(golden_dir):
     """precision 'f16gp32' = half storage + the gradient penalty's demo-row path in f32 (UpdateEngine._gp_f32): the agent maps
     the name, the first step's reported penalty is the reference's, every step runs."""
     G = torch.load(os.path.join(golden_dir, 'ase_tiny.pt'), weights_only=False)
+    ag = make_agent(G, EmuBackend(), precision='f16gpx3')          # (the emulator has one f32 arithmetic: same numbers)
+    assert ag.engine.gp32 and ag.engine.cfg['gp_f32'] == 'x3'
     ag = make_agent(G, EmuBackend(), precision='f16gp32')
     assert ag.engine.gp32 and ag.engine.dtype == torch.float16
     infos = replay_epochs(G, ag, rtol=0, wtol=0, check=False)
