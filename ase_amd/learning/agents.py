@@ -197,6 +197,11 @@ class CommonAgent:
         # so minibatch r of rank k is the k-th shard of the same global minibatch; Horovod mode: rank-distinct streams.
         self._gen = torch.Generator(device=self.ppo_device)
         self._gen.manual_seed(self.seed * 1000003 + 12345 + (0 if self.dp_mode == 'shard' else 7919 * self.rank))
+        # draws whose RESULT the host needs (the replay ring's keep mask decides how many rows are stored) are made on the host
+        # and uploaded asynchronously: no update ends in a device -> host read-back (_store_replay_amp_obs)
+        self._host_gen = torch.Generator()
+        self._host_gen.manual_seed(self.seed * 1000003 + 54321 + (0 if self.dp_mode == 'shard' else 7919 * self.rank))
+        self._upload_ring, self._upload_pos = [], 0
         self.dataset_perm = self._randperm(self.batch_size)
         self.action_rng = torch.tensor([(self.seed ^ 0xAC7105) + (0 if self.dp_mode == 'shard' else self.rank), 0],
                                        dtype=torch.int64, device=self.ppo_device)       # Philox stream of the rollout's actions
@@ -210,6 +215,25 @@ class CommonAgent:
 
     def _randperm(self, n):
         return torch.randperm(n, device=self.ppo_device, generator=self._gen).to(torch.int32)
+
+    def _upload_i32(self, t_cpu, cap):
+        """Host int32 vector -> device without blocking the host: pinned staging + device buffers in a ring of 8 (the host may
+        run several updates ahead of the GPU; a slot is reused only after the copy that last used it has completed, and its
+        consumer - the ring store of that update - was enqueued on the same stream right behind that copy)."""
+        n = int(t_cpu.numel())
+        if torch.device(self.ppo_device).type != 'cuda':
+            return t_cpu.to(self.ppo_device)
+        if not self._upload_ring:
+            for _ in range(8):
+                self._upload_ring.append((torch.empty(cap, dtype=torch.int32).pin_memory(),
+                                          torch.empty(cap, dtype=torch.int32, device=self.ppo_device), torch.cuda.Event()))
+        host, dev, ev = self._upload_ring[self._upload_pos % len(self._upload_ring)]
+        self._upload_pos += 1
+        ev.synchronize()
+        host[:n].copy_(t_cpu)
+        dev[:n].copy_(host[:n], non_blocking=True)
+        ev.record()
+        return dev[:n]
 
     def _sync_initial_state(self):
         """rl_games HorovodWrapper.setup_algo: rank 0's parameters / optimizer state / statistics everywhere."""
@@ -911,7 +935,15 @@ class AMPAgent(CommonAgent):
         B = self.batch_size
         idx = None
         n = B
-        if total > size:
+        if total > size and self.config.get('replay_keep_on_host', True):
+            # (learning/amp_agent.py:579-593: once the ring is full every sample is kept with probability keep_prob.)  The mask
+            # is drawn on the host: the NUMBER of kept rows moves the ring's head, and reading it back from the device ended
+            # every update in a synchronisation (the GPU idle for the host's turn-around at every update boundary).
+            keep = torch.bernoulli(torch.full((B,), float(self._amp_replay_keep_prob)), generator=self._host_gen) == 1.0
+            idx_cpu = keep.nonzero(as_tuple=False).flatten().to(torch.int32)
+            n = int(idx_cpu.numel())
+            idx = self._upload_i32(idx_cpu, B)
+        elif total > size:
             keep = torch.bernoulli(torch.full((B,), float(self._amp_replay_keep_prob), device=self.ppo_device),
                                    generator=self._gen) == 1.0
             idx = keep.nonzero(as_tuple=False).flatten().to(torch.int32)
