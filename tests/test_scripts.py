@@ -1,0 +1,46 @@
+"""Host-side checks of the measurement scripts (no GPU): they parse, and the PMC json bench.py quotes is what
+scripts/make_pmc_json.py derives from the committed counter summary."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_and_extra_parse_their_arguments():
+    for script in ('bench.py', os.path.join('scripts', 'bench_extra.py')):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, script), '--help'], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and 'usage' in r.stdout, (script, r.stderr[-500:])
+
+
+def test_pmc_json_is_regenerated_from_the_committed_summary(tmp_path):
+    out = tmp_path / 'pmc.json'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'make_pmc_json.py'),
+                        os.path.join(ROOT, 'profiles', 'r03_pmc_summary.txt'), str(out),
+                        os.path.join(ROOT, 'profiles', 'r03_kernel_stats_bf16_serial.txt')], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-500:]
+    new, old = json.load(open(out)), json.load(open(os.path.join(ROOT, 'profiles', 'r03_pmc.json')))
+    assert new['kernel_class'] == 'nt8' and new['hbm_bytes_per_launch'] == old['hbm_bytes_per_launch']
+    for k in ('nt8', 'tn8g', 'tn_reduce', 'apply_multi'):
+        assert new['kernels'][k]['hbm_bytes_per_launch'] == old['kernels'][k]['hbm_bytes_per_launch']
+    # the FETCH_SIZE doubling of the gfx950 note is applied exactly once
+    e = new['kernels']['nt8']
+    assert e['hbm_bytes_per_launch'] == int(round((2.0 * e['fetch_kib_raw'] + e['write_kib']) * 1024))
+
+
+def test_bench_json_line_of_the_round_has_the_contract_keys():
+    d = json.loads(open(os.path.join(ROOT, 'profiles', 'r03_bench_n1_bf16.json')).read().strip().splitlines()[-1])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['vs_baseline'] is None and d['n_gpus'] == 1 and 'workload' in d['config']
+    r = d['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert k in r, k
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
+    c = d['cpu_baseline']
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in c, k
+    q = d['qualifying_mode']
+    assert q['fresh_max_loss_rel'] <= 1e-4 and q['precision'] in d['modes']
