@@ -133,3 +133,35 @@ def test_horovod_mode_semantics(tmp_path):
     assert bool(torch.isfinite(r['flat']).all()) and bool(torch.isfinite(r['kl']).all())
     H, N = G['cfg']['horizon_length'], G['spec']['num_envs']
     assert r['frames'] == 2 * H * N                                        # summed over the two ranks
+
+
+# ------------------------------------------------------------------------------------------------ round 3
+def _worker_gp32(rank, world, port, name, out):
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    G = torch.load(os.path.join(GOLDEN, name + '.pt'), weights_only=False)
+    ag = make_agent(G, EmuBackend(), precision='f16gp32', world_size=world, rank=rank)
+    infos = replay_epochs(G, ag, rtol=0, wtol=0, check=False)
+    if rank == 0:
+        torch.save({'flat': ag.model.a2c_network.flat_params.clone(),
+                    'gp0': float(infos[0]['disc_grad_penalty'][0])}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_f16gp32_penalty_is_the_references(tmp_path):
+    """The f32 value path of the gradient penalty under row sharding: rank r runs it on its AMB / R demo rows, the squared
+    norms are summed with the other loss partial sums - the reported penalty of the first step is the reference's, and the
+    two-rank run ends where the one-rank run of the same precision ends."""
+    name = 'ase_tiny'
+    G = torch.load(os.path.join(GOLDEN, name + '.pt'), weights_only=False)
+    ag1 = make_agent(G, EmuBackend(), precision='f16gp32')
+    replay_epochs(G, ag1, rtol=0, wtol=0, check=False)
+    out = str(tmp_path / 'r0.pt')
+    mp.spawn(_worker_gp32, args=(2, _free_port(), name, out), nprocs=2, join=True)
+    r = torch.load(out)
+    ref = float(G['epochs'][0]['steps'][0]['disc_grad_penalty'])
+    assert abs(r['gp0'] - ref) <= 1e-5 * abs(ref), (r['gp0'], ref)
+    assert torch.allclose(r['flat'], ag1.model.a2c_network.flat_params, rtol=1e-4, atol=G['cfg']['learning_rate'] * 1.0)
