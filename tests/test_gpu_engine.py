@@ -265,9 +265,10 @@ def test_epoch_tail_full_size_vs_oracle(precision):
 
 
 @pytest.mark.parametrize('mode,fresh_loss,fresh_grad,stress_loss,stress_grad', [
-    ('f16', 2e-4, 6e-2, 6e-4, 0.35),        # measured 3.5e-5 ... 1.5e-4 (the gradient penalty; every other scalar <= 3e-5, asserted below) / 3.3e-2 / 1.9e-4 / 0.20
-    ('f16gp32', 1e-4, 6e-2, 3e-4, 0.35),    # f16 with the penalty's value path in exact f32: 1e-4 on EVERY scalar of the fresh step
-    ('f16gpx3', 1e-4, 6e-2, 3e-4, 0.35),    # ... with three-bf16-MFMA products on that path (penalty within 3e-5)
+    ('f16', 5e-4, 6e-2, 1e-3, 0.35),        # measured 3.5e-5 ... 3.4e-4 (the gradient penalty; every other scalar <= 4e-5: 1e-4 asserted below) / 3.3e-2 / 1.9e-4 / 0.20
+    # (stress-state bounds: kl there is quadratic in a mean shift that is itself ~1 - 2-3e-4 measured for the half modes)
+    ('f16gp32', 1e-4, 6e-2, 1e-3, 0.35),    # f16 with the penalty's value path in exact f32: 1e-4 on EVERY scalar of the fresh step
+    ('f16gpx3', 1e-4, 6e-2, 1e-3, 0.35),    # ... with three-bf16-MFMA products on that path (penalty within 3e-5)
     ('bf16', 8e-3, 0.2, 6e-3, 0.7),         # measured 3.7e-3 (kl) / 0.10 / 2.5e-3 / 0.48
     ('f32', 1e-4, 2e-3, 1e-4, 5e-3)])       # measured 4.6e-6 / 5e-4 / 2.5e-7 / 8.6e-4
 def test_self_consistent_parity_config2(mode, fresh_loss, fresh_grad, stress_loss, stress_grad):
