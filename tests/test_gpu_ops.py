@@ -219,6 +219,31 @@ def test_gather_rows(be):
         assert torch.equal(dg.cpu(), dc)
 
 
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16, torch.float32])
+def test_gather_multi_identity_map_is_a_conversion(be, dt):
+    """ase_hip_gather_multi with a NULL row map: several f32 matrices -> storage type in one launch (the gradient-penalty
+    chain handed to the 16-bit launches) - 8 values per thread where the field allows it, element-wise otherwise (odd width,
+    a view that starts off a 16-byte boundary); saturating for half."""
+    g = torch.Generator().manual_seed(3)
+    M = 777
+    srcs = [torch.randn(M, 1024, generator=g) * 3, torch.randn(M, 1408, generator=g) * 1e-3, torch.randn(M, 31, generator=g),
+            torch.randn(M, 520, generator=g)[:, 4:516]]
+    srcs[0][5, 7] = 1e6                                     # beyond half's range
+    srcs = [t.cuda() for t in srcs]
+    dsts = [torch.zeros(M, 1024, dtype=dt).cuda(), torch.zeros(M, 1472, dtype=dt).cuda()[:, :1408], torch.zeros(M, 64, dtype=dt).cuda(),
+            torch.zeros(M, 512, dtype=dt).cuda()]
+    code = {torch.bfloat16: L.BF16, torch.float16: L.F16, torch.float32: L.F32}[dt]
+    items = [(s_, s_.shape[1], d_) for s_, d_ in zip(srcs, dsts)]
+    desc = torch.tensor([[s_.data_ptr(), s_.stride(0), c, d_.data_ptr(), d_.stride(0), code] for s_, c, d_ in items],
+                        dtype=torch.int64, device='cuda')
+    be.gather_multi(desc, items, None, (0, 0), M)
+    torch.cuda.synchronize()
+    for s_, c, d_ in items:
+        ref = s_[:, :c].clamp(-65504, 65504).to(dt) if dt == torch.float16 else s_[:, :c].to(dt)
+        assert torch.equal(d_[:, :c], ref), (dt, c)
+    assert float(dsts[2][:, 31:].abs().max()) == 0.0        # columns past the field's width are left alone
+
+
 def _mb(M, D, Z, g, masked=True):
     mb = {'actions': torch.randn(M, D, generator=g) * 0.3, 'mu': torch.randn(M, D, generator=g) * 0.3,
           'sigma': torch.full((M, D), math.exp(-2.9)), 'old_logp_actions': torch.randn(M, 1, generator=g) * 2 - 60,
