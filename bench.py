@@ -66,6 +66,14 @@ class TimedBackend:
     def __getattr__(self, k):
         return getattr(self._be, k)
 
+    @property
+    def x3(self):                      # (the engine toggles it around the f32 value path of the penalty: forward, not shadow)
+        return self._be.x3
+
+    @x3.setter
+    def x3(self, v):
+        self._be.x3 = v
+
     def _timed(self, kind, flops, fn, *a, **kw):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
