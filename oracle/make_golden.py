@@ -84,6 +84,12 @@ def _case(kind):
         n['disc']['activation'] = 'swish'
         n['enc']['activation'] = 'swish'
         return n, c
+    if kind.startswith('ase_act_'):
+        # the other curved activations of rl_games' factory (elu, gelu, softplus, selu, sigmoid) through the same double backward
+        n, c = _case('ase')
+        for part in ('mlp', 'disc', 'enc'):
+            n[part]['activation'] = kind[len('ase_act_'):]
+        return n, c
     if kind == 'hrl_cfg4':
         # BASELINE.json configs[3]: the HRL high-level policy's PPO update at its real shape 258 -> [1024, 512] -> 64 with
         # tanh(mu) (learning/hrl_network_builder.py:26-29), ase/data/cfg/train/rlg/hrl_humanoid.yaml:9-39,45-77 verbatim
@@ -182,6 +188,7 @@ def make_case(name, kind, seed, num_envs=16, obs_size=37, act_size=7, amp_size=4
     regen: leave out every tensor the test can regenerate from the seeded synthetic source (observations, AMP observations,
     demo stream - tests/test_agent_emu.py:regenerate) and the duplicated dataset rows."""
     akind = {'ase_sep': 'ase', 'amp_cfg1': 'amp', 'ase_gp': 'ase', 'ase_sep_gp': 'ase', 'ase_cfg2': 'ase', 'ase_swish': 'ase',
+             **{'ase_act_' + a_: 'ase' for a_ in ('elu', 'gelu', 'softplus', 'selu', 'sigmoid')},
              'hrl_cfg4': 'ppo'}.get(kind, kind)
     net, cfg = _case(kind)
     akind_kind = kind
@@ -281,7 +288,7 @@ def make_case(name, kind, seed, num_envs=16, obs_size=37, act_size=7, amp_size=4
             steps.append({k: (v.detach().clone() if torch.is_tensor(v) else torch.tensor(float(v)))
                           for k, v in A.train_result.items()})
         A.calc_gradients = calc
-        A.play_steps = lambda: _tail(A, akind if kind in ('amp_cfg1', 'ase_cfg2', 'ase_swish', 'hrl_cfg4') else kind)
+        A.play_steps = lambda: _tail(A, akind if (kind in ('amp_cfg1', 'ase_cfg2', 'ase_swish', 'hrl_cfg4') or kind.startswith('ase_act_')) else kind)
         if akind != 'ppo':
             E['replay_total_before'] = A._amp_replay_buffer.get_total_count()
             E['replay_head_before'] = A._amp_replay_buffer._head
@@ -360,6 +367,10 @@ if __name__ == '__main__':
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'swish':
         make_case('ase_swish_tiny', 'ase_swish', seed=7, epochs=1)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'acts':           # one compact fixture per further activation of the factory
+        for i, act in enumerate(('elu', 'gelu', 'softplus', 'selu', 'sigmoid')):
+            make_case(f'ase_{act}_tiny', 'ase_act_' + act, seed=50 + i, epochs=1, regen=True, seeded=True, slim=True)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'encgp':          # only the N4 cases (the others are unchanged)
         make_case('ase_gp_tiny', 'ase_gp', seed=5, epochs=1)

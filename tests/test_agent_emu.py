@@ -376,3 +376,17 @@ def test_precision_f16gp32_selects_the_f32_penalty_path(golden_dir):
     ref = G['epochs'][0]['steps'][0]
     got = float(infos[0]['disc_grad_penalty'][0])
     assert abs(got - float(ref['disc_grad_penalty'])) <= 1e-5 * abs(float(ref['disc_grad_penalty'])), (got, float(ref['disc_grad_penalty']))
+
+
+@pytest.mark.parametrize('act', ['elu', 'gelu', 'softplus', 'selu', 'sigmoid'])
+def test_activation_family_against_the_reference(act, golden_dir):
+    """SURVEY 8 row X1 beyond swish: the unmodified reference agent with `activation: <act>` in every MLP of the yaml
+    (oracle/make_golden.py acts) - a whole update incl. the gradient penalty's double backward through the curved activation
+    (value, act', act'' of tests/emu_backend.py = csrc/act.h; the HIP side of that equality is
+    tests/test_gpu_ops.py::test_gemm_nt_smooth_activations, every activation, on the GPU)."""
+    G = torch.load(os.path.join(golden_dir, f'ase_{act}_tiny.pt'), weights_only=False)
+    assert G['net']['mlp']['activation'] == act and G['net']['disc']['activation'] == act
+    ag = make_agent(G, EmuBackend())
+    infos = replay_epochs(G, ag, rtol=2e-4, wtol=float(G['cfg']['learning_rate']) * 0.1)
+    ref = G['epochs'][0]['steps'][0]
+    assert abs(float(infos[0]['disc_grad_penalty'][0]) - float(ref['disc_grad_penalty'])) <= 1e-5 * abs(float(ref['disc_grad_penalty']))
