@@ -204,3 +204,19 @@ def get(kind):
     """(network params, agent config) deep copies for kind in {'ase', 'amp', 'hrl'}."""
     net, cfg = {'ase': (ASE_NETWORK, ASE_CONFIG), 'amp': (AMP_NETWORK, AMP_CONFIG), 'hrl': (HRL_NETWORK, HRL_CONFIG)}[kind]
     return copy.deepcopy(net), normalize(cfg)
+
+
+# ---- one precision resolver for trainers and players (the same checkpoint config must give the same numerics in both)
+_PRECISION_DTYPES = {'bf16': 'bfloat16', 'f16': 'float16', 'f16gp32': 'float16', 'f16gpx3': 'float16', 'f32': 'float32',
+                     'bf16x3': 'float32'}
+
+
+def resolve_precision(config):
+    """config -> (precision name, torch dtype of the storage / MFMA type).  `precision` wins; without it the reference's
+    `mixed_precision: True` (torch.cuda.amp autocast + GradScaler, learning/ase_agent.py:216,271-288) selects 'f16', else
+    'bf16'.  Unknown names raise - a player must never fall back to another arithmetic silently."""
+    import torch
+    precision = config.get('precision', 'f16' if config.get('mixed_precision', False) else 'bf16')
+    if precision not in _PRECISION_DTYPES:
+        raise ValueError(f"unknown precision {precision!r}; one of {sorted(_PRECISION_DTYPES)}")
+    return precision, getattr(torch, _PRECISION_DTYPES[precision])

@@ -378,13 +378,18 @@ __device__ __forceinline__ float twin_grad(int act, float t) {
     if (act == ASE_ACT_TANH) return 1.f - t * t;
     return act_grad(act, t);
 }
-// act'' / act'^2 (0 where act' vanishes: the chain value it multiplies is 0 there too)
-__device__ __forceinline__ float twin_curv(int act, float t) {
+// second-order factor act''(z) u r of the gradient penalty from the stored chain values g = act' u and dg = act' r:
+// (act'' / act') * (g / act') * dg, two separate divisions - act'^2 underflows to 0 for saturated sigmoid / ELU / SELU /
+// GELU units (|z| of a few tens) while act' itself is still a normal number, and act'' / act'^2 was inf there.  0 where act'
+// vanishes (the chain value it multiplies is 0 there too).
+__device__ __forceinline__ float twin_second(int act, float t, float g, float dg) {
     float d1, d2;
     if (act == ASE_ACT_RELU || act == ASE_ACT_NONE) return 0.f;
     if (act == ASE_ACT_TANH) { d1 = 1.f - t * t; d2 = -2.f * t * d1; }
     else { d1 = act_grad(act, t); d2 = act_grad2(act, t); }
-    return d1 != 0.f ? d2 / (d1 * d1) : 0.f;
+    if (d1 == 0.f) return 0.f;
+    const float e = (d2 / d1) * (g / d1) * dg;
+    return (e == e && fabsf(e) <= 3.0e38f) ? e : 0.f;
 }
 
 template <typename T>
@@ -407,8 +412,8 @@ __global__ __launch_bounds__(256) void gp_second_kernel(const T* __restrict__ t,
     const int64_t n = (int64_t)rows * width;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / width), j = (int)(i - (int64_t)r * width);
-        const float c = twin_curv(act, to_f32(t[(int64_t)r * ld_t + j]));
-        const float e = c * to_f32(g[(int64_t)r * ld_g + j]) * to_f32(dg[(int64_t)r * ld_dg + j]);
+        const float e = twin_second(act, to_f32(t[(int64_t)r * ld_t + j]), to_f32(g[(int64_t)r * ld_g + j]),
+                                    to_f32(dg[(int64_t)r * ld_dg + j]));
         T* o = dz + (int64_t)r * ld_dz + j;
         *o = from_f32<T>(to_f32(*o) + e);
     }

@@ -890,6 +890,7 @@ class UpdateEngine:
         c = self.cfg
         if self._dist_on() and self.shard:
             self._ar(self.acc[1:L.ACC_LOGIT_W2])
+        self._average_kl()
         self.be.finalize_scalars(self.acc, self.res, self.Mg if self.shard else self.M, self.AMBg if self.shard else self.AMB,
                                  self.masked, self.has_disc, self.has_enc, self.div_on, c,
                                  opt_state=self.opt_state if (self.adaptive_lr and self._lr_live) else None, kl_threshold=self.kl_threshold)
@@ -925,6 +926,7 @@ class UpdateEngine:
                 be.adam(self.params[:self.n_train], self.grads[:self.n_train], self.adam_m[:self.n_train],
                         self.adam_v[:self.n_train], self.opt_state)
                 self.refresh_shadows()
+        self._average_kl()
         be.finalize_scalars(self.acc, self.res, self.Mg if self.shard else self.M, self.AMBg if self.shard else self.AMB,
                             self.masked, self.has_disc, self.has_enc, self.div_on, c,
                             opt_state=self.opt_state if (self.adaptive_lr and apply) else None, kl_threshold=self.kl_threshold)
@@ -1221,6 +1223,17 @@ class UpdateEngine:
             else:
                 # Horovod semantics: every rank's loss is complete on its own minibatch; the optimizer sees the AVERAGE
                 self._host(lambda: self.grads[:self.n_train].mul_(1.0 / self.R))
+
+    def _average_kl(self):
+        """Horovod mode: the step's kl is averaged over the ranks before it is reported and before the adaptive schedule sees
+        it (learning/amp_agent.py:224-228, learning/common_agent.py:204-208: hvd.average_value(curr_train_info['kl']) under the
+        default 'legacy' schedule type) - every rank then derives the SAME learning rate from it; with local kls the ranks
+        would apply the averaged gradient with different rates and their parameters drift apart.  (Sharded mode: the kl sum
+        is part of the accumulator all-reduce already.)"""
+        if self._dist_on() and not self.shard:
+            kl = self.acc[L.ACC_KL:L.ACC_KL + 1]
+            self._ar(kl)
+            self._host(lambda: kl.mul_(1.0 / self.R))
 
     def _identity_stats(self, mean, std):
         self._host(lambda: (mean.zero_(), std.fill_(1.0)))

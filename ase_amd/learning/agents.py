@@ -170,9 +170,8 @@ class CommonAgent:
         #            'f16gp32' f16 with the gradient penalty's VALUE path (demo-row forward for exact masks, chain) in exact f32:
         #                   the penalty is a cancelling sum in the discriminator's weights and the one loss scalar half storage
         #                   does not hold to 1e-4 at every training state; its backward stays in half
-        precision = config.get('precision', 'f16' if config.get('mixed_precision', False) else 'bf16')
-        dtype = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f16gp32': torch.float16, 'f16gpx3': torch.float16,
-                 'f32': torch.float32, 'bf16x3': torch.float32}[precision]
+        from ..cfg import resolve_precision
+        precision, dtype = resolve_precision(config)
         if precision in ('f16gp32', 'f16gpx3'):      # (f16gpx3: the same path with three-bf16-MFMA products)
             config = self.config = dict(config, gp_f32=True if precision == 'f16gp32' else 'x3')
         self.precision = precision

@@ -91,10 +91,11 @@ class CommonPlayer:
         backend = self.config.get('backend', None)
         if backend is None:
             from ..backend import HipBackend
-            backend = HipBackend(self.device)
+            backend = HipBackend(self.device, x3=(self.config.get('precision') == 'bf16x3'))
         self.backend = backend
-        prec = self.config.get('precision', 'bf16')
-        dtype = {'bf16': torch.bfloat16, 'f16': torch.float16}.get(prec, torch.float32)
+        # the trainer's resolver: f16gp32 / f16gpx3 checkpoints play in f16, mixed_precision without a precision key = f16
+        from ..cfg import resolve_precision
+        self.precision, dtype = resolve_precision(self.config)
         self.engine = UpdateEngine(net.kind, net, self._engine_cfg(), backend, minibatch=0, amp_minibatch=0, dtype=dtype)
         net.infer = InferenceEngine(net, self.engine)
         self.action_rng = torch.tensor([int(self.config.get('seed', 0)) ^ 0x91A7E5, 0], dtype=torch.int64, device=self.device)

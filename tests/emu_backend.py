@@ -53,7 +53,7 @@ def _act_fns(act):
 
 
 def _twin_factors(act, t):
-    """(act', act'' / act'^2) from a layer's twin: its output for ReLU / tanh, its pre-activation otherwise."""
+    """(act', act'' / act') from a layer's twin: its output for ReLU / tanh, its pre-activation otherwise."""
     if act == L.ACT_RELU:
         return (t > 0).float(), torch.zeros_like(t)
     if act == L.ACT_TANH:
@@ -62,7 +62,7 @@ def _twin_factors(act, t):
     else:
         _, f1, f2 = _act_fns(act)
         d1, d2 = f1(t), f2(t)
-    return d1, torch.where(d1 != 0, d2 / (d1 * d1), torch.zeros_like(d1))
+    return d1, torch.where(d1 != 0, d2 / d1, torch.zeros_like(d1))
 
 
 class EmuBackend:
@@ -377,8 +377,11 @@ class EmuBackend:
         g[:rows, :width] = _store(scale * w[:width] * d1, g.dtype)
 
     def gp_second(self, twin, g, dg, dz, rows, width, act):
-        _, c = _twin_factors(act, twin[:rows, :width].float())
-        dz[:rows, :width] = _store(dz[:rows, :width].float() + c * g[:rows, :width].float() * dg[:rows, :width].float(), dz.dtype)
+        # (act'' / act') * (g / act') * dg, as ase_hip_gp_second: act'^2 underflows for saturated units while act' does not
+        d1, c = _twin_factors(act, twin[:rows, :width].float())
+        e = c * torch.where(d1 != 0, g[:rows, :width].float() / d1, torch.zeros_like(d1)) * dg[:rows, :width].float()
+        e = torch.where(torch.isfinite(e), e, torch.zeros_like(e))
+        dz[:rows, :width] = _store(dz[:rows, :width].float() + e, dz.dtype)
 
     def colsum(self, x, rows, cols, out, scale=1.0):
         out[:cols] += scale * x[:rows, :cols].float().sum(0)

@@ -364,3 +364,21 @@ def test_motion_lib_from_reference_object(golden_dir):
     ids, t = M['motion_ids'][:16].to(_DEV), M['times'][:16].to(_DEV)
     for x, y in zip(a.get_motion_state(ids, t), b.get_motion_state(ids, t)):
         assert torch.equal(x, y)
+
+
+def test_precision_resolver_is_shared_by_trainer_and_player():
+    """One resolver (ase_amd/cfg): f16gp32 / f16gpx3 play in f16, `mixed_precision: True` without a precision key means f16 in
+    both the agent and the player, unknown names raise instead of silently running another arithmetic."""
+    from ase_amd.cfg import resolve_precision
+    assert resolve_precision({}) == ('bf16', torch.bfloat16)
+    assert resolve_precision({'mixed_precision': True}) == ('f16', torch.float16)
+    assert resolve_precision({'mixed_precision': True, 'precision': 'f32'}) == ('f32', torch.float32)
+    for p in ('f16gp32', 'f16gpx3'):
+        assert resolve_precision({'precision': p}) == (p, torch.float16)
+    assert resolve_precision({'precision': 'bf16x3'})[1] == torch.float32
+    with pytest.raises(ValueError):
+        resolve_precision({'precision': 'fp8'})
+    import inspect
+    from ase_amd.learning import agents, players
+    assert 'resolve_precision' in inspect.getsource(agents.CommonAgent.__init__)
+    assert 'resolve_precision' in inspect.getsource(players)

@@ -165,3 +165,45 @@ def test_two_ranks_f16gp32_penalty_is_the_references(tmp_path):
     ref = float(G['epochs'][0]['steps'][0]['disc_grad_penalty'])
     assert abs(r['gp0'] - ref) <= 1e-5 * abs(ref), (r['gp0'], ref)
     assert torch.allclose(r['flat'], ag1.model.a2c_network.flat_params, rtol=1e-4, atol=G['cfg']['learning_rate'] * 1.0)
+
+
+# ------------------------------------------------------------------------------------------------ round 4
+def _worker_adaptive(rank, world, port, name, out):
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    torch.manual_seed(1000 + 17 * rank)
+    G = torch.load(os.path.join(GOLDEN, name + '.pt'), weights_only=False)
+    # a threshold the ranks' LOCAL kls straddle differently: rank-local schedules would diverge within a few steps
+    ag = make_agent(G, EmuBackend(), world_size=world, rank=rank, seed=5, dp_mode='horovod', lr_schedule='adaptive',
+                    kl_threshold=2e-4)
+    ag._sync_initial_state()
+    infos = _free_run(ag, G)
+    lr = ag.engine.opt_state[1:2].clone()
+    lrs = [torch.zeros_like(lr) for _ in range(world)]
+    dist.all_gather(lrs, lr)
+    kl = torch.stack([x.float().reshape(()) for x in infos[-1]['kl']])
+    kls = [torch.zeros_like(kl) for _ in range(world)]
+    dist.all_gather(kls, kl)
+    flat = ag.model.a2c_network.flat_params.clone()
+    flats = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(flats, flat)
+    if rank == 0:
+        torch.save({'lrs': lrs, 'kls': kls, 'flats': flats, 'lr0': G['cfg']['learning_rate'],
+                    'last_lr': [float(x) for x in infos[-1]['last_lr']]}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_horovod_adaptive_lr_is_the_same_on_every_rank(tmp_path):
+    """learning/amp_agent.py:224-228: under the legacy schedule the step's kl is averaged over the ranks BEFORE the scheduler
+    sees it - every rank derives the same learning rate and the replicas stay identical (round 3's advisor found each rank
+    scheduling from its local kl)."""
+    out = str(tmp_path / 'r0.pt')
+    mp.spawn(_worker_adaptive, args=(2, _free_port(), 'amp_tiny', out), nprocs=2, join=True)
+    r = torch.load(out)
+    assert torch.equal(r['lrs'][0], r['lrs'][1])                          # one schedule
+    assert torch.equal(r['kls'][0], r['kls'][1])                          # the reported kl is the rank average
+    assert torch.equal(r['flats'][0], r['flats'][1])                      # replicas identical
+    assert float(r['lrs'][0]) != r['lr0']                                 # (the schedule did move in this run)

@@ -56,6 +56,74 @@ def test_real_width_reference_goldens_16bit(be, name, precision, loss_tol, golde
                 assert a == a and abs(a - b) <= loss_tol * max(abs(b), scale.get(k, 0.0)), (precision, k, i, a, b)
 
 
+def _first_step_errors(G, ag):
+    """(|delta| / max(|ref|, floor), |delta| / |ref|) per loss scalar of the FIRST optimisation step against the reference's
+    recorded train_result; floor = 1 for the two means of signed O(1) summands (actor_loss, enc_loss), 0 otherwise."""
+    import copy
+    infos = replay_epochs(copy.deepcopy(G), ag, rtol=0, wtol=0, check=False, max_steps=1)
+    ref = G['epochs'][0]['steps'][0]
+    floor = {'actor_loss': 1.0, 'enc_loss': 1.0}
+    out = {}
+    for k in ('actor_loss', 'critic_loss', 'b_loss', 'kl', 'entropy', 'disc_loss', 'disc_grad_penalty', 'disc_logit_loss', 'enc_loss',
+              'amp_diversity_loss'):
+        if k in ref:
+            a, b = float(infos[0][k][0]), float(ref[k].mean())
+            assert a == a, k
+            out[k] = (abs(a - b) / max(abs(b), floor.get(k, 0.0), 1e-12), abs(a - b) / max(abs(b), 1e-12))
+    return out
+
+
+@pytest.mark.parametrize('precision', ['f16gpx3', 'f16gp32'])
+@pytest.mark.parametrize('name', ['ase_cfg2_small', 'ase_cfg2_small_s1', 'ase_cfg2_small_s2'])
+def test_real_width_reference_goldens_qualifying_modes(be, name, precision, golden_dir):
+    """The modes the bench names as qualifying, against the UNMODIFIED reference's first optimisation step at the real layer
+    widths (learning/ase_agent.py:228-258, learning/amp_agent.py:442-479).  Everything that does not pass through the foreign
+    old log-probabilities holds BASELINE's 1e-4: the gradient penalty (what the mode exists for) 1e-5, discriminator /
+    critic / encoder / diversity losses 1e-4, kl 2e-4 of its own value.  actor_loss alone carries the foreign-rollout
+    amplification (the reference's f32 mu_old against this engine's f16 mu: d logp = (a - mu) / sigma^2 d mu ~ 18 / sigma d mu):
+    5e-4 of its summand scale.  (Emulator, same goldens: 8e-8 / 1e-5 / 4e-5 / 4e-5 ... 1.5e-4.)"""
+    G = torch.load(os.path.join(golden_dir, name + '.pt'), weights_only=False)
+    err = _first_step_errors(G, make_agent(G, be, device='cuda', precision=precision))
+    assert err['disc_grad_penalty'][1] <= 1e-5, err
+    for k in ('critic_loss', 'disc_loss', 'disc_logit_loss', 'enc_loss', 'amp_diversity_loss', 'entropy', 'b_loss'):
+        if k in err:
+            assert err[k][0] <= 1e-4, (k, err)
+    assert err['kl'][1] <= 2e-4, err
+    assert err['actor_loss'][0] <= 5e-4, err
+
+
+@pytest.mark.parametrize('act', ['elu', 'gelu', 'softplus', 'selu', 'sigmoid'])
+def test_activation_family_f32(be, act, golden_dir):
+    """The reference agent with `activation: <act>` in every MLP (oracle/make_golden.py acts; emulator twin:
+    tests/test_agent_emu.py::test_activation_family_against_the_reference): a whole update on the GPU in f32, incl. the
+    gradient penalty's double backward through the curved activation.  (First run on hardware: round 3's driver, green.)"""
+    G = torch.load(os.path.join(golden_dir, f'ase_{act}_tiny.pt'), weights_only=False)
+    ag = make_agent(G, be, device='cuda', precision='f32')
+    replay_epochs(G, ag, rtol=3e-4, wtol=float(G['cfg']['learning_rate']) * 0.25)
+
+
+@pytest.mark.parametrize('name', ['ase_swish_tiny', 'ase_sigmoid_tiny'])
+def test_smooth_activation_discriminator_f16(be, name, golden_dir):
+    """Half storage through the CURVED gradient penalty (UpdateEngine._disc_backward_curved: the Sc / Sr split of the gradient
+    scale, pre-activation twins in f16, ase_hip_gp_second's act'' / act' path): first step of the reference's swish / sigmoid
+    agents - penalty within 5e-4 of its value, the other losses within 2e-3 of their scale, everything finite over the
+    whole two-epoch replay.  (Emulator: 6e-6 / 1.2e-4 on the penalty.)"""
+    import copy
+    G = torch.load(os.path.join(golden_dir, name + '.pt'), weights_only=False)
+    err = _first_step_errors(G, make_agent(G, be, device='cuda', precision='f16'))
+    assert err['disc_grad_penalty'][1] <= 5e-4, err
+    for k, (e, _) in err.items():
+        assert e <= 2e-3, (k, err)
+    ag = make_agent(G, be, device='cuda', precision='f16')
+    infos = replay_epochs(copy.deepcopy(G), ag, rtol=0, wtol=0, check=False)
+    for info in infos:
+        for k, v in info.items():
+            for x in v:
+                if torch.is_tensor(x):
+                    assert bool(torch.isfinite(x.float()).all()), k
+    assert bool(torch.isfinite(ag.model.a2c_network.flat_params).all())
+
+
 @pytest.mark.parametrize('name', ['amp_tiny', 'ppo_tiny'])
 def test_two_epochs_f32_hipgraph(be, name, golden_dir):
     """Same, with every optimisation step replayed from a captured hipGraph (no injected latents needed)."""

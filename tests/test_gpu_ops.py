@@ -844,3 +844,48 @@ def test_launch_program_replay(be):
         torch.cuda.synchronize()
         assert torch.allclose(w, torch.nn.functional.normalize(x, dim=-1), rtol=1e-6, atol=1e-6)
     be.prog_destroy(prog)
+
+
+@pytest.mark.parametrize('kl,expect', [(0.05, 2e-5 / 1.5), (0.001, 2e-5 * 1.5), (0.01, 2e-5)])
+def test_finalize_scalars_adaptive_lr(be, kl, expect):
+    """The rl_games AdaptiveScheduler branch of ase_hip_finalize_scalars (learning/common_agent.py:204-208): lr / 1.5 when the
+    step's kl exceeds 2 x kl_threshold, x 1.5 below half of it, unchanged between - device result = emulator = closed form.
+    (First run on hardware: round 3's driver, green.)"""
+    cfg = dict(critic_coef=5, entropy_coef=0.0, bounds_loss_coef=10, disc_coef=5, disc_logit_reg=0.01,
+               disc_grad_penalty=5, disc_weight_decay=1e-4, enc_coef=5, enc_weight_decay=0.0, amp_diversity_bonus=0.01,
+               enc_grad_penalty=0.0)
+    outs = []
+    for dev in ('cuda', 'cpu'):
+        b = be if dev == 'cuda' else EmuBackend()
+        acc = (torch.arange(L.ACC_COUNT, dtype=torch.float64) + 1.5).to(dev)
+        acc[L.ACC_KL] = kl * 1000                              # kl = acc / m_global
+        res = torch.zeros(L.RES_COUNT, device=dev)
+        st = torch.tensor([0.0, 2e-5, 0.9, 0.999, 1e-8, 1.0, 1.0, 0.0], dtype=torch.float64, device=dev)
+        b.finalize_scalars(acc, res, 1000, 250, 1, 1, 1, 1, cfg, opt_state=st, kl_threshold=0.008)
+        outs.append((res.cpu(), st.cpu()))
+    close(outs[0][0], outs[1][0], 1e-6, 1e-7, 'res')
+    assert abs(float(outs[0][1][1]) - expect) <= 1e-12 and abs(float(outs[1][1][1]) - expect) <= 1e-12, (outs[0][1], outs[1][1])
+
+
+def test_gp_second_saturated_units_stay_finite(be):
+    """ase_hip_gp_second at |z| of a few tens: act' is a tiny normal number, act'^2 underflows - the term is evaluated as
+    (act'' / act') (g / act') dg and must stay finite (round 3's advisor: act'' / act'^2 was inf there) and equal the emulator's."""
+    rows, width = 64, 128
+    g0 = torch.Generator().manual_seed(3)
+    z = torch.randn(rows, width, generator=g0) * 3
+    z[:8] = torch.linspace(-80.0, 80.0, 8 * width).view(8, width)          # saturated rows
+    u = torch.randn(rows, width, generator=g0) * 0.1
+    r = torch.randn(rows, width, generator=g0) * 0.1
+    for act in (L.ACT_SIGMOID, L.ACT_ELU, L.ACT_SELU, L.ACT_GELU, L.ACT_SILU, L.ACT_SOFTPLUS, L.ACT_TANH):
+        from tests.emu_backend import _twin_factors
+        twin = torch.tanh(z) if act == L.ACT_TANH else z
+        d1, _ = _twin_factors(act, twin)
+        gv, dg = d1 * u, d1 * r
+        outs = []
+        for dev in ('cuda', 'cpu'):
+            b = be if dev == 'cuda' else EmuBackend()
+            dz = torch.zeros(rows, width, device=dev)
+            b.gp_second(twin.to(dev), gv.to(dev), dg.to(dev), dz, rows, width, act)
+            outs.append(dz.cpu())
+        assert bool(torch.isfinite(outs[0]).all()) and bool(torch.isfinite(outs[1]).all()), act
+        close(outs[0], outs[1], 2e-4, 1e-7, f'gp_second act {act}')

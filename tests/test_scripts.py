@@ -44,3 +44,38 @@ def test_bench_json_line_of_the_round_has_the_contract_keys():
         assert k in c, k
     q = d['qualifying_mode']
     assert q['fresh_max_loss_rel'] <= 1e-4 and q['precision'] in d['modes']
+
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_module', os.path.join(ROOT, 'bench.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_bench_stdout_line_fits_the_drivers_tail():
+    """Round 3's line was 21.5 KB and the driver (8 KB stdout tail) could not parse it: the compact line built from that very
+    result must stay under 5 KB, keep the contract keys, and carry roofline / cpu_baseline / parity as scalars."""
+    bench = _load_bench()
+    full = json.loads(open(os.path.join(ROOT, 'profiles', 'r03_bench_n1_bf16.json')).read().strip().splitlines()[-1])
+    assert len(json.dumps(full)) > 8192          # (the canned input IS the oversized one)
+    full['config']['precision_mode'] = 'bf16: ' + bench.MODE_NOTE['bf16']
+    full['throughput_mode'] = {'precision': 'bf16', 'value': 2.0e6, 'unit': 'samples/s', 'ms_per_step': 65.0, 'timed': 'x', 'note': 'y'}
+    full['qualifying_mode'] = bench.qualifying_mode(full['modes'])
+    line = bench.compact_line(full, 'gpurun_out/bench_detail.json')
+    txt = json.dumps(line)
+    assert len(txt) < 5000, len(txt)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'parity', 'qualifying_mode', 'throughput_mode'):
+        assert k in line, k
+    r = line['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert k in r, k
+    assert all(not isinstance(v, (dict, list)) for v in r.values())          # scalars only
+    assert set(line['cpu_baseline']) >= {'value', 'unit', 'cores', 'kind', 'sample'}
+    assert line['parity']['fresh']['max_loss_rel'] == full['parity']['fresh']['max_loss_rel']
+    q = line['qualifying_mode']
+    assert q['precision'] == 'f16gpx3' and q['fresh_max_loss_rel'] <= 1e-4 and q['stress_ok'] is False
+    # every mode name the CLI accepts has its dtype and its one-line description
+    assert set(bench.DTYPE_OF) == set(bench.MODE_NOTE) == set(bench.MFMA_PEAK_TFLOPS)
