@@ -528,6 +528,7 @@ __global__ void finalize_scalars_kernel(const double* __restrict__ acc, float* _
         // step, from that step's kl (learning/common_agent.py:204-208)
         double lr = a.opt_state[1];
         const double cur = lr;
+        out[ASE_RES_LR] = (float)cur;          // the rate this step was taken with (train_result['last_lr'])
         if (kl > 2.0 * (double)a.kl_threshold) lr = fmax(cur / 1.5, 1e-6);
         if (kl < 0.5 * (double)a.kl_threshold) lr = fmin(cur * 1.5, 1e-2);
         a.opt_state[1] = lr;

@@ -133,8 +133,21 @@ class UpdateEngine:
         #   fused_apply     weight-only loss terms + Adam + shadow refresh in one launch per branch (apply_wide: its 16-byte path)
         #   side_streams    2 = critic and discriminator on their own streams, 1 = they share one
         #   gp_scale_split  f16 mode: the gradient scale split between the two factors of the penalty chain's products (_gp_scales)
+        #   xstep           the head of the discriminator branch (zero its gradient bucket, AMP moments -> normalise -> forward) is
+        #                   NOT chained behind the main stream: it follows the branch's own optimizer step of the PREVIOUS
+        #                   optimisation step on its stream and runs under that step's policy tail (grouped weight gradients ->
+        #                   reduce -> optimizer, ~290 us with one queue busy) and this step's prologue of tiny kernels
+        #   style_side      the style MLP's backward + its three weight gradients (style_wg > 0: own small grouped launch sized for
+        #                   that many workgroups; 0: direct launches of the split-M kernel) beside the policy's wide
+        #                   weight-gradient launch instead of in front of it.  Measured SLOWER (f16gpx3 73.9 -> 76.7 / 79.0 ms with
+        #                   64 / 32 workgroups: three narrow problems over 32768 rows on a few CUs outlast the wide launch): off
+        #   side_priority   HIP priority of the branch streams, one number or [critic, discriminator, penalty value path] (0 = default,
+        #                   -1 = high; the main stream's priority is the caller's)
+        #   gp_stream       gp_f32 modes: the penalty's value path (f32 / bf16x3 forward of the demo rows + chain: independent of
+        #                   the loss rows until the conversion launch) on its own stream beside the discriminator branch
         o = dict(tn_grouped=True, tn_wg_side=64, tn_early=False, disc_early=True, short_prologue=True, style_early=False,
-                 relu_bits=True, fused_apply=True, apply_wide=True, side_streams=2, gp_scale_split=True)
+                 relu_bits=True, fused_apply=True, apply_wide=True, side_streams=2, gp_scale_split=True, xstep=True,
+                 gp_stream=True, style_side=False, style_wg=0, side_priority=None)
         unknown = set(cfg.get('engine_opts', {}) or {}) - set(o)
         assert not unknown, f"unknown engine_opts {sorted(unknown)}"
         o.update(cfg.get('engine_opts', {}) or {})
@@ -152,6 +165,21 @@ class UpdateEngine:
         self._apply_groups = None
         self._use_bits = bool(o['relu_bits'])
         self._fused_apply = hasattr(backend, 'apply_multi') and bool(o['fused_apply'])
+        # (a captured hipGraph forks every stream from the capturing one: an un-chained branch head cannot be captured)
+        self._xstep = bool(o['xstep']) and cfg.get('graph_capture') != 'hipgraph'
+        self._gp_side = bool(o['gp_stream'])
+        self._style_side = bool(o['style_side'])
+        self._style_wg = int(o['style_wg'])
+        sp = o['side_priority']
+        if sp is None:
+            # measured on MI355X, config 2, with the main stream high (agents: main_stream_priority): the policy's second stream
+            # (critic) high and the discriminator's normal - 66.4 -> 62.9 ms (bf16); gp_f32 modes carry ~280 us more work per
+            # step on the discriminator side and want that stream high instead - 73.4 -> 72.8 ms (f16gpx3)
+            sp = [0, -1, 0] if self.gp32 else [-1, 0, 0]
+        self._side_prio = [int(x) for x in sp] if isinstance(sp, (list, tuple)) else [int(sp)] * 3      # critic, disc, gp streams
+        self._gp_stream_obj = None
+        self._xs = False                 # this step runs the cross-step schedule (decided per step in step())
+        self._disc_fwd_out = self._gp_value_done = None
         self._apply_wide = bool(o['apply_wide'])
         self._apply_desc = self._apply_items = None
         self.force_dist = bool(cfg.get('force_dist', False))   # exercise the collectives with a 1-rank group
@@ -366,7 +394,7 @@ class UpdateEngine:
         self.obs_state[self.obs:] = 1.0
         self.val_state = torch.tensor([0.0, 1.0, 1.0], dtype=torch.float64, device=dev)
         self.acc = torch.zeros(L.ACC_COUNT, dtype=torch.float64, device=dev)
-        self.res = torch.zeros(L.RES_COUNT, dtype=torch.float32, device=dev)
+        self.set_result_slots(1)
         # packed f32 minibatch fields
         self.mb = {'actions': zt(M, self.act, f32), 'mu': zt(M, self.act, f32), 'sigma': zt(M, self.act, f32),
                    'old_logp_actions': zt(M, 1, f32), 'advantages': zt(M, 1, f32), 'old_values': zt(M, 1, f32),
@@ -375,6 +403,22 @@ class UpdateEngine:
             self.mb['rand_action_mask'] = zt(M, 1, f32)
         if self.z:
             self.mb['ase_latents'] = zt(M, self.z, f32)
+
+    # ------------------------------------------------------------------ result ring
+    def set_result_slots(self, n):
+        """Per-update ring of result vectors: optimisation step i of an update writes its train_result scalars into slot i
+        (ase_hip_finalize_scalars' `out`) and its discriminator logits into logit slot i - nothing is snapshotted between two
+        steps (round 3: two small copies per step on a side stream that had to wait for the main stream's last kernel, which
+        chained the next step's discriminator head behind it).  The agent reads the whole ring once per update."""
+        dev = self.dev
+        self.res_ring = torch.zeros(n, L.RES_COUNT, dtype=torch.float32, device=dev)
+        self.logit_ring = torch.zeros(n, 3 * self.AMB, dtype=torch.float32, device=dev) if self.has_disc else None
+        self.use_slot(0)
+
+    def use_slot(self, i):
+        self.slot = i
+        self.res = self.res_ring[i]
+        self.logit_slot = self.logit_ring[i].view(-1, 1) if self.logit_ring is not None else None
 
     # ------------------------------------------------------------------ shadows
     def refresh_shadows(self):
@@ -591,17 +635,26 @@ class UpdateEngine:
                 dist.broadcast(t, 0)
         self.refresh_shadows()
 
-    def step(self, ds, idx, remap, amp_streams=None, new_z=None, apply=True):
+    def step(self, ds, idx, remap, amp_streams=None, new_z=None, apply=True, fence=True):
         """ds: dataset dict of physical-order device tensors; idx int32 [M] (this rank's rows);
         amp_streams: [(src, idx, remap)] x3 for agent / replay / demo (AMB rows each);
         new_z: optional injected diversity latents f32 [M, z] (else drawn on device).
         Phases separated by the exchange points of the data-parallel update (normaliser moments + mask sum; gradients).
         With apply (and the fused optimizer launch) every branch finishes by itself - weight gradients, gradient exchange of
-        its bucket, optimizer step of its parameters - so the discriminator's tail overlaps the policy's backward."""
+        its bucket, optimizer step of its parameters - so the discriminator's tail overlaps the policy's backward.
+        fence=False: the caller has ordered the branch streams behind its own writes (fence_side_streams) - required while a
+        launch program is being recorded (a torch-level stream wait is not a recordable entry)."""
+        inline = apply and self._fused_apply and not self.truncate
+        # cross-step schedule: single GPU, streams, every branch finishing by itself (its own optimizer step)
+        self._xs = bool(self._xstep and inline and self.has_disc and self._short_prologue and self._disc_early
+                        and self._amp_stats_in_branch())
+        if self._xs and fence:
+            # a caller that does not order the branch streams itself (the agents do, once per mini-epoch): whatever it did on
+            # the current stream - weights loaded, statistics set, index tensors built - happens before the un-chained head
+            self.fence_side_streams()
         self.phase_stats(ds, idx, remap, amp_streams, advance=apply, new_z=new_z)
         self._allreduce_stats()
         self._lr_live = apply          # (calc_gradients-style calls without the optimizer step leave the learning rate alone)
-        inline = apply and self._fused_apply and not self.truncate
         self.phase_main(ds, idx, remap, amp_streams, new_z, inline_apply=inline)
         if inline:
             self.phase_finish()
@@ -626,11 +679,46 @@ class UpdateEngine:
 
     def phase_stats(self, ds, idx, remap, amp_streams=None, advance=True, new_z=None):
         be, c, M, AMB = self.be, self.cfg, self.M, self.AMB
+        self._disc_fwd_out = None
+        if self._xs:
+            # Cross-step schedule: the head of the discriminator branch goes FIRST into the step's launch sequence and waits
+            # for nothing on the main stream.  On its own stream it follows the branch's optimizer step of the previous
+            # optimisation step (the only producer of what it reads: discriminator weights; the only earlier readers of what it
+            # writes: that step's weight-gradient and loss-head launches, same stream) - so it runs while the main stream is
+            # still in the previous step's policy tail and in this step's prologue.  It touches neither the accumulators nor
+            # the optimizer state; the loss heads further down wait for begin_step.
+            self._build_apply_desc()
+            lo, hi = self._apply_groups['disc'][2:]
+            with self._Branch(self, self._side(1), nowait=True):
+                be.zero_(self.grads[lo:hi])
+                be.zero_(self.amp_sums)
+                self._disc_fwd_out = self._disc_forward(amp_streams)
         # one launch: Adam step counter / bias corrections (advance=False - calc_gradients-style calls - leaves them),
         # loss accumulators and per-step partial statistics zeroed, position of the diversity-latent stream advanced
-        be.begin_step(self.opt_state if advance else None, self.acc, zero2=self.stats_flat,
+        be.begin_step(self.opt_state if advance else None, self.acc, zero2=self.obs_sums if self._xs else self.stats_flat,
                       rng_bump=self.div_rng if self.div_on else None)
         self._prep = None
+        if self._xs:
+            m0 = self._mark()
+            self._early_fork, self._fill_done = m0, None
+            plo, phi = self._apply_groups['policy'][2:]
+            with self._Branch(self, self._side(0), m0) as prep:
+                be.zero_(self.grads[plo:phi])
+                self.gather_minibatch(ds, idx, remap, part=2)
+                if self.div_on:
+                    self._draw_new_latents(new_z)
+                if self.style and self._style_early:
+                    sd = self.actor[0].split_dst
+                    h = self._fwd_chain(self.style[:-1], self.Zs, self.Hs, self.Ra)
+                    self._fwd(self.style[-1], h, self.Xa[:, sd:], self.Ra)
+                self._lat_ready = self._mark()
+                self.gather_minibatch(ds, idx, remap, part=1)
+                if self.masked:
+                    be.reduce_sum(self.mb['rand_action_mask'], M, False, self.acc, L.ACC_MASK_SUM)
+            self._prep = prep
+            if c.get('normalize_input', True):
+                be.rms_moments(ds['obs'], self.obs, idx, remap, M, self.obs_state, self.obs_sums)
+            return
         if self._short_prologue and self._amp_stats_in_branch():
             # Short prologue (single GPU, streams): the actor chain - the critical path - keeps only the observation chain
             # (moments -> finalise -> normalise) in front of it on the main stream.  The latent copies and the diversity draw
@@ -686,23 +774,36 @@ class UpdateEngine:
         if not self.multi_stream:
             return None
         if self._side_streams is None:
-            self._side_streams = [torch.cuda.Stream(device=self.dev) for _ in range(self._n_side)]
+            self._side_streams = [torch.cuda.Stream(device=self.dev, priority=self._side_prio[k % 3]) for k in range(self._n_side)]
         return self._side_streams[k % len(self._side_streams)]
+
+    def fence_side_streams(self):
+        """Everything the main stream holds so far happens before whatever the branch streams are given next.  Inside a step
+        the branches fork from marks on the main stream - except the head of the discriminator branch under the cross-step
+        schedule (engine_opts xstep), which waits for nothing: the agent calls this after it has written what that head reads
+        (per-mini-epoch index buffers, the demo / replay rings), once per mini-epoch."""
+        if not self.multi_stream or self.dev.type != 'cuda':
+            return
+        cur = torch.cuda.current_stream(self.dev)
+        self._side(0)                                     # (streams exist before their first use: a fresh stream is unordered)
+        for st in list(self._side_streams) + ([self._gp_stream()] if self.gp32 and self._gp_side else []):
+            st.wait_stream(cur)
 
     class _Branch:
         """Run a block of launches on a side stream: it starts after `after` (a mark on the main stream; default: everything
         the main stream holds so far) and leaves `done` for whoever needs its results.  Marks / waits go through the
         backend (ase_hip_mark / ase_hip_wait), so a recorded launch program contains them."""
 
-        def __init__(self, eng, stream, after=None):
-            self.eng, self.stream, self.after = eng, stream, after
+        def __init__(self, eng, stream, after=None, nowait=False):
+            self.eng, self.stream, self.after, self.nowait = eng, stream, after, nowait
 
         def __enter__(self):
             if self.stream is not None:
-                after = self.after if self.after is not None else self.eng.be.mark()
+                after = None if self.nowait else (self.after if self.after is not None else self.eng.be.mark())
                 self.ctx = torch.cuda.stream(self.stream)
                 self.ctx.__enter__()
-                self.eng.be.wait(after)
+                if after is not None:
+                    self.eng.be.wait(after)
             return self
 
         def __exit__(self, *a):
@@ -731,6 +832,56 @@ class UpdateEngine:
                     self._host(lambda: self.grads[lo:hi].mul_(1.0 / self.R))
             self.be.apply_multi(self._apply_desc[a:b], self._apply_items[a:b], self.dtype, self.opt_state, self.acc)
 
+    def _disc_forward(self, amp_streams):
+        """Head of the discriminator (+ encoder) branch: AMP-observation moments -> running statistics -> normalised rows
+        [agent | replay | demo] -> trunk forward -> joint [logit | enc] head (+ the separate encoder's chain).  Needs the
+        branch's weights and nothing of the step's accumulators."""
+        be, c, AMB = self.be, self.cfg, self.AMB
+        Rd = 3 * AMB
+        norm_amp = self.has_disc and c.get('normalize_amp_input', True)
+        amb_den = self.AMBg if self.shard else self.AMB
+        if self._amp_stats_in_branch():
+            self._amp_moments(amp_streams)
+        if norm_amp:
+            be.rms_finalize(self.amp_state, self.amp, self.amp_sums, amb_den, 3, self.amp_mean, self.amp_std)
+        else:
+            self._identity_stats(self.amp_mean, self.amp_std)
+        gp_fork = self._mark() if (self.gp32 and self._gp_side) else None
+        xd = [self.Xd[s * AMB:(s + 1) * AMB] for s in range(3)]
+        if self.amp % 4 == 0 and all(src.stride(0) % 4 == 0 for src, _, _ in amp_streams):
+            be.rms_normalize_multi(amp_streams, self.amp, AMB, [self.amp_mean[s] for s in range(3)],
+                                   [self.amp_std[s] for s in range(3)], xd)
+        else:                          # rows that are not whole 16-byte chunks: one launch per stream
+            for s, (src, sidx, srm) in enumerate(amp_streams):
+                be.rms_normalize(src, self.amp, sidx, srm, AMB, self.amp_mean[s], self.amp_std[s], [xd[s]])
+        self._gp_value_done = None
+        if self.gp32:
+            gp_coef = c['disc_coef'] * c['disc_grad_penalty']
+            if gp_fork is not None:
+                # the penalty's value path beside the loss rows' forward, on its own stream: it follows the statistics above
+                # (and, through them, the branch's previous optimizer step) and is joined before the conversion launch
+                with self._Branch(self, self._gp_stream(), gp_fork) as br:
+                    self._gp_value(amp_streams, gp_coef)
+                self._gp_value_done = br
+            else:
+                self._gp_value(amp_streams, gp_coef)
+        hd = self._fwd_chain(self.disc, self.Xd, self.Hd, Rd)
+        self._fwd(self.disc_head, hd, self.HD, Rd)
+        if self.logit_slot is not None:        # the step's logits into its slot of the result ring (train_result's disc_*_logit)
+            be.gather_rows(self.HD, 1, None, (0, 0), Rd, self.logit_slot)
+        he = None
+        if self.enc_chain:
+            he = self._fwd_chain(self.enc_chain, self.Xd[:AMB], self.He, AMB)
+            self._fwd(self.enc_head, he, self.E, AMB)
+        return hd, he
+
+    def _gp_stream(self):
+        if not self.multi_stream:
+            return None
+        if self._gp_stream_obj is None:
+            self._gp_stream_obj = torch.cuda.Stream(device=self.dev, priority=self._side_prio[2])
+        return self._gp_stream_obj
+
     # ---- phase B: normalise, forward, loss heads, backward -----------------------------------------
     def phase_main(self, ds, idx, remap, amp_streams=None, new_z=None, inline_apply=False):
         be, c, M, AMB = self.be, self.cfg, self.M, self.AMB
@@ -744,34 +895,11 @@ class UpdateEngine:
         amb_den = self.AMBg if self.shard else self.AMB
         Rd = 3 * AMB
 
-        def disc_forward():
-            if self._amp_stats_in_branch():
-                self._amp_moments(amp_streams)
-            if norm_amp:
-                be.rms_finalize(self.amp_state, self.amp, self.amp_sums, amb_den, 3, self.amp_mean, self.amp_std)
-            else:
-                self._identity_stats(self.amp_mean, self.amp_std)
-            xd = [self.Xd[s * AMB:(s + 1) * AMB] for s in range(3)]
-            if self.amp % 4 == 0 and all(src.stride(0) % 4 == 0 for src, _, _ in amp_streams):
-                be.rms_normalize_multi(amp_streams, self.amp, AMB, [self.amp_mean[s] for s in range(3)],
-                                       [self.amp_std[s] for s in range(3)], xd)
-            else:                          # rows that are not whole 16-byte chunks: one launch per stream
-                for s, (src, sidx, srm) in enumerate(amp_streams):
-                    be.rms_normalize(src, self.amp, sidx, srm, AMB, self.amp_mean[s], self.amp_std[s], [xd[s]])
-            if self.gp32:                  # the demo stream once more, into the f32 input of the penalty path
-                src, sidx, srm = amp_streams[2]
-                be.rms_normalize(src, self.amp, sidx, srm, AMB, self.amp_mean[2], self.amp_std[2], [self._gp32.X])
-            hd = self._fwd_chain(self.disc, self.Xd, self.Hd, Rd)
-            self._fwd(self.disc_head, hd, self.HD, Rd)
-            he = None
-            if self.enc_chain:
-                he = self._fwd_chain(self.enc_chain, self.Xd[:AMB], self.He, AMB)
-                self._fwd(self.enc_head, he, self.E, AMB)
-            return hd, he
-
-        if disc_early:
+        if self._disc_fwd_out is not None:           # cross-step schedule: submitted at the top of phase_stats
+            hd, he = self._disc_fwd_out
+        elif disc_early:
             with self._Branch(self, self._side(1), fork0):
-                hd, he = disc_forward()
+                hd, he = self._disc_forward(amp_streams)
         if norm_in:
             be.rms_finalize(self.obs_state, self.obs, self.obs_sums, self.Mg if self.shard else self.M, 1, self.obs_mean,
                             self.obs_std)
@@ -806,7 +934,7 @@ class UpdateEngine:
             tnq, self._tn_queue = self._tn_queue, []          # the branch queues (and flushes) its own weight gradients
             with self._Branch(self, self._side(1), fork0) as br_disc:
                 if not disc_early:
-                    hd, he = disc_forward()
+                    hd, he = self._disc_forward(amp_streams)
                 be.disc_head(self.HD, self.dHD, self.disc_head.gb[0], self.acc, AMB, amb_den, c['disc_coef'],
                              grad_scale=self.gs)
                 if self.has_enc:
@@ -836,7 +964,8 @@ class UpdateEngine:
         self._join_branch(br_critic)
         if self._prep is not None:
             self._join_branch(self._prep)      # (same stream as the critic branch: already implied; kept explicit)
-            be.wait(self._fill_done)           # gradients zeroed (discriminator's stream) before the loss head adds to them
+            if self._fill_done is not None:
+                be.wait(self._fill_done)       # gradients zeroed (discriminator's stream) before the loss head adds to them
 
         # -- PPO loss head (value + gradient w.r.t. mu / value + head bias gradients)
         be.ppo_head(self.MU, self.V, self.mb, self.new_z if self.div_on else None, self.logstd, self.dMU, self.dV,
@@ -867,7 +996,7 @@ class UpdateEngine:
             else:
                 tn_actor = tn_actor + self._tn_queue
                 self._tn_queue = []
-        if self.style:
+        def style_backward():
             a0, sdn = self.actor[0], self.style[-1]
             sd = a0.split_dst
             self._dgrad(a0, self.dZa[0], self.dStyle, Ra, self.Xa[:, sd:], sdn.act, wts=a0.Wts[sd:], n_out=P(self.z))
@@ -877,9 +1006,32 @@ class UpdateEngine:
                 p = self.style[-2]
                 self._dgrad(sdn, self.dStyle, self.dZs[-1], Ra, self.Hs[-1], p.act)
                 self._bwd_chain(self.style[:-1], self.Zs, self.Hs, self.dZs, Ra)
-        self._join_branch(br_cb)
-        if not self._tn_early:
-            self._tn_queue = tn_actor + self._tn_queue
+
+        if self.style and self._style_side and self.multi_stream and self._tn_defer and not self._tn_early:
+            # The style MLP's backward (three narrow data-gradient launches, ~75 us back to back) used to sit between the actor's
+            # data-gradient chain and the policy's grouped weight-gradient launch - on the step's critical path.  The wide
+            # launch needs nothing of it: it goes out as soon as the actor's and the critic's chains are through, and the style
+            # backward runs beside it on the critic's stream (idle by then) with its OWN small grouped launch for the three
+            # style weight gradients (sized for the CUs the wide launch leaves free); the optimizer step waits for both.
+            self._join_branch(br_cb)
+            wide, self._tn_queue = tn_actor, []
+            with self._Branch(self, self._side(0), actor_done) as br_style:
+                if self._style_wg <= 0:          # style weight gradients as direct launches of the 128 x 128 split-M kernel
+                    defer, self._tn_defer = self._tn_defer, False
+                    style_backward()
+                    self._tn_defer = defer
+                else:
+                    style_backward()
+                    self._flush_tn(self._style_wg)
+            self._tn_queue = wide
+            self._flush_tn(0)
+            self._join_branch(br_style)
+        else:
+            if self.style:
+                style_backward()
+            self._join_branch(br_cb)
+            if not self._tn_early:
+                self._tn_queue = tn_actor + self._tn_queue
         self._finish_branch('policy', inline_apply, last=True)        # (flushes what is still queued)
         if br_disc is not None:
             self._join_branch(br_disc)
@@ -1058,22 +1210,17 @@ class UpdateEngine:
             self._tn(self.dZd4[l], X, d.gW[0], 4 * AMB, d.n_pad, d.k_pad, d.N, d.K, d.split_src, d.split_dst,
                      gbias=d.gb[0], bias_rows=Rd)
 
-    def _gp_f32(self, gp_coef):
-        """The gradient penalty of the demo rows (learning/amp_agent.py:453-459) through an exact-f32 value path inside a
-        16-bit engine (config gp_f32 / precision 'f16gp32').  The penalty is driven towards zero by training, i.e.
-        d logit / d x becomes a CANCELLING sum over the trunk's weights: its relative error in 16-bit storage grows as it
-        shrinks (f16: 6e-5 at a penalty of 0.047, 6.6e-4 at 0.0077 - weight rounding first, ReLU mask flips second;
-        DESIGN 3.2).  So the VALUE takes nothing from the 16-bit launches: f32 shadows of the trunk, its own forward of the
-        AMB demo rows (exact masks), the chain g_l and |g_in|^2 as exact-f32 MFMA launches (6 launches, ~50 GFLOP per step for
-        config 2).  The chain is then handed to the 16-bit machinery - one conversion launch writes s g_l and S s g_0 into
-        the 4th row block of the discriminator's buffers - and the penalty's BACKWARD (dJ/dU_l through the exact masks, the
-        logit-weight term, the stacked weight-gradient problems) runs as in _disc_backward; the loss rows' data-gradient
-        launches shrink to 3 AMB rows."""
+    def _gp_value(self, amp_streams, gp_coef):
+        """VALUE path of the gradient penalty in a gp_f32 engine (see _gp_f32): the demo rows normalised into an f32 input,
+        f32 shadows of the trunk, forward (exact ReLU masks), seed, chain g_l, S s g_0 - six f32-storage matrix launches
+        ('x3': three bf16 MFMAs per product on hi / lo splits).  Reads the branch's master weights and the AMP statistics,
+        writes only its own buffers: it runs beside the loss rows' forward (engine_opts gp_stream)."""
         be, AMB, g = self.be, self.AMB, self._gp32
-        Rd, nl, S = 3 * AMB, len(self.disc), self.gs
-        cg = gp_coef * 2.0 / self.AMBg
-        s = math.sqrt(cg)
+        nl, S = len(self.disc), self.gs
+        s = math.sqrt(gp_coef * 2.0 / self.AMBg)
         bits = L.AUX_RELU_BITS
+        src, sidx, srm = amp_streams[2]        # the demo stream once more, into the f32 input of the penalty path
+        be.rms_normalize(src, self.amp, sidx, srm, AMB, self.amp_mean[2], self.amp_std[2], [g.X])
         # gp_f32 = 'x3': the six f32-storage launches multiply as three bf16 MFMAs on hi / lo splits (unit roundoff ~2^-17)
         # instead of the exact-f32 MFMA (1/16 of the 16-bit rate)
         x3_prev = getattr(be, 'x3', None)
@@ -1094,6 +1241,27 @@ class UpdateEngine:
         be.gemm_nt(g.Gp[0], g.Wts[0], g.G0, AMB, d0.k_pad, d0.n_pad, alpha=S)                    # S s * g_0, exact
         if x3_prev is not None:
             be.x3 = x3_prev
+
+    def _gp_f32(self, gp_coef):
+        """The gradient penalty of the demo rows (learning/amp_agent.py:453-459) through an exact-f32 value path inside a
+        16-bit engine (config gp_f32 / precision 'f16gp32').  The penalty is driven towards zero by training, i.e.
+        d logit / d x becomes a CANCELLING sum over the trunk's weights: its relative error in 16-bit storage grows as it
+        shrinks (f16: 6e-5 at a penalty of 0.047, 6.6e-4 at 0.0077 - weight rounding first, ReLU mask flips second;
+        DESIGN 3.2).  So the VALUE takes nothing from the 16-bit launches: f32 shadows of the trunk, its own forward of the
+        AMB demo rows (exact masks), the chain g_l and |g_in|^2 as exact-f32 MFMA launches (_gp_value: 6 launches, ~50 GFLOP
+        per step for config 2, submitted with the branch's head).  The chain is then handed to the 16-bit machinery - one
+        conversion launch writes s g_l and S s g_0 into the 4th row block of the discriminator's buffers - and the penalty's
+        BACKWARD (dJ/dU_l through the exact masks, the logit-weight term, the stacked weight-gradient problems) runs as in
+        _disc_backward; the loss rows' data-gradient launches shrink to 3 AMB rows."""
+        be, AMB, g = self.be, self.AMB, self._gp32
+        Rd, nl, S = 3 * AMB, len(self.disc), self.gs
+        cg = gp_coef * 2.0 / self.AMBg
+        s = math.sqrt(cg)
+        bits = L.AUX_RELU_BITS
+        d0 = self.disc[0]
+        if self._gp_value_done is not None:
+            self._join_branch(self._gp_value_done)
+            self._gp_value_done = None
         be.sqnorm(g.G0, AMB, d0.k_pad, self.acc, L.ACC_GP, scale=1.0 / (cg * S * S))
         # [dZ_l ; s g_l] and [X ; S s g_0]: the exact chain, rounded once, in the storage type
         if g.cast is None:
@@ -1244,11 +1412,12 @@ class UpdateEngine:
         views of ONE copy of the scalar vector (+ one of the logit column), instead of live views the next step
         overwrites: two small device copies per optimisation step."""
         r = self.res.clone() if snapshot else self.res
+        r = r.view(-1)
         out = {'entropy': r[L.RES_ENTROPY], 'kl': r[L.RES_KL], 'b_loss': r[L.RES_B_LOSS], 'actor_loss': r[L.RES_A_LOSS],
                'actor_clip_frac': r[L.RES_CLIP_FRAC], 'critic_loss': r[L.RES_C_LOSS], 'loss': r[L.RES_LOSS]}
         if self.has_disc:
             AMB = self.AMB
-            logit = self.HD[:, 0:1].clone() if snapshot else self.HD[:, 0:1]
+            logit = self.logit_slot.clone() if snapshot else self.logit_slot       # (written by the branch's head, _disc_forward)
             out.update({'disc_loss': r[L.RES_DISC_LOSS], 'disc_grad_penalty': r[L.RES_DISC_GP],
                         'disc_logit_loss': r[L.RES_DISC_LOGIT_LOSS], 'disc_agent_acc': r[L.RES_DISC_AGENT_ACC],
                         'disc_demo_acc': r[L.RES_DISC_DEMO_ACC], 'disc_agent_logit': logit[:2 * AMB],

@@ -188,6 +188,16 @@ class CommonAgent:
         self.use_graph = bool(config.get('graph_capture', False))
         self._snapshot_aside = bool(config.get('snapshot_aside', True))     # per-step result snapshots on a side stream
         self._snapshot_stream = None
+        # Result rings (default): every optimisation step of an update writes its train_result scalars and discriminator logits
+        # into its own slot of a device ring, read ONCE at the end of the update - no per-step snapshot copies between two steps.
+        # (A captured hipGraph binds one slot per minibatch position: that mode keeps the per-step snapshots.)
+        self._use_rings = bool(config.get('result_rings', True)) and config.get('graph_capture') != 'hipgraph'
+        # the update's own stream (see update()); a captured hipGraph and the CPU emulator keep the caller's
+        prio = int(config.get('main_stream_priority', -1))
+        self._main_stream = torch.cuda.Stream(device=self.ppo_device, priority=prio) \
+            if (prio != 0 and getattr(backend, 'name', '') == 'hip' and config.get('graph_capture') != 'hipgraph') else None
+        if self._use_rings:
+            self.engine.set_result_slots(self.mini_epochs_num * self.num_minibatches)
         self._graphs = {}
         self._train_mode = True
         self.train_result = None
@@ -370,6 +380,7 @@ class CommonAgent:
             step = float(st['step'])
         e.opt_state[0] = step
         e.opt_state[1] = float(sd['param_groups'][0]['lr'])
+        self.last_lr = float(sd['param_groups'][0]['lr'])          # host mirror (constant AND adaptive schedule)
 
     def get_full_state_weights(self):
         state = self.get_weights()
@@ -572,11 +583,13 @@ class CommonAgent:
             self._perm_buf = torch.empty(self.batch_size, dtype=torch.int32, device=self.ppo_device)
         self._perm_buf.copy_(perm)
 
-    def _step(self, idx, new_z=None):
+    def _step(self, idx, new_z=None, slot=0):
         streams = self._amp_streams(idx)
+        if self._use_rings:
+            self.engine.use_slot(slot)           # this step's slot of the result ring (engine.set_result_slots)
         if self.use_graph and new_z is None:
             return self._graph_step(idx, streams)
-        return self.engine.step(self._ds, idx, self._remap, streams, new_z=new_z)
+        return self.engine.step(self._ds, idx, self._remap, streams, new_z=new_z, fence=False)      # (update() fences per mini-epoch)
 
     def _graph_step(self, idx, streams):
         """Replay the optimisation step from a recorded launch sequence.  config['graph_capture']:
@@ -592,14 +605,17 @@ class CommonAgent:
         slices of persistent per-mini-epoch buffers (permutation, composed demo / replay indices), so a replay needs no
         copies."""
         eng = self.engine
-        key = (int(idx.data_ptr()),) + (tuple((int(s[0].data_ptr()), int(s[1].data_ptr())) for s in streams) if streams else ())
+        # (result rings: the step's result slot is an argument of its launches - one program per optimisation step of the
+        #  update instead of one per minibatch position)
+        key = (int(idx.data_ptr()), eng.slot if self._use_rings else 0) + \
+            (tuple((int(s[0].data_ptr()), int(s[1].data_ptr())) for s in streams) if streams else ())
         g = self._graphs.get(key)
         hipgraph = self.config.get('graph_capture') == 'hipgraph'
         single = (self.world_size == 1 and not eng.force_dist) or not hipgraph
         if g is None:
-            eng.step(self._ds, idx, self._remap, streams)                # this call's real step; also warms up lazies
+            eng.step(self._ds, idx, self._remap, streams, fence=False)   # this call's real step; also warms up lazies
             torch.cuda.synchronize()
-            phases = [lambda: eng.step(self._ds, idx, self._remap, streams)] if single else \
+            phases = [lambda: eng.step(self._ds, idx, self._remap, streams, fence=False)] if single else \
                 [lambda: eng.phase_stats(self._ds, idx, self._remap, streams),
                  lambda: eng.phase_main(self._ds, idx, self._remap, streams),
                  lambda: eng.phase_apply(True)]
@@ -667,7 +683,9 @@ class CommonAgent:
             self._snapshot_stream = side
         else:
             r = dict(eng.results(snapshot=True))
-        r['last_lr'] = self.engine.opt_state[1].clone() if self.engine.adaptive_lr else self.last_lr
+        # (adaptive schedule: the rate the step was TAKEN with, recorded by the device before the schedule moved it)
+        from .. import lib as L
+        r['last_lr'] = eng.res.view(-1)[L.RES_LR].clone() if eng.adaptive_lr else self.last_lr
         r['lr_mul'] = 1.0
         return r
 
@@ -786,7 +804,28 @@ class CommonAgent:
     def update(self, batch_dict, perms=None, new_zs=None, max_steps=None):
         """Everything train_epoch does after the rollout (learning/amp_agent.py:194-262): the timed region of
         the benchmark together with the tail inside play_steps.  perms / new_zs: injected random draws
-        (parity tests); otherwise drawn on the device."""
+        (parity tests); otherwise drawn on the device.
+
+        The update runs on the agent's own HIGH-priority stream (config['main_stream_priority'], default -1; 0 = the caller's
+        stream): the step's critical path is the policy chain on the engine's main stream, and when its narrow launches
+        (style MLP, heads, loss kernels) compete for CUs with the wide launches of the other branches the hardware serves the
+        higher-priority queue first (MI355X, config 2 bf16: 66.4 -> 62.9 ms per update with the policy streams high and the
+        discriminator's stream normal).  Ordered behind the caller's stream on entry, the caller's stream behind it on exit."""
+        ms = self._main_stream
+        if ms is None:
+            return self._update(batch_dict, perms, new_zs, max_steps)
+        cur = torch.cuda.current_stream(self.ppo_device)
+        ms.wait_stream(cur)
+        with torch.cuda.stream(ms):
+            info = self._update(batch_dict, perms, new_zs, max_steps)
+            for v in info.values() if info else ():
+                for t in v:
+                    if torch.is_tensor(t) and t.is_cuda:
+                        t.record_stream(cur)          # (allocated on the update's stream, read on the caller's)
+        cur.wait_stream(ms)
+        return info
+
+    def _update(self, batch_dict, perms=None, new_zs=None, max_steps=None):
         self._pre_update(batch_dict)
         self.set_train()
         self.curr_frames = batch_dict.pop('played_frames', self.batch_size)
@@ -797,10 +836,14 @@ class CommonAgent:
         m = MB // R
         train_info = None
         step = 0
+        rings = self._use_rings
         for ep in range(self.mini_epochs_num):
             perm = self.dataset_perm if perms is None else perms[ep].to(self.ppo_device, torch.int32)
             self._set_epoch_perm(perm)
             perm = self._perm_buf                      # persistent storage: minibatch slices keep stable addresses
+            # the branch streams read this mini-epoch's index buffers (and, in the first one, what _pre_update stored) without
+            # waiting for the main stream inside a step (engine_opts xstep): order them here, once per mini-epoch
+            self.engine.fence_side_streams()
             for i in range(self.num_minibatches):
                 if max_steps is not None and step >= max_steps:
                     break
@@ -808,23 +851,70 @@ class CommonAgent:
                 self._mb_idx_full = mb_idx
                 self._mb_pos = i
                 idx = mb_idx[rk * m:(rk + 1) * m]
-                self._step(idx, None if new_zs is None else new_zs[step].to(self.ppo_device)[rk * m:(rk + 1) * m])
-                cur = self._collect_result()
-                if train_info is None:
-                    train_info = {k: [v] for k, v in cur.items()}
-                else:
-                    for k, v in cur.items():
-                        train_info[k].append(v)
+                self._step(idx, None if new_zs is None else new_zs[step].to(self.ppo_device)[rk * m:(rk + 1) * m], slot=step)
+                if not rings:
+                    cur = self._collect_result()
+                    if train_info is None:
+                        train_info = {k: [v] for k, v in cur.items()}
+                    else:
+                        for k, v in cur.items():
+                            train_info[k].append(v)
                 step += 1
             if perms is None:          # AMPDataset reshuffles after the last minibatch (learning/amp_datasets.py:24-30)
                 self.dataset_perm = self._randperm(self.batch_size)
         if self._snapshot_stream is not None:
             torch.cuda.current_stream().wait_stream(self._snapshot_stream)
             self._snapshot_stream = None
+        if rings:
+            train_info = self._ring_results(step)
+            self.train_result = {k: v[-1] for k, v in train_info.items()} if step else None
         self._post_update(batch_dict)
-        if self.engine.adaptive_lr:            # host mirror of the device-side schedule (checkpoints, logs): once per update
-            self.last_lr = float(self.engine.opt_state[1])
+        self._lr_stale = self.engine.adaptive_lr      # (the host mirror `last_lr` is refreshed lazily: no read-back here)
         return train_info
+
+    def _ring_results(self, n):
+        """train_info of an update from the engine's result rings: ONE copy of the n result vectors (+ one of the n logit
+        columns) on the main stream - every branch joined it at the end of its step - and per-step views of those copies
+        under the reference's keys (learning/ase_agent.py:296-306, learning/common_agent.py:425-435)."""
+        from .. import lib as L
+        eng = self.engine
+        R = eng.res_ring[:n].clone()
+        cols = {'entropy': L.RES_ENTROPY, 'kl': L.RES_KL, 'b_loss': L.RES_B_LOSS, 'actor_loss': L.RES_A_LOSS,
+                'actor_clip_frac': L.RES_CLIP_FRAC, 'critic_loss': L.RES_C_LOSS, 'loss': L.RES_LOSS}
+        if eng.has_disc:
+            cols.update({'disc_loss': L.RES_DISC_LOSS, 'disc_grad_penalty': L.RES_DISC_GP, 'disc_logit_loss': L.RES_DISC_LOGIT_LOSS,
+                         'disc_agent_acc': L.RES_DISC_AGENT_ACC, 'disc_demo_acc': L.RES_DISC_DEMO_ACC})
+        if eng.has_enc:
+            cols['enc_loss'] = L.RES_ENC_LOSS
+            if eng.enc_gp:
+                cols['enc_grad_penalty'] = L.RES_ENC_GP
+        if eng.div_on:
+            cols['amp_diversity_loss'] = L.RES_DIV_LOSS
+        info = {k: [R[i, c] for i in range(n)] for k, c in cols.items()}
+        if eng.has_disc:
+            LG = eng.logit_ring[:n].clone()
+            a = 2 * eng.AMB
+            info['disc_agent_logit'] = [LG[i, :a].view(-1, 1) for i in range(n)]
+            info['disc_demo_logit'] = [LG[i, a:].view(-1, 1) for i in range(n)]
+        # the learning rate every step was TAKEN with (train_result['last_lr'], learning/common_agent.py:430): adaptive schedule -
+        # recorded on the device before the schedule moved it; constant - the host value
+        info['last_lr'] = [R[i, L.RES_LR] for i in range(n)] if eng.adaptive_lr else [self._last_lr] * n
+        info['lr_mul'] = [1.0] * n
+        return info
+
+    @property
+    def last_lr(self):
+        """Host mirror of the learning rate (checkpoints, logs).  With the adaptive schedule the rate lives on the device
+        (ase_hip_finalize_scalars moves it every step): read back on demand, not at the end of every update."""
+        if getattr(self, '_lr_stale', False) and getattr(self, 'engine', None) is not None:
+            self._last_lr = float(self.engine.opt_state[1])
+            self._lr_stale = False
+        return self._last_lr
+
+    @last_lr.setter
+    def last_lr(self, v):
+        self._last_lr = float(v)
+        self._lr_stale = False
 
 
 class AMPAgent(CommonAgent):

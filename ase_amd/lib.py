@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libase_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 PPO_SCRATCH = 1024 * 72 + 8       # ASE_PPO_SCRATCH: doubles of ase_hip_ppo_head's workspace
 TN_SLAB = 65536 + 256        # ASE_TN_SLAB: floats per work item in the grouped weight-gradient launch's workspace
 F32, BF16, F32X3, F16 = 0, 1, 2, 3
@@ -24,8 +24,8 @@ ACC_COUNT = 24
 # result slots (ASE_RES_*)
 (RES_A_LOSS, RES_C_LOSS, RES_B_LOSS, RES_ENTROPY, RES_CLIP_FRAC, RES_KL, RES_DISC_LOSS, RES_DISC_GP,
  RES_DISC_LOGIT_LOSS, RES_DISC_AGENT_ACC, RES_DISC_DEMO_ACC, RES_ENC_LOSS, RES_DIV_LOSS, RES_LOSS,
- RES_MASK_SUM, RES_ENC_GP) = range(16)
-RES_COUNT = 16
+ RES_MASK_SUM, RES_ENC_GP, RES_LR) = range(17)
+RES_COUNT = 20
 
 _p, _i, _i64, _f, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 

@@ -147,6 +147,9 @@ def compact_line(full, detail_path=None):
 
 
 
+ENGINE_OPTS = {}          # --engine-opts: applied to every agent the run builds
+
+
 def load_cfg():
     from ase_amd import cfg as defaults
     return defaults.get('ase')
@@ -349,7 +352,7 @@ def algorithmic_flops_per_step(eng):
     return f
 
 
-def make_agent(device, precision, use_graph, world, rank, seed=0, force_dist=False, multi_stream=True, dp_mode='horovod'):
+def make_agent(device, precision, use_graph, world, rank, seed=0, force_dist=False, multi_stream=True, dp_mode='shard', engine_opts=None):
     from ase_amd.learning import agents, models
     from ase_amd.learning.network_builder import ASEBuilder
     from ase_amd.synthetic import EnvSpec, SyntheticSource
@@ -367,7 +370,7 @@ def make_agent(device, precision, use_graph, world, rank, seed=0, force_dist=Fal
     cfg = dict(cfg)
     cfg.update(network=models.ModelASEContinuous(b), num_actors=spec.num_envs, device=device, precision=precision,
                graph_capture=use_graph, world_size=world, rank=rank, vec_env=src, force_dist=force_dist,
-               multi_stream=multi_stream, dp_mode=dp_mode,
+               multi_stream=multi_stream, dp_mode=dp_mode, engine_opts=dict(engine_opts or ENGINE_OPTS),
                env_info={'observation_space': sp(253), 'action_space': sp(31), 'amp_observation_space': sp(1400)})
     return agents.ASEAgent('bench', cfg), cfg, spec
 
@@ -595,6 +598,10 @@ def main():
                     help='torch CPU threads during the GPU-timed part (the CPU oracle leg sets its own): every intra-op parallel '
                          'region leaves its OpenMP workers spinning, and on a box whose cgroup quota is smaller than the core count '
                          'torch sees (16 of 256 here) that gets the whole process throttled for the rest of the CFS period')
+    ap.add_argument('--main-priority', type=int, default=0, help='run everything on a non-default stream of this HIP priority '
+                    '(-1 = high): the engine\'s main stream is whatever stream is current')
+    ap.add_argument('--engine-opts', default='', help='JSON dict of UpdateEngine.engine_opts overrides (schedule A/Bs), e.g. '
+                    '\'{"xstep": false}\'')
     ap.add_argument('--gc', default='freeze', choices=['on', 'freeze'],
                     help="'freeze' (default; the agents' config['manual_gc']): gc.freeze() + gc.disable() around the timed updates (no "
                          "generation-2 pass of Python's collector inside an update); 'on': leave the collector alone")
@@ -607,6 +614,8 @@ def main():
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = f'cuda:{local}'
+    if args.main_priority != 0:
+        torch.cuda.set_stream(torch.cuda.Stream(device=device, priority=args.main_priority))
     if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -619,6 +628,8 @@ def main():
             dist.init_process_group(args.dist_backend)                            # (test rigs without one GPU per rank)
 
     use_graph = False if args.no_graph else ('hipgraph' if args.hipgraph else 'program')
+    if args.engine_opts:
+        ENGINE_OPTS.update(json.loads(args.engine_opts))
     torch.set_num_threads(max(1, args.host_threads))
     t_setup = time.time()
     _dbg('init done')
@@ -827,6 +838,7 @@ def main():
                             'gradients averaged by RCCL all-reduce, one bucket per branch' if weak else
                             f'dp{world} shard: the SAME 4096 envs, every 16384-row minibatch row-sharded over the ranks, RCCL '
                             'gradient all-reduce (sum), the R-rank update equals the 1-rank update')},
+                'engine_opts': dict(ENGINE_OPTS),
                 'runtime': ase_amd.hw_queue_note + ('; Python cyclic GC frozen during the timed updates' if args.gc == 'freeze' else '')
                 + f'; torch CPU threads {max(1, args.host_threads)} during the GPU-timed part',
                 'roofline': roof, 'cpu_baseline': cpu, 'qualifying_mode': qualifying, 'throughput_mode': thr, 'modes': modes,

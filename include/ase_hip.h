@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ASE_HIP_ABI_VERSION 2
+#define ASE_HIP_ABI_VERSION 3
 
 enum { ASE_F32 = 0, ASE_BF16 = 1, ASE_F32X3 = 2 /* f32 storage, products as 3 bf16 MFMAs on a hi/lo split (GEMMs only) */,
        ASE_F16 = 3 /* IEEE half storage + v_mfma_f32_32x32x16_f16, f32 accumulate: what the reference's mixed_precision flag
@@ -296,12 +296,15 @@ int ase_hip_sqnorm(const void* x, int64_t ld, int rows, int cols, double* acc, i
  * out f32[ASE_RES_COUNT].  opt_state_lr (nullable: constant lr): the optimizer state of ase_hip_begin_step - the learning rate
  * opt_state[1] is then adapted from this step's kl as rl_games' AdaptiveScheduler does under the 'legacy' schedule after every
  * minibatch (learning/common_agent.py:204-208; lr_schedule: adaptive, kl_threshold): kl > 2 thr: lr / 1.5 (>= 1e-6),
- * kl < thr / 2: lr * 1.5 (<= 1e-2) - on the device, no .item() per step. */
+ * kl < thr / 2: lr * 1.5 (<= 1e-2) - on the device, no .item() per step.  out[ASE_RES_LR] = the learning rate THIS step was
+ * taken with (the reference's train_result['last_lr'], learning/common_agent.py:430), 0 with a constant rate (the host
+ * knows it).  ABI 3: ASE_RES_COUNT 16 -> 20 (ASE_RES_LR; result vectors are slots of a per-update ring, 80-byte pitch). */
 enum {
     ASE_RES_A_LOSS = 0, ASE_RES_C_LOSS, ASE_RES_B_LOSS, ASE_RES_ENTROPY, ASE_RES_CLIP_FRAC, ASE_RES_KL,
     ASE_RES_DISC_LOSS, ASE_RES_DISC_GP, ASE_RES_DISC_LOGIT_LOSS, ASE_RES_DISC_AGENT_ACC,
     ASE_RES_DISC_DEMO_ACC, ASE_RES_ENC_LOSS, ASE_RES_DIV_LOSS, ASE_RES_LOSS, ASE_RES_MASK_SUM, ASE_RES_ENC_GP,
-    ASE_RES_COUNT = 16
+    ASE_RES_LR,
+    ASE_RES_COUNT = 20
 };
 int ase_hip_finalize_scalars(const double* acc, float* out, int m_global, int amb_global, int masked,
                              int has_disc, int has_enc, int has_div, float critic_coef,

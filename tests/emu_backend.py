@@ -395,8 +395,9 @@ class EmuBackend:
         den = S if masked else float(m_global)
         al, bl, ent, cf = a[L.ACC_A_LOSS] / den, a[L.ACC_B_LOSS] / den, a[L.ACC_ENTROPY] / den, a[L.ACC_CLIPPED] / den
         cl, kl = a[L.ACC_C_LOSS] / m_global, a[L.ACC_KL] / m_global
+        lr_used = 0.0
         if opt_state is not None:                 # rl_games AdaptiveScheduler (schedulers.py), 'legacy' schedule
-            lr = cur = float(opt_state[1])
+            lr = cur = lr_used = float(opt_state[1])
             if kl > 2.0 * kl_threshold:
                 lr = max(cur / 1.5, 1e-6)
             if kl < 0.5 * kl_threshold:
@@ -406,6 +407,7 @@ class EmuBackend:
         out.zero_()
         out[L.RES_A_LOSS], out[L.RES_C_LOSS], out[L.RES_B_LOSS] = al, cl, bl
         out[L.RES_ENTROPY], out[L.RES_CLIP_FRAC], out[L.RES_KL], out[L.RES_MASK_SUM] = ent, cf, kl, S
+        out[L.RES_LR] = lr_used                   # the rate this step was taken with (0 with a constant schedule)
         if has_disc:
             amb = float(amb_global)
             bce = 0.5 * (a[L.ACC_BCE_AGENT] / (2 * amb) + a[L.ACC_BCE_DEMO] / amb)

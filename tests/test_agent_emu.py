@@ -235,7 +235,9 @@ def test_diversity_and_rollout_latents_use_different_streams(golden_dir):
 def test_adaptive_lr_schedule_follows_every_steps_kl(golden_dir):
     """lr_schedule: adaptive (N4): rl_games' AdaptiveScheduler under the default 'legacy' schedule - after EVERY optimisation step
     lr <- lr / 1.5 if that step's kl > 2 thr, lr * 1.5 if kl < thr / 2 (clamped to [1e-6, 1e-2]), restated here from
-    rl_games/common/schedulers.py; the engine applies it on the device inside the launch that forms the reported scalars."""
+    rl_games/common/schedulers.py; the engine applies it on the device inside the launch that forms the reported scalars.
+    train_result['last_lr'] of step i is the rate step i was TAKEN with (the reference fills it inside calc_gradients,
+    learning/common_agent.py:425-435, before train_epoch's scheduler.update moves it)."""
     import copy
     G = copy.deepcopy(torch.load(os.path.join(golden_dir, 'ppo_tiny.pt'), weights_only=False))
     G['cfg'].update(lr_schedule='adaptive', kl_threshold=0.5)
@@ -246,12 +248,12 @@ def test_adaptive_lr_schedule_follows_every_steps_kl(golden_dir):
     for info in infos:
         for i in range(len(info['kl'])):
             kl = float(info['kl'][i])
+            assert abs(float(info['last_lr'][i]) - lr) <= 1e-6 * lr, (i, float(info['last_lr'][i]), lr, kl)      # (f32 slot)
             if kl > 2.0 * 0.5:
                 lr = max(lr / 1.5, 1e-6)
             elif kl < 0.5 * 0.5:
                 lr = min(lr * 1.5, 1e-2)
             seen.append(lr)
-            assert abs(float(info['last_lr'][i]) - lr) <= 1e-12 * lr, (i, float(info['last_lr'][i]), lr, kl)
     assert len(set(seen)) > 2 and abs(ag.last_lr - lr) <= 1e-12 * lr          # the schedule actually moved
 
 

@@ -78,13 +78,14 @@ def _first_step_errors(G, ag):
 def test_real_width_reference_goldens_qualifying_modes(be, name, precision, golden_dir):
     """The modes the bench names as qualifying, against the UNMODIFIED reference's first optimisation step at the real layer
     widths (learning/ase_agent.py:228-258, learning/amp_agent.py:442-479).  Everything that does not pass through the foreign
-    old log-probabilities holds BASELINE's 1e-4: the gradient penalty (what the mode exists for) 1e-5, discriminator /
+    old log-probabilities holds BASELINE's 1e-4: the gradient penalty (what the mode exists for) 1e-5 / 5e-5, discriminator /
     critic / encoder / diversity losses 1e-4, kl 2e-4 of its own value.  actor_loss alone carries the foreign-rollout
     amplification (the reference's f32 mu_old against this engine's f16 mu: d logp = (a - mu) / sigma^2 d mu ~ 18 / sigma d mu):
     5e-4 of its summand scale.  (Emulator, same goldens: 8e-8 / 1e-5 / 4e-5 / 4e-5 ... 1.5e-4.)"""
     G = torch.load(os.path.join(golden_dir, name + '.pt'), weights_only=False)
     err = _first_step_errors(G, make_agent(G, be, device='cuda', precision=precision))
-    assert err['disc_grad_penalty'][1] <= 1e-5, err
+    # (exact-f32 value path: 1e-5; three-bf16-MFMA products carry a unit roundoff of ~2^-17 per product: 5e-5, 2.2e-5 measured)
+    assert err['disc_grad_penalty'][1] <= (1e-5 if precision == 'f16gp32' else 5e-5), err
     for k in ('critic_loss', 'disc_loss', 'disc_logit_loss', 'enc_loss', 'amp_diversity_loss', 'entropy', 'b_loss'):
         if k in err:
             assert err[k][0] <= 1e-4, (k, err)

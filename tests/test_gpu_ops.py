@@ -888,4 +888,4 @@ def test_gp_second_saturated_units_stay_finite(be):
             b.gp_second(twin.to(dev), gv.to(dev), dg.to(dev), dz, rows, width, act)
             outs.append(dz.cpu())
         assert bool(torch.isfinite(outs[0]).all()) and bool(torch.isfinite(outs[1]).all()), act
-        close(outs[0], outs[1], 2e-4, 1e-7, f'gp_second act {act}')
+        close(outs[0], outs[1], 1e-3, 1e-5 * float(outs[1].abs().max()) + 1e-9, f'gp_second act {act}')     # (device erf / exp vs torch's)
