@@ -141,13 +141,20 @@ class UpdateEngine:
         #                   that many workgroups; 0: direct launches of the split-M kernel) beside the policy's wide
         #                   weight-gradient launch instead of in front of it.  Measured SLOWER (f16gpx3 73.9 -> 76.7 / 79.0 ms with
         #                   64 / 32 workgroups: three narrow problems over 32768 rows on a few CUs outlast the wide launch): off
+        #   prefetch        (with xstep) the step's weight-independent prologue - observation moments -> running statistics ->
+        #                   normalised [obs | latent] inputs, latent copies, diversity draw, loss-head fields - is submitted at the top
+        #                   of the step on the critic's stream WITHOUT waiting for the main stream: it runs under the previous step's
+        #                   policy tail, the inputs it writes are double-buffered by step parity (Xa / Xc / Zs)
+        #   disc_after_style  (with xstep) the discriminator head's matrix launches wait until the main stream has launched the style
+        #                   MLP's forward (its statistics / normalisation half stays un-chained).  Measured SLOWER (bf16 62.9 ->
+        #                   65.2 ms): the update is bound by total matrix-pipe time, CUs left idle for the critical path are lost
         #   side_priority   HIP priority of the branch streams, one number or [critic, discriminator, penalty value path] (0 = default,
         #                   -1 = high; the main stream's priority is the caller's)
         #   gp_stream       gp_f32 modes: the penalty's value path (f32 / bf16x3 forward of the demo rows + chain: independent of
         #                   the loss rows until the conversion launch) on its own stream beside the discriminator branch
         o = dict(tn_grouped=True, tn_wg_side=64, tn_early=False, disc_early=True, short_prologue=True, style_early=False,
                  relu_bits=True, fused_apply=True, apply_wide=True, side_streams=2, gp_scale_split=True, xstep=True,
-                 gp_stream=True, style_side=False, style_wg=0, side_priority=None)
+                 gp_stream=True, style_side=0, style_wg=0, side_priority=None, prefetch=True, disc_after_style=False)
         unknown = set(cfg.get('engine_opts', {}) or {}) - set(o)
         assert not unknown, f"unknown engine_opts {sorted(unknown)}"
         o.update(cfg.get('engine_opts', {}) or {})
@@ -168,7 +175,11 @@ class UpdateEngine:
         # (a captured hipGraph forks every stream from the capturing one: an un-chained branch head cannot be captured)
         self._xstep = bool(o['xstep']) and cfg.get('graph_capture') != 'hipgraph'
         self._gp_side = bool(o['gp_stream'])
-        self._style_side = bool(o['style_side'])
+        self._style_side = int(o['style_side'])
+        self._disc_after_style = bool(o['disc_after_style'])
+        self._disc_split = False
+        self._prefetch = bool(o['prefetch'])
+        self._par = 0
         self._style_wg = int(o['style_wg'])
         sp = o['side_priority']
         if sp is None:
@@ -179,7 +190,7 @@ class UpdateEngine:
         self._side_prio = [int(x) for x in sp] if isinstance(sp, (list, tuple)) else [int(sp)] * 3      # critic, disc, gp streams
         self._gp_stream_obj = None
         self._xs = False                 # this step runs the cross-step schedule (decided per step in step())
-        self._disc_fwd_out = self._gp_value_done = None
+        self._disc_fwd_out = self._gp_value_done = self._pre_done = None
         self._apply_wide = bool(o['apply_wide'])
         self._apply_desc = self._apply_items = None
         self.force_dist = bool(cfg.get('force_dist', False))   # exercise the collectives with a 1-rank group
@@ -308,8 +319,13 @@ class UpdateEngine:
             return [with_bits(zt(rows, d.n_pad), d) for d in chain], [zt(rows, d.n_pad) for d in chain]
 
         f32 = torch.float32
-        self.Xa = zt(Ra, self.actor[0].k_pad)
-        self.Xc = zt(M, self.critic[0].k_pad)
+        # inputs of the first actor / critic layers ([obs | pad | latent or style code]) and the latent copies the style MLP
+        # reads: TWO sets, selected by the parity of the step's result slot - the next step's prologue writes one set while the
+        # previous step's weight-gradient launch still reads the other (engine_opts prefetch)
+        nset = 2 if (self._prefetch and self._xstep and self.multi_stream) else 1
+        self._Xa2 = [zt(Ra, self.actor[0].k_pad) for _ in range(nset)]
+        self._Xc2 = [zt(M, self.critic[0].k_pad) for _ in range(nset)]
+        self.Xa, self.Xc = self._Xa2[0], self._Xc2[0]
         self.Ha, self.dZa = chain_bufs(self.actor, Ra)
         self.Hc, self.dZc = chain_bufs(self.critic, M)
         self.MU = zt(Ra, self.mu_head.n_pad, f32)
@@ -317,7 +333,8 @@ class UpdateEngine:
         self.V = zt(M, self.value_head.n_pad, f32)
         self.dV = zt(M, self.value_head.n_pad)
         if self.style:
-            self.Zs = zt(Ra, P(self.z))
+            self._Zs2 = [zt(Ra, P(self.z)) for _ in range(nset)]
+            self.Zs = self._Zs2[0]
             self.Hs, self.dZs = chain_bufs(self.style[:-1], Ra)
             self.dStyle = zt(Ra, P(self.z))
             self.new_z = zt(M, self.z, f32)
@@ -417,6 +434,10 @@ class UpdateEngine:
 
     def use_slot(self, i):
         self.slot = i
+        self._par = p = i % len(self._Xa2)                 # input-buffer set of this step (see _alloc)
+        self.Xa, self.Xc = self._Xa2[p], self._Xc2[p]
+        if self.style:
+            self.Zs = self._Zs2[p]
         self.res = self.res_ring[i]
         self.logit_slot = self.logit_ring[i].view(-1, 1) if self.logit_ring is not None else None
 
@@ -597,14 +618,16 @@ class UpdateEngine:
         key = tuple(ds[k].data_ptr() for k in self.mb)
         if self._mb_desc_key != key:
             self._mb_desc, self._mb_items, self._mb_desc_key = {}, {}, key
+        part_in = part
+        part = (part, self._par)           # (the latent copies go into this step's set of input buffers)
         if part not in self._mb_desc:
             rows, items = [], []
-            if part != 2:
+            if part_in != 2:
                 for k, dst in self.mb.items():
                     src = ds[k].view(ds[k].shape[0], -1)
                     rows.append([src.data_ptr(), src.stride(0), src.shape[1], dst.data_ptr(), dst.stride(0), L.F32])
                     items.append((src, src.shape[1], dst))
-            if self.z and part != 1:
+            if self.z and part_in != 1:
                 src = ds['ase_latents'].view(ds['ase_latents'].shape[0], -1)
                 code = {torch.bfloat16: L.BF16, torch.float16: L.F16}.get(self.dtype, L.F32)
                 for dst in (self.Zs[:self.M], self.Xc[:, self.actor[0].split_dst:]):
@@ -648,7 +671,7 @@ class UpdateEngine:
         # cross-step schedule: single GPU, streams, every branch finishing by itself (its own optimizer step)
         self._xs = bool(self._xstep and inline and self.has_disc and self._short_prologue and self._disc_early
                         and self._amp_stats_in_branch())
-        if self._xs and fence:
+        if self._xs and (fence or new_z is not None):        # (injected latents are a fresh tensor of the caller's stream)
             # a caller that does not order the branch streams itself (the agents do, once per mini-epoch): whatever it did on
             # the current stream - weights loaded, statistics set, index tensors built - happens before the un-chained head
             self.fence_side_streams()
@@ -689,36 +712,64 @@ class UpdateEngine:
             # the optimizer state; the loss heads further down wait for begin_step.
             self._build_apply_desc()
             lo, hi = self._apply_groups['disc'][2:]
+            # disc_after_style: only the HBM-bound half of the head is submitted here; its matrix launches are held back until the
+            # main stream has launched the style MLP's forward (phase_main) - three narrow launches that open the step's critical
+            # path and took 105 us instead of ~35 when they had to queue for CUs behind the 120-us tiles of this branch
+            self._disc_split = bool(self._disc_after_style and self.style)
             with self._Branch(self, self._side(1), nowait=True):
                 be.zero_(self.grads[lo:hi])
                 be.zero_(self.amp_sums)
-                self._disc_fwd_out = self._disc_forward(amp_streams)
-        # one launch: Adam step counter / bias corrections (advance=False - calc_gradients-style calls - leaves them),
-        # loss accumulators and per-step partial statistics zeroed, position of the diversity-latent stream advanced
-        be.begin_step(self.opt_state if advance else None, self.acc, zero2=self.obs_sums if self._xs else self.stats_flat,
-                      rng_bump=self.div_rng if self.div_on else None)
-        self._prep = None
-        if self._xs:
-            m0 = self._mark()
-            self._early_fork, self._fill_done = m0, None
-            plo, phi = self._apply_groups['policy'][2:]
-            with self._Branch(self, self._side(0), m0) as prep:
-                be.zero_(self.grads[plo:phi])
+                if self._disc_split:
+                    self._disc_inputs(amp_streams)
+                    self._disc_fwd_out = 'split'
+                else:
+                    self._disc_fwd_out = self._disc_forward(amp_streams)
+        pf = self._xs and self._prefetch and len(self._Xa2) == 2
+        pre = None
+        if pf:
+            # The weight-independent prologue, un-chained like the discriminator's head: on the critic's stream it follows that
+            # branch's backward of the previous step (whose loss head was the last reader of the minibatch fields) and runs
+            # under the previous step's policy tail.  It zeroes its own partial sums and advances the diversity stream itself
+            # (one begin_step launch without optimizer state); the accumulators are not touched before the main stream's
+            # begin_step below (the mask sum follows it).
+            with self._Branch(self, self._side(0), nowait=True) as pre:
+                be.begin_step(None, None, zero2=self.obs_sums, rng_bump=self.div_rng if self.div_on else None)
+                if c.get('normalize_input', True):
+                    be.rms_moments(ds['obs'], self.obs, idx, remap, M, self.obs_state, self.obs_sums)
+                    be.rms_finalize(self.obs_state, self.obs, self.obs_sums, self.M, 1, self.obs_mean, self.obs_std)
+                else:
+                    self._identity_stats(self.obs_mean, self.obs_std)
+                outs = [self.Xa[:M], self.Xc]
+                if self.div_on:
+                    outs.append(self.Xa[M:])
+                be.rms_normalize(ds['obs'], self.obs, idx, remap, M, self.obs_mean[0], self.obs_std[0], outs)
                 self.gather_minibatch(ds, idx, remap, part=2)
                 if self.div_on:
                     self._draw_new_latents(new_z)
-                if self.style and self._style_early:
-                    sd = self.actor[0].split_dst
-                    h = self._fwd_chain(self.style[:-1], self.Zs, self.Hs, self.Ra)
-                    self._fwd(self.style[-1], h, self.Xa[:, sd:], self.Ra)
-                self._lat_ready = self._mark()
+                self._lat_ready = self._mark()        # everything the style MLP / the first actor layer read is in place
                 self.gather_minibatch(ds, idx, remap, part=1)
+        self._pre_done = pre
+        if pf:
+            # begin_step leaves the main stream: nothing in front of the loss heads reads the accumulators or the optimizer
+            # state, so the launch (after the previous step's last kernel: mark on the main stream) and what follows it - zeroing
+            # the policy's gradient bucket, the mask sum - go to the critic's stream; the main stream opens with the style MLP
+            tail = self._mark()
+            plo, phi = self._apply_groups['policy'][2:]
+            with self._Branch(self, self._side(0), tail) as prep:           # (same stream as the prologue above: after it)
+                be.begin_step(self.opt_state if advance else None, self.acc, zero2=None, rng_bump=None)
+                self._early_fork = self._mark()
+                be.zero_(self.grads[plo:phi])
                 if self.masked:
                     be.reduce_sum(self.mb['rand_action_mask'], M, False, self.acc, L.ACC_MASK_SUM)
+            self._fill_done = None
             self._prep = prep
-            if c.get('normalize_input', True):
-                be.rms_moments(ds['obs'], self.obs, idx, remap, M, self.obs_state, self.obs_sums)
             return
+        # one launch: Adam step counter / bias corrections (advance=False - calc_gradients-style calls - leaves them),
+        # loss accumulators and per-step partial statistics zeroed, position of the diversity-latent stream advanced
+        be.begin_step(self.opt_state if advance else None, self.acc,
+                      zero2=None if pf else (self.obs_sums if self._xs else self.stats_flat),
+                      rng_bump=self.div_rng if (self.div_on and not pf) else None)
+        self._prep = None
         if self._short_prologue and self._amp_stats_in_branch():
             # Short prologue (single GPU, streams): the actor chain - the critical path - keeps only the observation chain
             # (moments -> finalise -> normalise) in front of it on the main stream.  The latent copies and the diversity draw
@@ -836,6 +887,12 @@ class UpdateEngine:
         """Head of the discriminator (+ encoder) branch: AMP-observation moments -> running statistics -> normalised rows
         [agent | replay | demo] -> trunk forward -> joint [logit | enc] head (+ the separate encoder's chain).  Needs the
         branch's weights and nothing of the step's accumulators."""
+        self._disc_inputs(amp_streams)
+        return self._disc_matrices()
+
+    def _disc_inputs(self, amp_streams):
+        """First half of the branch's head: statistics and normalised inputs (HBM-bound streams) + the fork of the penalty's
+        value path (gp_f32 modes)."""
         be, c, AMB = self.be, self.cfg, self.AMB
         Rd = 3 * AMB
         norm_amp = self.has_disc and c.get('normalize_amp_input', True)
@@ -865,6 +922,11 @@ class UpdateEngine:
                 self._gp_value_done = br
             else:
                 self._gp_value(amp_streams, gp_coef)
+
+    def _disc_matrices(self):
+        """Second half: the matrix launches (trunk forward, joint head) and the logit snapshot."""
+        be, AMB = self.be, self.AMB
+        Rd = 3 * AMB
         hd = self._fwd_chain(self.disc, self.Xd, self.Hd, Rd)
         self._fwd(self.disc_head, hd, self.HD, Rd)
         if self.logit_slot is not None:        # the step's logits into its slot of the result ring (train_result's disc_*_logit)
@@ -895,20 +957,23 @@ class UpdateEngine:
         amb_den = self.AMBg if self.shard else self.AMB
         Rd = 3 * AMB
 
-        if self._disc_fwd_out is not None:           # cross-step schedule: submitted at the top of phase_stats
+        if self._disc_fwd_out == 'split':            # (its matrix half follows the style forward below)
+            hd = he = None
+        elif self._disc_fwd_out is not None:         # cross-step schedule: submitted at the top of phase_stats
             hd, he = self._disc_fwd_out
         elif disc_early:
             with self._Branch(self, self._side(1), fork0):
                 hd, he = self._disc_forward(amp_streams)
-        if norm_in:
-            be.rms_finalize(self.obs_state, self.obs, self.obs_sums, self.Mg if self.shard else self.M, 1, self.obs_mean,
-                            self.obs_std)
-        else:
-            self._identity_stats(self.obs_mean, self.obs_std)
-        outs = [self.Xa[:M], self.Xc]
-        if self.div_on:
-            outs.append(self.Xa[M:])
-        be.rms_normalize(ds['obs'], self.obs, idx, remap, M, self.obs_mean[0], self.obs_std[0], outs)
+        if self._pre_done is None:            # (prefetch: statistics + normalised inputs came with the un-chained prologue)
+            if norm_in:
+                be.rms_finalize(self.obs_state, self.obs, self.obs_sums, self.Mg if self.shard else self.M, 1, self.obs_mean,
+                                self.obs_std)
+            else:
+                self._identity_stats(self.obs_mean, self.obs_std)
+            outs = [self.Xa[:M], self.Xc]
+            if self.div_on:
+                outs.append(self.Xa[M:])
+            be.rms_normalize(ds['obs'], self.obs, idx, remap, M, self.obs_mean[0], self.obs_std[0], outs)
         fork1 = self._mark()                 # critic: observations normalised, latents in place (gather_minibatch)
         if self._prep is not None:
             be.wait(self._lat_ready)         # latent copies + diversity draw of the short prologue (critic's stream)
@@ -921,6 +986,7 @@ class UpdateEngine:
             sd = self.actor[0].split_dst
             h = self._fwd_chain(self.style[:-1], self.Zs, self.Hs, Ra)
             self._fwd(self.style[-1], h, self.Xa[:, sd:], Ra)
+        style_launched = self._mark() if self._disc_fwd_out == 'split' else None
         ha = self._fwd_chain(self.actor, self.Xa, self.Ha, Ra)
         self._fwd(self.mu_head, ha, self.MU, Ra)
 
@@ -933,7 +999,10 @@ class UpdateEngine:
         if self.has_disc:
             tnq, self._tn_queue = self._tn_queue, []          # the branch queues (and flushes) its own weight gradients
             with self._Branch(self, self._side(1), fork0) as br_disc:
-                if not disc_early:
+                if self._disc_fwd_out == 'split':
+                    be.wait(style_launched)
+                    hd, he = self._disc_matrices()
+                elif not disc_early:
                     hd, he = self._disc_forward(amp_streams)
                 be.disc_head(self.HD, self.dHD, self.disc_head.gb[0], self.acc, AMB, amb_den, c['disc_coef'],
                              grad_scale=self.gs)
@@ -1007,7 +1076,19 @@ class UpdateEngine:
                 self._dgrad(sdn, self.dStyle, self.dZs[-1], Ra, self.Hs[-1], p.act)
                 self._bwd_chain(self.style[:-1], self.Zs, self.Hs, self.dZs, Ra)
 
-        if self.style and self._style_side and self.multi_stream and self._tn_defer and not self._tn_early:
+        if self.style and self._style_side == 2 and self.multi_stream and self._tn_defer and not self._tn_early:
+            # variant: only the style MLP's three data-gradient launches leave the critical path (critic's stream, beside the
+            # wide weight-gradient launch); its weight gradients follow the wide launch on the main stream as a second grouped
+            # launch over the whole chip
+            self._join_branch(br_cb)
+            wide, self._tn_queue = tn_actor, []
+            with self._Branch(self, self._side(0), actor_done) as br_style:
+                style_backward()
+            narrow, self._tn_queue = self._tn_queue, wide
+            self._flush_tn(0)
+            self._join_branch(br_style)
+            self._tn_queue = narrow
+        elif self.style and self._style_side and self.multi_stream and self._tn_defer and not self._tn_early:
             # The style MLP's backward (three narrow data-gradient launches, ~75 us back to back) used to sit between the actor's
             # data-gradient chain and the policy's grouped weight-gradient launch - on the step's critical path.  The wide
             # launch needs nothing of it: it goes out as soon as the actor's and the critic's chains are through, and the style
