@@ -509,6 +509,15 @@ def cpu_from_times(times, cfg, B, MB, AMB, ncpu):
            'sample': f'{len(tt)} of the {n_steps} optimisation steps of one update at full size (minibatch {MB}, amp {AMB}; one '
                      f'more as warm-up), median {t_step:.2f} s/step on {ncpu} threads, extrapolated x{n_steps}; '
                      'oracle/restated.py (f32 torch CPU)'}
+    # the UNMODIFIED reference cannot travel to the GPU box (/root/reference is not there): it was timed beside this port in the
+    # authoring container, same inputs, same process (oracle/time_reference.py) - the port is the faster of the two
+    try:
+        j = json.load(open(os.path.join(ROOT, 'profiles', 'r04_reference_cpu_timing.json')))
+        cpu['reference_beside_port'] = {'port_over_reference_time': j['port_over_reference'], 'cores': j['cores'],
+                                        'reference_s_per_step': j['reference']['s_per_step'], 'port_s_per_step': j['port']['s_per_step'],
+                                        'source': 'profiles/r04_reference_cpu_timing.json (oracle/time_reference.py, authoring container)'}
+    except (OSError, KeyError, ValueError):
+        pass
     return cpu
 
 
