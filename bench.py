@@ -352,7 +352,7 @@ def algorithmic_flops_per_step(eng):
     return f
 
 
-def make_agent(device, precision, use_graph, world, rank, seed=0, force_dist=False, multi_stream=True, dp_mode='shard', engine_opts=None):
+def make_agent(device, precision, use_graph, world, rank, seed=0, force_dist=False, multi_stream=True, dp_mode='shard', engine_opts=None, extra_cfg=None):
     from ase_amd.learning import agents, models
     from ase_amd.learning.network_builder import ASEBuilder
     from ase_amd.synthetic import EnvSpec, SyntheticSource
@@ -372,6 +372,7 @@ def make_agent(device, precision, use_graph, world, rank, seed=0, force_dist=Fal
                graph_capture=use_graph, world_size=world, rank=rank, vec_env=src, force_dist=force_dist,
                multi_stream=multi_stream, dp_mode=dp_mode, engine_opts=dict(engine_opts or ENGINE_OPTS),
                env_info={'observation_space': sp(253), 'action_space': sp(31), 'amp_observation_space': sp(1400)})
+    cfg.update(extra_cfg or {})
     return agents.ASEAgent('bench', cfg), cfg, spec
 
 

@@ -306,3 +306,43 @@ def test_self_consistent_parity_config2(mode, fresh_loss, fresh_grad, stress_los
     assert st['train_result_before']['actor_clip_frac'] > 0.2          # the stress state IS off-policy
     del agent
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('precision,w_mean,s_rtol', [('f32', 0.1, 5e-3), ('f16gpx3', 0.5, 5e-2), ('bf16', 1.0, 0.25)])
+def test_schedule_variants_agree_config2(precision, w_mean, s_rtol):
+    """The round-4 schedule (discriminator head and prologue un-chained from the main stream, penalty value path on its own
+    stream, result rings, per-step launch programs, the agent's own high-priority stream) changes WHEN kernels run, never what
+    they compute: BASELINE config 2 at full size, two updates under program replay, against the same agent with every
+    cross-step option off and plain per-step snapshots - same weights, same statistics, same reported scalars.  (Not bitwise:
+    the normalisers' batch moments are f64 atomics, whose order moves the last bit of a mean.)  A race - a branch reading a
+    buffer before its producer, a double-buffered input overwritten early - shows up as a gross difference.  f32 carries the
+    tight bounds (two f32 runs drift by ~2e-3 over an update); the 16-bit modes amplify the last-bit differences
+    chaotically over 144 Adam steps (bf16: per-step scalars 10 % apart after three updates, two identical-arithmetic runs) and
+    are held to gross-error bounds - f16gpx3 is here for the penalty's value path on its own stream."""
+    import bench
+    outs = []
+    for opts, extra in (({'xstep': False, 'prefetch': False, 'gp_stream': False}, {'main_stream_priority': 0, 'result_rings': False}),
+                        ({}, {})):
+        agent, cfg, spec = bench.make_agent('cuda:0', precision, 'program', 1, 0, engine_opts=opts or {'xstep': True}, extra_cfg=extra)
+        bench.fill_rollout(agent, 'cuda:0')
+        agent._init_amp_demo_buf()
+        infos = [agent.update(agent._play_steps_tail()) for _ in range(3)]      # (first update records, the others replay)
+        torch.cuda.synchronize()
+        outs.append((agent.model.a2c_network.flat_params.detach().float().cpu().clone(), agent.engine.obs_state.cpu().clone(),
+                     agent.engine.amp_state.cpu().clone(),
+                     {k: torch.stack([torch.as_tensor(x).float().reshape(-1)[0].cpu() for x in infos[-1][k]])
+                      for k in ('kl', 'actor_loss', 'critic_loss', 'disc_loss', 'disc_grad_penalty', 'enc_loss', 'amp_diversity_loss')}))
+        del agent
+        torch.cuda.empty_cache()
+    (w0, o0, a0, r0), (w1, o1, a1, r1) = outs
+    lr = 2e-5
+    # weights: after 144 Adam steps two runs differ by a few lr where a gradient's sign is rounding noise (measured: mean
+    # 0.08 lr, two identical-arithmetic runs) - not by more
+    assert float((w0 - w1).abs().max()) <= 20 * lr, float((w0 - w1).abs().max())
+    assert float((w0 - w1).abs().mean()) <= w_mean * lr, float((w0 - w1).abs().mean())
+    close(o1, o0, 1e-6, 1e-6, 'obs running statistics')
+    close(a1, a0, 1e-6, 1e-6, 'amp running statistics')
+    for k in r0:
+        assert bool(torch.isfinite(r1[k]).all()) and bool(torch.isfinite(r0[k]).all()), k
+        a, b = float(r1[k].mean()), float(r0[k].mean())          # mean over the update's 48 steps
+        assert abs(a - b) <= s_rtol * max(abs(b), 0.05), ('last update mean ' + k, a, b)
