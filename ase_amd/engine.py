@@ -178,6 +178,7 @@ class UpdateEngine:
         self._style_side = int(o['style_side'])
         self._disc_after_style = bool(o['disc_after_style'])
         self._disc_split = False
+        self._enc_z_ready = False
         self._prefetch = bool(o['prefetch'])
         self._par = 0
         self._style_wg = int(o['style_wg'])
@@ -720,10 +721,10 @@ class UpdateEngine:
                 be.zero_(self.grads[lo:hi])
                 be.zero_(self.amp_sums)
                 if self._disc_split:
-                    self._disc_inputs(amp_streams)
+                    self._disc_inputs(amp_streams, ds)
                     self._disc_fwd_out = 'split'
                 else:
-                    self._disc_fwd_out = self._disc_forward(amp_streams)
+                    self._disc_fwd_out = self._disc_forward(amp_streams, ds)
         pf = self._xs and self._prefetch and len(self._Xa2) == 2
         pre = None
         if pf:
@@ -883,14 +884,14 @@ class UpdateEngine:
                     self._host(lambda: self.grads[lo:hi].mul_(1.0 / self.R))
             self.be.apply_multi(self._apply_desc[a:b], self._apply_items[a:b], self.dtype, self.opt_state, self.acc)
 
-    def _disc_forward(self, amp_streams):
+    def _disc_forward(self, amp_streams, ds=None):
         """Head of the discriminator (+ encoder) branch: AMP-observation moments -> running statistics -> normalised rows
         [agent | replay | demo] -> trunk forward -> joint [logit | enc] head (+ the separate encoder's chain).  Needs the
         branch's weights and nothing of the step's accumulators."""
-        self._disc_inputs(amp_streams)
+        self._disc_inputs(amp_streams, ds)
         return self._disc_matrices()
 
-    def _disc_inputs(self, amp_streams):
+    def _disc_inputs(self, amp_streams, ds=None):
         """First half of the branch's head: statistics and normalised inputs (HBM-bound streams) + the fork of the penalty's
         value path (gp_f32 modes)."""
         be, c, AMB = self.be, self.cfg, self.AMB
@@ -904,6 +905,14 @@ class UpdateEngine:
         else:
             self._identity_stats(self.amp_mean, self.amp_std)
         gp_fork = self._mark() if (self.gp32 and self._gp_side) else None
+        self._enc_z_ready = False
+        if self.has_enc and ds is not None:
+            # enc_latents = ase_latents[0:amp_minibatch] (learning/ase_agent.py:247): a row gather that needs nothing but the
+            # step's indices - with the un-chained head instead of between the discriminator's loss heads
+            src, sidx, srm = amp_streams[0]
+            zsrc = ds['ase_latents'].view(ds['ase_latents'].shape[0], -1)
+            be.gather_rows(zsrc, self.z, sidx, srm, AMB, self.enc_z)
+            self._enc_z_ready = True
         xd = [self.Xd[s * AMB:(s + 1) * AMB] for s in range(3)]
         if self.amp % 4 == 0 and all(src.stride(0) % 4 == 0 for src, _, _ in amp_streams):
             be.rms_normalize_multi(amp_streams, self.amp, AMB, [self.amp_mean[s] for s in range(3)],
@@ -1009,7 +1018,8 @@ class UpdateEngine:
                 if self.has_enc:
                     src, sidx, srm = amp_streams[0]   # enc_latents = ase_latents[0:amp_minibatch] (learning/ase_agent.py:247)
                     zsrc = ds['ase_latents'].view(ds['ase_latents'].shape[0], -1)
-                    be.gather_rows(zsrc, self.z, sidx, srm, AMB, self.enc_z)
+                    if not self._enc_z_ready:
+                        be.gather_rows(zsrc, self.z, sidx, srm, AMB, self.enc_z)
                     if self.enc_sep:
                         be.enc_head(self.E, self.enc_z, self.dE, self.enc_head.gb[0], None, self.acc, AMB, amb_den,
                                     self.z, c['enc_coef'], grad_scale=self.gs)

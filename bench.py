@@ -141,6 +141,8 @@ def compact_line(full, detail_path=None):
         out['qualifying_mode'] = None
     t = full.get('throughput_mode')
     out['throughput_mode'] = {k: t.get(k) for k in ('precision', 'value', 'unit', 'ms_per_step')} if t else None
+    c5 = full.get('config5_16384_envs')
+    out['config5_16384_envs'] = {k: c5.get(k) for k in ('precision', 'value', 'unit', 'ms_per_step')} if c5 else None
     out['runtime'] = full.get('runtime')
     out['detail'] = detail_path
     return out
@@ -352,13 +354,14 @@ def algorithmic_flops_per_step(eng):
     return f
 
 
-def make_agent(device, precision, use_graph, world, rank, seed=0, force_dist=False, multi_stream=True, dp_mode='shard', engine_opts=None, extra_cfg=None):
+def make_agent(device, precision, use_graph, world, rank, seed=0, force_dist=False, multi_stream=True, dp_mode='shard', engine_opts=None, extra_cfg=None,
+               num_envs=4096):
     from ase_amd.learning import agents, models
     from ase_amd.learning.network_builder import ASEBuilder
     from ase_amd.synthetic import EnvSpec, SyntheticSource
     import types
     net_p, cfg = load_cfg()
-    spec = EnvSpec(num_envs=4096, horizon=cfg['horizon_length'], obs_size=253, act_size=31, amp_obs_size=1400,
+    spec = EnvSpec(num_envs=num_envs, horizon=cfg['horizon_length'], obs_size=253, act_size=31, amp_obs_size=1400,
                    latent_dim=cfg['latent_dim'], latent_steps_min=cfg['latent_steps_min'],
                    latent_steps_max=cfg['latent_steps_max'])
     torch.manual_seed(seed)
@@ -608,6 +611,8 @@ def main():
                     help='torch CPU threads during the GPU-timed part (the CPU oracle leg sets its own): every intra-op parallel '
                          'region leaves its OpenMP workers spinning, and on a box whose cgroup quota is smaller than the core count '
                          'torch sees (16 of 256 here) that gets the whole process throttled for the rest of the CFS period')
+    ap.add_argument('--no-config5', dest='config5', action='store_false', help='skip the 16384-environment batch (BASELINE configs[4] '
+                    'on one GPU) timed after everything else at N = 1')
     ap.add_argument('--main-priority', type=int, default=0, help='run everything on a non-default stream of this HIP priority '
                     '(-1 = high): the engine\'s main stream is whatever stream is current')
     ap.add_argument('--engine-opts', default='', help='JSON dict of UpdateEngine.engine_opts overrides (schedule A/Bs), e.g. '
@@ -826,6 +831,23 @@ def main():
         thr['timed'] = 'median of 7 updates after 3 priming ones, same workload'
         thr['note'] = 'outside the 1e-4 parity bar (8 significant bits: loss scalars 1e-4 ... 4e-3 off the f32 reference); reported, not the headline'
 
+    # ---- BASELINE configs[4]'s batch (16384 envs x horizon 32 = 524288 samples, 192 optimisation steps) on ONE GPU, with the
+    # reference's network: the reference has no 'every'-layer style net (its AMPStyleCatNet1 concatenates the style code in front
+    # of the first dense layer only, learning/ase_network_builder.py:262-311), and 8 GPUs are the driver's to measure
+    cfg5 = None
+    if rank == 0 and world == 1 and args.config5:
+        del agent
+        torch.cuda.empty_cache()
+        ag, cfg_5, _ = make_agent(device, args.precision, use_graph, world, rank, num_envs=16384)
+        fill_rollout(ag, device)
+        ag._init_amp_demo_buf()
+        ms5 = time_updates(ag, 3, prime=2)
+        cfg5 = {'workload': 'BASELINE configs[4] batch: 16384 envs x horizon 32 = 524288 samples, 192 optimisation steps per update, '
+                            'the reference\'s ASE network, 1 GPU', 'precision': args.precision, 'value': round(ag.batch_size / (ms5 * 1e-3), 1),
+                'unit': 'samples/s', 'ms_per_step': round(ms5, 3), 'timed': 'median of 3 updates after 2 priming ones'}
+        del ag
+        torch.cuda.empty_cache()
+
     if world > 1 or args.force_dist:
         import torch.distributed as dist
         dist.barrier()
@@ -851,7 +873,8 @@ def main():
                 'engine_opts': dict(ENGINE_OPTS),
                 'runtime': ase_amd.hw_queue_note + ('; Python cyclic GC frozen during the timed updates' if args.gc == 'freeze' else '')
                 + f'; torch CPU threads {max(1, args.host_threads)} during the GPU-timed part',
-                'roofline': roof, 'cpu_baseline': cpu, 'qualifying_mode': qualifying, 'throughput_mode': thr, 'modes': modes,
+                'roofline': roof, 'cpu_baseline': cpu, 'qualifying_mode': qualifying, 'throughput_mode': thr,
+                'config5_16384_envs': cfg5, 'modes': modes,
                 'parity': (modes.get(args.precision) or {}).get('parity'),
                 'last_train_result': {k: round(v, 6) for k, v in last.items()}}
         detail = write_detail(full, args.detail)
