@@ -594,7 +594,7 @@ def main():
     ap.add_argument('--modes', default='', help='MORE precision modes whose parity (fresh rollout + stale-rollout stress state) and '
                     'throughput go into the detail file beside the headline (comma list of bf16,f16,f16gpx3,f16gp32,f32,bf16x3; '
                     'each costs ~20-60 s)')
-    ap.add_argument('--throughput-mode', default='bf16', help='a second mode timed (no parity leg) and reported as throughput_mode; "" = none')
+    ap.add_argument('--throughput-mode', default='bf16', help='a second mode timed (no parity leg) and reported as throughput_mode; "" or none = skip')
     ap.add_argument('--detail', default=os.path.join(ROOT, 'gpurun_out', 'bench_detail.json'),
                     help='side file for everything that does not fit the compact stdout line ("" = stderr only)')
     ap.add_argument('--no-parity-mode', action='store_true', help='same as --modes ""')
@@ -643,6 +643,8 @@ def main():
             dist.init_process_group(args.dist_backend)                            # (test rigs without one GPU per rank)
 
     use_graph = False if args.no_graph else ('hipgraph' if args.hipgraph else 'program')
+    if args.throughput_mode in ('none', '""', "''"):
+        args.throughput_mode = ''
     if args.engine_opts:
         ENGINE_OPTS.update(json.loads(args.engine_opts))
     torch.set_num_threads(max(1, args.host_threads))
@@ -750,7 +752,7 @@ def main():
         peak = MFMA_PEAK_TFLOPS[args.precision]
         # the dominant kernel = the GEMM kernel class with the most time (bf16: the phased 256 x 256 NT kernel)
         dom = max(summ, key=lambda k: summ[k]['ms'])
-        dname = {'nt8': 'gemm_nt8_kernel (phased 256x256 NT, bf16: forward + data-gradient of the wide layers)',
+        dname = {'nt8': f'gemm_nt8_kernel<{DTYPE_OF[args.precision]}> (phased 256x256 NT: forward + data-gradient of the wide layers)',
                  'nt': 'gemm_nt_kernel (NT tiles 64/128/256)', 'tn': 'gemm_tn kernels (weight gradients)'}[dom]
         dv = summ[dom]
         achieved = dv['flops'] / (dv['ms'] * 1e-3) / 1e12

@@ -12,7 +12,7 @@ while [ $# -gt 0 ]; do
 done
 for rep in 1 2; do
   for o in "${OPTS[@]}"; do
-    out=$(python bench.py --gpus 1 --steps 20 --warmup 3 --precision "$P" --no-cpu-baseline --no-config5 --throughput-mode "" --detail "" \
+    out=$(python bench.py --gpus 1 --steps 20 --warmup 3 --precision "$P" --no-cpu-baseline --no-config5 --throughput-mode none --detail "" \
           --engine-opts "$o" "${EXTRA[@]}" 2>/dev/null | tail -1)
     echo "$P $o ${EXTRA[*]} :: $(echo "$out" | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["ms_per_step"], d["value"])')"
   done

@@ -1,0 +1,6 @@
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+for R in 4 2; do
+rm -rf /tmp/ps$R
+rocprofv3 --kernel-trace --stats -d /tmp/ps$R -o t -- python scripts/bench_extra.py --shard-of $R --updates 3 > gpurun_out/shard${R}_prof.log 2>&1
+python scripts/rocpd_stats.py /tmp/ps$R/t_results.db 25 > gpurun_out/shard${R}_kstats.txt
+done

@@ -17,10 +17,10 @@ def test_bench_and_extra_parse_their_arguments():
 def test_pmc_json_is_regenerated_from_the_committed_summary(tmp_path):
     out = tmp_path / 'pmc.json'
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'make_pmc_json.py'),
-                        os.path.join(ROOT, 'profiles', 'r03_pmc_summary.txt'), str(out),
-                        os.path.join(ROOT, 'profiles', 'r03_kernel_stats_bf16_serial.txt')], capture_output=True, text=True, timeout=120)
+                        os.path.join(ROOT, 'profiles', 'r04_pmc_summary.txt'), str(out),
+                        os.path.join(ROOT, 'profiles', 'r04_kernel_stats_f16gpx3_serial.txt')], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-500:]
-    new, old = json.load(open(out)), json.load(open(os.path.join(ROOT, 'profiles', 'r03_pmc.json')))
+    new, old = json.load(open(out)), json.load(open(os.path.join(ROOT, 'profiles', 'r04_pmc.json')))
     assert new['kernel_class'] == 'nt8' and new['hbm_bytes_per_launch'] == old['hbm_bytes_per_launch']
     for k in ('nt8', 'tn8g', 'tn_reduce', 'apply_multi'):
         assert new['kernels'][k]['hbm_bytes_per_launch'] == old['kernels'][k]['hbm_bytes_per_launch']
