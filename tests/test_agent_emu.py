@@ -392,3 +392,22 @@ def test_activation_family_against_the_reference(act, golden_dir):
     infos = replay_epochs(G, ag, rtol=2e-4, wtol=float(G['cfg']['learning_rate']) * 0.1)
     ref = G['epochs'][0]['steps'][0]
     assert abs(float(infos[0]['disc_grad_penalty'][0]) - float(ref['disc_grad_penalty'])) <= 1e-5 * abs(float(ref['disc_grad_penalty']))
+
+
+def test_result_rings_equal_per_step_snapshots(golden_dir):
+    """The per-update result rings (one slot per optimisation step, read once at the end of update()) return the same
+    train_info as round 3's per-step snapshots (config result_rings=False): same keys, same values, same shapes."""
+    import copy
+    G = torch.load(os.path.join(golden_dir, 'ase_tiny.pt'), weights_only=False)
+    infos = []
+    for rings in (True, False):
+        ag = make_agent(copy.deepcopy(G), EmuBackend(), result_rings=rings)
+        assert ag._use_rings == rings
+        infos.append(replay_epochs(copy.deepcopy(G), ag, rtol=0, wtol=0, check=False))
+    for a, b in zip(*infos):
+        assert set(a) == set(b)
+        for k in a:
+            assert len(a[k]) == len(b[k]), k
+            for x, y in zip(a[k], b[k]):
+                x, y = torch.as_tensor(x), torch.as_tensor(y)
+                assert x.shape == y.shape and torch.equal(x.float(), y.float()), k
