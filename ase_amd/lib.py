@@ -94,6 +94,10 @@ class AseHipError(RuntimeError):
 
 
 def load():
+    # torch first: PyTorch-ROCm ships its own libamdhip64; libase_hip.so must bind to THAT copy of the HIP runtime (the one
+    # that owns torch's streams and allocations).  Loaded before torch, the library resolves libamdhip64 from the system
+    # ROCm instead and its first launch fails with "no ROCm-capable device is detected" (two runtimes in one process).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise AseHipError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
