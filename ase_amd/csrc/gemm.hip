@@ -573,7 +573,7 @@ __device__ __forceinline__ void nt8_mma(f32x16& c0, f32x16& c1, const i32x4 (&a0
 // ~60 issue cycles beside MFMAs (the matrix pipe stays fed by the 32-cycle MFMA issue cadence) but 100-185 cycles in the
 // read half of a phase, where it sat on the critical path of the OTHER wave group's MFMA block (measured by ablation:
 // DMA and fragment reads were additive on top of the MFMA time)
-template <typename T, int KIND, bool DM, bool MM, bool SW>
+template <typename T, int KIND, bool DM, bool MM, bool SW, bool MS = false>
 __device__ __forceinline__ void nt8_mma_issue(f32x16& c0, f32x16& c1, const i32x4 (&a0)[4], const i32x4 (&a1)[4],
                                               const i32x4 (&b)[4], const NT8Lane& L, char* smem, int tile, bool live) {
     if constexpr (!MM) {
@@ -584,6 +584,37 @@ __device__ __forceinline__ void nt8_mma_issue(f32x16& c0, f32x16& c1, const i32x
     constexpr int kBuf = 512 * 128;
     char* buf = smem + (tile & 1) * kBuf;
     const int64_t koff = (int64_t)tile * 128;
+#ifdef ASE_LAB
+    if constexpr (MS && std::is_same<T, bf16_t>::value) {
+        // Lab ablation (TIMING ONLY, wrong results): the phase's 8 x 32x32x16 MFMAs on two accumulators replaced by the same
+        // flop count as 16 x 16x16x32 MFMAs on EIGHT independent 4-register accumulators (the pieces of c0 / c1), each used
+        // twice eight issues apart - the instruction mix of the 16x16x32 form of this schedule.  Question it answers: is the
+        // loop's ~80 % matrix-pipe occupancy a property of the 32x32x16 issue / dependency cadence?
+        f32x4 q[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            q[e] = f32x4{c0[4 * e], c0[4 * e + 1], c0[4 * e + 2], c0[4 * e + 3]};
+            q[4 + e] = f32x4{c1[4 * e], c1[4 * e + 1], c1[4 * e + 2], c1[4 * e + 3]};
+        }
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            const int ks = (n >> 1) & 3;
+            const bf16x8 av = __builtin_bit_cast(bf16x8, (n & 1) ? a1[ks] : a0[ks]), bv = __builtin_bit_cast(bf16x8, b[ks]);
+            q[n & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv, av, q[n & 7], 0, 0, 0);
+            if (DM && (n == 3 || n == 11)) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (live)
+                    __builtin_amdgcn_global_load_lds((gptr_t*)(L.src[KIND][n >> 3] + koff), (lptr_t*)(buf + L.dst[KIND][n >> 3]), 16, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { c0[4 * e + t] = q[e][t]; c1[4 * e + t] = q[4 + e][t]; }
+        return;
+    }
+#endif
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         c0 = nt8_mfma<T, SW>(a0[ks], b[ks], c0);
@@ -635,26 +666,26 @@ __device__ __forceinline__ void nt8_ktile_m(int t, int nk, const NT8Lane& L, cha
     if (!TAIL) wait_dma_units<3>();
     else wait_dma_units_rt(min(U, 4 * t + 6) - (4 * t + 3));
     nt8_sync_in<V>();
-    nt8_mma_issue<T, 2, DM && !BF, MM, SW>(acc[0][0], acc[1][0], a0, a1, b0, L, smem, t + 1, l1);
+    nt8_mma_issue<T, 2, DM && !BF, MM, SW, (V & 512) != 0>(acc[0][0], acc[1][0], a0, a1, b0, L, smem, t + 1, l1);
     nt8_sync_out<V>();
     // ---- phase 1
     nt8_read<RD && !BF>(b1, bP + 32 * RB, L);
     if (!TAIL) wait_dma_units<3>();
     else wait_dma_units_rt(min(U, 4 * t + 7) - (4 * t + 4));
     nt8_sync_in<V>();
-    nt8_mma_issue<T, 3, DM, MM, SW>(acc[0][1], acc[1][1], a0, a1, b1, L, smem, t + 1, l1);
+    nt8_mma_issue<T, 3, DM, MM, SW, (V & 512) != 0>(acc[0][1], acc[1][1], a0, a1, b1, L, smem, t + 1, l1);
     nt8_sync_out<V>();
     // ---- phase 2
     nt8_read<RD>(a0, aP + 64 * RB, L);
     nt8_read<RD>(a1, aP + 96 * RB, L);
     nt8_sync_in<V>();
-    nt8_mma_issue<T, 0, DM, MM, SW>(acc[2][1], acc[3][1], a0, a1, b1, L, smem, t + 2, l2);
+    nt8_mma_issue<T, 0, DM, MM, SW, (V & 512) != 0>(acc[2][1], acc[3][1], a0, a1, b1, L, smem, t + 2, l2);
     nt8_sync_out<V>();
     // ---- phase 3
     if (!TAIL) wait_dma_units<3>();
     else if (t + 1 < nk) wait_dma_units_rt(min(U, 4 * t + 9) - (4 * t + 6));
     nt8_sync_in<V>();
-    nt8_mma_issue<T, 1, DM && !BF, MM, SW>(acc[2][0], acc[3][0], a0, a1, b0, L, smem, t + 2, l2);
+    nt8_mma_issue<T, 1, DM && !BF, MM, SW, (V & 512) != 0>(acc[2][0], acc[3][0], a0, a1, b0, L, smem, t + 2, l2);
     nt8_sync_out<V>();
 }
 
@@ -961,6 +992,8 @@ template <typename T> int dispatch_nt(const NTParams& p, hipStream_t s) {
                         case 72: return launch_nt8<T, 72>(p, s);
                         case 80: return launch_nt8<T, 80>(p, s);
                         case 0: return launch_nt8<T, 0>(p, s);
+                        case 576: return launch_nt8<T, 576, true>(p, s);     // MFMA-shape ablation: 16 x 16x16x32 per phase (wrong results)
+                        case 64: return launch_nt8<T, 64, true>(p, s);       // the product's schedule, for the same-run A/B
                         case 320: return launch_nt8<T, 320, true>(p, s);     // "B operand for free" bound (wrong results)
                         case 328: return launch_nt8<T, 328, true>(p, s);     // ... and no A fragment reads either
                         default: break;
