@@ -1,7 +1,8 @@
 """MI355X-native ASE / AMP training update.
 
 Hardware queues.  The update engine runs the three network branches of an optimisation step (policy | critic |
-discriminator) on three HIP streams.  How many streams the runtime lets execute side by side is its hardware-queue
+discriminator) on three HIP streams - four with the gradient penalty's value path of the gp_f32 modes, and the agents run the
+update on a high-priority stream of their own.  How many streams the runtime lets execute side by side is its hardware-queue
 count, ``GPU_MAX_HW_QUEUES``, which libamdhip64 reads ONCE when it initialises (the first HIP call of the process, not
 ``import torch``).  Measured on MI355X with the launch programs of this package: 75.9 ms per update with 4 queues,
 78.5 ms with 3 (the null stream's work shares a queue with one branch), 80.5 ms with 6.
