@@ -1,3 +1,6 @@
+#!/bin/bash
+# rocprofv3 kernel statistics of ONE rank's share of the row-sharded update (scripts/bench_extra.py --shard-of R) for R = 4 and 2:
+# where the time of a small-minibatch step goes (12-18 us launches).  Through gpurun: bash scripts/lab/shard_prof.sh -> gpurun_out/shard<R>_kstats.txt
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for R in 4 2; do
 rm -rf /tmp/ps$R
