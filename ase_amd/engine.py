@@ -991,7 +991,9 @@ class UpdateEngine:
 
         # The actor chain (2 M rows with the diversity pass) is the longest: it is launched FIRST on the main stream, the
         # critic and the discriminator branches follow on their streams, forked from the events above.
-        if self.style and not (self._prep is not None and self._style_early):
+        # (style_early ran the style MLP with the short prologue on the critic's stream; the un-chained prologue of `prefetch`
+        #  cannot - it precedes the optimizer step that writes the style weights - so the option is ignored there)
+        if self.style and not (self._prep is not None and self._style_early and self._pre_done is None):
             sd = self.actor[0].split_dst
             h = self._fwd_chain(self.style[:-1], self.Zs, self.Hs, Ra)
             self._fwd(self.style[-1], h, self.Xa[:, sd:], Ra)
