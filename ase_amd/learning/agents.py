@@ -818,10 +818,16 @@ class CommonAgent:
         ms.wait_stream(cur)
         with torch.cuda.stream(ms):
             info = self._update(batch_dict, perms, new_zs, max_steps)
-            for v in info.values() if info else ():
-                for t in v:
-                    if torch.is_tensor(t) and t.is_cuda:
-                        t.record_stream(cur)          # (allocated on the update's stream, read on the caller's)
+            # (what update() returns was allocated on the update's stream and is read on the caller's)
+            bases = getattr(self, '_ring_bases', None) if self._use_rings else None
+            if bases is not None:
+                for t in bases:
+                    t.record_stream(cur)
+            else:
+                for v in info.values() if info else ():
+                    for t in v:
+                        if torch.is_tensor(t) and t.is_cuda:
+                            t.record_stream(cur)
         cur.wait_stream(ms)
         return info
 
@@ -879,6 +885,7 @@ class CommonAgent:
         from .. import lib as L
         eng = self.engine
         R = eng.res_ring[:n].clone()
+        self._ring_bases = [R]
         cols = {'entropy': L.RES_ENTROPY, 'kl': L.RES_KL, 'b_loss': L.RES_B_LOSS, 'actor_loss': L.RES_A_LOSS,
                 'actor_clip_frac': L.RES_CLIP_FRAC, 'critic_loss': L.RES_C_LOSS, 'loss': L.RES_LOSS}
         if eng.has_disc:
@@ -893,6 +900,7 @@ class CommonAgent:
         info = {k: [R[i, c] for i in range(n)] for k, c in cols.items()}
         if eng.has_disc:
             LG = eng.logit_ring[:n].clone()
+            self._ring_bases.append(LG)
             a = 2 * eng.AMB
             info['disc_agent_logit'] = [LG[i, :a].view(-1, 1) for i in range(n)]
             info['disc_demo_logit'] = [LG[i, a:].view(-1, 1) for i in range(n)]
