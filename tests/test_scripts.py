@@ -79,3 +79,25 @@ def test_bench_stdout_line_fits_the_drivers_tail():
     assert q['precision'] == 'f16gpx3' and q['fresh_max_loss_rel'] <= 1e-4 and q['stress_ok'] is False
     # every mode name the CLI accepts has its dtype and its one-line description
     assert set(bench.DTYPE_OF) == set(bench.MODE_NOTE) == set(bench.MFMA_PEAK_TFLOPS)
+
+
+def test_round4_bench_line_is_compact_and_complete():
+    """The driver-form line of round 4 as committed (profiles/r04_bench_n1.json): under the driver's 8 KB tail, headline = the
+    qualifying mode, roofline / cpu_baseline / parity present as scalars, fresh-state parity inside BASELINE's 1e-4."""
+    raw = open(os.path.join(ROOT, 'profiles', 'r04_bench_n1.json')).read().strip().splitlines()[-1]
+    assert len(raw) < 5000
+    d = json.loads(raw)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['scaling'] == 'n/a' and d['vs_baseline'] is None and d['dtype'] == 'f16'
+    assert d['config']['precision_mode'].startswith('f16gpx3') and 'workload' in d['config']
+    assert abs(d['value'] - d['config']['samples_per_step'] / (d['ms_per_step'] * 1e-3)) <= 1e-3 * d['value']
+    r = d['roofline']
+    assert r['bound'] == 'mfma' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and r['traffic'] > r['algorithmic_bytes_per_launch']
+    assert set(d['cpu_baseline']) >= {'value', 'unit', 'cores', 'kind', 'sample'} and d['cpu_baseline']['kind'] == 'port'
+    p = d['parity']
+    assert p['fresh']['ok'] and p['fresh']['max_loss_rel'] <= 1e-4 and p['fresh']['max_count_stat_abs'] <= 1e-3
+    assert d['qualifying_mode']['precision'] == 'f16gpx3' and d['qualifying_mode']['is_headline']
+    assert d['throughput_mode']['precision'] == 'bf16' and d['throughput_mode']['value'] > d['value']
+    assert d['config5_16384_envs']['value'] > 0
