@@ -731,7 +731,7 @@ class UpdateEngine:
             # The weight-independent prologue, un-chained like the discriminator's head: on the critic's stream it follows that
             # branch's backward of the previous step (whose loss head was the last reader of the minibatch fields) and runs
             # under the previous step's policy tail.  It zeroes its own partial sums and advances the diversity stream itself
-            # (one begin_step launch without optimizer state); the accumulators are not touched before the main stream's
+            # (one begin_step launch without optimizer state); the accumulators are not touched before the step's real
             # begin_step below (the mask sum follows it).
             with self._Branch(self, self._side(0), nowait=True) as pre:
                 be.begin_step(None, None, zero2=self.obs_sums, rng_bump=self.div_rng if self.div_on else None)
