@@ -38,8 +38,10 @@ class HipBackend:
     name = "hip"
 
     def __init__(self, device=None, x3=False):
-        # x3: f32-stored GEMM operands are multiplied as three bf16 MFMAs on a hi/lo split (ASE_F32X3)
-        self.x3 = bool(x3)
+        # x3: f32-stored GEMM operands are multiplied as three 16-bit MFMAs on a hi/lo split - True: bf16 parts (ASE_F32X3, any
+        # operand range), 'f16': half parts of operands scaled by 2^ea / 2^eb (ASE_F32H3, gemm_nt only; the caller passes the
+        # exponents of a launch as x3_exps=(ea, eb), see f32h_t in csrc/common.h)
+        self.x3 = x3 if x3 == 'f16' else bool(x3)
         self._recording, self._host_keep, self._host_error = None, {}, None
         self.tn_workspace = True     # grouped weight gradients: partial tiles + reduce kernel (False: f32 atomics into G)
         if not torch.cuda.is_available():
@@ -115,14 +117,18 @@ class HipBackend:
         self.lib.ase_hip_prog_destroy(prog)
         self._host_keep.pop(prog.value, None)
 
-    def _gemm_code(self, dtype):
+    def _gemm_code(self, dtype, exps=None):
         c = _code(dtype)
-        return L.F32X3 if (self.x3 and c == L.F32) else c
+        if self.x3 and c == L.F32:
+            if self.x3 == 'f16' and exps is not None:
+                return L.F32H3 | (int(exps[0]) << 8) | (int(exps[1]) << 16)
+            return L.F32X3
+        return c
 
     # ------------------------------------------------------------------ GEMMs
     def gemm_nt(self, A, B, Cm, M, N, K, bias=None, aux=None, aux_mode=L.AUX_NONE, colsum=None, colsum_n=0,
-                act=L.ACT_NONE, alpha=1.0, aux_split=0, aux_delta=0, mask_out=None):
-        dt = self._gemm_code(A.dtype)
+                act=L.ACT_NONE, alpha=1.0, aux_split=0, aux_delta=0, mask_out=None, x3_exps=None):
+        dt = self._gemm_code(A.dtype, x3_exps)
         assert B.dtype == A.dtype
         if aux_mode == L.AUX_RELU_BITS:
             assert aux.dtype == torch.int32

@@ -39,17 +39,25 @@ void ase_set_error(const char* fmt, ...);
 // lo = bf16(a - hi); a*b ~= hi*hi + hi*lo + lo*hi): ~16 mantissa bits per operand at 1/3 of the bf16 MFMA rate
 // instead of the 1/16 of the exact-f32 MFMA (gfx950 has no TF32).
 struct f32s_t { float v; };
+// f32 storage whose matrix products run as THREE f16 MFMAs on a hi/lo split of SCALED operands: sx = x * 2^e (exact),
+// hi = half(sx), lo = half(sx - hi); sx*sy ~= hi*hi + hi*lo + lo*hi, undone by 2^-(ea + eb) in the epilogue's alpha.  Half
+// keeps 11 significant bits per part (bf16: 8), so hi + lo carries ~22 bits against the bf16 split's ~16 at the same three
+// MFMAs - but half's exponent range is narrow: the caller chooses ea / eb so that the operands' magnitudes land in
+// [2^-2, 2^15] (above: the conversion saturates; below: lo turns subnormal and the product degrades towards 2^-13).
+struct f32h_t { float v; };
 
 // ---- storage type conversion --------------------------------------------------------------
 __device__ __forceinline__ float to_f32(float x) { return x; }
 __device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }
 __device__ __forceinline__ float to_f32(f32s_t x) { return x.v; }
+__device__ __forceinline__ float to_f32(f32h_t x) { return x.v; }
 __device__ __forceinline__ float to_f32(f16_t x) { return (float)x; }
 
 template <typename T> __device__ __forceinline__ T from_f32(float x);
 template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }  // RNE
 template <> __device__ __forceinline__ f32s_t from_f32<f32s_t>(float x) { return f32s_t{x}; }
+template <> __device__ __forceinline__ f32h_t from_f32<f32h_t>(float x) { return f32h_t{x}; }
 // f16: RNE, saturating at the largest finite half (a scaled gradient that overflows must not turn into inf -> NaN)
 template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float x) { return (f16_t)__builtin_amdgcn_fmed3f(x, -65504.f, 65504.f); }
 

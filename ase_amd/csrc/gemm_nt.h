@@ -40,6 +40,7 @@ struct NTParams {
     int M, N, K;                    // K in elements (multiple of 128/sizeof(T))
     int act, aux_mode, out_f32;
     float alpha;
+    float sa, sb;                   // f32h_t storage: power-of-two scales of the A / B operand before the half split (alpha undoes them)
     int tiles_m, tiles_n;
     unsigned long long* prof;       // debug: per-workgroup phase timestamps (ase_hip_debug_nt_profile), else null
     int prof_clk;                   // debug: stamps 1 and 2 (main loop) in shader clocks instead of the 100 MHz clock
@@ -140,9 +141,46 @@ __device__ __forceinline__ void nt8_epilogue_rows(const NTParams& p, f32x16 (&ac
 }
 
 
-#ifdef ASE_LAB
-// lab variant: the 4-wave register-staged 256 x 256 kernel (scripts/lab/gemm_nt4r_variant.hip); prof: debug stamps or null
-template <typename T> int launch_nt4r(const NTParams& p, unsigned long long* prof, hipStream_t stream);
-#endif
+// ---- counted waits / barriers of the phased kernels (NT and TN share the schedule) ----------------------------------
+template <int UNITS> __device__ __forceinline__ void wait_dma_units() { wait_vmcnt<2 * UNITS>(); }
+__device__ __forceinline__ void wait_dma_units_rt(int units) {      // wave-uniform runtime count (loop tail)
+    if (units >= 4) wait_vmcnt<8>();
+    else if (units == 3) wait_vmcnt<6>();
+    else if (units == 2) wait_vmcnt<4>();
+    else if (units == 1) wait_vmcnt<2>();
+    else wait_vmcnt<0>();
+}
+// end of the read half of a phase: barrier, THEN retire the LDS reads (hipcc puts a vmcnt(0) in front of any LDS read that
+// follows a global_load_lds without a barrier in between, so the DMA is always issued after the phase's fragment reads),
+// MFMA block at raised priority
+__device__ __forceinline__ void nt8_sync_in() {
+    NT8_BARRIER();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+}
+__device__ __forceinline__ void nt8_sync_out() {                    // end of the MFMA half
+    __builtin_amdgcn_s_setprio(0);
+    NT8_BARRIER();
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+extern unsigned long long* g_nt_prof;      // tuning aid, see ase_hip_debug_nt_profile (defined in gemm.hip)
+extern int g_nt_prof_clk;                  // ... stamps 1, 2 in shader clocks (ase_hip_debug_nt_profile_clock)
+
+// Kernel choice of an NT launch (also reported by ase_hip_gemm_nt_kernel_id):
+//   0:  64 x  64 tile, 4 waves   narrow heads (N <= 64): more workgroups
+//   1: 128 x 128 tile, 4 waves   grids that would leave a 256 x 256 tiling with a ragged round
+//   2: 256 x 256 tile, 8 waves, PHASED (16-bit storage, K in whole 128-byte steps)   192+ tiles in whole rounds
+//   3: 256 x 256 tile, 8 waves, lock-step (the 4-byte storage types)
+//   4:  64 x 128 tile, 4 waves / 5: 64 x 64 tile, 4 waves   small grids (M = 2048 ... 4096 rows, or N = 512): two workgroups per CU
+int nt_choice(int M, int N, int K, int es, bool b16);
+
+// one translation unit per storage type (gemm_nt_<type>.hip)
+int dispatch_nt_bf16(const NTParams& p, hipStream_t s);
+int dispatch_nt_f16(const NTParams& p, hipStream_t s);
+int dispatch_nt_f32(const NTParams& p, hipStream_t s);
+int dispatch_nt_x3(const NTParams& p, hipStream_t s);      // f32s_t: three bf16 MFMAs per product
+int dispatch_nt_h3(const NTParams& p, hipStream_t s);      // f32h_t: three f16 MFMAs per product, scaled operands
 
 }  // namespace ase_nt

@@ -1306,7 +1306,7 @@ class UpdateEngine:
     def _gp_value(self, amp_streams, gp_coef):
         """VALUE path of the gradient penalty in a gp_f32 engine (see _gp_f32): the demo rows normalised into an f32 input,
         f32 shadows of the trunk, forward (exact ReLU masks), seed, chain g_l, S s g_0 - six f32-storage matrix launches
-        ('x3': three bf16 MFMAs per product on hi / lo splits).  Reads the branch's master weights and the AMP statistics,
+        ('x3': three f16 MFMAs per product on hi / lo splits of scaled operands).  Reads the branch's master weights and the AMP statistics,
         writes only its own buffers: it runs beside the loss rows' forward (engine_opts gp_stream)."""
         be, AMB, g = self.be, self.AMB, self._gp32
         nl, S = len(self.disc), self.gs
@@ -1314,24 +1314,35 @@ class UpdateEngine:
         bits = L.AUX_RELU_BITS
         src, sidx, srm = amp_streams[2]        # the demo stream once more, into the f32 input of the penalty path
         be.rms_normalize(src, self.amp, sidx, srm, AMB, self.amp_mean[2], self.amp_std[2], [g.X])
-        # gp_f32 = 'x3': the six f32-storage launches multiply as three bf16 MFMAs on hi / lo splits (unit roundoff ~2^-17)
-        # instead of the exact-f32 MFMA (1/16 of the 16-bit rate)
+        # gp_f32 = 'x3': the six f32-storage launches multiply as three 16-bit MFMAs per product on hi / lo splits instead of the
+        # exact-f32 MFMA (1/16 of the 16-bit rate): IEEE-half parts of power-of-two scaled operands (ASE_F32H3, unit roundoff
+        # ~2^-22; round 4 used bf16 parts, ~2^-17, and the driver's run missed the 1e-4 bar on the penalty by 8 %).  Half's
+        # narrow exponent range needs the operands near [2^-2, 2^15] after scaling - and the ranges here are known:
+        #   normalised observations  |x| <= 5 (the normaliser's clamp)          2^12
+        #   hidden activations       O(1); saturation above 1023                2^6
+        #   chain values s g_l       O(1e-3 .. 1e-1); saturation above 16       2^12
+        #   weights                  O(1/sqrt(K)); saturation above 32          2^11
+        # (gp_f32 = 'x3bf16' keeps the bf16 split: no range assumption at all)
         x3_prev = getattr(be, 'x3', None)
-        if self.cfg.get('gp_f32') == 'x3' and x3_prev is not None:
-            be.x3 = True
+        mode = self.cfg.get('gp_f32')
+        half = mode == 'x3' and x3_prev is not None
+        if mode in ('x3', 'x3bf16') and x3_prev is not None:
+            be.x3 = 'f16' if half else True
+        ex = (lambda ea: {'x3_exps': (ea, 11)}) if half else (lambda ea: {})
         for l, d in enumerate(self.disc):
             be.refresh_shadow(d.W[0], g.Ws[l], g.Wts[l], d.split_src, d.split_dst)
         x = g.X
         for l, d in enumerate(self.disc):
-            be.gemm_nt(x, g.Ws[l], g.H[l], AMB, d.n_pad, d.k_pad, bias=d.bs, act=L.ACT_RELU, mask_out=g.bits[l])
+            be.gemm_nt(x, g.Ws[l], g.H[l], AMB, d.n_pad, d.k_pad, bias=d.bs, act=L.ACT_RELU, mask_out=g.bits[l],
+                       **ex(12 if l == 0 else 6))
             x = g.H[l]
         top = self.disc[-1]
         be.gp_seed(g.H[-1], self.disc_head.W[0].view(-1), g.Gp[-1], AMB, top.N, scale=s)
         for l in range(nl - 1, 0, -1):
             d = self.disc[l]
-            be.gemm_nt(g.Gp[l], g.Wts[l], g.Gp[l - 1], AMB, d.k_pad, d.n_pad, aux=g.bits[l - 1], aux_mode=bits)
+            be.gemm_nt(g.Gp[l], g.Wts[l], g.Gp[l - 1], AMB, d.k_pad, d.n_pad, aux=g.bits[l - 1], aux_mode=bits, **ex(12))
         d0 = self.disc[0]
-        be.gemm_nt(g.Gp[0], g.Wts[0], g.G0, AMB, d0.k_pad, d0.n_pad, alpha=S)                    # S s * g_0, exact
+        be.gemm_nt(g.Gp[0], g.Wts[0], g.G0, AMB, d0.k_pad, d0.n_pad, alpha=S, **ex(12))         # S s * g_0
         if x3_prev is not None:
             be.x3 = x3_prev
 

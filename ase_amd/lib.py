@@ -9,10 +9,10 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libase_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 PPO_SCRATCH = 1024 * 72 + 8       # ASE_PPO_SCRATCH: doubles of ase_hip_ppo_head's workspace
 TN_SLAB = 65536 + 256        # ASE_TN_SLAB: floats per work item in the grouped weight-gradient launch's workspace
-F32, BF16, F32X3, F16 = 0, 1, 2, 3
+F32, BF16, F32X3, F16, F32H3 = 0, 1, 2, 3, 4
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SILU, ACT_ELU, ACT_GELU, ACT_SIGMOID, ACT_SELU, ACT_SOFTPLUS = range(9)
 AUX_NONE, AUX_RELU_MASK, AUX_TANH_GRAD, AUX_RELU_BITS, AUX_PREACT = 0, 1, 2, 3, 4
 

@@ -12,7 +12,8 @@
  *   - matrices are row-major with an explicit leading dimension in ELEMENTS.
  *   - `dtype` selects the storage type of activations / shadow weights that feed the matrix
  *     cores: ASE_F32 (exact f32 MFMA, parity mode), ASE_BF16 (bf16 MFMA, f32 accumulate) or — for the two GEMM
- *     entry points only — ASE_F32X3 (f32 storage like ASE_F32, each product as three bf16 MFMAs on a hi/lo split).
+ *     entry points only — ASE_F32X3 (f32 storage like ASE_F32, each product as three bf16 MFMAs on a hi/lo split) and, for
+ *     ase_hip_gemm_nt, ASE_F32H3 (three f16 MFMAs on a hi/lo split of power-of-two scaled operands: ~22 significant bits).
  *     Running statistics are f64, master weights / gradients / Adam state / loss math are f32.
  *   - GEMM operands live in "padded" buffers: K (the contracted, contiguous dimension) is a
  *     multiple of 128 bytes / sizeof(type) and the padding is zero.
@@ -31,9 +32,11 @@
 extern "C" {
 #endif
 
-#define ASE_HIP_ABI_VERSION 3
+#define ASE_HIP_ABI_VERSION 4
 
 enum { ASE_F32 = 0, ASE_BF16 = 1, ASE_F32X3 = 2 /* f32 storage, products as 3 bf16 MFMAs on a hi/lo split (GEMMs only) */,
+       ASE_F32H3 = 4 /* f32 storage, products as 3 f16 MFMAs on a hi/lo split of operands scaled by 2^ea / 2^eb (ase_hip_gemm_nt only;
+                        the exponents ride in bits 8-15 / 16-23 of dtype: ASE_F32H3 | (ea << 8) | (eb << 16)) */,
        ASE_F16 = 3 /* IEEE half storage + v_mfma_f32_32x32x16_f16, f32 accumulate: what the reference's mixed_precision flag
                       (torch.cuda.amp autocast + GradScaler, learning/ase_agent.py:216,271-288) computes in; conversions saturate */ };
 /* activations: the names of rl_games' activations_factory (learning/ase_network_builder.py:162); swish = SiLU */

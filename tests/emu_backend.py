@@ -65,6 +65,23 @@ def _twin_factors(act, t):
     return d1, torch.where(d1 != 0, d2 / d1, torch.zeros_like(d1))
 
 
+def half_split(x, e):
+    """x (f32) -> (hi, lo) as the ASE_F32H3 kernels form them: sx = x * 2^e, hi = half(sx) saturating at +-65504, lo = half(sx - hi)
+    (csrc/gemm_nt_kernels.h split_f16), both returned as f64 values."""
+    sx = x.float() * (2.0 ** e)
+    hi = sx.clamp(-65504.0, 65504.0).half()
+    lo = (sx - hi.float()).clamp(-65504.0, 65504.0).half()
+    return hi.double(), lo.double()
+
+
+def x3_half_product(a, b, ea, eb):
+    """a @ b^T as the three-product form hi*hi + hi*lo + lo*hi of the scaled half splits, exact accumulation (f64), scale undone."""
+    ah, al = half_split(a, ea)
+    bh, bl = half_split(b, eb)
+    v = ah @ bh.t() + ah @ bl.t() + al @ bh.t()
+    return (v * 2.0 ** -(ea + eb)).float()
+
+
 class EmuBackend:
     name = "emu"
 
@@ -90,14 +107,17 @@ class EmuBackend:
 
     # ------------------------------------------------------------------ GEMMs
     def gemm_nt(self, A, B, Cm, M, N, K, bias=None, aux=None, aux_mode=L.AUX_NONE, colsum=None, colsum_n=0,
-                act=L.ACT_NONE, alpha=1.0, aux_split=0, aux_delta=0, mask_out=None):
+                act=L.ACT_NONE, alpha=1.0, aux_split=0, aux_delta=0, mask_out=None, x3_exps=None):
         if aux is not None and aux_split > 0:
             rows = torch.arange(M)
             rows = torch.where(rows >= aux_split, rows - aux_delta, rows)
             aux = aux[rows]
         a = A[:M, :K].float()
         b = B[:N, :K].float()
-        v = alpha * (a @ b.t())
+        if x3_exps is not None and getattr(self, 'x3', None) == 'f16':
+            v = alpha * x3_half_product(a, b, *x3_exps)
+        else:
+            v = alpha * (a @ b.t())
         if bias is not None:
             v = v + bias[:N]
         z_pre = v

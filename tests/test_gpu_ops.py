@@ -555,6 +555,58 @@ def test_gemm_x3_split_mode(M, N, K):
     assert float((G.cpu().double() - gref).abs().max()) <= 3e-5 * gscale
 
 
+@pytest.mark.parametrize('M,N,K,ea,eb,sa,sb', [(513, 320, 1408, 12, 11, 1.5, 0.03), (4096, 1024, 1408, 12, 11, 1.5, 0.03),
+                                                (4096, 512, 1024, 6, 11, 0.7, 0.03), (4096, 1408, 1024, 12, 11, 0.02, 0.03),
+                                                (77, 64, 128, 6, 11, 30.0, 0.5), (1024, 1024, 320, 12, 11, 1e-3, 1e-3),
+                                                (512, 256, 128, 6, 11, 1e-4, 0.03)])
+def test_gemm_x3_half_split(M, N, K, ea, eb, sa, sb):
+    """ASE_F32H3 (the gradient penalty's value path in 'f16gpx3'): f32 storage, every product as three f16 MFMAs on hi / lo splits
+    of operands scaled by 2^ea / 2^eb.  Against the emulator's restatement of the same split (f64 accumulation) and against the
+    exact product: ~22 significant bits per operand - 1e-6 of the row/column scale where the bf16 split (ASE_F32X3) holds 3e-5.
+    Cases 5 and 7 sit at the edges of half's range (large activations; tiny operands whose lo parts are SUBNORMAL halves - the
+    matrix cores of gfx950 do not flush them, which the bit-level comparison with the emulator pins)."""
+    from ase_amd.backend import HipBackend
+    from tests.emu_backend import x3_half_product
+    bh = HipBackend(x3='f16')
+    g = torch.Generator().manual_seed(M + N + ea)
+    A = torch.randn(M, K, generator=g) * sa
+    A[:, ::7] = 0.0                                            # ReLU-style exact zeros
+    B = torch.randn(N, K, generator=g) * sb
+    bias = torch.randn(N, generator=g)
+    Cg = torch.zeros(M, N).cuda()
+    bits = torch.zeros(M, (N + 31) // 32, dtype=torch.int32).cuda()
+    relu = N % 32 == 0
+    bh.gemm_nt(A.cuda(), B.cuda(), Cg, M, N, K, bias=bias.cuda(), act=L.ACT_RELU if relu else L.ACT_NONE,
+               mask_out=bits if relu else None, x3_exps=(ea, eb))
+    pre = A.double() @ B.double().t() + bias.double()
+    ref = pre.clamp_min(0) if relu else pre
+    emu = x3_half_product(A, B, ea, eb).double() + bias.double()
+    emu = emu.clamp_min(0) if relu else emu
+    scale = float((A.abs().double() @ B.abs().double().t()).max()) + float(bias.abs().max())
+    got = Cg.cpu().double()
+    assert float((got - emu).abs().max()) <= 2e-7 * scale, float((got - emu).abs().max()) / scale      # f32 accumulation order only
+    tol = 1e-6 if sa * 2.0 ** ea >= 1.0 else 2e-5             # (tiny operands: lo parts subnormal, documented degradation)
+    assert float((got - ref).abs().max()) <= tol * scale, float((got - ref).abs().max()) / scale
+    if relu:                                                   # the mask twin is the sign of what was stored
+        w = bits.cpu().to(torch.int64) & 0xFFFFFFFF
+        mb = ((w.unsqueeze(-1) >> torch.arange(32)) & 1).reshape(M, -1)[:, :N].bool()
+        assert bool((mb == (got > 0)).all())
+    # the same launch in the bf16 split is at least 8x further from the exact product (why the value path moved)
+    b3 = HipBackend(x3=True)
+    C3 = torch.zeros(M, N).cuda()
+    b3.gemm_nt(A.cuda(), B.cuda(), C3, M, N, K, bias=bias.cuda(), act=L.ACT_RELU if relu else L.ACT_NONE)
+    if sa * 2.0 ** ea >= 1.0:
+        assert float((C3.cpu().double() - ref).abs().max()) >= 8 * float((got - ref).abs().max())
+
+
+def test_gemm_x3_half_split_rejects_bad_scales():
+    from ase_amd.backend import HipBackend
+    bh = HipBackend(x3='f16')
+    A, B, C_ = torch.zeros(64, 64).cuda(), torch.zeros(64, 64).cuda(), torch.zeros(64, 64).cuda()
+    with pytest.raises(L.AseHipError):
+        bh.gemm_nt(A, B, C_, 64, 64, 64, x3_exps=(30, 11))
+
+
 @pytest.mark.parametrize('dt', DT)
 @pytest.mark.parametrize('M,N,K', [(300, 192, 256), (777, 64, 128), (1024, 1024, 1024), (4096, 512, 320), (16384, 1024, 256)])
 def test_gemm_nt_relu_bit_mask(be, dt, M, N, K):
