@@ -381,7 +381,8 @@ __device__ __forceinline__ float twin_grad(int act, float t) {
 // second-order factor act''(z) u r of the gradient penalty from the stored chain values g = act' u and dg = act' r:
 // (act'' / act') * (g / act') * dg, two separate divisions - act'^2 underflows to 0 for saturated sigmoid / ELU / SELU /
 // GELU units (|z| of a few tens) while act' itself is still a normal number, and act'' / act'^2 was inf there.  0 where act'
-// vanishes (the chain value it multiplies is 0 there too).
+// vanishes (the chain value it multiplies is 0 there too), and 0 where FINITE chain values overflow through a tiny act' (the
+// underflow case above); a NaN / inf that ARRIVES in g or dg - a diverging penalty chain - is passed on, not swallowed.
 __device__ __forceinline__ float twin_second(int act, float t, float g, float dg) {
     float d1, d2;
     if (act == ASE_ACT_RELU || act == ASE_ACT_NONE) return 0.f;
@@ -389,7 +390,8 @@ __device__ __forceinline__ float twin_second(int act, float t, float g, float dg
     else { d1 = act_grad(act, t); d2 = act_grad2(act, t); }
     if (d1 == 0.f) return 0.f;
     const float e = (d2 / d1) * (g / d1) * dg;
-    return (e == e && fabsf(e) <= 3.0e38f) ? e : 0.f;
+    const bool in_finite = fabsf(g) <= 3.0e38f && fabsf(dg) <= 3.0e38f;          // (false for NaN)
+    return (!in_finite || (e == e && fabsf(e) <= 3.0e38f)) ? e : 0.f;
 }
 
 template <typename T>

@@ -180,7 +180,7 @@ class UpdateEngine:
         self._disc_split = False
         self._enc_z_ready = False
         self._prefetch = bool(o['prefetch'])
-        self._par = 0
+        self._par, self._par_set, self._last_par, self._fenced = 0, False, None, False
         self._style_wg = int(o['style_wg'])
         sp = o['side_priority']
         if sp is None:
@@ -435,12 +435,22 @@ class UpdateEngine:
 
     def use_slot(self, i):
         self.slot = i
-        self._par = p = i % len(self._Xa2)                 # input-buffer set of this step (see _alloc)
+        self.use_parity(i)
+        self.res = self.res_ring[i]
+        self.logit_slot = self.logit_ring[i].view(-1, 1) if self.logit_ring is not None else None
+
+    def use_parity(self, p):
+        """Input-buffer set of the next step (see _alloc: Xa / Xc / Zs exist twice under the cross-step schedule).  Consecutive
+        steps must alternate - the next step's un-chained prologue writes one set while the previous step's weight-gradient
+        launch still reads the other - unless the branch streams were fenced in between (fence_side_streams, which the agents
+        call once per mini-epoch).  use_slot implies it; a caller that drives neither is alternated by step() itself, and a
+        repeated parity without a fence is fenced there (or refused while a launch program records: a torch-level stream wait
+        is not a recordable entry)."""
+        self._par = p = p % len(self._Xa2)
+        self._par_set = True
         self.Xa, self.Xc = self._Xa2[p], self._Xc2[p]
         if self.style:
             self.Zs = self._Zs2[p]
-        self.res = self.res_ring[i]
-        self.logit_slot = self.logit_ring[i].view(-1, 1) if self.logit_ring is not None else None
 
     # ------------------------------------------------------------------ shadows
     def refresh_shadows(self):
@@ -676,6 +686,16 @@ class UpdateEngine:
             # a caller that does not order the branch streams itself (the agents do, once per mini-epoch): whatever it did on
             # the current stream - weights loaded, statistics set, index tensors built - happens before the un-chained head
             self.fence_side_streams()
+        if len(self._Xa2) == 2:
+            # double-buffered inputs of the un-chained prologue (use_parity): alternate when the caller drives neither slots nor
+            # parity; the same set twice in a row is only safe behind a fence of the branch streams
+            if not self._par_set:
+                self.use_parity(self._par ^ 1 if self._last_par is not None else self._par)
+            if self._xs and self._par == self._last_par and not self._fenced:
+                assert getattr(self.be, '_recording', None) is None, \
+                    "two consecutive steps on the same input-buffer set without fence_side_streams() while a launch program records"
+                self.fence_side_streams()
+            self._last_par, self._par_set, self._fenced = self._par, False, False
         self.phase_stats(ds, idx, remap, amp_streams, advance=apply, new_z=new_z)
         self._allreduce_stats()
         self._lr_live = apply          # (calc_gradients-style calls without the optimizer step leave the learning rate alone)
@@ -840,6 +860,15 @@ class UpdateEngine:
         self._side(0)                                     # (streams exist before their first use: a fresh stream is unordered)
         for st in list(self._side_streams) + ([self._gp_stream()] if self.gp32 and self._gp_side else []):
             st.wait_stream(cur)
+        self._fenced = True
+
+    def fence_main_behind_sides(self, main):
+        """`main` waits for everything the branch streams hold (error path of the agents' update(): inside a step the branches
+        are joined by marks, which an exception may have skipped)."""
+        if not self.multi_stream or self.dev.type != 'cuda' or self._side_streams is None:
+            return
+        for st in list(self._side_streams) + ([self._gp_stream_obj] if self._gp_stream_obj is not None else []):
+            main.wait_stream(st)
 
     class _Branch:
         """Run a block of launches on a side stream: it starts after `after` (a mark on the main stream; default: everything

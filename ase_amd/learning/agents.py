@@ -587,6 +587,11 @@ class CommonAgent:
         streams = self._amp_streams(idx)
         if self._use_rings:
             self.engine.use_slot(slot)           # this step's slot of the result ring (engine.set_result_slots)
+        else:
+            # without rings the step's launch program is keyed by its minibatch POSITION: the double-buffered inputs of the
+            # un-chained prologue follow the position's parity (consecutive steps of a mini-epoch alternate; update() fences
+            # the branch streams between mini-epochs)
+            self.engine.use_parity(getattr(self, '_mb_pos', slot))
         if self.use_graph and new_z is None:
             return self._graph_step(idx, streams)
         return self.engine.step(self._ds, idx, self._remap, streams, new_z=new_z, fence=False)      # (update() fences per mini-epoch)
@@ -816,19 +821,24 @@ class CommonAgent:
             return self._update(batch_dict, perms, new_zs, max_steps)
         cur = torch.cuda.current_stream(self.ppo_device)
         ms.wait_stream(cur)
-        with torch.cuda.stream(ms):
-            info = self._update(batch_dict, perms, new_zs, max_steps)
-            # (what update() returns was allocated on the update's stream and is read on the caller's)
-            bases = getattr(self, '_ring_bases', None) if self._use_rings else None
-            if bases is not None:
-                for t in bases:
-                    t.record_stream(cur)
-            else:
-                for v in info.values() if info else ():
-                    for t in v:
-                        if torch.is_tensor(t) and t.is_cuda:
-                            t.record_stream(cur)
-        cur.wait_stream(ms)
+        try:
+            with torch.cuda.stream(ms):
+                info = self._update(batch_dict, perms, new_zs, max_steps)
+                # (what update() returns was allocated on the update's stream and is read on the caller's)
+                bases = getattr(self, '_ring_bases', None) if self._use_rings else None
+                if bases is not None:
+                    for t in bases:
+                        t.record_stream(cur)
+                else:
+                    for v in info.values() if info else ():
+                        for t in v:
+                            if torch.is_tensor(t) and t.is_cuda:
+                                t.record_stream(cur)
+        finally:
+            # also when a step raised (OOM, AseHipError, a host callback): the caller's stream stays ordered behind whatever
+            # the update's stream and its branch streams still hold - a checkpoint written next must not read half an update
+            self.engine.fence_main_behind_sides(ms)
+            cur.wait_stream(ms)
         return info
 
     def _update(self, batch_dict, perms=None, new_zs=None, max_steps=None):

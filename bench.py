@@ -1,6 +1,6 @@
 """Benchmark of the ASE PPO-update hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision bf16|f32] [--no-graph]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision auto|f16gpx3|f16gp32|f32|bf16|...] [--no-graph]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -48,6 +48,12 @@ MODE_NOTE = {
     'f32': 'f32 storage, exact-f32 MFMA', 'bf16x3': 'f32 storage, three bf16 MFMAs per product'}
 PARITY_TOL = 1e-4          # BASELINE.json north_star: "losses matching the reference CPU path to rtol 1e-4"
 COUNT_TOL = 1e-3           # the three counting statistics move in steps of 1 / rows: absolute
+# The bar as it is APPLIED to a loss scalar x against the oracle's r:  |x - r| <= PARITY_TOL * max(|r|, floor)  - i.e. rtol 1e-4 with
+# an absolute tolerance atol = 1e-4 * floor underneath.  floor = 1 for the two scalars that are means of signed O(1) summands
+# whose VALUE is a small remainder (actor_loss = mean(-A r): normalised advantages have zero mean; enc_loss = -mean <z, e>), 0 for
+# the others.  It is an atol, and the line says so (`parity.tol`); the TRUE relative error |x - r| / |r| of every scalar is
+# reported beside it (`max_loss_true_rel`), and `strict_mode` is the mode that needs no floor at all.
+PARITY_ATOL = {'actor_loss': 1e-4, 'enc_loss': 1e-4}
 
 
 def _state_ok(p):
@@ -55,25 +61,26 @@ def _state_ok(p):
 
 
 def qualifying_mode(modes):
-    """The fastest measured mode whose ten continuous loss scalars are all within 1e-4 (relative to their scale) of the f32
-    reference arithmetic on the first step of a FRESH rollout, counting statistics within 1e-3 absolute; whether it also
-    holds in the stale-rollout STRESS state is reported beside it (`stress_ok`), never folded away."""
-    ok = [m for m, r in modes.items() if _state_ok(r['parity']['fresh'])]
+    """The fastest measured mode whose ten continuous loss scalars are all within the bar (PARITY_TOL / PARITY_ATOL) of the f32
+    reference arithmetic on the first step of a FRESH rollout AND in the stale-rollout STRESS state, counting statistics within
+    1e-3 absolute - in this run.  (Round 4 qualified on the fresh state alone and reported `stress_ok` beside it.)"""
+    ok = [m for m, r in modes.items() if r.get('parity') and _state_ok(r['parity']['fresh']) and _state_ok(r['parity']['stress'])]
     if not ok:
         return None
     q = max(ok, key=lambda m: modes[m]['value'])
     r = modes[q]
     f, st = r['parity']['fresh'], r['parity']['stress']
     out = {'precision': q, 'value': r['value'], 'unit': 'samples/s', 'ms_per_step': r['ms_per_step'],
-           'criterion': 'all 10 continuous loss scalars within 1e-4 (relative to their scale) of the reference arithmetic '
-                        '(f32 CPU oracle) on the first step of a fresh rollout; the 3 counting statistics within 1e-3 absolute',
+           'criterion': 'all 10 continuous loss scalars within max(1e-4 |ref|, atol) of the reference arithmetic (f32 CPU oracle) on the '
+                        'first step of a fresh rollout AND in the stress state; the 3 counting statistics within 1e-3 absolute',
            'fresh_max_loss_rel': f['max_loss_rel'], 'fresh_max_loss_rel_without_grad_penalty': f['max_loss_rel_without_grad_penalty'],
            'fresh_trajectory_max_loss_rel': f['trajectory']['max_loss_rel'], 'stress_max_loss_rel': st['max_loss_rel'],
            'stress_ok': _state_ok(st), 'fresh_worst_grad_rel_l2': f['worst_grad_rel_l2'],
            'by_mode': {m: {'fresh_max_loss_rel': x['parity']['fresh']['max_loss_rel'],
                            'worst_scalar': x['parity']['fresh']['max_loss_rel_scalar'],
                            'without_grad_penalty': x['parity']['fresh']['max_loss_rel_without_grad_penalty'],
-                           'stress_max_loss_rel': x['parity']['stress']['max_loss_rel'], 'value': x['value']} for m, x in modes.items()}}
+                           'stress_max_loss_rel': x['parity']['stress']['max_loss_rel'], 'value': x['value']}
+                       for m, x in modes.items() if x.get('parity')}}
     return out
 
 
@@ -102,6 +109,9 @@ def _parity_scalars(p):
             'max_loss_true_rel': p.get('max_loss_true_rel'), 'true_rel_scalar': p.get('max_loss_true_rel_scalar'),
             'max_count_stat_abs': p['max_count_stat_abs'], 'worst_grad_rel_l2': p['worst_grad_rel_l2'],
             'median_grad_rel_l2': p['median_grad_rel_l2'],
+            'grad_at_engine_masks': {k: (p.get('grad_at_engine_masks') or {}).get(k) for k in ('median_grad_rel_l2', 'worst_grad_rel_l2',
+                                                                                              'flipped_mask_fraction')}
+            if p.get('grad_at_engine_masks') else None,
             'trajectory_max_loss_rel': (p.get('trajectory') or {}).get('max_loss_rel'),
             'trajectory_steps': (p.get('trajectory') or {}).get('steps'), 'ok': _state_ok(p)}
 
@@ -112,6 +122,7 @@ def compact_line(full, detail_path=None):
     keep = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
             'dtype', 'data', 'config')
     out = {k: full[k] for k in keep}
+    out['config'] = {k: v for k, v in full['config'].items()}
     r = full.get('roofline')
     if r:
         out['roofline'] = {k: r.get(k) for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source',
@@ -128,8 +139,11 @@ def compact_line(full, detail_path=None):
     out['cpu_baseline'] = full.get('cpu_baseline')
     par = full.get('parity')
     if par:
-        out['parity'] = {'tol': PARITY_TOL, 'reference': 'oracle/restated.py (f32, host) on identical inputs, full-size step',
-                         'fresh': _parity_scalars(par.get('fresh')), 'stress': _parity_scalars(par.get('stress'))}
+        out['parity'] = {'tol': {'rtol': PARITY_TOL, 'atol': dict(PARITY_ATOL), 'atol_other_scalars': 0.0, 'counting_stats_abs': COUNT_TOL,
+                                 'form': '|x - ref| <= max(rtol * |ref|, atol)'},
+                         'reference': 'oracle/restated.py (f32, host) on identical inputs, full-size step',
+                         'fresh': _parity_scalars(par.get('fresh')), 'stress': _parity_scalars(par.get('stress')),
+                         'headline_ok': full.get('headline_parity_ok')}
     else:
         out['parity'] = None
     q = full.get('qualifying_mode')
@@ -141,6 +155,12 @@ def compact_line(full, detail_path=None):
         out['qualifying_mode'] = None
     t = full.get('throughput_mode')
     out['throughput_mode'] = {k: t.get(k) for k in ('precision', 'value', 'unit', 'ms_per_step')} if t else None
+    st = full.get('strict_mode')
+    out['strict_mode'] = {k: st.get(k) for k in ('precision', 'value', 'unit', 'ms_per_step', 'ok', 'fresh_max_true_rel', 'fresh_scalar',
+                                                 'stress_max_true_rel', 'stress_scalar', 'fresh_worst_grad_rel_l2')} if st else None
+    out['fallthrough'] = [{k: f.get(k) for k in ('precision', 'value', 'fresh_ok', 'stress_ok')} | {'stress_worst': f['stress']}
+                          for f in (full.get('fallthrough') or [])]
+    out['dist'] = full.get('dist')
     c5 = full.get('config5_16384_envs')
     out['config5_16384_envs'] = {k: c5.get(k) for k in ('precision', 'value', 'unit', 'ms_per_step')} if c5 else None
     out['runtime'] = full.get('runtime')
@@ -385,6 +405,53 @@ def _rms_dict(vec):
     return {'mean': v[:D].clone(), 'var': v[D:2 * D].clone(), 'count': v[2 * D].clone()}
 
 
+class _EngineMaskedRelu:
+    """`act` callable for oracle/restated.py: ReLU with the ENGINE's 0/1 derivative masks, consumed in the oracle's call order
+    (y = x * mask: the value differs from relu(x) only where the two forwards disagree about a sign, i.e. |x| of the order of the
+    engine's rounding error; the DERIVATIVE is the engine's everywhere).  Diagnostic only - see `grad_at_engine_masks`."""
+
+    def __init__(self, masks):
+        self.masks, self.i, self.flipped, self.total = masks, 0, 0.0, 0.0
+
+    def __call__(self, x):
+        m = self.masks[self.i]
+        self.i += 1
+        assert m.shape == x.shape, (self.i, m.shape, x.shape)
+        self.flipped += float((m != (x > 0).to(m.dtype)).sum())
+        self.total += float(m.numel())
+        return x * m
+
+
+def engine_relu_masks(eng):
+    """The ReLU derivative masks of the engine's LAST step (its bit-mask twins) as float 0/1 tensors on the host, in the order
+    oracle/restated.calc_gradients('ase', ...) calls its activation: actor (style MLP, dense layers), critic, discriminator on
+    agent / replay / demo rows, encoder (the agent rows' trunk again), diversity pass (style MLP, dense layers on the new latents).
+    None when the net is not the all-ReLU shared-trunk ASE net with bit masks."""
+    from ase_amd import lib as L
+    if eng.kind != 'ase' or eng.enc_sep or not eng._use_bits or not eng.div_on:
+        return None
+    layers = eng.style[:-1] + eng.actor + eng.critic + eng.disc
+    if any(d.act != L.ACT_RELU for d in layers):
+        return None
+    M, AMB = eng.M, eng.AMB
+
+    def unpack(h, d, r0, r1):
+        bits = eng._mask_of(h)
+        w = bits[r0:r1].to(torch.int64) & 0xFFFFFFFF
+        b = ((w.unsqueeze(-1) >> torch.arange(32, device=w.device)) & 1).reshape(w.shape[0], -1)[:, :d.N]
+        return b.to(torch.float32).cpu()
+    out = []
+    for r0 in (0,):
+        out += [unpack(h, d, r0, r0 + M) for h, d in zip(eng.Hs, eng.style[:-1])]
+        out += [unpack(h, d, r0, r0 + M) for h, d in zip(eng.Ha, eng.actor)]
+    out += [unpack(h, d, 0, M) for h, d in zip(eng.Hc, eng.critic)]
+    for blk in (0, 1, 2, 0):                                    # agent, replay, demo, encoder (= agent rows)
+        out += [unpack(h, d, blk * AMB, (blk + 1) * AMB) for h, d in zip(eng.Hd4, eng.disc)]
+    out += [unpack(h, d, M, 2 * M) for h, d in zip(eng.Hs, eng.style[:-1])]
+    out += [unpack(h, d, M, 2 * M) for h, d in zip(eng.Ha, eng.actor)]
+    return out
+
+
 def cpu_baseline_and_parity(agent, cfg, steps=8, mode='bf16', traj_steps=None, state=None, with_times=False):
     """The reference's arithmetic (oracle/restated.py, f32, torch CPU threads = host cores) on a bounded sample of the SAME
     workload: `steps` full-size optimisation steps (minibatch 16384 / amp 4096, median step time), extrapolated to the 48
@@ -425,7 +492,7 @@ def cpu_baseline_and_parity(agent, cfg, steps=8, mode='bf16', traj_steps=None, s
     eng.adam_v.zero_()
     eng.opt_state[0] = 0.0
     counts = ('actor_clip_frac', 'disc_agent_acc', 'disc_demo_acc')
-    scale = {'actor_loss': 1.0, 'enc_loss': 1.0}          # means of signed O(1) summands: error relative to the summand scale
+    scale = {k: a / PARITY_TOL for k, a in PARITY_ATOL.items()}     # the atol as a floor on |ref|: see PARITY_ATOL
     traj = []
     for i in range(steps):
         pos = i % (B // MB)
@@ -443,6 +510,8 @@ def cpu_baseline_and_parity(agent, cfg, steps=8, mode='bf16', traj_steps=None, s
             res_g = {k: v.detach().cpu().clone() for k, v in eng.results().items()}
             if i == 0:
                 grads_g = {k: v.detach().cpu().clone() for k, v in eng.export_grads().items()}
+                masks_g = engine_relu_masks(eng)
+                rms0 = {k: {kk: vv.clone() for kk, vv in v.items()} for k, v in rms.items()}
             # its optimizer step (the weight-only loss terms are in the gradients already): step counter, Adam, shadows
             eng.be.begin_step(eng.opt_state, None)
             eng.be.adam(eng.params[:eng.n_train], eng.grads[:eng.n_train], eng.adam_m[:eng.n_train], eng.adam_v[:eng.n_train],
@@ -469,6 +538,24 @@ def cpu_baseline_and_parity(agent, cfg, steps=8, mode='bf16', traj_steps=None, s
                 if p.requires_grad:
                     grad_rel[k] = float((grads_g[k].double() - p.grad.double()).norm() / p.grad.double().norm().clamp_min(1e-30))
             wk = max(grad_rel, key=grad_rel.get)
+            # the same comparison with the oracle's ReLU derivative masks replaced by the ENGINE's: what remains is the error of the
+            # arithmetic proper.  A hidden unit whose pre-activation changes sign under the forward's storage rounding (|z| ~ 2^-12
+            # of its scale in half) is an O(1) error of one element of dZ; a flipped fraction f shows as sqrt(f) in relative L2 -
+            # ~1e-4 of the units, 1-3 % of the gradient norm in half (bf16: sqrt(8) x more), for ANY precision of the backward
+            # (profiles/r05_grad_error_sources.txt).  Both choices are subgradients at the kink; the loss scalars above never see it.
+            masked = None
+            if masks_g is not None:
+                sd_m = {k: (v.detach().clone().requires_grad_(True) if v.requires_grad else v) for k, v in sd.items()}
+                act_m = _EngineMaskedRelu(masks_g)
+                R.calc_gradients('ase', sd_m, rms0, mb, cfg, z, act=act_m)
+                gm = {k: float((grads_g[k].double() - p.grad.double()).norm() / p.grad.double().norm().clamp_min(1e-30))
+                      for k, p in sd_m.items() if p.requires_grad}
+                wm = max(gm, key=gm.get)
+                masked = {'median_grad_rel_l2': float(f'{sorted(gm.values())[len(gm) // 2]:.3e}'), 'worst_grad_rel_l2': float(f'{gm[wm]:.3e}'),
+                          'worst_grad_tensor': wm, 'flipped_mask_fraction': float(f'{act_m.flipped / max(act_m.total, 1.0):.3e}'),
+                          'what': 'gradient tensors against the oracle evaluated with the ENGINE\'s ReLU derivative masks (0/1 '
+                                  'multipliers in place of relu\'): the arithmetic error without the sign flips of near-zero units'}
+                del sd_m, masks_g
             # counting statistics (fractions of samples on one side of a threshold) move in steps of 1/rows whenever a
             # near-threshold sample flips: reported separately from the continuous loss scalars
             wl = max((k for k in loss_rel if k not in counts), key=loss_rel.get)
@@ -489,7 +576,8 @@ def cpu_baseline_and_parity(agent, cfg, steps=8, mode='bf16', traj_steps=None, s
                       'max_loss_true_rel': float(f'{max(v for k, v in true0.items() if k not in counts):.3e}'),
                       'max_loss_true_rel_scalar': max((k for k in true0 if k not in counts), key=true0.get),
                       'worst_grad_rel_l2': float(f'{grad_rel[wk]:.3e}'), 'worst_grad_tensor': wk,
-                      'median_grad_rel_l2': float(f'{sorted(grad_rel.values())[len(grad_rel) // 2]:.3e}')}
+                      'median_grad_rel_l2': float(f'{sorted(grad_rel.values())[len(grad_rel) // 2]:.3e}'),
+                      'grad_at_engine_masks': masked}
         R.adam_step(sd, adam, cfg['learning_rate'])
         times.append(time.time() - t0)
     if parity is not None and traj:
@@ -517,7 +605,7 @@ def cpu_from_times(times, cfg, B, MB, AMB, ncpu):
     # authoring container, same inputs, same process (oracle/time_reference.py) - the port is the faster of the two
     try:
         j = json.load(open(os.path.join(ROOT, 'profiles', 'r04_reference_cpu_timing.json')))
-        cpu['reference_beside_port'] = {'port_over_reference_time': j['port_over_reference'], 'cores': j['cores'],
+        cpu['reference_beside_port'] = {'measured_in_this_run': False, 'port_over_reference_time': j['port_over_reference'], 'cores': j['cores'],
                                         'reference_s_per_step': j['reference']['s_per_step'], 'port_s_per_step': j['port']['s_per_step'],
                                         'source': 'profiles/r04_reference_cpu_timing.json (oracle/time_reference.py, authoring container)'}
     except (OSError, KeyError, ValueError):
@@ -578,93 +666,35 @@ def _dbg(msg):
         print(f'[rank {os.environ.get("RANK", 0)}] {msg}', file=sys.stderr, flush=True)
 
 
-def main():
-    import faulthandler
-    faulthandler.enable()
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--precision', default='f16gpx3', help='headline precision mode; default = the fastest mode that holds the 1e-4 parity bar', choices=['bf16', 'f16', 'f16gp32', 'f16gpx3', 'f32', 'bf16x3'])
-    ap.add_argument('--no-graph', action='store_true', help='eager launches from Python (no recorded launch program)')
-    ap.add_argument('--hipgraph', action='store_true', help='replay captured hipGraphs instead of the library launch programs')
-    ap.add_argument('--no-multi-stream', action='store_true', help='launch the three network branches on ONE stream')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-steps', type=int, default=8)
-    ap.add_argument('--modes', default='', help='MORE precision modes whose parity (fresh rollout + stale-rollout stress state) and '
-                    'throughput go into the detail file beside the headline (comma list of bf16,f16,f16gpx3,f16gp32,f32,bf16x3; '
-                    'each costs ~20-60 s)')
-    ap.add_argument('--throughput-mode', default='bf16', help='a second mode timed (no parity leg) and reported as throughput_mode; "" or none = skip')
-    ap.add_argument('--detail', default=os.path.join(ROOT, 'gpurun_out', 'bench_detail.json'),
-                    help='side file for everything that does not fit the compact stdout line ("" = stderr only)')
-    ap.add_argument('--no-parity-mode', action='store_true', help='same as --modes ""')
-    ap.add_argument('--force-dist', action='store_true', help='run the collectives even with one rank (RCCL smoke)')
-    ap.add_argument('--dp-mode', default='shard', choices=['horovod', 'shard'],
-                    help='N > 1: horovod = the reference\'s own multi-GPU semantics (rl_games HorovodWrapper, learning/common_agent.py:'
-                         '94-107): every rank owns 4096 environments and its own 16384-row minibatches, gradients averaged by one RCCL '
-                         'all-reduce per branch and step - WEAK scaling, per-GPU work fixed; shard = the same 4096 environments with '
-                         'every minibatch row-sharded over the ranks (the R-rank update equals the 1-rank update) - STRONG scaling')
-    ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'])
-    ap.add_argument('--breakdown', action='store_true', help='per-shape GEMM time table on stderr')
-    ap.add_argument('--verbose', action='store_true', help='per-update times on stderr')
-    ap.add_argument('--host-threads', type=int, default=1,
-                    help='torch CPU threads during the GPU-timed part (the CPU oracle leg sets its own): every intra-op parallel '
-                         'region leaves its OpenMP workers spinning, and on a box whose cgroup quota is smaller than the core count '
-                         'torch sees (16 of 256 here) that gets the whole process throttled for the rest of the CFS period')
-    ap.add_argument('--no-config5', dest='config5', action='store_false', help='skip the 16384-environment batch (BASELINE configs[4] '
-                    'on one GPU) timed after everything else at N = 1')
-    ap.add_argument('--main-priority', type=int, default=0, help='run everything on a non-default stream of this HIP priority '
-                    '(-1 = high): the engine\'s main stream is whatever stream is current')
-    ap.add_argument('--engine-opts', default='', help='JSON dict of UpdateEngine.engine_opts overrides (schedule A/Bs), e.g. '
-                    '\'{"xstep": false}\'')
-    ap.add_argument('--gc', default='freeze', choices=['on', 'freeze'],
-                    help="'freeze' (default; the agents' config['manual_gc']): gc.freeze() + gc.disable() around the timed updates (no "
-                         "generation-2 pass of Python's collector inside an update); 'on': leave the collector alone")
-    args = ap.parse_args()
+HEADLINE_CANDIDATES = ['f16gpx3', 'f16gp32', 'f32']     # fastest first; the headline is the first whose parity holds IN THIS RUN
+STRICT_CANDIDATES = ['bf16x3', 'f32']                    # strict mode: true |delta| / |ref| <= 1e-4 on every loss scalar, no floor
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
-    local = local % torch.cuda.device_count()
-    torch.cuda.set_device(local)
-    device = f'cuda:{local}'
-    if args.main_priority != 0:
-        torch.cuda.set_stream(torch.cuda.Stream(device=device, priority=args.main_priority))
-    if world > 1 or args.force_dist:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29533')
-        os.environ.setdefault('RANK', '0')
-        os.environ.setdefault('WORLD_SIZE', '1')
-        if args.dist_backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device(device))      # RCCL over xGMI
-        else:
-            dist.init_process_group(args.dist_backend)                            # (test rigs without one GPU per rank)
 
-    use_graph = False if args.no_graph else ('hipgraph' if args.hipgraph else 'program')
-    if args.throughput_mode in ('none', '""', "''"):
-        args.throughput_mode = ''
-    if args.engine_opts:
-        ENGINE_OPTS.update(json.loads(args.engine_opts))
-    torch.set_num_threads(max(1, args.host_threads))
+def _mode_ok(par):
+    return bool(par) and _state_ok(par['fresh']) and _state_ok(par['stress'])
+
+
+def _strict_ok(par):
+    """True relative error (no scale floor) of every continuous loss scalar within 1e-4 in both rollout states."""
+    return bool(par) and all(par[s_]['max_loss_true_rel'] <= PARITY_TOL and par[s_]['max_count_stat_abs'] <= COUNT_TOL
+                             for s_ in ('fresh', 'stress'))
+
+
+def measure_mode(args, precision, device, world, rank, use_graph):
+    """The contract's timed protocol for one precision mode: build the agent, synthetic rollout into HBM, W untimed warm-up
+    updates, EXACTLY K timed updates between barrier + synchronize brackets (max over ranks), then the instrumented eager
+    single-stream update for the roofline of the dominant kernel."""
     t_setup = time.time()
-    _dbg('init done')
-    agent, cfg, spec = make_agent(device, args.precision, use_graph, world, rank, force_dist=args.force_dist,
+    agent, cfg, spec = make_agent(device, precision, use_graph, world, rank, force_dist=args.force_dist,
                                    multi_stream=not args.no_multi_stream, dp_mode=args.dp_mode)
     weak = world > 1 and args.dp_mode == 'horovod'
     Bl = agent.batch_size                                    # this rank's samples per update
     B = Bl * (world if weak else 1)                          # samples of one update over ALL ranks
-    _dbg('agent built')
-
-    # ---- untimed: synthetic rollout into HBM (the policy outputs come from the engine's own inference path)
     fill_rollout(agent, device)
     agent._init_amp_demo_buf()
     torch.cuda.synchronize()
-    _dbg('rollout in HBM')
     if rank == 0:
-        print(f'[bench] setup + synthetic rollout: {time.time() - t_setup:.1f} s', file=sys.stderr)
-
+        print(f'[bench] {precision}: setup + synthetic rollout: {time.time() - t_setup:.1f} s', file=sys.stderr)
     tail_marks = []            # (event before the tail, event after it) per update: SURVEY §8d also wants the 48-step-only figure
 
     def one_update():
@@ -682,9 +712,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # hipGraph capture (one graph per minibatch position, for the "first epoch" and the "replay ring" variant of the
-    # replay source) is setup, like a compile step: two untimed priming updates capture everything, so that the W
-    # warm-up and K timed steps below are pure replays whatever W is.
+    torch.set_num_threads(max(1, args.host_threads))
+    # recording the launch programs (one per optimisation step, for the "first epoch" and the "replay ring" variant of the
+    # replay source) is setup, like a compile step: two untimed priming updates record everything, so that the W warm-up and
+    # K timed steps below are pure replays whatever W is.
     if use_graph:
         for _ in range(2):
             one_update()
@@ -731,93 +762,236 @@ def main():
     # ---- roofline of the dominant kernel class (matrix-core GEMMs): HIP events around every launch of one
     # additional, eager (un-graphed) update on the same stream the kernels are launched on.
     eng = agent.engine
-    roof = None
-    if True:      # every rank runs the instrumented update (it contains collectives); rank 0 reports
-        tb = TimedBackend(eng.be)
-        eng.be = tb
-        agent.use_graph = False
-        ms_flag, eng.multi_stream = eng.multi_stream, False       # serial launches: clean per-kernel durations
-        one_update()
-        summ = tb.summary()
-        if args.breakdown:
-            print('\n'.join(tb.breakdown(peak_tflops=MFMA_PEAK_TFLOPS[args.precision])), file=sys.stderr)
-        eng.be = tb._be
-        eng.multi_stream = ms_flag
-        agent.use_graph = use_graph
-        n_opt = cfg['mini_epochs'] * (Bl // cfg['minibatch_size'])
-        alg = algorithmic_flops_per_step(eng) * n_opt + 2.0 * Bl * sum(d.N * d.K for d in eng.disc) \
-            + 2.0 * Bl * (1 + eng.z) * eng.disc_head.K
-        gemm_ms = sum(v['ms'] for v in summ.values())
-        launches = sum(v['launches'] for v in summ.values())
-        peak = MFMA_PEAK_TFLOPS[args.precision]
-        # the dominant kernel = the GEMM kernel class with the most time (bf16: the phased 256 x 256 NT kernel)
-        dom = max(summ, key=lambda k: summ[k]['ms'])
-        dname = {'nt8': f'gemm_nt8_kernel<{DTYPE_OF[args.precision]}> (phased 256x256 NT: forward + data-gradient of the wide layers)',
-                 'nt': 'gemm_nt_kernel (NT tiles 64/128/256)', 'tn': 'gemm_tn kernels (weight gradients)'}[dom]
-        dv = summ[dom]
-        achieved = dv['flops'] / (dv['ms'] * 1e-3) / 1e12
-        # HBM traffic of that kernel per launch: PMC measurement committed under profiles/ (rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE in separate passes, FETCH doubled per the gfx950 note); bench cannot profile itself
-        traffic, traffic_src = None, None
-        pmc = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_pmc.json')) \
-            if os.path.isdir(os.path.join(ROOT, 'profiles')) else []
-        if pmc and args.precision in ('bf16', 'f16', 'f16gp32', 'f16gpx3'):
-            j = json.load(open(os.path.join(ROOT, 'profiles', pmc[-1])))
-            if j.get('kernel_class') == dom:
-                traffic, traffic_src = j['hbm_bytes_per_launch'], 'profiles/' + pmc[-1]
-        clk = sustained_clock(eng.be, device, eng.dtype) if (dom == 'nt8' and rank == 0) else None
-        roof = {'bound': 'mfma', 'kernel': dname,
-                'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
-                # the peak is quoted at the 2.4 GHz boost clock; what the chip holds under THIS kernel is measured in the kernel
-                # (shader-clock vs real-time stamps around its main loop): frac_at_sustained_clock prices the same achieved rate
-                # against peak x sustained / 2400, main_loop_mfma_busy = the matrix pipe's share of the main loop's CYCLES
-                'sustained_clock_mhz': clk[0] if clk else None,
-                'frac_at_sustained_clock': round(achieved / (peak * clk[0] / 2400.0), 4) if clk else None,
-                'main_loop': {'shape': '16384 x 1024 x 1024 (ReLU forward)', 'us': clk[1], 'shader_cycles': clk[2],
-                              'mfma_cycles': 16 * 2048, 'mfma_busy': round(16 * 2048 / clk[2], 4)} if clk else None,
-                'traffic': traffic, 'traffic_unit': 'HBM bytes per launch of that kernel (PMC)', 'traffic_source': traffic_src,
-                'launches': dv['launches'], 'avg_launch_us': round(dv['ms'] * 1e3 / dv['launches'], 2),
-                'algorithmic_flop_per_launch': round(dv['flops'] / dv['launches']),
-                'algorithmic_bytes_per_launch': round(tb.bytes.get(dom, 0.0) / dv['launches']) if dom in tb.bytes else None,
-                'share_of_gemm_time': round(dv['ms'] / gemm_ms, 3),
-                'all_gemm': {'achieved': round(alg / (gemm_ms * 1e-3) / 1e12, 2), 'frac': round(alg / (gemm_ms * 1e-3) / 1e12 / peak, 4),
-                             'launches_per_update': launches, 'gemm_ms_per_update': round(gemm_ms, 3),
-                             'algorithmic_tflop_per_update': round(alg / 1e12, 3)},
-                'per_kind': {k: {'launches': v['launches'], 'ms': round(v['ms'], 3),
-                                 'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1)} for k, v in summ.items()},
-                'hbm_kernels': tb.hbm_summary()}
+    tb = TimedBackend(eng.be)          # every rank runs the instrumented update (it contains collectives); rank 0 reports
+    eng.be = tb
+    agent.use_graph = False
+    ms_flag, eng.multi_stream = eng.multi_stream, False       # serial launches: clean per-kernel durations
+    one_update()
+    summ = tb.summary()
+    if args.breakdown:
+        print('\n'.join(tb.breakdown(peak_tflops=MFMA_PEAK_TFLOPS[precision])), file=sys.stderr)
+    eng.be = tb._be
+    eng.multi_stream = ms_flag
+    agent.use_graph = use_graph
+    n_opt = cfg['mini_epochs'] * (Bl // cfg['minibatch_size'])
+    alg = algorithmic_flops_per_step(eng) * n_opt + 2.0 * Bl * sum(d.N * d.K for d in eng.disc) \
+        + 2.0 * Bl * (1 + eng.z) * eng.disc_head.K
+    gemm_ms = sum(v['ms'] for v in summ.values())
+    launches = sum(v['launches'] for v in summ.values())
+    peak = MFMA_PEAK_TFLOPS[precision]
+    # the dominant kernel = the GEMM kernel class with the most time (16-bit modes: the phased 256 x 256 NT kernel)
+    dom = max(summ, key=lambda k: summ[k]['ms'])
+    dname = {'nt8': f'gemm_nt8_kernel<{DTYPE_OF[precision]}> (phased 256x256 NT: forward + data-gradient of the wide layers)',
+             'nt': 'gemm_nt_kernel (NT tiles 64/128/256)', 'tn': 'gemm_tn kernels (weight gradients)'}[dom]
+    dv = summ[dom]
+    achieved = dv['flops'] / (dv['ms'] * 1e-3) / 1e12
+    # HBM traffic of that kernel per launch: PMC measurement committed under profiles/ (rocprofv3 --pmc FETCH_SIZE /
+    # WRITE_SIZE in separate passes, FETCH doubled per the gfx950 note); bench cannot profile itself
+    traffic, traffic_src = None, None
+    pmc = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_pmc.json')) \
+        if os.path.isdir(os.path.join(ROOT, 'profiles')) else []
+    if pmc and precision in ('bf16', 'f16', 'f16gp32', 'f16gpx3'):
+        j = json.load(open(os.path.join(ROOT, 'profiles', pmc[-1])))
+        if j.get('kernel_class') == dom:
+            traffic, traffic_src = j['hbm_bytes_per_launch'], 'profiles/' + pmc[-1]
+    clk = sustained_clock(eng.be, device, eng.dtype) if (dom == 'nt8' and rank == 0) else None
+    roof = {'bound': 'mfma', 'kernel': dname,
+            'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
+            # the peak is quoted at the 2.4 GHz boost clock; what the chip holds under THIS kernel is measured in the kernel
+            # (shader-clock vs real-time stamps around its main loop): frac_at_sustained_clock prices the same achieved rate
+            # against peak x sustained / 2400, main_loop_mfma_busy = the matrix pipe's share of the main loop's CYCLES
+            'sustained_clock_mhz': clk[0] if clk else None,
+            'frac_at_sustained_clock': round(achieved / (peak * clk[0] / 2400.0), 4) if clk else None,
+            'main_loop': {'shape': '16384 x 1024 x 1024 (ReLU forward)', 'us': clk[1], 'shader_cycles': clk[2],
+                          'mfma_cycles': 16 * 2048, 'mfma_busy': round(16 * 2048 / clk[2], 4)} if clk else None,
+            'traffic': traffic, 'traffic_unit': 'HBM bytes per launch of that kernel (PMC)', 'traffic_source': traffic_src,
+            'launches': dv['launches'], 'avg_launch_us': round(dv['ms'] * 1e3 / dv['launches'], 2),
+            'algorithmic_flop_per_launch': round(dv['flops'] / dv['launches']),
+            'algorithmic_bytes_per_launch': round(tb.bytes.get(dom, 0.0) / dv['launches']) if dom in tb.bytes else None,
+            'share_of_gemm_time': round(dv['ms'] / gemm_ms, 3),
+            'all_gemm': {'achieved': round(alg / (gemm_ms * 1e-3) / 1e12, 2), 'frac': round(alg / (gemm_ms * 1e-3) / 1e12 / peak, 4),
+                         'launches_per_update': launches, 'gemm_ms_per_update': round(gemm_ms, 3),
+                         'algorithmic_tflop_per_update': round(alg / 1e12, 3)},
+            'per_kind': {k: {'launches': v['launches'], 'ms': round(v['ms'], 3),
+                             'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1)} for k, v in summ.items()},
+            'hbm_kernels': tb.hbm_summary()}
+    return {'precision': precision, 'agent': agent, 'cfg': cfg, 'value': value, 'ms_per_step': ms_per_step, 'ms_tail': ms_tail,
+            'last': last, 'roofline': roof, 'B': B, 'Bl': Bl, 'weak': weak,
+            'grad_scale': agent.engine.gs}
 
-    cpu = None
-    modes = {}
-    qualifying = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        B_, MB_, AMB_ = agent.batch_size, agent.minibatch_size, cfg['amp_minibatch_size']
-        want = [] if args.no_parity_mode else [m for m in args.modes.split(',') if m]
-        order = [args.precision] + [m for m in want if m != args.precision]
-        for m in order:
-            head = m == args.precision
-            if head:
-                ag, cfg_m, ms_m = agent, cfg, ms_per_step
-            else:
+
+def main():
+    import faulthandler
+    faulthandler.enable()
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--precision', default='auto',
+                    help="headline precision mode.  'auto' (default): the FASTEST of f16gpx3 > f16gp32 > f32 whose loss scalars hold the "
+                         '1e-4 parity bar on a fresh rollout AND in the stale-rollout stress state IN THIS RUN - a candidate that misses '
+                         'is reported under `fallthrough` and the next one is measured with the same timed protocol (N > 1 or '
+                         '--no-cpu-baseline: no oracle leg, the first candidate is taken).  A named mode is measured as given.',
+                    choices=['auto', 'bf16', 'f16', 'f16gp32', 'f16gpx3', 'f32', 'bf16x3'])
+    ap.add_argument('--no-graph', action='store_true', help='eager launches from Python (no recorded launch program)')
+    ap.add_argument('--hipgraph', action='store_true', help='replay captured hipGraphs instead of the library launch programs')
+    ap.add_argument('--no-multi-stream', action='store_true', help='launch the three network branches on ONE stream')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-steps', type=int, default=8)
+    ap.add_argument('--modes', default='', help='MORE precision modes whose parity (fresh rollout + stale-rollout stress state) and '
+                    'throughput go into the detail file beside the headline (comma list of bf16,f16,f16gpx3,f16gp32,f32,bf16x3; '
+                    'each costs ~20-60 s)')
+    ap.add_argument('--throughput-mode', default='bf16', help='a second mode timed (no parity leg) and reported as throughput_mode; "" or none = skip')
+    ap.add_argument('--no-strict-mode', dest='strict', action='store_false',
+                    help='skip the strict-mode block (the fastest of bf16x3 / f32 whose TRUE relative error - no scale floor - is '
+                         'within 1e-4 on every loss scalar in both states; ~15-25 s)')
+    ap.add_argument('--detail', default=os.path.join(ROOT, 'gpurun_out', 'bench_detail.json'),
+                    help='side file for everything that does not fit the compact stdout line ("" = stderr only)')
+    ap.add_argument('--no-parity-mode', action='store_true', help='same as --modes ""')
+    ap.add_argument('--force-dist', action='store_true', help='run the collectives even with one rank (RCCL smoke)')
+    ap.add_argument('--dp-mode', default='shard', choices=['horovod', 'shard'],
+                    help='N > 1: horovod = the reference\'s own multi-GPU semantics (rl_games HorovodWrapper, learning/common_agent.py:'
+                         '94-107): every rank owns 4096 environments and its own 16384-row minibatches, gradients averaged by one RCCL '
+                         'all-reduce per branch and step - WEAK scaling, per-GPU work fixed; shard = the same 4096 environments with '
+                         'every minibatch row-sharded over the ranks (the R-rank update equals the 1-rank update) - STRONG scaling')
+    ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'])
+    ap.add_argument('--breakdown', action='store_true', help='per-shape GEMM time table on stderr')
+    ap.add_argument('--verbose', action='store_true', help='per-update times on stderr')
+    ap.add_argument('--host-threads', type=int, default=1,
+                    help='torch CPU threads during the GPU-timed part (the CPU oracle leg sets its own): every intra-op parallel '
+                         'region leaves its OpenMP workers spinning, and on a box whose cgroup quota is smaller than the core count '
+                         'torch sees (16 of 256 here) that gets the whole process throttled for the rest of the CFS period')
+    ap.add_argument('--no-config5', dest='config5', action='store_false', help='skip the 16384-environment batch (BASELINE configs[4] '
+                    'on one GPU) timed after everything else at N = 1')
+    ap.add_argument('--main-priority', type=int, default=0, help='run everything on a non-default stream of this HIP priority '
+                    '(-1 = high): the engine\'s main stream is whatever stream is current')
+    ap.add_argument('--engine-opts', default='', help='JSON dict of UpdateEngine.engine_opts overrides (schedule A/Bs), e.g. '
+                    '\'{"xstep": false}\'')
+    ap.add_argument('--gc', default='freeze', choices=['on', 'freeze'],
+                    help="'freeze' (default; the agents' config['manual_gc']): gc.freeze() + gc.disable() around the timed updates (no "
+                         "generation-2 pass of Python's collector inside an update); 'on': leave the collector alone")
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    local = local % torch.cuda.device_count()
+    torch.cuda.set_device(local)
+    device = f'cuda:{local}'
+    if args.main_priority != 0:
+        torch.cuda.set_stream(torch.cuda.Stream(device=device, priority=args.main_priority))
+    dist_info = None
+    if world > 1 or args.force_dist:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+        if args.dist_backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device(device))      # RCCL over xGMI
+        else:
+            dist.init_process_group(args.dist_backend)                            # (test rigs without one GPU per rank)
+        # what the collective library itself saw (the driver checks that RCCL carried N ranks): every rank contributes 1 to a
+        # SUM all-reduce on the device; the distinct GPUs behind the ranks come from an all-gather of their PCI bus ids
+        one = torch.ones(1, device=device)
+        dist.all_reduce(one)
+        ids = [None] * dist.get_world_size()
+        dist.all_gather_object(ids, torch.cuda.get_device_properties(local).name + ':' + str(getattr(torch.cuda.get_device_properties(local), 'pci_bus_id', local)))
+        dist_info = {'dist_backend': dist.get_backend() + (' (RCCL)' if dist.get_backend() == 'nccl' else ''),
+                     'world_size': dist.get_world_size(), 'ranks_counted_by_allreduce': int(one.item()),
+                     'distinct_devices': len(set(ids))}
+
+    use_graph = False if args.no_graph else ('hipgraph' if args.hipgraph else 'program')
+    if args.throughput_mode in ('none', '""', "''"):
+        args.throughput_mode = ''
+    if args.engine_opts:
+        ENGINE_OPTS.update(json.loads(args.engine_opts))
+    oracle_leg = world == 1 and not args.no_cpu_baseline          # (rank 0 is the only rank then)
+    candidates = HEADLINE_CANDIDATES if args.precision == 'auto' else [args.precision]
+
+    # ---- the headline: candidates in order of speed; the first whose parity holds in BOTH rollout states is the line's value
+    cpu, modes, fallthrough, head = None, {}, [], None
+    for ci, prec in enumerate(candidates):
+        r = measure_mode(args, prec, device, world, rank, use_graph)
+        agent, cfg = r['agent'], r['cfg']
+        par = None
+        if oracle_leg:
+            n_f = (args.cpu_steps + 2) // 2 if cpu is None else 3
+            n_s = (args.cpu_steps + 1 - n_f + 1) if cpu is None else 3
+            times, par = parity_both_states(agent, cfg, device, prec, steps_fresh=n_f, steps_stress=n_s)
+            if cpu is None:          # the oracle's step times of the first candidate's leg ARE the cpu baseline (8 full-size steps)
+                cpu = cpu_from_times(times, cfg, agent.batch_size, agent.minibatch_size, cfg['amp_minibatch_size'], host_cores())
+        r['parity'] = par
+        modes[prec] = {'value': round(r['value'], 1), 'unit': 'samples/s', 'ms_per_step': round(r['ms_per_step'], 3),
+                       'timed': f'{args.steps} updates after {args.warmup} warm-up ones (the contract\'s protocol)',
+                       'grad_scale': r['grad_scale'], 'parity': par}
+        ok = _mode_ok(par) if oracle_leg else True
+        if ok or ci == len(candidates) - 1:
+            head = r
+            head['parity_ok'] = ok if oracle_leg else None
+            break
+        fallthrough.append({'precision': prec, 'value': round(r['value'], 1), 'ms_per_step': round(r['ms_per_step'], 3),
+                            'fresh_ok': _state_ok(par['fresh']), 'stress_ok': _state_ok(par['stress']),
+                            'fresh': {'max_loss_rel': par['fresh']['max_loss_rel'], 'scalar': par['fresh']['max_loss_rel_scalar']},
+                            'stress': {'max_loss_rel': par['stress']['max_loss_rel'], 'scalar': par['stress']['max_loss_rel_scalar']},
+                            'why': 'missed the 1e-4 bar in this run; the next candidate was measured with the same protocol'})
+        if rank == 0:
+            print(f'[bench] {prec} missed the parity bar in this run (fresh {par["fresh"]["max_loss_rel"]:.2e} '
+                  f'{par["fresh"]["max_loss_rel_scalar"]}, stress {par["stress"]["max_loss_rel"]:.2e} '
+                  f'{par["stress"]["max_loss_rel_scalar"]}): falling through', file=sys.stderr)
+        del agent, r
+        torch.cuda.empty_cache()
+    precision = head['precision']
+    agent, cfg = head['agent'], head['cfg']
+    B, Bl, weak = head['B'], head['Bl'], head['weak']
+
+    # ---- more modes on request (parity in both states + throughput; detail file)
+    if rank == 0 and oracle_leg:
+        for m in ([] if args.no_parity_mode else [m for m in args.modes.split(',') if m and m not in modes]):
+            ag, cfg_m, _ = make_agent(device, m, use_graph, world, rank)
+            fill_rollout(ag, device)
+            ag._init_amp_demo_buf()
+            ms_m = time_updates(ag, 3 if m in ('f32', 'bf16x3') else 7, prime=3)
+            _, par = parity_both_states(ag, cfg_m, device, m, steps_fresh=3, steps_stress=3)
+            modes[m] = {'value': round(B / (ms_m * 1e-3), 1), 'unit': 'samples/s', 'ms_per_step': round(ms_m, 3),
+                        'timed': 'median of 7 (f32 / bf16x3: 3) updates after 3 priming ones, same workload',
+                        'grad_scale': ag.engine.gs, 'parity': par}
+            del ag
+            torch.cuda.empty_cache()
+    qualifying = qualifying_mode(modes) if (rank == 0 and oracle_leg) else None
+
+    # ---- strict mode: ONE number that meets north_star's tolerance as a TRUE relative error, no scale floor, no asterisk
+    strict = None
+    if rank == 0 and oracle_leg and args.strict:
+        tried = []
+        for m in STRICT_CANDIDATES:
+            if m not in modes:
                 ag, cfg_m, _ = make_agent(device, m, use_graph, world, rank)
                 fill_rollout(ag, device)
                 ag._init_amp_demo_buf()
-                ms_m = time_updates(ag, 3 if m in ('f32', 'bf16x3') else 7, prime=3)
-            n_f = (args.cpu_steps + 2) // 2 if head else 3
-            times, par = parity_both_states(ag, cfg_m, device, m, steps_fresh=n_f, steps_stress=(args.cpu_steps + 1 - n_f + 1) if head else 3)
-            if head:
-                cpu = cpu_from_times(times, cfg, B_, MB_, AMB_, host_cores())
-            modes[m] = {'value': round(B / (ms_m * 1e-3), 1), 'unit': 'samples/s', 'ms_per_step': round(ms_m, 3),
-                        'timed': f'{args.steps} updates (the headline)' if head else 'median of 7 (f32: 3) updates after 3 priming ones, same workload',
-                        'grad_scale': ag.engine.gs, 'parity': par}
-            if not head:
+                ms_m = time_updates(ag, 3, prime=2)
+                _, par = parity_both_states(ag, cfg_m, device, m, steps_fresh=2, steps_stress=2)
+                modes[m] = {'value': round(B / (ms_m * 1e-3), 1), 'unit': 'samples/s', 'ms_per_step': round(ms_m, 3),
+                            'timed': 'median of 3 updates after 2 priming ones, same workload', 'grad_scale': ag.engine.gs, 'parity': par}
                 del ag
                 torch.cuda.empty_cache()
-        qualifying = qualifying_mode(modes)
+            par = modes[m]['parity']
+            ok = _strict_ok(par)
+            tried.append({'precision': m, 'ok': ok, 'value': modes[m]['value']})
+            if ok or m == STRICT_CANDIDATES[-1]:
+                strict = {'precision': m, 'note': MODE_NOTE[m], 'value': modes[m]['value'], 'unit': 'samples/s',
+                          'ms_per_step': modes[m]['ms_per_step'], 'ok': ok,
+                          'criterion': 'TRUE |delta| / |ref| <= 1e-4 on every continuous loss scalar (no scale floor), counting '
+                                       'statistics within 1e-3 absolute, fresh rollout AND stress state, in this run',
+                          'fresh_max_true_rel': par['fresh']['max_loss_true_rel'], 'fresh_scalar': par['fresh']['max_loss_true_rel_scalar'],
+                          'stress_max_true_rel': par['stress']['max_loss_true_rel'], 'stress_scalar': par['stress']['max_loss_true_rel_scalar'],
+                          'fresh_worst_grad_rel_l2': par['fresh']['worst_grad_rel_l2'], 'tried': tried}
+                break
 
     # ---- the throughput mode (bf16: the storage type north_star names; it does NOT hold 1e-4) timed beside the headline
     thr = None
-    if rank == 0 and world == 1 and args.throughput_mode and args.throughput_mode != args.precision:
+    if rank == 0 and world == 1 and args.throughput_mode and args.throughput_mode != precision:
         m = args.throughput_mode
         if m in modes:
             thr = {'precision': m, 'value': modes[m]['value'], 'ms_per_step': modes[m]['ms_per_step']}
@@ -837,15 +1011,17 @@ def main():
     # reference's network: the reference has no 'every'-layer style net (its AMPStyleCatNet1 concatenates the style code in front
     # of the first dense layer only, learning/ase_network_builder.py:262-311), and 8 GPUs are the driver's to measure
     cfg5 = None
+    n_opt_head = cfg['mini_epochs'] * (Bl // cfg['minibatch_size'])
     if rank == 0 and world == 1 and args.config5:
         del agent
+        head['agent'] = None
         torch.cuda.empty_cache()
-        ag, cfg_5, _ = make_agent(device, args.precision, use_graph, world, rank, num_envs=16384)
+        ag, cfg_5, _ = make_agent(device, precision, use_graph, world, rank, num_envs=16384)
         fill_rollout(ag, device)
         ag._init_amp_demo_buf()
         ms5 = time_updates(ag, 3, prime=2)
         cfg5 = {'workload': 'BASELINE configs[4] batch: 16384 envs x horizon 32 = 524288 samples, 192 optimisation steps per update, '
-                            'the reference\'s ASE network, 1 GPU', 'precision': args.precision, 'value': round(ag.batch_size / (ms5 * 1e-3), 1),
+                            'the reference\'s ASE network, 1 GPU', 'precision': precision, 'value': round(ag.batch_size / (ms5 * 1e-3), 1),
                 'unit': 'samples/s', 'ms_per_step': round(ms5, 3), 'timed': 'median of 3 updates after 2 priming ones'}
         del ag
         torch.cuda.empty_cache()
@@ -855,17 +1031,21 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        full = {'metric': 'ASE PPO-update samples/sec (4096 envs x horizon 32)', 'value': round(value, 1),
+        par = head.get('parity')
+        full = {'metric': 'ASE PPO-update samples/sec (4096 envs x horizon 32)', 'value': round(head['value'], 1),
                 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-                'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
+                'ms_per_step': round(head['ms_per_step'], 3), 'higher_is_better': True,
                 'scaling': 'n/a' if world == 1 else ('weak' if weak else 'strong'),
-                'vs_baseline': None, 'dtype': DTYPE_OF[args.precision], 'data': 'synthetic',
+                'vs_baseline': None, 'dtype': DTYPE_OF[precision], 'data': 'synthetic',
                 'config': {'workload': 'BASELINE configs[1]: ASE agent, 4096 envs x horizon 32, obs 253 / act 31 / amp obs '
                                        '1400 / latent 64, [1024,1024,512] MLPs + disc + shared-trunk encoder, minibatch 16384 '
                                        '(amp 4096) x 6 mini-epochs = 48 optimisation steps per update; random-init weights',
-                           'precision_mode': args.precision + ': ' + MODE_NOTE[args.precision],
-                           'samples_per_step': B, 'optimisation_steps_per_step': cfg['mini_epochs'] * (Bl // cfg['minibatch_size']),
-                           'ms_epoch_tail': round(ms_tail, 3), 'ms_optimisation_steps_only': round(ms_per_step - ms_tail, 3),
+                           'precision_mode': precision + ': ' + MODE_NOTE[precision],
+                           'precision_choice': ('auto: first of ' + ' > '.join(HEADLINE_CANDIDATES) + ' that held the parity bar in this run'
+                                                if args.precision == 'auto' and oracle_leg else
+                                                ('auto without an oracle leg: the first candidate' if args.precision == 'auto' else 'named on the command line')),
+                           'samples_per_step': B, 'optimisation_steps_per_step': n_opt_head,
+                           'ms_epoch_tail': round(head['ms_tail'], 3), 'ms_optimisation_steps_only': round(head['ms_per_step'] - head['ms_tail'], 3),
                            'replay': use_graph if use_graph else 'eager',
                            'parallelism': 'single GPU' if world == 1 else
                            (f'dp{world} horovod semantics (learning/common_agent.py:94-107): 4096 envs + a 16384-row minibatch per GPU, '
@@ -875,10 +1055,11 @@ def main():
                 'engine_opts': dict(ENGINE_OPTS),
                 'runtime': ase_amd.hw_queue_note + ('; Python cyclic GC frozen during the timed updates' if args.gc == 'freeze' else '')
                 + f'; torch CPU threads {max(1, args.host_threads)} during the GPU-timed part',
-                'roofline': roof, 'cpu_baseline': cpu, 'qualifying_mode': qualifying, 'throughput_mode': thr,
-                'config5_16384_envs': cfg5, 'modes': modes,
-                'parity': (modes.get(args.precision) or {}).get('parity'),
-                'last_train_result': {k: round(v, 6) for k, v in last.items()}}
+                'roofline': head['roofline'], 'cpu_baseline': cpu, 'qualifying_mode': qualifying, 'throughput_mode': thr,
+                'strict_mode': strict, 'fallthrough': fallthrough, 'headline_parity_ok': head.get('parity_ok'),
+                'dist': dist_info,
+                'config5_16384_envs': cfg5, 'modes': modes, 'parity': par,
+                'last_train_result': {k: round(v, 6) for k, v in head['last'].items()}}
         detail = write_detail(full, args.detail)
         line = compact_line(full, detail)
         sys.stdout.flush()

@@ -400,7 +400,8 @@ class EmuBackend:
         # (act'' / act') * (g / act') * dg, as ase_hip_gp_second: act'^2 underflows for saturated units while act' does not
         d1, c = _twin_factors(act, twin[:rows, :width].float())
         e = c * torch.where(d1 != 0, g[:rows, :width].float() / d1, torch.zeros_like(d1)) * dg[:rows, :width].float()
-        e = torch.where(torch.isfinite(e), e, torch.zeros_like(e))
+        gin, dgin = g[:rows, :width].float(), dg[:rows, :width].float()
+        e = torch.where(torch.isfinite(e) | ~torch.isfinite(gin) | ~torch.isfinite(dgin), e, torch.zeros_like(e))     # (inputs' NaN / inf pass)
         dz[:rows, :width] = _store(dz[:rows, :width].float() + e, dz.dtype)
 
     def colsum(self, x, rows, cols, out, scale=1.0):

@@ -118,20 +118,19 @@ def test_deferred_weight_gradients(name, early, golden_dir):
     check_first_step(G, net, eng, rtol=2e-5, gtol=2e-4, wtol=lr * 0.05)
 
 
-@pytest.mark.parametrize('name', ['ase_tiny', 'ppo_tiny'])
-def test_truncate_grads_matches_clip_grad_norm(name, golden_dir):
-    """truncate_grads: the step with the global-norm clip equals the oracle's step with
-    torch.nn.utils.clip_grad_norm_ restated (learning/ase_agent.py:273-288) - gradients after the clip and post-Adam weights.
-    grad_norm is set below the actual norm so that the clip is active."""
+def check_truncate_grads(G, be, device='cpu'):
+    """The step with the global-norm clip against the reference's golden gradients -> torch.nn.utils.clip_grad_norm_ (restated,
+    and checked against torch's own) -> Adam: gradients after the clip and post-Adam weights.  grad_norm is set to half the
+    actual norm so that the clip is active.  Shared by the emulator test below and the GPU test (tests/test_gpu_engine.py)."""
     import copy
     from oracle import restated as R
-    G = copy.deepcopy(torch.load(os.path.join(golden_dir, name + '.pt'), weights_only=False))
+    G = copy.deepcopy(G)
     E = G['epochs'][0]
     total0 = float(torch.sqrt(sum((g.double() ** 2).sum() for g in E['first_grads'].values())))
     G['cfg'].update(truncate_grads=True, grad_norm=0.5 * total0)
-    net, eng = first_step(G, EmuBackend(), torch.float32)
+    net, eng = first_step(G, be, torch.float32, device=device)
     assert eng.truncate
-    grads = eng.export_grads()
+    grads = {k: v.detach().cpu() for k, v in eng.export_grads().items()}
     tot = float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())))
     assert abs(tot - 0.5 * total0) <= 1e-4 * total0                       # clipped to grad_norm
     for k, g in E['first_grads'].items():
@@ -152,7 +151,19 @@ def test_truncate_grads_matches_clip_grad_norm(name, golden_dir):
     R.adam_step(sd, R.adam_new(), G['cfg']['learning_rate'])
     got = net.state_dict()
     for k in G['trainable']:
-        close(got[k], sd[k].detach(), 1e-6, G['cfg']['learning_rate'] * 0.05, 'weight ' + k)
+        close(got[k].detach().cpu(), sd[k].detach(), 1e-6, G['cfg']['learning_rate'] * 0.05, 'weight ' + k)
+    # and the reported scalars are those of the unclipped step (the clip touches gradients only)
+    res, ref = eng.results(), E['steps'][0]
+    for k in SCALARS:
+        if k in ref:
+            close(res[k], ref[k], 1e-4, 1e-5, k)
+
+
+@pytest.mark.parametrize('name', ['ase_tiny', 'ppo_tiny'])
+def test_truncate_grads_matches_clip_grad_norm(name, golden_dir):
+    """truncate_grads (learning/ase_agent.py:273-288) on the emulator: see check_truncate_grads."""
+    G = torch.load(os.path.join(golden_dir, name + '.pt'), weights_only=False)
+    check_truncate_grads(G, EmuBackend())
 
 
 @pytest.mark.parametrize('name', ['ase_tiny', 'amp_tiny', 'ase_sep_tiny'])

@@ -73,6 +73,40 @@ def _first_step_errors(G, ag):
     return out
 
 
+def _post_adam_and_gradients(G, ag):
+    """Gradients and post-Adam weights of the FIRST optimisation step of a half-storage engine against the reference's goldens at the
+    real widths (round 4's verdict: only f32 was checked).  Gradients: relative L2 on the goldens' seeded samples - bounded by
+    what ReLU mask flips leave (profiles/r05_grad_error_sources.txt: a unit whose pre-activation changes sign under the forward's
+    2^-12 rounding is an O(1) error of one element of dZ; a flipped fraction f is sqrt(f) in relative L2, ~1-3 % in half, whatever
+    the backward's precision).  Weights: the first Adam step moves every element by exactly +-lr (m / sqrt(v) = sign(g)), so an
+    element differs by 2 lr where the two gradients disagree in SIGN and by ~0 elsewhere: no element beyond 2.2 lr, at most 6 % of
+    the sampled elements beyond lr / 2, mean difference below 0.12 lr."""
+    from tests.helpers import sample_index
+    E, sseed = G['epochs'][0], G['sample']['seed']
+    lr = float(G['cfg']['learning_rate'])
+    grads = ag.engine.export_grads()
+    rels = {}
+    for k, g in E['first_grads'].items():
+        a = grads[k].detach().cpu().reshape(-1)
+        ref = g['vals'] if isinstance(g, dict) else g.reshape(-1)
+        if isinstance(g, dict):
+            a = a[sample_index(k, a.numel(), ref.numel(), sseed)]
+        rels[k] = float((a.double() - ref.double()).norm() / ref.double().norm().clamp_min(1e-30))
+    vals = sorted(rels.values())
+    print('first-step gradient rel L2 vs the reference: median', vals[len(vals) // 2], 'worst', max(rels, key=rels.get), vals[-1])
+    assert vals[len(vals) // 2] <= 0.05 and vals[-1] <= 0.15, rels
+    sd = ag.model.state_dict()
+    for k, w in E['sd_after_step0'].items():
+        a = sd['a2c_network.' + k].detach().cpu().reshape(-1)
+        ref = w['vals'] if isinstance(w, dict) else w.reshape(-1)
+        if isinstance(w, dict):
+            a = a[sample_index(k, a.numel(), ref.numel(), sseed)]
+        e = (a.double() - ref.double()).abs()
+        assert float(e.max()) <= 2.2 * lr + 1e-6 * float(ref.abs().max()), ('weight after step 0 ' + k, float(e.max()) / lr)
+        assert float((e > 0.5 * lr).double().mean()) <= 0.06 and float(e.mean()) <= 0.12 * lr, \
+            ('weight after step 0 ' + k, float((e > 0.5 * lr).double().mean()), float(e.mean()) / lr)
+
+
 @pytest.mark.parametrize('precision', ['f16gpx3', 'f16gp32'])
 @pytest.mark.parametrize('name', ['ase_cfg2_small', 'ase_cfg2_small_s1', 'ase_cfg2_small_s2'])
 def test_real_width_reference_goldens_qualifying_modes(be, name, precision, golden_dir):
@@ -83,9 +117,12 @@ def test_real_width_reference_goldens_qualifying_modes(be, name, precision, gold
     amplification (the reference's f32 mu_old against this engine's f16 mu: d logp = (a - mu) / sigma^2 d mu ~ 18 / sigma d mu):
     5e-4 of its summand scale.  (Emulator, same goldens: 8e-8 / 1e-5 / 4e-5 / 4e-5 ... 1.5e-4.)"""
     G = torch.load(os.path.join(golden_dir, name + '.pt'), weights_only=False)
-    err = _first_step_errors(G, make_agent(G, be, device='cuda', precision=precision))
-    # (exact-f32 value path: 1e-5; three-bf16-MFMA products carry a unit roundoff of ~2^-17 per product: 5e-5, 2.2e-5 measured)
-    assert err['disc_grad_penalty'][1] <= (1e-5 if precision == 'f16gp32' else 5e-5), err
+    ag = make_agent(G, be, device='cuda', precision=precision)
+    err = _first_step_errors(G, ag)
+    # (exact-f32 value path: 1e-5; three f16 MFMAs on hi / lo splits of scaled operands, unit roundoff ~2^-22 per product: 1e-5 as
+    #  well - round 4's bf16 split, ~2^-17, was held to 5e-5 here and measured 2.2e-5)
+    assert err['disc_grad_penalty'][1] <= 1e-5, err
+    _post_adam_and_gradients(G, ag)
     for k in ('critic_loss', 'disc_loss', 'disc_logit_loss', 'enc_loss', 'amp_diversity_loss', 'entropy', 'b_loss'):
         if k in err:
             assert err[k][0] <= 1e-4, (k, err)

@@ -10,7 +10,7 @@ import torch
 
 from oracle import restated as R
 from tests.helpers import build_net, close, get_rms, set_rms
-from tests.test_engine_emu import CASES, check_first_step, first_step
+from tests.test_engine_emu import CASES, check_first_step, check_truncate_grads, first_step
 
 pytestmark = pytest.mark.gpu
 
@@ -46,6 +46,16 @@ def test_first_step_vs_reference_golden_f16(be, name, golden_dir):
     for k, g in E['first_grads'].items():
         rel = float((grads[k].cpu().double() - g.double()).norm() / (g.double().norm() + 1e-30))
         assert rel < 0.08, ('grad ' + k, rel)
+
+
+@pytest.mark.parametrize('name', ['ase_tiny', 'ppo_tiny', 'amp_tiny', 'ase_gp_tiny'])
+def test_truncate_grads_on_gpu(be, name, golden_dir):
+    """truncate_grads (learning/ase_agent.py:273-288, amp_agent.py:359-375, common_agent.py:406-422) through the HIP
+    library: the end-of-step form (weight-only loss terms -> ase_hip_reduce_sum of the whole gradient -> ase_hip_clip_scale ->
+    ase_hip_adam -> shadow refresh) with the clip ACTIVE, against the reference's golden gradients clipped by
+    torch.nn.utils.clip_grad_norm_ and the oracle's Adam.  Round 4 covered this path on the emulator only."""
+    G = torch.load(os.path.join(golden_dir, name + '.pt'), weights_only=False)
+    check_truncate_grads(G, be, device='cuda')
 
 
 @pytest.mark.parametrize('name', ['ase_tiny', 'amp_tiny', 'ase_sep_tiny'])
@@ -308,6 +318,34 @@ def test_self_consistent_parity_config2(mode, fresh_loss, fresh_grad, stress_los
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize('mode,loss_tol,grad_tol', [('f32', 1e-4, 2e-3), ('f16gpx3', 1e-4, 6e-2)])
+def test_parity_at_16384_envs(mode, loss_tol, grad_tol):
+    """BASELINE configs[4]'s batch (16384 envs x horizon 32 = 524288 samples, 192 optimisation steps per update; the reference's
+    network - SURVEY F10) on one GPU: round 4 measured its throughput and never compared it with the oracle.  The epoch tail at
+    that size (rewards, GAE over 16384 environments, the index maps with N = 16384) feeds one full-size optimisation step
+    (minibatch 16384 of 524288 rows, amp 4096) executed by the GPU engine and by the f32 CPU oracle on identical inputs -
+    bench.py's own parity leg -, plus the size-independent property of the tail (GAE telescopes exactly)."""
+    import bench
+    agent, cfg, spec = bench.make_agent('cuda:0', mode, False, 1, 0, num_envs=16384)
+    assert agent.batch_size == 524288 and agent.batch_size // agent.minibatch_size == 32
+    bench.fill_rollout(agent, 'cuda:0')
+    agent._init_amp_demo_buf()
+    agent.update(agent._play_steps_tail(), max_steps=8)                 # not the initial weights
+    bench.fill_rollout(agent, 'cuda:0')
+    batch = agent._play_steps_tail()
+    assert torch.equal(batch['mb_returns'].view(-1), (batch['mb_advs'].view(-1) + agent.experience['values'].view(-1)))
+    adv = batch['advantages'].view(-1).double()
+    mask = agent.experience['rand_action_mask'].view(-1).double()
+    mean = float((adv * mask).sum() / mask.sum())                       # masked normalisation over all 524288 rows
+    assert abs(mean) <= 1e-4, mean
+    _, par = bench.cpu_baseline_and_parity(agent, cfg, steps=2, mode=mode, state='16384 envs, fresh rollout', with_times=True)
+    print(mode, par['max_loss_rel'], par['max_loss_rel_scalar'], par['max_loss_true_rel'], par['worst_grad_rel_l2'])
+    assert par['max_loss_rel'] <= loss_tol and par['max_count_stat_abs'] <= 1e-3 and par['worst_grad_rel_l2'] <= grad_tol, par
+    assert par['trajectory']['steps'] == 2 and par['trajectory']['max_loss_rel'] <= 50 * loss_tol, par['trajectory']
+    del agent
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize('precision,w_max,w_mean,s_rtol', [('f32', 20, 0.1, 5e-3), ('f16gpx3', 80, 0.5, 5e-2), ('bf16', 120, 1.0, 0.25)])
 def test_schedule_variants_agree_config2(precision, w_max, w_mean, s_rtol):
     """The round-4 schedule (discriminator head and prologue un-chained from the main stream, penalty value path on its own
@@ -321,8 +359,10 @@ def test_schedule_variants_agree_config2(precision, w_max, w_mean, s_rtol):
     are held to gross-error bounds - f16gpx3 is here for the penalty's value path on its own stream."""
     import bench
     outs = []
+    # third variant (round 5, advisor): the cross-step schedule WITHOUT result rings - the double-buffered prologue inputs
+    # then follow the minibatch position's parity (engine.use_parity) instead of the ring slot's
     for opts, extra in (({'xstep': False, 'prefetch': False, 'gp_stream': False}, {'main_stream_priority': 0, 'result_rings': False}),
-                        ({}, {})):
+                        ({}, {}), ({}, {'result_rings': False})):
         agent, cfg, spec = bench.make_agent('cuda:0', precision, 'program', 1, 0, engine_opts=opts or {'xstep': True}, extra_cfg=extra)
         bench.fill_rollout(agent, 'cuda:0')
         agent._init_amp_demo_buf()
@@ -334,7 +374,11 @@ def test_schedule_variants_agree_config2(precision, w_max, w_mean, s_rtol):
                       for k in ('kl', 'actor_loss', 'critic_loss', 'disc_loss', 'disc_grad_penalty', 'enc_loss', 'amp_diversity_loss')}))
         del agent
         torch.cuda.empty_cache()
-    (w0, o0, a0, r0), (w1, o1, a1, r1) = outs
+    for (w0, o0, a0, r0), (w1, o1, a1, r1) in ((outs[0], outs[1]), (outs[0], outs[2])):
+        _schedule_pair_agrees(w0, o0, a0, r0, w1, o1, a1, r1, w_max, w_mean, s_rtol)
+
+
+def _schedule_pair_agrees(w0, o0, a0, r0, w1, o1, a1, r1, w_max, w_mean, s_rtol):
     lr = 2e-5
     # weights: after 144 Adam steps two runs differ by a few lr where a gradient's sign is rounding noise (measured: mean
     # 0.08 lr; worst single element of the 7 M: f32 < 20 lr, 16-bit modes 20-25 lr of the 288 lr two runs could drift apart)

@@ -941,3 +941,11 @@ def test_gp_second_saturated_units_stay_finite(be):
             outs.append(dz.cpu())
         assert bool(torch.isfinite(outs[0]).all()) and bool(torch.isfinite(outs[1]).all()), act
         close(outs[0], outs[1], 1e-3, 1e-5 * float(outs[1].abs().max()) + 1e-9, f'gp_second act {act}')     # (device erf / exp vs torch's)
+        # a NaN / inf that ARRIVES in the chain values (a diverging penalty) is passed on, not zeroed (round 4's advisor)
+        gv2 = gv.clone()
+        gv2[20, 5], gv2[21, 6] = float('nan'), float('inf')
+        for dev in ('cuda', 'cpu'):
+            b = be if dev == 'cuda' else EmuBackend()
+            dz = torch.zeros(rows, width, device=dev)
+            b.gp_second(twin.to(dev), gv2.to(dev), dg.to(dev), dz, rows, width, act)
+            assert bool(torch.isnan(dz[20, 5])) and not bool(torch.isfinite(dz[21, 6])), (act, dev, dz[20, 5], dz[21, 6])
