@@ -150,11 +150,13 @@ class UpdateEngine:
         #                   65.2 ms): the update is bound by total matrix-pipe time, CUs left idle for the critical path are lost
         #   side_priority   HIP priority of the branch streams, one number or [critic, discriminator, penalty value path] (0 = default,
         #                   -1 = high; the main stream's priority is the caller's)
+        #   gp_split        gp_f32 = 'x3': 'f16' = three f16 MFMAs per product on hi / lo splits of scaled operands (ASE_F32H3, ~2^-22),
+        #                   'bf16' = round 4's bf16 split (ASE_F32X3, ~2^-17; penalty 1.08e-4 off in the driver's round-4 run)
         #   gp_stream       gp_f32 modes: the penalty's value path (f32 / bf16x3 forward of the demo rows + chain: independent of
         #                   the loss rows until the conversion launch) on its own stream beside the discriminator branch
         o = dict(tn_grouped=True, tn_wg_side=64, tn_early=False, disc_early=True, short_prologue=True, style_early=False,
                  relu_bits=True, fused_apply=True, apply_wide=True, side_streams=2, gp_scale_split=True, xstep=True,
-                 gp_stream=True, style_side=0, style_wg=0, side_priority=None, prefetch=True, disc_after_style=False)
+                 gp_stream=True, style_side=0, style_wg=0, side_priority=None, prefetch=True, disc_after_style=False, gp_split='f16')
         unknown = set(cfg.get('engine_opts', {}) or {}) - set(o)
         assert not unknown, f"unknown engine_opts {sorted(unknown)}"
         o.update(cfg.get('engine_opts', {}) or {})
@@ -1351,11 +1353,11 @@ class UpdateEngine:
         #   hidden activations       O(1); saturation above 1023                2^6
         #   chain values s g_l       O(1e-3 .. 1e-1); saturation above 16       2^12
         #   weights                  O(1/sqrt(K)); saturation above 32          2^11
-        # (gp_f32 = 'x3bf16' keeps the bf16 split: no range assumption at all)
+        # (engine_opts gp_split = 'bf16' keeps round 4's bf16 split - no range assumption at all - for the same-box A/B)
         x3_prev = getattr(be, 'x3', None)
         mode = self.cfg.get('gp_f32')
-        half = mode == 'x3' and x3_prev is not None
-        if mode in ('x3', 'x3bf16') and x3_prev is not None:
+        half = mode == 'x3' and x3_prev is not None and self.engine_opts['gp_split'] == 'f16'
+        if mode == 'x3' and x3_prev is not None:
             be.x3 = 'f16' if half else True
         ex = (lambda ea: {'x3_exps': (ea, 11)}) if half else (lambda ea: {})
         for l, d in enumerate(self.disc):
