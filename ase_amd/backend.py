@@ -190,11 +190,17 @@ class HipBackend:
                                                  plan['n_red'], _ptr(plan['ws']), plan['dtype'], self._stream()),
                 "gemm_tn_grouped")
 
-    def refresh_shadow(self, W, Ws, Wts, split_src, split_dst):
+    def refresh_shadow(self, W, Ws, Wts, split_src, split_dst, x3_exp=None):
+        """x3_exp (f32 shadows only): write them in the packed half-split format of ASE_F32H3 - W * 2^x3_exp as [8 hi | 8 lo] halves
+        per group of 8 elements, the B operand of gemm_nt(..., x3_exps=(ea, x3_exp)) under x3 = 'f16'."""
         n, k = W.shape
         ref = Ws if Ws is not None else Wts
+        code = _code(ref.dtype)
+        if x3_exp is not None:
+            assert ref.dtype == torch.float32
+            code = L.F32H3 | (int(x3_exp) << 16)
         L.check(self.lib.ase_hip_refresh_shadow(_ptr(W), n, k, _ptr(Ws), _ld(Ws), _ptr(Wts), _ld(Wts), split_src,
-                                                split_dst, _code(ref.dtype), self._stream()), "refresh_shadow")
+                                                split_dst, code, self._stream()), "refresh_shadow")
 
     def refresh_shadow_multi(self, desc, items, dtype):
         """desc: device int64 [n, 12] pointer table (see ase_hip.h); items: the same tensors (kept alive by the caller)."""

@@ -83,13 +83,12 @@ extern "C" int ase_hip_gemm_nt(const void* A, int64_t lda, const void* B, int64_
     p.tiles_m = p.tiles_n = 0;
     p.prof = nullptr;
     p.prof_clk = 0;
-    p.sa = p.sb = 1.f;
+    p.sa = 1.f;
     if (dtype == ASE_BF16) return dispatch_nt_bf16(p, (hipStream_t)stream);
     if (dtype == ASE_F16) return dispatch_nt_f16(p, (hipStream_t)stream);
     if (dtype == ASE_F32X3) return dispatch_nt_x3(p, (hipStream_t)stream);
     if (dtype == ASE_F32H3) {
-        p.sa = ldexpf(1.f, ea);
-        p.sb = ldexpf(1.f, eb);
+        p.sa = ldexpf(1.f, ea);            // (B: pre-split and scaled by 2^eb by ase_hip_refresh_shadow)
         p.alpha = ldexpf(alpha, -(ea + eb));          // exact: powers of two
         return dispatch_nt_h3(p, (hipStream_t)stream);
     }

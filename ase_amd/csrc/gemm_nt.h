@@ -40,7 +40,8 @@ struct NTParams {
     int M, N, K;                    // K in elements (multiple of 128/sizeof(T))
     int act, aux_mode, out_f32;
     float alpha;
-    float sa, sb;                   // f32h_t storage: power-of-two scales of the A / B operand before the half split (alpha undoes them)
+    float sa;                       // f32h_t storage: power-of-two scale of the A operand before its half split (B arrives pre-split and
+                                    // pre-scaled; alpha undoes both scales)
     int tiles_m, tiles_n;
     unsigned long long* prof;       // debug: per-workgroup phase timestamps (ase_hip_debug_nt_profile), else null
     int prof_clk;                   // debug: stamps 1 and 2 (main loop) in shader clocks instead of the 100 MHz clock

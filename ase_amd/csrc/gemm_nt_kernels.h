@@ -119,24 +119,32 @@ template <> struct Mma<f32s_t> {
     }
 };
 
-// f32 operands scaled by a power of two and split into IEEE-half hi / lo parts (see f32h_t in common.h): sx = x * scale (exact),
-// hi = half(sx) (saturating), lo = half(sx - hi).  With |sx| >= 2^-2 both parts are normal halves and hi + lo carries 22
-// significant bits of x; smaller values degrade gracefully (lo becomes subnormal: absolute error 2^-25 of the scaled range).
+// f32h_t (ASE_F32H3): f32-sized storage whose products run as three f16 MFMAs on hi / lo splits of power-of-two SCALED operands.
+//   A (activations, chain values: f32 in HBM and LDS) is split in registers:  sx = x * sa (exact), hi = half(sx), lo = half(sx - hi).
+//     With |sx| >= 2^-2 both parts are normal halves and hi + lo carries 22 significant bits of x; smaller values degrade gracefully
+//     (lo subnormal: absolute error 2^-25 of the scaled range); |sx| > 65504 overflows to inf and the launch's output is NaN - loud
+//     on purpose (the caller's scale exponent was wrong), never a silently saturated value.
+//   B (weights) arrives PRE-SPLIT: ase_hip_refresh_shadow(dtype = ASE_F32H3 | eb << 16) writes the shadows in the packed format
+//     [8 hi halves | 8 lo halves] per group of 8 consecutive k (32 bytes, the footprint of 8 floats), already scaled by 2^eb.  A B
+//     element is needed by every row tile of the launch (64 of them at 4096 rows): splitting it once per optimisation step instead
+//     of once per tile removes two thirds of the kernel's VALU work, which is what bounded it (round 5: 5 VALU operations per
+//     element and fragment against 3 MFMAs of 32 cycles per fragment pair).
 __device__ __forceinline__ void split_f16(const f32x4& x0, const f32x4& x1, float scale, f16x8& hi, f16x8& lo) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const float s0 = x0[q] * scale, s1 = x1[q] * scale;
-        hi[q] = from_f32<f16_t>(s0);
-        hi[q + 4] = from_f32<f16_t>(s1);
-        lo[q] = from_f32<f16_t>(s0 - (float)hi[q]);
-        lo[q + 4] = from_f32<f16_t>(s1 - (float)hi[q + 4]);
+        hi[q] = (f16_t)s0;
+        hi[q + 4] = (f16_t)s1;
+        lo[q] = (f16_t)(s0 - (float)hi[q]);
+        lo[q + 4] = (f16_t)(s1 - (float)hi[q + 4]);
     }
 }
 
 template <> struct Mma<f32h_t> {
-    // the f32s_t walk over the staged f32 rows with the split above; the epilogue's alpha undoes sa * sb
+    // rows of 128 / 64 bytes = 32 / 16 k-values; per k-step of 16 a lane (r, h) owns the 8 k-values of group 2 ks + h = two
+    // 16-byte chunks: A - 8 floats to split; B - its 8 hi halves and its 8 lo halves
     template <int FM, int FN, int RB>
-    static __device__ __forceinline__ void tile(const char* sA, const char* sB, int lane, f32x16 (&acc)[FM][FN], float sa, float sb) {
+    static __device__ __forceinline__ void tile(const char* sA, const char* sB, int lane, f32x16 (&acc)[FM][FN], float sa) {
         const int r = lane & 31, h = lane >> 5, sw = lds_swz<RB>(r);
 #pragma unroll
         for (int ks = 0; ks < RB / 64; ++ks) {
@@ -148,9 +156,10 @@ template <> struct Mma<f32h_t> {
                 split_f16(*reinterpret_cast<const f32x4*>(sA + i * 32 * RB + o0),
                           *reinterpret_cast<const f32x4*>(sA + i * 32 * RB + o1), sa, ah[i], al[i]);
 #pragma unroll
-            for (int j = 0; j < FN; ++j)
-                split_f16(*reinterpret_cast<const f32x4*>(sB + j * 32 * RB + o0),
-                          *reinterpret_cast<const f32x4*>(sB + j * 32 * RB + o1), sb, bh[j], bl[j]);
+            for (int j = 0; j < FN; ++j) {
+                bh[j] = *reinterpret_cast<const f16x8*>(sB + j * 32 * RB + o0);
+                bl[j] = *reinterpret_cast<const f16x8*>(sB + j * 32 * RB + o1);
+            }
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -499,7 +508,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, WPE) void gemm_nt_kernel(NTParams p
         const char* sA = smem + buf * kBuf + (wm * FM * 32) * RB;
         const char* sB = smem + buf * kBuf + (BM + wn * FN * 32) * RB;
         if constexpr (SW && sizeof(T) == 2) Mma<T>::template tile<FM, FN, RB, true>(sA, sB, lane, acc);
-        else if constexpr (std::is_same<T, f32h_t>::value) Mma<T>::template tile<FM, FN, RB>(sA, sB, lane, acc, p.sa, p.sb);
+        else if constexpr (std::is_same<T, f32h_t>::value) Mma<T>::template tile<FM, FN, RB>(sA, sB, lane, acc, p.sa);
         else Mma<T>::template tile<FM, FN, RB>(sA, sB, lane, acc);
         buf = (buf + 1 == S) ? 0 : buf + 1;
     }

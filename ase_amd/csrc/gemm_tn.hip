@@ -6,6 +6,7 @@
 //       partial tiles into workspace slabs folded by tn_reduce_kernel).
 #include "gemm_nt.h"
 #include <stdlib.h>
+#include <math.h>
 #include <algorithm>
 #include <vector>
 
@@ -776,6 +777,40 @@ __global__ void refresh_shadow_kernel(const float* __restrict__ W, int n_real, i
     }
 }
 
+// f32h_t shadows (ASE_F32H3): W * 2^e split into half hi / lo parts, packed [8 hi | 8 lo] per group of 8 consecutive elements of
+// the contracted (contiguous) dimension - k for W_s, n for W_s^T; 4 bytes per element, leading dimensions in 4-byte units like the
+// f32 shadows they replace.  (See Mma<f32h_t> in gemm_nt_kernels.h.)
+__device__ __forceinline__ void store_split(char* row, int col, float v, float scale) {
+    const float s = v * scale;
+    const f16_t hi = (f16_t)s, lo = (f16_t)(s - (float)hi);
+    char* g = row + (col >> 3) * 32 + (col & 7) * 2;
+    *reinterpret_cast<f16_t*>(g) = hi;
+    *reinterpret_cast<f16_t*>(g + 16) = lo;
+}
+__global__ void refresh_shadow_split_kernel(const float* __restrict__ W, int n_real, int k_real, char* __restrict__ Ws, int64_t ldws,
+                                            char* __restrict__ Wts, int64_t ldwts, int split_src, int gap, float scale) {
+    __shared__ float tile[32][33];
+    const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + ty + 8 * i, k = k0 + tx;
+        float v = 0.f;
+        if (n < n_real && k < k_real) v = W[(int64_t)n * k_real + k];
+        tile[ty + 8 * i][tx] = v;
+        if (Ws && n < n_real && k < k_real) store_split(Ws + (int64_t)n * ldws * 4, (k < split_src) ? k : k + gap, v, scale);
+    }
+    __syncthreads();
+    if (Wts) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + ty + 8 * i, n = n0 + tx;
+            if (k < k_real && n < n_real)
+                store_split(Wts + (int64_t)((k < split_src) ? k : k + gap) * ldwts * 4, n, tile[tx][ty + 8 * i], scale);
+        }
+    }
+}
+
 // All layers in one launch: desc[l] = {W, n_real, k_real, Ws, ldws, Wts, ldwts, split_src, gap, bias, bias_shadow, tiles_k}
 // (int64 each); blockIdx.y = layer, blockIdx.x = 32x32 tile (grid-stride), bias copied by the first workgroup.
 template <typename T>
@@ -1021,6 +1056,16 @@ extern "C" int ase_hip_refresh_shadow(const float* W, int n_real, int k_real, vo
     ASE_CHECK_ARG(split_src <= split_dst && split_src <= k_real, "refresh_shadow: bad split");
     const dim3 grid((k_real + 31) / 32, (n_real + 31) / 32), block(256);
     const int gap = split_dst - split_src;
+    if ((dtype & 0xFF) == ASE_F32H3) {           // packed half split of W * 2^eb (eb in bits 16-23, as in ase_hip_gemm_nt's dtype word)
+        const int eb = (dtype >> 16) & 0xFF;
+        ASE_CHECK_ARG(eb <= 24 && ((dtype >> 8) & 0xFF) == 0, "refresh_shadow: ASE_F32H3 takes the weight scale exponent 0..24 in bits 16-23");
+        ASE_CHECK_ARG((Ws == nullptr || (ldws % 8 == 0 && ((uintptr_t)Ws % 32) == 0)) && (Wts == nullptr || (ldwts % 8 == 0 && ((uintptr_t)Wts % 32) == 0)),
+                      "refresh_shadow: packed split shadows need 32-byte aligned rows (leading dimensions in whole groups of 8)");
+        ASE_LAUNCH(refresh_shadow_split_kernel, grid, block, 0, (hipStream_t)stream, W, n_real, k_real, (char*)Ws, ldws, (char*)Wts, ldwts,
+                   split_src, gap, ldexpf(1.f, eb));
+        ASE_CHECK_LAUNCH("refresh_shadow");
+        return ASE_OK;
+    }
     const int rc = ase_dispatch_storage(dtype, [&](auto tag) {
         typedef typename decltype(tag)::type T;
         ASE_LAUNCH(refresh_shadow_kernel<T>, grid, block, 0, (hipStream_t)stream, W, n_real, k_real, (T*)Ws, ldws, (T*)Wts, ldwts,

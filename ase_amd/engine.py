@@ -1361,7 +1361,9 @@ class UpdateEngine:
             be.x3 = 'f16' if half else True
         ex = (lambda ea: {'x3_exps': (ea, 11)}) if half else (lambda ea: {})
         for l, d in enumerate(self.disc):
-            be.refresh_shadow(d.W[0], g.Ws[l], g.Wts[l], d.split_src, d.split_dst)
+            # (half split: the shadows are written PRE-SPLIT - scaled, [8 hi | 8 lo] halves per group of 8 - once per step instead
+            #  of being split again by every row tile of the six launches)
+            be.refresh_shadow(d.W[0], g.Ws[l], g.Wts[l], d.split_src, d.split_dst, **({'x3_exp': 11} if half else {}))
         x = g.X
         for l, d in enumerate(self.disc):
             be.gemm_nt(x, g.Ws[l], g.H[l], AMB, d.n_pad, d.k_pad, bias=d.bs, act=L.ACT_RELU, mask_out=g.bits[l],

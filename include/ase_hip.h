@@ -35,8 +35,11 @@ extern "C" {
 #define ASE_HIP_ABI_VERSION 4
 
 enum { ASE_F32 = 0, ASE_BF16 = 1, ASE_F32X3 = 2 /* f32 storage, products as 3 bf16 MFMAs on a hi/lo split (GEMMs only) */,
-       ASE_F32H3 = 4 /* f32 storage, products as 3 f16 MFMAs on a hi/lo split of operands scaled by 2^ea / 2^eb (ase_hip_gemm_nt only;
-                        the exponents ride in bits 8-15 / 16-23 of dtype: ASE_F32H3 | (ea << 8) | (eb << 16)) */,
+       ASE_F32H3 = 4 /* 4-byte storage, products as 3 f16 MFMAs on hi/lo splits of operands scaled by 2^ea / 2^eb (the exponents ride in
+                        bits 8-15 / 16-23 of dtype: ASE_F32H3 | (ea << 8) | (eb << 16)).  ase_hip_gemm_nt: A is plain f32 (split in the
+                        kernel), B is the PACKED SPLIT format ase_hip_refresh_shadow(dtype = ASE_F32H3 | eb << 16) writes - per group of
+                        8 consecutive k: 8 hi halves, then 8 lo halves, of W * 2^eb (32 bytes, leading dimension as for f32).  Operands
+                        must satisfy |x| * 2^e < 65504 (overflow turns the output into NaN); best accuracy for |x| * 2^e >= 2^-2 */,
        ASE_F16 = 3 /* IEEE half storage + v_mfma_f32_32x32x16_f16, f32 accumulate: what the reference's mixed_precision flag
                       (torch.cuda.amp autocast + GradScaler, learning/ase_agent.py:216,271-288) computes in; conversions saturate */ };
 /* activations: the names of rl_games' activations_factory (learning/ase_network_builder.py:162); swish = SiLU */
@@ -130,7 +133,8 @@ int ase_hip_gemm_tn_grouped(const int64_t* problems, const int32_t* work, int n_
 
 /* Shadow copies of one weight matrix for the matrix cores: W_s [n_pad,k_pad] and its transpose
  * Wt_s [k_pad,n_pad] (both dtype, zero padded, concat columns moved to split_dst).  Run after
- * every optimizer step.  (No reference counterpart: the reference multiplies f32 masters.) */
+ * every optimizer step.  (No reference counterpart: the reference multiplies f32 masters.)
+ * dtype = ASE_F32H3 | (eb << 16): the packed half-split shadows of W * 2^eb (see ASE_F32H3; buffers sized and strided as f32). */
 int ase_hip_refresh_shadow(const float* W, int n_real, int k_real, void* Ws, int64_t ldws,
                            void* Wts, int64_t ldwts, int split_src, int split_dst, int dtype,
                            void* stream);

@@ -74,6 +74,14 @@ def half_split(x, e):
     return hi.double(), lo.double()
 
 
+def unpack_split(buf, rows, cols, e):
+    """A packed half-split shadow (ase_hip_refresh_shadow with ASE_F32H3: per group of 8 elements 8 hi halves then 8 lo halves,
+    in a float32-typed buffer) -> (hi + lo) / 2^e as f64 [rows, cols]."""
+    raw = buf.contiguous().view(torch.float16).view(buf.shape[0], -1, 2, 8)        # [row, group, hi|lo, 8]
+    v = (raw[:, :, 0, :].double() + raw[:, :, 1, :].double()).reshape(buf.shape[0], -1)
+    return v[:rows, :cols] * 2.0 ** -e
+
+
 def x3_half_product(a, b, ea, eb):
     """a @ b^T as the three-product form hi*hi + hi*lo + lo*hi of the scaled half splits, exact accumulation (f64), scale undone."""
     ah, al = half_split(a, ea)
@@ -173,7 +181,9 @@ class EmuBackend:
         for (A, B, G, gb, br, M, N, K, nr, kr, ss, sd, alpha) in plan['keep']:
             self.gemm_tn(A, B, G, M, N, K, nr, kr, ss, sd, alpha=alpha, gbias=gb, bias_rows=br)
 
-    def refresh_shadow(self, W, Ws, Wts, split_src, split_dst):
+    def refresh_shadow(self, W, Ws, Wts, split_src, split_dst, x3_exp=None):
+        # (x3_exp: the HIP backend packs half splits there; the emulator keeps plain f32 shadows - its x3 products are formed
+        #  from the f32 values by x3_half_product)
         n, k = W.shape
         gap = split_dst - split_src
         kd = torch.tensor([j if j < split_src else j + gap for j in range(k)])

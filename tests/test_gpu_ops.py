@@ -576,7 +576,14 @@ def test_gemm_x3_half_split(M, N, K, ea, eb, sa, sb):
     Cg = torch.zeros(M, N).cuda()
     bits = torch.zeros(M, (N + 31) // 32, dtype=torch.int32).cuda()
     relu = N % 32 == 0
-    bh.gemm_nt(A.cuda(), B.cuda(), Cg, M, N, K, bias=bias.cuda(), act=L.ACT_RELU if relu else L.ACT_NONE,
+    # B in the packed split format the shadow refresh writes (and its transpose: checked through the unpacker)
+    Bs, Bts = torch.zeros(N, K).cuda(), torch.zeros(K, (N + 7) // 8 * 8).cuda()
+    bh.refresh_shadow(B.cuda(), Bs, Bts, K, K, x3_exp=eb)
+    from tests.emu_backend import half_split, unpack_split
+    hi, lo = half_split(B, eb)
+    want = (hi + lo) * 2.0 ** -eb
+    assert torch.equal(unpack_split(Bs.cpu(), N, K, eb), want) and torch.equal(unpack_split(Bts.cpu(), K, N, eb), want.t())
+    bh.gemm_nt(A.cuda(), Bs, Cg, M, N, K, bias=bias.cuda(), act=L.ACT_RELU if relu else L.ACT_NONE,
                mask_out=bits if relu else None, x3_exps=(ea, eb))
     pre = A.double() @ B.double().t() + bias.double()
     ref = pre.clamp_min(0) if relu else pre
@@ -584,7 +591,7 @@ def test_gemm_x3_half_split(M, N, K, ea, eb, sa, sb):
     emu = emu.clamp_min(0) if relu else emu
     scale = float((A.abs().double() @ B.abs().double().t()).max()) + float(bias.abs().max())
     got = Cg.cpu().double()
-    assert float((got - emu).abs().max()) <= 2e-7 * scale, float((got - emu).abs().max()) / scale      # f32 accumulation order only
+    assert float((got - emu).abs().max()) <= 5e-7 * scale, float((got - emu).abs().max()) / scale      # f32 accumulation order only
     tol = 1e-6 if sa * 2.0 ** ea >= 1.0 else 2e-5             # (tiny operands: lo parts subnormal, documented degradation)
     assert float((got - ref).abs().max()) <= tol * scale, float((got - ref).abs().max()) / scale
     if relu:                                                   # the mask twin is the sign of what was stored
@@ -596,7 +603,7 @@ def test_gemm_x3_half_split(M, N, K, ea, eb, sa, sb):
     b3 = HipBackend(x3=True)
     C3 = torch.zeros(M, N).cuda()
     b3.gemm_nt(A.cuda(), B.cuda(), C3, M, N, K, bias=bias.cuda(), act=L.ACT_RELU if relu else L.ACT_NONE)
-    if sa * 2.0 ** ea >= 1.0:
+    if K >= 1024 and sa >= 0.5:        # (long sums of O(1) terms: elsewhere both errors sit in the f32 rounding of the bias add)
         assert float((C3.cpu().double() - ref).abs().max()) >= 3 * float((got - ref).abs().max())
 
 
@@ -606,6 +613,13 @@ def test_gemm_x3_half_split_rejects_bad_scales():
     A, B, C_ = torch.zeros(64, 64).cuda(), torch.zeros(64, 64).cuda(), torch.zeros(64, 64).cuda()
     with pytest.raises(L.AseHipError):
         bh.gemm_nt(A, B, C_, 64, 64, 64, x3_exps=(30, 11))
+    with pytest.raises(L.AseHipError):
+        bh.refresh_shadow(A, B, None, 64, 64, x3_exp=30)
+    # an operand beyond half's range is LOUD: the output turns NaN instead of carrying a silently saturated product
+    A[3, 5] = 3000.0
+    bh.refresh_shadow(torch.ones(64, 64).cuda(), B, None, 64, 64, x3_exp=11)
+    bh.gemm_nt(A, B, C_, 64, 64, 64, x3_exps=(12, 11))
+    assert bool(torch.isnan(C_[3]).all()) and bool(torch.isfinite(C_[4]).all())
 
 
 @pytest.mark.parametrize('dt', DT)
