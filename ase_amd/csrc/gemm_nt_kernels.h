@@ -572,6 +572,11 @@ int launch_nt(const NTParams& p0, hipStream_t stream) {
 //   by the 32-cycle MFMA issue cadence - but 100-185 cycles in the read half of a phase, where it sat on the critical path
 //   of the OTHER wave group's MFMA block): at the counted wait of a phase the newest issued unit is the one of the previous
 //   phase, three units may stay in flight.
+//   LDS balance (round 5, measured and NOT adopted): the fragment reads are 12 / 4 / 8 / 0 KB per wave over the four phases; reading
+//   B fragment 0 of the next K-tile in phase 3 instead (8 / 4 / 8 / 4, 12 more registers) left the main loop where it was - 41831
+//   against 41708 shader cycles for 16 K-tiles of 16384 x 1024 x 1024 (profiles/r05_nt8_lds_rebalance.txt): a phase costs ~650
+//   cycles for 2 x 256 of MFMA issue, and the ~70 cycles per hand-over between the two wave groups (barrier release, lgkmcnt,
+//   priority switch, the DMA issue inside the block) are what is left, not the LDS port.
 //   (Round 2-4 ablations of this schedule - no DMA / no reads / no MFMAs / other MFMA shapes / DMA in the read half - lived
 //   behind a lab switch in this file up to commit 9f99095; their results are in profiles/r03_lab_*.log, r04_lab_mfma_shape.txt.)
 // ------------------------------------------------------------------------------------------------
@@ -598,7 +603,12 @@ __device__ __forceinline__ void nt8_read(i32x4 (&f)[4], const char* base, const 
     for (int ks = 0; ks < 4; ++ks) f[ks] = *reinterpret_cast<const i32x4*>(base + L.roff[ks]);
 }
 
-// the 8 MFMAs of a phase with the two DMA pieces of unit KIND (K-tile `tile`) issued among them
+// the 8 MFMAs of a phase with the two DMA pieces of unit KIND (K-tile `tile`) issued among them, and the phase's CLOSING barrier
+// in front of the last MFMA pair: every s_barrier of the loop is the end of one wave group's MFMA block and the start of the
+// other's, and between the first group's last MFMA issue and the second group's first one lie the barrier's release, an lgkmcnt
+// wait and a priority switch (~70 of the ~650 cycles a phase took, round 5's cycle stamps).  With two MFMAs (64 cycles of
+// matrix-pipe work) still to issue behind the barrier, the pipe stays fed across the hand-over.  Nothing those two MFMAs touch
+// is shared: their operands are in registers since the phase's first barrier.
 template <typename T, int KIND, bool SW>
 __device__ __forceinline__ void nt8_mma_issue(f32x16& c0, f32x16& c1, const i32x4 (&a0)[4], const i32x4 (&a1)[4],
                                               const i32x4 (&b)[4], const NT8Lane& L, char* smem, int tile, bool live) {
@@ -607,6 +617,7 @@ __device__ __forceinline__ void nt8_mma_issue(f32x16& c0, f32x16& c1, const i32x
     const int64_t koff = (int64_t)tile * 128;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
+        if (ks == 3) NT8_BARRIER();                       // (closes the phase: see above)
         c0 = nt8_mfma<T, SW>(a0[ks], b[ks], c0);
         c1 = nt8_mfma<T, SW>(a1[ks], b[ks], c1);
         if (ks == 0 || ks == 2) {
@@ -616,66 +627,43 @@ __device__ __forceinline__ void nt8_mma_issue(f32x16& c0, f32x16& c1, const i32x
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // one K-tile = 4 phases.  TAIL = false: every issued unit exists (t + 2 < nk) and the waits are compile-time counts.
-// LDS balance: the fragment reads of a K-tile are 24 KB per wave (A 16 KB, B 8 KB) and the LDS port is as busy as the matrix
-// pipe (192 KB of reads + 64 KB of DMA writes per K-tile and CU at 128 B/clk = the 2048 cycles of its MFMAs), so the reads
-// must be spread evenly over the four phases: each phase's reads of one wave group run under the OTHER group's 256-cycle MFMA
-// block.  Rounds 2-4 read {b0 + a0 + a1, b1, a0 + a1, -} = 12 / 4 / 8 / 0 KB per wave: phase 0's 48 KB per group took 384
-// cycles of LDS time under a 256-cycle block (and phase 3 left the port idle).  Now B fragment 0 of the NEXT K-tile is read
-// in phase 3 (into b0n; copied to b0 after the phase's MFMAs, which still use the current one): 8 / 4 / 8 / 4 KB.  Its DMA
-// unit (B0 of K-tile t + 1, issued in phase 3 of K-tile t - 1) is retired by an extra counted wait in phase 2.
 template <typename T, bool TAIL, bool SW>
 __device__ __forceinline__ void nt8_ktile(int t, int nk, const NT8Lane& L, char* smem, const char* aP, const char* bP,
-                                          const char* bPn, f32x16 (&acc)[4][2], i32x4 (&a0)[4], i32x4 (&a1)[4],
-                                          i32x4 (&b0)[4], i32x4 (&b1)[4], i32x4 (&b0n)[4]) {
+                                          f32x16 (&acc)[4][2], i32x4 (&a0)[4], i32x4 (&a1)[4], i32x4 (&b0)[4],
+                                          i32x4 (&b1)[4]) {
     constexpr int RB = 128;
     const int U = 4 * nk;
     const bool l1 = !TAIL || t + 1 < nk, l2 = !TAIL || t + 2 < nk;
-    // (the LDS-slab epilogue variant keeps its first mask chunk in 16 registers: no room for b0n - it reads b0 in phase 0 as before)
-    constexpr bool AHEAD = SW;
-    // ---- phase 0: A sub-tile 0 (B fragment 0 is in registers) -> quadrant (0, 0); issues B1 of K-tile t + 1
-    if constexpr (!AHEAD) nt8_read(b0, bP, L);
+    // ---- phase 0: A sub-tile 0, B fragment 0 -> quadrant (0, 0); issues B1 of K-tile t + 1
+    nt8_read(b0, bP, L);
     nt8_read(a0, aP, L);
     nt8_read(a1, aP + 32 * RB, L);
     if (!TAIL) wait_dma_units<3>();
     else wait_dma_units_rt(min(U, 4 * t + 6) - (4 * t + 3));
     nt8_sync_in();
     nt8_mma_issue<T, 2, SW>(acc[0][0], acc[1][0], a0, a1, b0, L, smem, t + 1, l1);
-    nt8_sync_out();
     // ---- phase 1: B fragment 1 -> quadrant (0, 1); issues A1 of K-tile t + 1
     nt8_read(b1, bP + 32 * RB, L);
     if (!TAIL) wait_dma_units<3>();
     else wait_dma_units_rt(min(U, 4 * t + 7) - (4 * t + 4));
     nt8_sync_in();
     nt8_mma_issue<T, 3, SW>(acc[0][1], acc[1][1], a0, a1, b1, L, smem, t + 1, l1);
-    nt8_sync_out();
-    // ---- phase 2: A sub-tile 1 -> quadrant (1, 1); issues A0 of K-tile t + 2; the wait retires B0 of K-tile t + 1 (unit
-    // 4 t + 5; issued so far: up to 4 t + 7) for the read in phase 3
+    // ---- phase 2: A sub-tile 1 -> quadrant (1, 1); issues A0 of K-tile t + 2
     nt8_read(a0, aP + 64 * RB, L);
     nt8_read(a1, aP + 96 * RB, L);
-    if constexpr (AHEAD) {
-        if (!TAIL) wait_dma_units<2>();
-        else if (t + 1 < nk) wait_dma_units_rt(min(U, 4 * t + 8) - (4 * t + 6));
-    }
     nt8_sync_in();
     nt8_mma_issue<T, 0, SW>(acc[2][1], acc[3][1], a0, a1, b1, L, smem, t + 2, l2);
-    nt8_sync_out();
-    // ---- phase 3: quadrant (1, 0) with the current b0; reads B fragment 0 of K-tile t + 1; issues B0 of K-tile t + 2; the
-    // wait retires A0 of K-tile t + 1 for the next phase 0
-    if constexpr (AHEAD) {
-        if (!TAIL || t + 1 < nk) nt8_read(b0n, bPn, L);
-    }
+    // ---- phase 3: quadrant (1, 0); issues B0 of K-tile t + 2; the wait retires A0 / B0 of K-tile t + 1 for the next phase 0
     if (!TAIL) wait_dma_units<3>();
     else if (t + 1 < nk) wait_dma_units_rt(min(U, 4 * t + 9) - (4 * t + 6));
     nt8_sync_in();
     nt8_mma_issue<T, 1, SW>(acc[2][0], acc[3][0], a0, a1, b0, L, smem, t + 2, l2);
-    nt8_sync_out();
-    if constexpr (AHEAD) {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) b0[ks] = b0n[ks];
-    }
 }
 
 
@@ -773,20 +761,16 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(NTParams p) {
     if (p.prof && tid == 0) p.prof[blockIdx.x * 4 + 1] = p.prof_clk ? (unsigned long long)clock64() : wall_clock64();
     if (wr == 1) NT8_BARRIER();                  // the second wave group runs one barrier behind
 
-    i32x4 a0[4], a1[4], b0[4], b1[4], b0n[4];
+    i32x4 a0[4], a1[4], b0[4], b1[4];
     const int aoff = wr * 128 * RB, boff = BM * RB + wc * 64 * RB;
-    // B fragment 0 of K-tile 0 (landed: the prologue's wait + barrier); every later one is read in phase 3 of the tile before
-    if constexpr (SW) nt8_read(b0, smem + boff, L);
     int t = 0;
     for (; t + 2 < nk; ++t) {
         const char* buf = smem + (t & 1) * kBuf;
-        const char* nxt = smem + ((t + 1) & 1) * kBuf;
-        nt8_ktile<T, false, SW>(t, nk, L, smem, buf + aoff, buf + boff, nxt + boff, acc, a0, a1, b0, b1, b0n);
+        nt8_ktile<T, false, SW>(t, nk, L, smem, buf + aoff, buf + boff, acc, a0, a1, b0, b1);
     }
     for (; t < nk; ++t) {
         const char* buf = smem + (t & 1) * kBuf;
-        const char* nxt = smem + ((t + 1) & 1) * kBuf;
-        nt8_ktile<T, true, SW>(t, nk, L, smem, buf + aoff, buf + boff, nxt + boff, acc, a0, a1, b0, b1, b0n);
+        nt8_ktile<T, true, SW>(t, nk, L, smem, buf + aoff, buf + boff, acc, a0, a1, b0, b1);
     }
     if (wr == 0) NT8_BARRIER();
     __syncthreads();                             // the ring becomes the epilogue slab
