@@ -5,6 +5,7 @@ port's figure can be read as the reference's.  TEST / MEASUREMENT INFRASTRUCTURE
 container); writes profiles/r04_reference_cpu_timing.json.
 
     python oracle/time_reference.py [--steps 6] [--threads N]
+    python oracle/time_reference.py --config amp_cfg1      # BASELINE configs[0]: the reference's whole train_epoch update, CPU
 """
 import argparse
 import json
@@ -23,12 +24,62 @@ from oracle import restated as R  # noqa: E402
 from oracle.make_golden import _yaml  # noqa: E402
 
 
+def time_amp_cfg1(a):
+    """BASELINE.json configs[0] ("this IS the baseline config"): the reference's AMPAgent - 64 envs x horizon 16,
+    obs 253 / act 31 / amp obs 1400, [256, 128] MLPs, minibatch 256 / amp 64, 6 mini-epochs = 24 optimisation steps - running its
+    OWN train_epoch (learning/amp_agent.py:181-264: demo refresh, tail of play_steps, dataset, 24 x calc_gradients + Adam, replay
+    store) on the synthetic rollout, the simulator loop replaced by the statements behind it exactly as oracle/make_golden.py does
+    for the golden vectors (amp_cfg1.pt).  Metric = BASELINE's: samples / update time."""
+    from oracle import make_golden as MG
+    from ase_amd.synthetic import EnvSpec, SyntheticSource
+    ncpu = a.threads or len(os.sched_getaffinity(0))
+    torch.set_num_threads(ncpu)
+    net, cfg = MG._case('amp_cfg1')
+    N, H = 64, cfg['horizon_length']
+    spec = EnvSpec(num_envs=N, horizon=H, obs_size=253, act_size=31, amp_obs_size=1400, latent_dim=0, latent_steps_min=1,
+                   latent_steps_max=2, episode_length=20)
+    src = SyntheticSource(spec, seed=1234 + 21)
+    torch.manual_seed(21)
+    A = ref_runner.build_ref_agent('amp', net, cfg, num_envs=N, obs_size=253, act_size=31, amp_obs_size=1400,
+                                   demo_fetch=src.fetch_amp_obs_demo, seed=21)
+    A._init_amp_demo_buf()
+    A.play_steps = lambda: MG._tail(A, 'amp')
+    times = []
+    for ep in range(a.steps + 2):
+        exp = src.experience(MG._policy_from_agent(A, 'amp'), with_amp=True, with_latents=False)
+        td = A.experience_buffer.tensor_dict
+        for k, v in exp.items():
+            if k in td:
+                td[k].copy_(v)
+        A.epoch_num += 1
+        t0 = time.time()
+        with ref_runner._Quiet():
+            A.train_epoch()          # REFERENCE CODE, unmodified
+        times.append(time.time() - t0)
+    tt = sorted(times[2:])
+    med = tt[len(tt) // 2]
+    n_steps = cfg['mini_epochs'] * (N * H // cfg['minibatch_size'])
+    out = {'what': 'BASELINE configs[0]: the UNMODIFIED reference AMPAgent.train_epoch (learning/amp_agent.py:181-264) without the simulator '
+                   'loop, 64 envs x horizon 16 = 1024 samples, [256, 128] MLPs, 24 optimisation steps per update; median of the updates '
+                   'after two warm-up ones, host CPU',
+           'cores': ncpu, 'updates_timed': len(tt), 's_per_update': round(med, 4), 'samples_per_s': round(N * H / med, 1),
+           'optimisation_steps_per_update': n_steps, 'ms_per_optimisation_step': round(med / n_steps * 1e3, 2),
+           'all_s': [round(t, 4) for t in times], 'code': 'ase/learning/amp_agent.py (imported unmodified through oracle/ref_runner.py)'}
+    path = os.path.join(ROOT, 'profiles', 'r05_reference_cpu_timing_cfg1.json')
+    with open(path, 'w') as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument('--config', default='ase_cfg2', choices=['ase_cfg2', 'amp_cfg1'])
     ap.add_argument('--steps', type=int, default=6)
     ap.add_argument('--threads', type=int, default=0, help='torch CPU threads (0 = all cores this process may use)')
     ap.add_argument('--out', default=os.path.join(ROOT, 'profiles', 'r04_reference_cpu_timing.json'))
     a = ap.parse_args()
+    if a.config == 'amp_cfg1':
+        return time_amp_cfg1(a)
     ncpu = a.threads or len(os.sched_getaffinity(0))
     torch.set_num_threads(ncpu)
     y = _yaml('ase_humanoid.yaml')                       # the reference's own yaml, verbatim: config 2

@@ -27,12 +27,15 @@ ase_amd.configure(cpu_threads=1)     # hardware queues before HIP initialises; o
 import torch  # noqa: E402
 
 
-def build(kind, num_envs, precision, graph=True, overrides=None):
+def build(kind, num_envs, precision, graph=True, overrides=None, net_overrides=None):
     from ase_amd import cfg as defaults
     from ase_amd.learning import agents, models
     from ase_amd.learning.network_builder import AMPBuilder, ASEBuilder, HRLBuilder
     from ase_amd.synthetic import EnvSpec, SyntheticSource
     net_p, cfg = defaults.get(kind)
+    cfg.update({k: v for k, v in (overrides or {}).items() if k == 'horizon_length'})
+    for part, units in (net_overrides or {}).items():
+        net_p[part]['units'] = list(units)
     obs, act, amp = {'ase': (253, 31, 1400), 'amp': (253, 31, 1400), 'hrl': (258, 64, 0)}[kind]
     z = cfg.get('latent_dim', 0) if kind == 'ase' else 0
     spec = EnvSpec(num_envs=num_envs, horizon=cfg['horizon_length'], obs_size=obs, act_size=act, amp_obs_size=amp,
@@ -109,12 +112,20 @@ def main():
             del ag
             torch.cuda.empty_cache()
         return
+    # BASELINE configs[0] at its OWN size (64 envs x horizon 16, [256, 128] MLPs, minibatch 256 / amp 64, 24 optimisation steps):
+    # the case the reference's CPU path is timed on (oracle/time_reference.py --config amp_cfg1) - launch-bound on a GPU
+    cfg1 = dict(horizon_length=16, minibatch_size=256, mini_epochs=6, amp_minibatch_size=64, amp_batch_size=128,
+                amp_obs_demo_buffer_size=512, amp_replay_buffer_size=2048)
     runs = [('amp', 'amp', 4096, 'bf16'), ('hrl', 'hrl', 4096, 'bf16'), ('ase16k', 'ase', 16384, 'bf16'),
-            ('ase-f32', 'ase', 4096, 'f32'), ('ase-bf16x3', 'ase', 4096, 'bf16x3')]
+            ('ase-f32', 'ase', 4096, 'f32'), ('ase-bf16x3', 'ase', 4096, 'bf16x3'), ('amp-cfg1', 'amp', 64, 'f32'),
+            ('amp-cfg1-bf16', 'amp', 64, 'bf16')]
     for name, kind, envs, prec in runs:
         if args.only and name not in args.only.split(','):
             continue
-        ag, cfg, spec = build(kind, envs, prec)
+        if name.startswith('amp-cfg1'):
+            ag, cfg, spec = build(kind, envs, prec, overrides=cfg1, net_overrides={'mlp': [256, 128], 'disc': [256, 128]})
+        else:
+            ag, cfg, spec = build(kind, envs, prec)
         dt = time_updates(ag, args.updates if prec == 'bf16' else 2)
         B = ag.batch_size
         steps = cfg['mini_epochs'] * (B // cfg['minibatch_size'])

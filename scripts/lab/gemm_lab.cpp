@@ -104,7 +104,15 @@ static int run_grouped(int reps) {
     double flops = 0;
     for (int i = 0; i < P; ++i) {
         const Shape& h = shapes[i];
-        CK(hipMalloc(&A[i], (int64_t)h.M * h.N * 2)); CK(hipMalloc(&B[i], (int64_t)h.M * h.K * 2));
+        // LAB_TNG_ALIAS=1: every problem reads the SAME two operand buffers (the largest shapes': 64 + 92 MB, inside the 256 MB
+        // Infinity Cache) - the launch's time with its operand traffic served on-die, i.e. how much of it is memory time
+        static bf16_t *A0 = nullptr, *B0 = nullptr;
+        if (getenv("LAB_TNG_ALIAS") && atoi(getenv("LAB_TNG_ALIAS"))) {
+            if (!A0) { CK(hipMalloc(&A0, (int64_t)32768 * 1024 * 2)); CK(hipMalloc(&B0, (int64_t)32768 * 1408 * 2)); }
+            A[i] = A0; B[i] = B0;
+        } else {
+            CK(hipMalloc(&A[i], (int64_t)h.M * h.N * 2)); CK(hipMalloc(&B[i], (int64_t)h.M * h.K * 2));
+        }
         CK(hipMalloc(&G[i], (int64_t)h.N * h.K * 4)); CK(hipMalloc(&gb[i], h.N * 4));
         fill_kernel<<<1024, 256, 0, st>>>(A[i], (int64_t)h.M * h.N, 11 + i, 1.0f);
         fill_kernel<<<1024, 256, 0, st>>>(B[i], (int64_t)h.M * h.K, 77 + i, 0.05f);
