@@ -402,12 +402,15 @@ class UpdateEngine:
             self.amp_state = torch.zeros(2 * self.amp + 1, dtype=torch.float64, device=dev)
             self.amp_state[self.amp:] = 1.0
         # every per-step partial statistic that the data-parallel ranks exchange lives in ONE f64 buffer
-        # [obs sums | amp sums x3 | mask sum]: one small all-reduce per step
+        # [amp sums x3 | obs sums | mask sum]: one small all-reduce per step when the step runs its statistics in a
+        # serial prologue; with the branch heads un-chained (cross-step schedule) each head exchanges ITS slice on its own stream -
+        # the amp block from the discriminator's head, [obs | mask] (contiguous) from the policy prologue
         n_amp = 3 * 2 * self.amp if self.has_disc else 0
-        self.stats_flat = torch.zeros(2 * self.obs + n_amp + 1, dtype=torch.float64, device=dev)
-        self.obs_sums = self.stats_flat[:2 * self.obs]
+        self.stats_flat = torch.zeros(n_amp + 2 * self.obs + 1, dtype=torch.float64, device=dev)
+        self.obs_sums = self.stats_flat[n_amp:n_amp + 2 * self.obs]
         if self.has_disc:
-            self.amp_sums = self.stats_flat[2 * self.obs:2 * self.obs + n_amp].view(3, 2 * self.amp)
+            self.amp_sums_flat = self.stats_flat[:n_amp]
+            self.amp_sums = self.amp_sums_flat.view(3, 2 * self.amp)
         self.obs_mean = zt(1, self.obs, f32)
         self.obs_std = zt(1, self.obs, f32)
         self.obs_state = torch.zeros(2 * self.obs + 1, dtype=torch.float64, device=dev)
@@ -726,6 +729,7 @@ class UpdateEngine:
     def phase_stats(self, ds, idx, remap, amp_streams=None, advance=True, new_z=None):
         be, c, M, AMB = self.be, self.cfg, self.M, self.AMB
         self._disc_fwd_out = None
+        self._stats_exchanged = False
         if self._xs:
             # Cross-step schedule: the head of the discriminator branch goes FIRST into the step's launch sequence and waits
             # for nothing on the main stream.  On its own stream it follows the branch's optimizer step of the previous
@@ -759,7 +763,10 @@ class UpdateEngine:
                 be.begin_step(None, None, zero2=self.obs_sums, rng_bump=self.div_rng if self.div_on else None)
                 if c.get('normalize_input', True):
                     be.rms_moments(ds['obs'], self.obs, idx, remap, M, self.obs_state, self.obs_sums)
-                    be.rms_finalize(self.obs_state, self.obs, self.obs_sums, self.M, 1, self.obs_mean, self.obs_std)
+                    if self._dist_shard():
+                        self._ar(self.obs_sums)          # (sharded data parallel: the ranks' partial sums, on this stream)
+                    be.rms_finalize(self.obs_state, self.obs, self.obs_sums, self.Mg if self.shard else self.M, 1, self.obs_mean,
+                                    self.obs_std)
                 else:
                     self._identity_stats(self.obs_mean, self.obs_std)
                 outs = [self.Xa[:M], self.Xc]
@@ -784,8 +791,11 @@ class UpdateEngine:
                 be.zero_(self.grads[plo:phi])
                 if self.masked:
                     be.reduce_sum(self.mb['rand_action_mask'], M, False, self.acc, L.ACC_MASK_SUM)
+                    if self._dist_shard():
+                        self._ar(self.acc[L.ACC_MASK_SUM:L.ACC_MASK_SUM + 1])
             self._fill_done = None
             self._prep = prep
+            self._stats_exchanged = True
             return
         # one launch: Adam step counter / bias corrections (advance=False - calc_gradients-style calls - leaves them),
         # loss accumulators and per-step partial statistics zeroed, position of the diversity-latent stream advanced
@@ -833,9 +843,19 @@ class UpdateEngine:
             self._amp_moments(amp_streams)
 
     def _amp_stats_in_branch(self):
-        """Single GPU: nothing is exchanged between the phases, so the amp-observation moments run at the head of the
-        discriminator branch (its own stream) next to the actor / critic kernels instead of in the serial prologue."""
-        return self.multi_stream and not self._dist_on()
+        """With streams the amp-observation moments run at the head of the discriminator branch (its own stream) next to the
+        actor / critic kernels instead of in a serial prologue.  Sharded data parallel: the head exchanges its block of partial
+        sums itself (_exchange_amp_sums) - round 4 fell back to the serial prologue and, with it, to round 3's schedule whenever
+        a step contained collectives.  (Captured hipGraphs cannot hold a collective: that mode keeps the serial prologue and
+        the exchange between its graphs.)"""
+        return self.multi_stream and not (self._dist_shard() and self.cfg.get('graph_capture') == 'hipgraph')
+
+    def _dist_shard(self):
+        return self._dist_on() and self.shard
+
+    def _exchange_amp_sums(self):
+        if self._dist_shard():
+            self._ar(self.amp_sums_flat)
 
     def _amp_moments(self, amp_streams):
         if self.cfg.get('normalize_amp_input', True):       # (the partial sums were zeroed by begin_step)
@@ -931,6 +951,7 @@ class UpdateEngine:
         amb_den = self.AMBg if self.shard else self.AMB
         if self._amp_stats_in_branch():
             self._amp_moments(amp_streams)
+            self._exchange_amp_sums()
         if norm_amp:
             be.rms_finalize(self.amp_state, self.amp, self.amp_sums, amb_den, 3, self.amp_mean, self.amp_std)
         else:
@@ -1513,10 +1534,16 @@ class UpdateEngine:
         return self.R > 1 or self.force_dist
 
     def _allreduce_stats(self):
-        if self._dist_on() and self.shard:
+        """Exchange of the step's partial statistics when it is NOT done inside the un-chained heads (_stats_exchanged): the
+        observation sums and the mask sum here; the amp block too unless the discriminator's head - which computes it on its own
+        stream whenever streams exist - has exchanged it (_exchange_amp_sums)."""
+        if self._dist_shard() and not self._stats_exchanged:
+            if self._prep is not None:
+                self._join_branch(self._prep)          # (short prologue: the mask sum was formed on the critic's stream)
             if self.masked:
                 self.be.copy_(self.stats_flat[-1:], self.acc[L.ACC_MASK_SUM:L.ACC_MASK_SUM + 1])
-            self._ar(self.stats_flat)
+            n_amp = self.amp_sums_flat.numel() if (self.has_disc and self._amp_stats_in_branch()) else 0
+            self._ar(self.stats_flat[n_amp:])
             if self.masked:
                 self.be.copy_(self.acc[L.ACC_MASK_SUM:L.ACC_MASK_SUM + 1], self.stats_flat[-1:])
 
