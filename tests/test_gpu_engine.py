@@ -275,10 +275,11 @@ def test_epoch_tail_full_size_vs_oracle(precision):
 
 
 @pytest.mark.parametrize('mode,fresh_loss,fresh_grad,stress_loss,stress_grad', [
-    ('f16', 5e-4, 6e-2, 1e-3, 0.35),        # measured 3.5e-5 ... 3.4e-4 (the gradient penalty; every other scalar <= 4e-5: 1e-4 asserted below) / 3.3e-2 / 1.9e-4 / 0.20
-    # (stress-state bounds: kl there is quadratic in a mean shift that is itself ~1 - 2-3e-4 measured for the half modes)
-    ('f16gp32', 1e-4, 6e-2, 1e-3, 0.35),    # f16 with the penalty's value path in exact f32: 1e-4 on EVERY scalar of the fresh step
-    ('f16gpx3', 1e-4, 6e-2, 1e-3, 0.35),    # ... with three-bf16-MFMA products on that path (penalty within 3e-5)
+    ('f16', 5e-4, 5e-2, 1e-3, 0.35),        # measured 3.5e-5 ... 3.4e-4 (the gradient penalty; every other scalar <= 4e-5: 1e-4 asserted below) / 3.3e-2 / 1.9e-4 / 0.20
+    # (stress-state bounds: kl there is quadratic in a mean shift that is itself ~1 - 1e-4 ... 3e-4 measured for the half modes,
+    #  a systematic error of the 16-bit weight shadows: bench.py's KL_TOL; every TERM OF THE LOSS is held to 1e-4 in both states below)
+    ('f16gp32', 1e-4, 5e-2, 1e-3, 0.35),    # f16 with the penalty's value path in exact f32: 1e-4 on EVERY scalar of the fresh step
+    ('f16gpx3', 1e-4, 5e-2, 1e-3, 0.35),    # ... with three f16 MFMAs per product on scaled hi / lo splits (penalty within 2e-6)
     ('bf16', 8e-3, 0.2, 6e-3, 0.7),         # measured 3.7e-3 (kl) / 0.10 / 2.5e-3 / 0.48
     ('f32', 1e-4, 2e-3, 1e-4, 5e-3)])       # measured 4.6e-6 / 5e-4 / 2.5e-7 / 8.6e-4
 def test_self_consistent_parity_config2(mode, fresh_loss, fresh_grad, stress_loss, stress_grad):
@@ -304,6 +305,20 @@ def test_self_consistent_parity_config2(mode, fresh_loss, fresh_grad, stress_los
     assert f['max_loss_rel'] <= fresh_loss and f['max_count_stat_abs'] <= 1e-3 and f['worst_grad_rel_l2'] <= fresh_grad, f
     if mode == 'f16':      # BASELINE's 1e-4 on everything but the penalty (a cancelling sum in half-rounded weights: DESIGN 3.2)
         assert f['max_loss_rel_without_grad_penalty'] <= 1e-4, f
+    if mode in ('f16gp32', 'f16gpx3', 'f32'):
+        # the bench's bar, both states: every TERM OF THE LOSS within 1e-4 (kl judged apart, see above), and the penalty - what
+        # the value path exists for - within 2e-5 even in the stress state (round 4's bf16 split: 1.08e-4 in the driver's run)
+        assert bench._state_ok(f, 'fresh') and bench._state_ok(st, 'stress'), (f['loss_rel'], st['loss_rel'])
+        assert bench._loss_terms_rel(st)[0] <= 1e-4 and st['loss_rel']['disc_grad_penalty'] <= 2e-5, st['loss_rel']
+    # gradients with the oracle evaluated at the ENGINE's ReLU derivative masks: the arithmetic error without the sign flips of
+    # near-zero units (a flipped fraction f of the masks is sqrt(f) in relative L2: ~1e-4 of the units = 1-3 % in half storage,
+    # profiles/r05_grad_error_sources.txt) - round 4's verdict asked for median 5e-3 / worst 2e-2 on the fresh rollout
+    gm = f.get('grad_at_engine_masks')
+    assert gm is not None
+    print(mode, 'fresh gradients at the engine masks', gm['median_grad_rel_l2'], gm['worst_grad_rel_l2'], gm['flipped_mask_fraction'])
+    if mode != 'bf16':
+        assert gm['median_grad_rel_l2'] <= 5e-3 and gm['worst_grad_rel_l2'] <= 2e-2, gm
+        assert gm['flipped_mask_fraction'] <= (1e-6 if mode == 'f32' else 5e-4), gm
     # (bf16's importance ratio is noisy enough to flip ~0.4 % of the clip decisions in the off-policy state)
     assert st['max_loss_rel'] <= stress_loss and st['max_count_stat_abs'] <= (1e-2 if mode == 'bf16' else 2e-3), st
     # off-policy, 94 % of the samples are clipped and the actor gradient is what the few unclipped ones leave: when ONE sample
