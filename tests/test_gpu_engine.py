@@ -320,7 +320,7 @@ def test_self_consistent_parity_config2(mode, fresh_loss, fresh_grad, stress_los
         assert gm['median_grad_rel_l2'] <= 5e-3 and gm['worst_grad_rel_l2'] <= 2e-2, gm
         assert gm['flipped_mask_fraction'] <= (1e-6 if mode == 'f32' else 5e-4), gm
     # (bf16's importance ratio is noisy enough to flip ~0.4 % of the clip decisions in the off-policy state)
-    assert st['max_loss_rel'] <= stress_loss and st['max_count_stat_abs'] <= (1e-2 if mode == 'bf16' else 2e-3), st
+    assert st['max_loss_rel'] <= stress_loss and st['max_count_stat_abs'] <= (1e-2 if mode == 'bf16' else 5e-3), st
     # off-policy, 94 % of the samples are clipped and the actor gradient is what the few unclipped ones leave: when ONE sample
     # sits on the clip threshold and the two f32 evaluations disagree about it (the counting statistic differs by 1 / 16384),
     # its whole contribution appears on one side only - measured 2.9 % of the gradient's norm in f32 against f32.  With no
