@@ -107,3 +107,31 @@ def test_round4_bench_line_is_compact_and_complete():
     assert d['qualifying_mode']['precision'] == 'f16gpx3' and d['qualifying_mode']['is_headline']
     assert d['throughput_mode']['precision'] == 'bf16' and d['throughput_mode']['value'] > d['value']
     assert d['config5_16384_envs']['value'] > 0
+
+
+def test_round5_bench_line_headline_holds_the_bar():
+    """The driver-form line of round 5 as committed (profiles/r05_bench_n1.json): --precision auto chose f16gpx3 with NO fall-through,
+    every term of the loss within 1e-4 in both rollout states, the gradient penalty within 1e-5, the tolerances spelled out in the
+    line, strict_mode present with a true relative error below 1e-4, and the detail file beside it carries the mask-aware gradients."""
+    raw = open(os.path.join(ROOT, 'profiles', 'r05_bench_n1.json')).read().strip().splitlines()[-1]
+    assert len(raw) < 5000
+    d = json.loads(raw)
+    assert d['config']['precision_mode'].startswith('f16gpx3') and d['config']['precision_choice'].startswith('auto')
+    assert d['fallthrough'] == [] and d['parity']['headline_ok'] is True
+    assert abs(d['value'] - d['config']['samples_per_step'] / (d['ms_per_step'] * 1e-3)) <= 1e-3 * d['value']
+    tol = d['parity']['tol']
+    assert tol['rtol'] == 1e-4 and tol['atol'] == {'actor_loss': 1e-4, 'enc_loss': 1e-4} and tol['kl'] == {**tol['kl'], 'fresh_rtol': 1e-4, 'stress_rtol': 1e-3}
+    for st in ('fresh', 'stress'):
+        p = d['parity'][st]
+        assert p['ok'] and p['max_loss_term_rel'] <= 1e-4 and p['kl_rel'] <= tol['kl'][st + '_rtol'], (st, p)
+        assert p['grad_at_engine_masks']['median_grad_rel_l2'] <= 5e-3
+    assert d['parity']['fresh']['grad_at_engine_masks']['worst_grad_rel_l2'] <= 2e-2
+    sm = d['strict_mode']
+    assert sm['ok'] and sm['fresh_max_true_rel'] <= 1e-4 and sm['stress_max_true_rel'] <= 1e-4 and sm['precision'] in ('bf16x3', 'f32')
+    r = d['roofline']
+    assert r['bound'] == 'mfma' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and r['traffic'] > r['algorithmic_bytes_per_launch']
+    assert r['traffic_source'] == 'profiles/r05_pmc.json'
+    full = json.load(open(os.path.join(ROOT, 'profiles', 'r05_bench_n1_detail.json')))
+    for st in ('fresh', 'stress'):
+        lr = full['parity'][st]['loss_rel']
+        assert lr['disc_grad_penalty'] <= 1e-5, (st, lr['disc_grad_penalty'])
