@@ -183,6 +183,7 @@ class UpdateEngine:
         self._enc_z_ready = False
         self._prefetch = bool(o['prefetch'])
         self._par, self._par_set, self._last_par, self._fenced = 0, False, None, False
+        self._stats_exchanged = False    # this step's partial statistics were exchanged inside the un-chained heads (phase_stats)
         self._style_wg = int(o['style_wg'])
         sp = o['side_priority']
         if sp is None:
