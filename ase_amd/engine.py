@@ -450,8 +450,7 @@ class UpdateEngine:
         steps must alternate - the next step's un-chained prologue writes one set while the previous step's weight-gradient
         launch still reads the other - unless the branch streams were fenced in between (fence_side_streams, which the agents
         call once per mini-epoch).  use_slot implies it; a caller that drives neither is alternated by step() itself, and a
-        repeated parity without a fence is fenced there (or refused while a launch program records: a torch-level stream wait
-        is not a recordable entry)."""
+        repeated parity without a fence is fenced there."""
         self._par = p = p % len(self._Xa2)
         self._par_set = True
         self.Xa, self.Xc = self._Xa2[p], self._Xc2[p]
@@ -694,14 +693,17 @@ class UpdateEngine:
             self.fence_side_streams()
         if len(self._Xa2) == 2:
             # double-buffered inputs of the un-chained prologue (use_parity): alternate when the caller drives neither slots nor
-            # parity; the same set twice in a row is only safe behind a fence of the branch streams
-            if not self._par_set:
-                self.use_parity(self._par ^ 1 if self._last_par is not None else self._par)
-            if self._xs and self._par == self._last_par and not self._fenced:
-                assert getattr(self.be, '_recording', None) is None, \
-                    "two consecutive steps on the same input-buffer set without fence_side_streams() while a launch program records"
-                self.fence_side_streams()
-            self._last_par, self._par_set, self._fenced = self._par, False, False
+            # parity; the same set twice in a row is only safe behind a fence of the branch streams.  While a launch program
+            # records, the call RE-ISSUES the step the caller has just executed eagerly (agents._graph_step): same set, nothing
+            # is launched - its replays are ordered by the alternation of the recorded slots and the caller's per-mini-epoch fences
+            rec = getattr(self.be, '_recording', None) is not None
+            if not rec:
+                if not self._par_set:
+                    self.use_parity(self._par ^ 1 if self._last_par is not None else self._par)
+                if self._xs and self._par == self._last_par and not self._fenced:
+                    self.fence_side_streams()
+                self._last_par = self._par
+            self._par_set, self._fenced = False, False
         self.phase_stats(ds, idx, remap, amp_streams, advance=apply, new_z=new_z)
         self._allreduce_stats()
         self._lr_live = apply          # (calc_gradients-style calls without the optimizer step leave the learning rate alone)
