@@ -13,7 +13,12 @@ int nt_choice(int M, int N, int K, int es, bool b16) {
     if (N <= 64) return 0;
     const int t256 = ((M + 255) / 256) * ((N + 255) / 256);
     const bool big = N % 256 == 0 && t256 >= 192 && (t256 <= 256 || t256 % 256 == 0 || t256 >= 1024);
-    if (big) return (b16 && (K * es) % 128 == 0) ? 2 : 3;
+    if (big) {
+        if (!(b16 && (K * es) % 128 == 0)) return 3;
+        // one round that leaves CUs idle (12288 x 1024: 192 tiles): 192-row tiles of the same schedule fill them
+        const int t192 = ((M + 191) / 192) * (N / 256);
+        return (t256 < 256 && t192 <= 256 && t192 > t256) ? 6 : 2;
+    }
     if ((K * es) % 128 != 0) return 1;
     // grids that do not fill the phased kernel's rounds: the LARGEST of the 128 x 128 / 64 x 128 / 64 x 64 tiles that still
     // gives two workgroups per CU (measured: 4096 x 1024 x 1024  21.1 -> 17.6 us, 4096 x 512 x 1024  19.3 -> 11.4 us,

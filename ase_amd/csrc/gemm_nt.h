@@ -79,9 +79,10 @@ __device__ __forceinline__ f32x16 nt8_mfma(const i32x4& a, const i32x4& b, const
 // a wave tile are fetched before the main loop (bits[]); the forward's mask_out word is assembled from the two
 // half-waves' 16 bits each with one more swap.  Needs whole 64-column wave tiles (N % 64 == 0) and a bf16 output.
 // NJ: 32-column fragments of the wave tile (2: the 8-wave kernel's 128 x 64, 4: the 4-wave kernel's 128 x 128).
-template <typename T, int AUXK, int NJ = 2>
-__device__ __forceinline__ void nt8_epilogue_rows(const NTParams& p, f32x16 (&acc)[4][NJ], int lane, int mrow0, int ncol0,
-                                                  const uint32_t (&bits)[4][NJ]) {
+// NI: 32-row blocks of the wave tile (4: the 256 x 256 tiles' 128 rows per wave row, 3: the 192 x 256 tile's 96).
+template <typename T, int AUXK, int NJ = 2, int NI = 4>
+__device__ __forceinline__ void nt8_epilogue_rows(const NTParams& p, f32x16 (&acc)[NI][NJ], int lane, int mrow0, int ncol0,
+                                                  const uint32_t (&bits)[NI][NJ]) {
     if (ncol0 >= p.N) return;                                   // wave-uniform: N is a multiple of the wave tile's width
     const int r = lane & 31, h = lane >> 5;
     f32x4 bias[NJ][4];
@@ -93,7 +94,7 @@ __device__ __forceinline__ void nt8_epilogue_rows(const NTParams& p, f32x16 (&ac
             else bias[j][g] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
         const int m = mrow0 + i * 32 + r;
         const bool row_ok = m < p.M;
         char* crow = p.C + (int64_t)m * p.ldc + (int64_t)ncol0 * 2 + h * 16;
@@ -175,6 +176,8 @@ extern int g_nt_prof_clk;                  // ... stamps 1, 2 in shader clocks (
 //   2: 256 x 256 tile, 8 waves, PHASED (16-bit storage, K in whole 128-byte steps)   192+ tiles in whole rounds
 //   3: 256 x 256 tile, 8 waves, lock-step (the 4-byte storage types)
 //   4:  64 x 128 tile, 4 waves / 5: 64 x 64 tile, 4 waves   small grids (M = 2048 ... 4096 rows, or N = 512): two workgroups per CU
+//   6: 192 x 256 tile, 8 waves, PHASED   grids of 192 ... 255 tiles of 256 x 256 that become <= 256 tiles of 192 x 256 (the
+//      discriminator's 12288 rows x 1024: 192 -> 256 workgroups)
 int nt_choice(int M, int N, int K, int es, bool b16);
 
 // one translation unit per storage type (gemm_nt_<type>.hip)

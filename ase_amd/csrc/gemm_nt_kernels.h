@@ -632,10 +632,34 @@ __device__ __forceinline__ void nt8_mma_issue(f32x16& c0, f32x16& c1, const i32x
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// ... and its half-height twin for the 192 x 256 tile's third A block: 4 MFMAs on one accumulator, same DMA / barrier placement
+template <typename T, int KIND, bool SW>
+__device__ __forceinline__ void nt8_mma_issue1(f32x16& c0, const i32x4 (&a0)[4], const i32x4 (&b)[4], const NT8Lane& L, char* smem,
+                                               int tile, bool live) {
+    constexpr int kBuf = 512 * 128;
+    char* buf = smem + (tile & 1) * kBuf;
+    const int64_t koff = (int64_t)tile * 128;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        if (ks == 3) NT8_BARRIER();
+        c0 = nt8_mfma<T, SW>(a0[ks], b[ks], c0);
+        if (ks == 0 || ks == 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (live)
+                __builtin_amdgcn_global_load_lds((gptr_t*)(L.src[KIND][ks >> 1] + koff), (lptr_t*)(buf + L.dst[KIND][ks >> 1]), 16, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // one K-tile = 4 phases.  TAIL = false: every issued unit exists (t + 2 < nk) and the waits are compile-time counts.
-template <typename T, bool TAIL, bool SW>
+// NI = 4: wave tile 128 x 64 (256 x 256 tile); NI = 3: wave tile 96 x 64 (192 x 256 tile) - phases 2 and 3 multiply ONE A block
+template <typename T, bool TAIL, bool SW, int NI = 4>
 __device__ __forceinline__ void nt8_ktile(int t, int nk, const NT8Lane& L, char* smem, const char* aP, const char* bP,
-                                          f32x16 (&acc)[4][2], i32x4 (&a0)[4], i32x4 (&a1)[4], i32x4 (&b0)[4],
+                                          f32x16 (&acc)[NI][2], i32x4 (&a0)[4], i32x4 (&a1)[4], i32x4 (&b0)[4],
                                           i32x4 (&b1)[4]) {
     constexpr int RB = 128;
     const int U = 4 * nk;
@@ -656,23 +680,30 @@ __device__ __forceinline__ void nt8_ktile(int t, int nk, const NT8Lane& L, char*
     nt8_mma_issue<T, 3, SW>(acc[0][1], acc[1][1], a0, a1, b1, L, smem, t + 1, l1);
     // ---- phase 2: A sub-tile 1 -> quadrant (1, 1); issues A0 of K-tile t + 2
     nt8_read(a0, aP + 64 * RB, L);
-    nt8_read(a1, aP + 96 * RB, L);
+    if constexpr (NI == 4) nt8_read(a1, aP + 96 * RB, L);
     nt8_sync_in();
-    nt8_mma_issue<T, 0, SW>(acc[2][1], acc[3][1], a0, a1, b1, L, smem, t + 2, l2);
+    if constexpr (NI == 4) nt8_mma_issue<T, 0, SW>(acc[2][1], acc[3][1], a0, a1, b1, L, smem, t + 2, l2);
+    else nt8_mma_issue1<T, 0, SW>(acc[2][1], a0, b1, L, smem, t + 2, l2);
     // ---- phase 3: quadrant (1, 0); issues B0 of K-tile t + 2; the wait retires A0 / B0 of K-tile t + 1 for the next phase 0
     if (!TAIL) wait_dma_units<3>();
     else if (t + 1 < nk) wait_dma_units_rt(min(U, 4 * t + 9) - (4 * t + 6));
     nt8_sync_in();
-    nt8_mma_issue<T, 1, SW>(acc[2][0], acc[3][0], a0, a1, b0, L, smem, t + 2, l2);
+    if constexpr (NI == 4) nt8_mma_issue<T, 1, SW>(acc[2][0], acc[3][0], a0, a1, b0, L, smem, t + 2, l2);
+    else nt8_mma_issue1<T, 1, SW>(acc[2][0], a0, b0, L, smem, t + 2, l2);
 }
 
 
 // SW: swapped MFMA operands + row-per-lane epilogue (nt8_epilogue_rows), else the LDS-slab epilogue
-template <typename T, bool SW>
+// BM = 192 (row-per-lane epilogue only): the same schedule on a 192 x 256 tile - wave tile 96 x 64, phases 2 / 3 are 4 MFMAs - for
+// row counts whose 256-row tiling leaves a quarter of the CUs idle (12288 x 1024: 192 tiles of 256 rows, 256 tiles of 192).  The
+// K-tile buffers keep their 64-KiB stride and B keeps following A (offset BM * 128); unit A1 covers rows 64-95 of BOTH wave rows
+// with one piece, its second piece repeats the first (same bytes, same place) so that the counted waits stay what they are.
+template <typename T, bool SW, int BM = 256>
 __global__ __launch_bounds__(512) void gemm_nt8_kernel(NTParams p) {
     static_assert(sizeof(T) == 2, "the phased kernel takes the 16-bit storage types");
-    constexpr int RB = 128, BM = 256, BN = 256, BK = 64;
-    constexpr int kBuf = (BM + BN) * RB;
+    static_assert(BM == 256 || (BM == 192 && SW), "192-row tiles come with the row-per-lane epilogue");
+    constexpr int RB = 128, BN = 256, BK = 64, WM = BM / 2, NI = WM / 32;
+    constexpr int kBuf = 512 * RB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -688,9 +719,10 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(NTParams p) {
         const int lr = lane >> 3, slot = lane & 7;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            const int ra = g * 128 + wid * 8;                           // A0 piece (A1: + 64)
+            const int ra = g * WM + wid * 8;                            // A0 piece (A1 of the 256-row tile: + 64)
             const int rb = (g * 2 + (wid >> 2)) * 64 + (wid & 3) * 8;   // B0 piece (B1: + 32)
-            const int rows[4] = {ra, rb, rb + 32, ra + 64};             // kind 0..3 = A0, B0, B1, A1
+            const int ra1 = BM == 256 ? ra + 64 : (wid >> 2) * WM + 64 + (wid & 3) * 8;
+            const int rows[4] = {ra, rb, rb + 32, ra1};                 // kind 0..3 = A0, B0, B1, A1
 #pragma unroll
             for (int kind = 0; kind < 4; ++kind) {
                 const int r = rows[kind] + lr;
@@ -705,9 +737,9 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(NTParams p) {
         for (int ks = 0; ks < 4; ++ks) L.roff[ks] = r * RB + (((ks * 2 + h) ^ sw) << 4);
     }
 
-    f32x16 acc[4][2];
+    f32x16 acc[NI][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -716,9 +748,9 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(NTParams p) {
     // the first chunk's mask words (16 registers) are fetched before anything else: older than every DMA, they retire
     // first and the epilogue finds them in registers instead of waiting an HBM round trip after the last K-tile
     AuxReg<T, 2> pre_bits[16];
-    uint32_t row_bits[4][2];
+    uint32_t row_bits[NI][2];
     if constexpr (!SW) {
-        if (p.aux_mode == ASE_AUX_RELU_BITS) nt_aux_load<T, 4, 2, 2, 2, 2>(p, 0, lane, bm0 + wr * 128, bn0 + wc * 64, pre_bits);
+        if (p.aux_mode == ASE_AUX_RELU_BITS) nt_aux_load<T, 4, 2, 2, 2, 2>(p, 0, lane, bm0 + wr * WM, bn0 + wc * 64, pre_bits);
     }
 
     const int nk = p.K / BK;
@@ -742,8 +774,8 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(NTParams p) {
         if (mask_dma) {
             char* mlds = smem + 2 * kBuf + wid * 1024;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = bm0 + wr * 128 + i * 32 + (lane & 31);
+            for (int i = 0; i < NI; ++i) {
+                const int m = bm0 + wr * WM + i * 32 + (lane & 31);
                 const int ma = (m >= p.aux_split) ? m - p.aux_delta : m;
                 const uint32_t* w = reinterpret_cast<const uint32_t*>(p.aux + (int64_t)min(ma, p.M - 1) * p.ldaux) +
                                     ((bn0 + wc * 64) >> 5) + (lane >> 5);
@@ -751,26 +783,26 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(NTParams p) {
             }
         }
     }
-    // units 0, 1 (A0 / B0 of K-tile 0) must have landed; the mask pieces (if any) are the 4 youngest entries of the queue
+    // units 0, 1 (A0 / B0 of K-tile 0) must have landed; the mask pieces (if any) are the NI youngest entries of the queue
     if (nk > 1) {
-        if (mask_dma) wait_vmcnt<8 + 4>(); else wait_dma_units<4>();
+        if (mask_dma) wait_vmcnt<8 + NI>(); else wait_dma_units<4>();
     } else {
-        if (mask_dma) wait_vmcnt<4 + 4>(); else wait_dma_units<2>();
+        if (mask_dma) wait_vmcnt<4 + NI>(); else wait_dma_units<2>();
     }
     NT8_BARRIER();
     if (p.prof && tid == 0) p.prof[blockIdx.x * 4 + 1] = p.prof_clk ? (unsigned long long)clock64() : wall_clock64();
     if (wr == 1) NT8_BARRIER();                  // the second wave group runs one barrier behind
 
     i32x4 a0[4], a1[4], b0[4], b1[4];
-    const int aoff = wr * 128 * RB, boff = BM * RB + wc * 64 * RB;
+    const int aoff = wr * WM * RB, boff = BM * RB + wc * 64 * RB;
     int t = 0;
     for (; t + 2 < nk; ++t) {
         const char* buf = smem + (t & 1) * kBuf;
-        nt8_ktile<T, false, SW>(t, nk, L, smem, buf + aoff, buf + boff, acc, a0, a1, b0, b1);
+        nt8_ktile<T, false, SW, NI>(t, nk, L, smem, buf + aoff, buf + boff, acc, a0, a1, b0, b1);
     }
     for (; t < nk; ++t) {
         const char* buf = smem + (t & 1) * kBuf;
-        nt8_ktile<T, true, SW>(t, nk, L, smem, buf + aoff, buf + boff, acc, a0, a1, b0, b1);
+        nt8_ktile<T, true, SW, NI>(t, nk, L, smem, buf + aoff, buf + boff, acc, a0, a1, b0, b1);
     }
     if (wr == 0) NT8_BARRIER();
     __syncthreads();                             // the ring becomes the epilogue slab
@@ -781,16 +813,18 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(NTParams p) {
         if (p.aux_mode == ASE_AUX_RELU_BITS) {
             const uint32_t* mw = reinterpret_cast<const uint32_t*>(smem + 2 * kBuf + wid * 1024);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NI; ++i) {
                 row_bits[i][0] = mw[i * 64 + (lane & 31)];
                 row_bits[i][1] = mw[i * 64 + 32 + (lane & 31)];
             }
-            nt8_epilogue_rows<T, 2>(p, acc, lane, bm0 + wr * 128, bn0 + wc * 64, row_bits);
-        } else nt8_epilogue_rows<T, 0>(p, acc, lane, bm0 + wr * 128, bn0 + wc * 64, row_bits);
-    } else if (p.aux_mode == ASE_AUX_RELU_BITS)
-        nt_epilogue_impl<T, 4, 2, 2, 2, 2, true>(p, acc, slab, lane, bm0 + wr * 128, bn0 + wc * 64, &pre_bits);
-    else
-        nt_epilogue<T, 4, 2, 2, 2>(p, acc, slab, lane, bm0 + wr * 128, bn0 + wc * 64);
+            nt8_epilogue_rows<T, 2, 2, NI>(p, acc, lane, bm0 + wr * WM, bn0 + wc * 64, row_bits);
+        } else nt8_epilogue_rows<T, 0, 2, NI>(p, acc, lane, bm0 + wr * WM, bn0 + wc * 64, row_bits);
+    } else if constexpr (BM == 256) {
+        if (p.aux_mode == ASE_AUX_RELU_BITS)
+            nt_epilogue_impl<T, 4, 2, 2, 2, 2, true>(p, acc, slab, lane, bm0 + wr * 128, bn0 + wc * 64, &pre_bits);
+        else
+            nt_epilogue<T, 4, 2, 2, 2>(p, acc, slab, lane, bm0 + wr * 128, bn0 + wc * 64);
+    }
     if (p.prof) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -798,10 +832,10 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(NTParams p) {
     }
 }
 
-template <typename T, bool SW = false> int launch_nt8(const NTParams& p0, hipStream_t stream) {
+template <typename T, bool SW = false, int BM = 256> int launch_nt8(const NTParams& p0, hipStream_t stream) {
     constexpr int lds = 2 * 512 * 128 + (SW ? 8 * 1024 : 0);     // ring + (row-per-lane epilogue) 1 KiB of mask words per wave
     static bool attr_done = false;
-    auto kern = gemm_nt8_kernel<T, SW>;
+    auto kern = gemm_nt8_kernel<T, SW, BM>;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -814,7 +848,7 @@ template <typename T, bool SW = false> int launch_nt8(const NTParams& p0, hipStr
     NTParams p = p0;
     p.prof = g_nt_prof;
     p.prof_clk = g_nt_prof_clk;
-    p.tiles_m = (p.M + 255) / 256;
+    p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + 255) / 256;
     ASE_LAUNCH(kern, dim3(p.tiles_m * p.tiles_n), dim3(512), lds, stream, p);
     ASE_CHECK_LAUNCH("gemm_nt8");
@@ -832,6 +866,9 @@ template <typename T> int dispatch_nt(const NTParams& p, hipStream_t s) {
     const bool k128 = (p.K * (int)sizeof(T)) % 128 == 0;       // 128-byte staged rows need K in whole 128-byte steps
     switch (nt_choice(p.M, p.N, p.K, (int)sizeof(T), sizeof(T) == 2)) {
         case 0: return launch_nt<T, 2, 2, 1, 1, 64, 4>(p, s);
+        case 6:
+            if constexpr (sizeof(T) == 2) if (rows_epi(p, 64)) return launch_nt8<T, true, 192>(p, s);
+            [[fallthrough]];
         case 2:
             if constexpr (sizeof(T) == 2) {
                 // row-per-lane epilogue (swapped MFMA operands): 16-bit output in whole 64-column wave tiles, no column sums,

@@ -254,11 +254,11 @@ class TimedBackend:
         aux = kw.get('aux')
         nbytes = (M * K + N * K) * es + M * N * Cm.element_size() + (aux.shape[1] * aux.element_size() * M if aux is not None else 0) \
             + (M * N // 8 if kw.get('mask_out') is not None else 0)
-        # 2 = the phased 256 x 256 kernel (the dominant kernel of the update): timed as its own class
+        # 2 / 6 = the phased kernel, 256 x 256 / 192 x 256 tile (the dominant kernel of the update): timed as its own class
         kid = self._be.lib.ase_hip_gemm_nt_kernel_id(M, N, K, self._be._gemm_code(A.dtype))
         # (the penalty's value path - f32 storage, three 16-bit MFMAs per product - is its own class: its flop count below is the
         #  ALGORITHMIC one, a third of what its matrix instructions execute)
-        kind = 'nt8' if kid == 2 else ('nt_x3' if (A.dtype == torch.float32 and self._be.x3) else 'nt')
+        kind = 'nt8' if kid in (2, 6) else ('nt_x3' if (A.dtype == torch.float32 and self._be.x3) else 'nt')
         self.bytes[kind] = self.bytes.get(kind, 0.0) + nbytes
         self._nbytes = float(nbytes)
         self._timed(kind, 2.0 * M * N * K, self._be.gemm_nt, A, B, Cm, M, N, K, **kw)

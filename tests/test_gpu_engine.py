@@ -281,7 +281,9 @@ def test_epoch_tail_full_size_vs_oracle(precision):
     ('f16gp32', 1e-4, 5e-2, 1e-3, 0.35),    # f16 with the penalty's value path in exact f32: 1e-4 on EVERY scalar of the fresh step
     ('f16gpx3', 1e-4, 5e-2, 1e-3, 0.35),    # ... with three f16 MFMAs per product on scaled hi / lo splits (penalty within 2e-6)
     ('bf16', 8e-3, 0.2, 6e-3, 0.7),         # measured 3.7e-3 (kl) / 0.10 / 2.5e-3 / 0.48
-    ('f32', 1e-4, 2e-3, 1e-4, 5e-3)])       # measured 4.6e-6 / 5e-4 / 2.5e-7 / 8.6e-4
+    # f32: measured 4.6e-6 / 5e-4 ... 2.1e-3 / 2.5e-7 / 8.6e-4 - the fresh gradient figure is a handful of flipped ReLU units
+    # (1.3e-7 of the masks: the two f32 codes sum in different orders) in one narrow tensor; at the engine's masks the median is 8e-7
+    ('f32', 1e-4, 5e-3, 1e-4, 5e-3)])
 def test_self_consistent_parity_config2(mode, fresh_loss, fresh_grad, stress_loss, stress_grad):
     """BASELINE config 2 at full size (minibatch 16384, amp 4096, 7,039,905 parameters) in the self-consistent setting of
     real training - the rollout's mu / neglogp / values come from the engine's OWN inference path in the same precision -
@@ -319,6 +321,8 @@ def test_self_consistent_parity_config2(mode, fresh_loss, fresh_grad, stress_los
     if mode != 'bf16':
         assert gm['median_grad_rel_l2'] <= 5e-3 and gm['worst_grad_rel_l2'] <= 2e-2, gm
         assert gm['flipped_mask_fraction'] <= (1e-6 if mode == 'f32' else 5e-4), gm
+    if mode == 'f32':      # f32 against f32 with the flips taken out: summation order only
+        assert gm['median_grad_rel_l2'] <= 1e-5 and gm['worst_grad_rel_l2'] <= 1e-3, gm
     # (bf16's importance ratio is noisy enough to flip ~0.4 % of the clip decisions in the off-policy state)
     assert st['max_loss_rel'] <= stress_loss and st['max_count_stat_abs'] <= (1e-2 if mode == 'bf16' else 5e-3), st
     # off-policy, 94 % of the samples are clipped and the actor gradient is what the few unclipped ones leave: when ONE sample

@@ -694,6 +694,38 @@ def test_gemm_nt_phased_tile(be, dt, M, N, K):
     close(Cg.float(), Cc.float(), rt, at * math.sqrt(K / 64), f'nt phased {M}x{N}x{K}')
 
 
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('M,N,K', [(12288, 1024, 1408), (12288, 1024, 64), (12200, 1024, 192), (6144, 2048, 512)])
+def test_gemm_nt_phased_tile_192_rows(be, dt, M, N, K):
+    """Row counts whose 256-row tiling leaves CUs idle in a single round take the 192 x 256 variant of the phased kernel
+    (kernel id 6; 12288 rows = the discriminator's three 4096-row blocks): forward ReLU with the bit-mask twin, then the
+    data-gradient launch reading those bits with a wrapped row block, incl. a ragged last row tile and 1 / 3 / 8 / 22 K-tiles."""
+    assert be.lib.ase_hip_gemm_nt_kernel_id(M, N, K, be._gemm_code(dt)) == 6
+    g = torch.Generator().manual_seed(K)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(dt)
+    B = (torch.randn(N, K, generator=g) * 0.1).to(dt)
+    bias = torch.randn(N, generator=g)
+    Cg, Cc = torch.zeros(M, N, dtype=dt).cuda(), torch.zeros(M, N, dtype=dt)
+    Wg, Wc = torch.zeros(M, N // 32, dtype=torch.int32).cuda(), torch.zeros(M, N // 32, dtype=torch.int32)
+    be.gemm_nt(A.cuda(), B.cuda(), Cg, M, N, K, bias=bias.cuda(), act=L.ACT_RELU, mask_out=Wg)
+    EmuBackend().gemm_nt(A, B, Cc, M, N, K, bias=bias, act=L.ACT_RELU, mask_out=Wc)
+    rt, at = _tol(dt)
+    close(Cg.float(), Cc.float(), rt, at * math.sqrt(K / 64), f'nt 192-row tile {M}x{N}x{K}')
+    w = Wg.cpu().to(torch.int64) & 0xFFFFFFFF
+    bits = ((w.unsqueeze(-1) >> torch.arange(32)) & 1).reshape(M, N).bool()
+    assert torch.equal(bits, Cg.float().cpu() > 0)
+    # data gradient: rows [M/2, M) read the masks of rows [0, M/2) again (aux_split / aux_delta), bits == activation masks
+    split = M // 2
+    dY = (torch.randn(M, K, generator=g) * 0.3).to(dt).cuda()
+    Wt = (torch.randn(N, K, generator=g) * 0.1).to(dt).cuda()
+    d1, d2 = torch.zeros(M, N, dtype=dt).cuda(), torch.zeros(M, N, dtype=dt).cuda()
+    be.gemm_nt(dY, Wt, d1, M, N, K, aux=Cg, aux_mode=L.AUX_RELU_MASK, aux_split=split, aux_delta=split)
+    be.gemm_nt(dY, Wt, d2, M, N, K, aux=Wg, aux_mode=L.AUX_RELU_BITS, aux_split=split, aux_delta=split)
+    assert torch.equal(d1, d2)
+    ref = (dY.float().cpu() @ Wt.float().cpu().t()) * (Cg.float().cpu() > 0).float()[torch.cat([torch.arange(split), torch.arange(M - split)])]
+    close(d2.float().cpu(), ref.to(dt).float(), rt, at * math.sqrt(K / 64), 'nt 192-row tile data gradient')
+
+
 @pytest.mark.parametrize('dt', DT)
 def test_apply_multi_fused_optimizer_step(be, dt):
     """ase_hip_apply_multi = weight-only gradient terms + their norms + Adam + shadow refresh, against the separate ops
