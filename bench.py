@@ -254,11 +254,12 @@ class TimedBackend:
         aux = kw.get('aux')
         nbytes = (M * K + N * K) * es + M * N * Cm.element_size() + (aux.shape[1] * aux.element_size() * M if aux is not None else 0) \
             + (M * N // 8 if kw.get('mask_out') is not None else 0)
-        # 2 / 6 = the phased kernel, 256 x 256 / 192 x 256 tile (the dominant kernel of the update): timed as its own class
+        # 2 = the phased 256 x 256 kernel (the dominant kernel of the update), 6 = its 192 x 256 variant (another symbol in a kernel
+        # trace): each timed as its own class
         kid = self._be.lib.ase_hip_gemm_nt_kernel_id(M, N, K, self._be._gemm_code(A.dtype))
         # (the penalty's value path - f32 storage, three 16-bit MFMAs per product - is its own class: its flop count below is the
         #  ALGORITHMIC one, a third of what its matrix instructions execute)
-        kind = 'nt8' if kid in (2, 6) else ('nt_x3' if (A.dtype == torch.float32 and self._be.x3) else 'nt')
+        kind = 'nt8' if kid == 2 else 'nt8_192' if kid == 6 else ('nt_x3' if (A.dtype == torch.float32 and self._be.x3) else 'nt')
         self.bytes[kind] = self.bytes.get(kind, 0.0) + nbytes
         self._nbytes = float(nbytes)
         self._timed(kind, 2.0 * M * N * K, self._be.gemm_nt, A, B, Cm, M, N, K, **kw)
@@ -324,7 +325,7 @@ class TimedBackend:
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for kind in ('nt8', 'nt', 'nt_x3', 'tn'):
+        for kind in ('nt8', 'nt8_192', 'nt', 'nt_x3', 'tn'):
             rs = [r for r in self.records if r[0] == kind]
             if rs:
                 ms = sum(r[2].elapsed_time(r[3]) for r in rs)
@@ -814,7 +815,7 @@ def measure_mode(args, precision, device, world, rank, use_graph):
     # the dominant kernel = the GEMM kernel class with the most time (16-bit modes: the phased 256 x 256 NT kernel)
     dom = max(summ, key=lambda k: summ[k]['ms'])
     dname = {'nt8': f'gemm_nt8_kernel<{DTYPE_OF[precision]}> (phased 256x256 NT: forward + data-gradient of the wide layers)',
-             'nt': 'gemm_nt_kernel (NT tiles 64/128/256)', 'tn': 'gemm_tn kernels (weight gradients)',
+             'nt8_192': f'gemm_nt8_kernel<{DTYPE_OF[precision]}, 192> (phased 192x256 NT)', 'nt': 'gemm_nt_kernel (NT tiles 64/128/256)', 'tn': 'gemm_tn kernels (weight gradients)',
              'nt_x3': 'gemm_nt_kernel<f32h_t> (the penalty value path: three f16 MFMAs per product)'}[dom]
     dv = summ[dom]
     achieved = dv['flops'] / (dv['ms'] * 1e-3) / 1e12

@@ -3,11 +3,12 @@
 # libase_hip.so): every build twice, interleaved, on (1) the carrying NT shapes in f16 (back-to-back launches, HIP events) and
 # (2) the benchmark update.  The build is chosen by patching ase_amd.lib.LIB_PATH in the driver process - the product has no
 # environment switch for it.
-#   bash scripts/lab/ab_lib.sh libase_hip.so libase_hip_eb.so [precision]
+#   bash scripts/lab/ab_lib.sh libase_hip.so libase_hip_eb.so [more builds ...] [precision]
 cd "$(dirname "$0")/../.."
-P=${3:-f16gpx3}
+LIBS=(); P=f16gpx3
+for a in "$@"; do case "$a" in *.so) LIBS+=("$a");; *) P="$a";; esac; done      # any number of builds, then (optionally) the precision
 for rep in 1 2; do
-  for lib in "$1" "$2"; do
+  for lib in "${LIBS[@]}"; do
     python - "$lib" "$P" 2>/dev/null <<'PY'
 import sys, os, json, io, contextlib, runpy
 sys.path.insert(0, os.getcwd())
@@ -24,7 +25,8 @@ def timeit(fn, n=20):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n
 out = []
-for M, N, K in [(16384, 1024, 1024), (32768, 1024, 1024), (32768, 1024, 320), (16384, 1024, 512), (12288, 1024, 1408), (131072, 1024, 1024)]:
+for M, N, K in [(16384, 1024, 1024), (32768, 1024, 1024), (32768, 1024, 320), (16384, 1024, 512), (12288, 1024, 1408), (131072, 1024, 1024),
+                (32768, 1024, 512), (32768, 512, 256), (32768, 512, 64), (16384, 1024, 320), (12288, 1024, 512)]:
     A = (torch.randn(M, K, device='cuda') * 0.5).half(); B = (torch.randn(N, K, device='cuda') * 0.1).half()
     C = torch.zeros(M, N, device='cuda', dtype=torch.float16); bias = torch.randn(N, device='cuda')
     bits = torch.zeros(M, N // 32, dtype=torch.int32, device='cuda')
