@@ -172,7 +172,7 @@ class CommonAgent:
         #                   does not hold to 1e-4 at every training state; its backward stays in half
         from ..cfg import resolve_precision
         precision, dtype = resolve_precision(config)
-        if precision in ('f16gp32', 'f16gpx3'):      # (f16gpx3: the same path with three-bf16-MFMA products)
+        if precision in ('f16gp32', 'f16gpx3'):      # (f16gpx3: the same path with three f16 MFMAs per product on hi / lo half splits)
             config = self.config = dict(config, gp_f32=True if precision == 'f16gp32' else 'x3')
         self.precision = precision
         backend = config.get('backend', None)

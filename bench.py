@@ -44,7 +44,7 @@ MODE_NOTE = {
     'f16': 'IEEE-half storage / MFMA, f32 accumulate, f32 heads and losses, static gradient scale (= the reference\'s mixed_precision)',
     'f16gp32': 'f16 engine; the gradient penalty\'s value path (demo-row forward, chain) in exact f32',
     'f16gpx3': 'f16 engine (half storage / MFMA, f32 accumulate, static gradient scale); the gradient penalty\'s value path '
-               '(6 launches of 4096 rows) as three-bf16-MFMA products on hi/lo splits of f32 operands',
+               '(6 launches of 4096 rows) as three f16 MFMAs per product on hi/lo half splits of power-of-two scaled f32 operands (ASE_F32H3)',
     'f32': 'f32 storage, exact-f32 MFMA', 'bf16x3': 'f32 storage, three bf16 MFMAs per product'}
 PARITY_TOL = 1e-4          # BASELINE.json north_star: "losses matching the reference CPU path to rtol 1e-4"
 COUNT_TOL = 1e-3           # the three counting statistics move in steps of 1 / rows: absolute (fresh rollout)
