@@ -53,8 +53,10 @@ enum { ASE_OK = 0, ASE_EINVAL = -1, ASE_ELAUNCH = -2, ASE_EUNSUPPORTED = -3 };
 int ase_hip_abi_version(void);
 const char* ase_hip_last_error(void);
 
-/* Which kernel ase_hip_gemm_nt launches for a shape (host only): 0 = 64 x 64 tile, 1 = 128 x 128, 2 = phased 256 x 256
- * (bf16), 3 = lock-step 256 x 256.  bench.py uses it to attribute launch times to the dominant kernel. */
+/* Which kernel ase_hip_gemm_nt launches for a shape (host only): 0 = 64 x 64 tile (narrow outputs), 1 = 128 x 128,
+ * 2 = phased 256 x 256 (16-bit storage), 3 = lock-step 256 x 256 (4-byte storage), 4 = 64 x 128, 5 = 64 x 64 with
+ * 128-byte rows, 6 = phased 192 x 256 (16-bit storage, single rounds of 192-255 tiles; falls back to 2 when the
+ * launch needs the LDS-slab epilogue).  bench.py uses it to attribute launch times to the dominant kernel. */
 int ase_hip_gemm_nt_kernel_id(int M, int N, int K, int dtype);
 
 /* Kernel-tuning aid (scripts/lab): when buf is a device uint64[4 * workgroups] array, the phased NT kernel stamps

@@ -26,7 +26,8 @@ def timeit(fn, n=20):
     return s.elapsed_time(e) / n
 out = []
 for M, N, K in [(16384, 1024, 1024), (32768, 1024, 1024), (32768, 1024, 320), (16384, 1024, 512), (12288, 1024, 1408), (131072, 1024, 1024),
-                (32768, 1024, 512), (32768, 512, 256), (32768, 512, 64), (16384, 1024, 320), (12288, 1024, 512)]:
+                (32768, 1024, 512), (32768, 512, 256), (32768, 512, 64), (16384, 1024, 320), (12288, 1024, 512),
+                (32768, 64, 1024), (32768, 64, 512), (16384, 64, 512), (32768, 64, 256), (12288, 128, 512)]:
     A = (torch.randn(M, K, device='cuda') * 0.5).half(); B = (torch.randn(N, K, device='cuda') * 0.1).half()
     C = torch.zeros(M, N, device='cuda', dtype=torch.float16); bias = torch.randn(N, device='cuda')
     bits = torch.zeros(M, N // 32, dtype=torch.int32, device='cuda')
