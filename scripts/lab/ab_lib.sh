@@ -7,7 +7,7 @@
 cd "$(dirname "$0")/../.."
 LIBS=(); P=f16gpx3
 for a in "$@"; do case "$a" in *.so) LIBS+=("$a");; *) P="$a";; esac; done      # any number of builds, then (optionally) the precision
-for rep in 1 2; do
+for rep in $(seq 1 ${REPS:-2}); do
   for lib in "${LIBS[@]}"; do
     python - "$lib" "$P" 2>/dev/null <<'PY'
 import sys, os, json, io, contextlib, runpy

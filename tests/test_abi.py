@@ -144,6 +144,11 @@ def test_nt_kernel_choice_is_reported():
     assert lib.ase_hip_gemm_nt_kernel_id(4096, 512, 1024, L.BF16) == 5        # 64 x 64
     assert lib.ase_hip_gemm_nt_kernel_id(2048, 1024, 1024, L.BF16) == 5       # one rank's shard at 8 GPUs
     assert lib.ase_hip_gemm_nt_kernel_id(16384, 64, 512, L.BF16) == 0         # narrow head
+    # single rounds of 192-255 tiles of 256 x 256 that become <= 256 tiles of 192 x 256: the phased kernel's 192-row variant
+    assert lib.ase_hip_gemm_nt_kernel_id(12288, 1024, 1408, L.F16) == 6        # the discriminator's 3 x 4096 rows: 192 -> 256 workgroups
+    assert lib.ase_hip_gemm_nt_kernel_id(6144, 2048, 512, L.BF16) == 6
+    assert lib.ase_hip_gemm_nt_kernel_id(12288, 1024, 1408, L.F32) == 3        # (4-byte storage: lock-step)
+    assert lib.ase_hip_gemm_nt_kernel_id(12288, 512, 1024, L.F16) == 4         # 96 tiles: not a phased grid
 
 
 def test_grouped_plan_random_layer_sets():
