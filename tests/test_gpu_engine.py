@@ -365,7 +365,9 @@ def test_parity_at_16384_envs(mode, loss_tol, grad_tol):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize('precision,w_max,w_mean,s_rtol', [('f32', 20, 0.1, 5e-3), ('f16gpx3', 80, 0.5, 5e-2), ('bf16', 120, 1.0, 0.25)])
+# (f32 bounds: twice what two runs of ONE schedule measured - max 20 lr, mean 0.08 lr, scalars 2e-3; at the measured values the
+#  case failed once in ~8 runs of the round on an unchanged build.  A race shows as hundreds of lr / non-finite scalars.)
+@pytest.mark.parametrize('precision,w_max,w_mean,s_rtol', [('f32', 40, 0.2, 1e-2), ('f16gpx3', 80, 0.5, 5e-2), ('bf16', 120, 1.0, 0.25)])
 def test_schedule_variants_agree_config2(precision, w_max, w_mean, s_rtol):
     """The round-4 schedule (discriminator head and prologue un-chained from the main stream, penalty value path on its own
     stream, result rings, per-step launch programs, the agent's own high-priority stream) changes WHEN kernels run, never what
