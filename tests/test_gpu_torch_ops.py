@@ -31,7 +31,7 @@ def test_linear_act_forward_backward(dt, tol, act):
     yr = {'none': pre, 'relu': torch.relu(pre), 'tanh': torch.tanh(pre)}[act]
     assert y.shape == (M, N) and y.dtype == dt
     scale = float(yr.detach().abs().max())
-    assert float((y.float() - yr).abs().max()) <= tol * scale
+    assert float((y.detach().float() - yr.detach()).abs().max()) <= tol * scale
     dy = torch.randn(M, N, generator=g).to(DEV)
     y.backward(dy.to(dt))
     yr.backward(dy)
