@@ -379,6 +379,17 @@ class HipBackend:
     def axpy(self, g, w, c):
         L.check(self.lib.ase_hip_axpy(_ptr(g), _ptr(w), g.numel(), float(c), self._stream()), "axpy")
 
+    def scaler_check(self, buf, scaler):
+        """GradScaler's found_inf test over one buffer of the scaled backward (any view of contiguous storage)."""
+        assert buf.is_contiguous()
+        L.check(self.lib.ase_hip_scaler_check(_ptr(buf), buf.numel(), _code(buf.dtype), _ptr(scaler), self._stream()),
+                "scaler_check")
+
+    def scaler_step(self, scaler, opt_state, opt_eff, grads):
+        """GradScaler.step's decision: a found overflow zeroes the gradient and hands the optimizer launch the identity step."""
+        L.check(self.lib.ase_hip_scaler_step(_ptr(scaler), _ptr(opt_state), _ptr(opt_eff), _ptr(grads), grads.numel(),
+                                             self._stream()), "scaler_step")
+
     # ------------------------------------------------------------------ rollout tail
     def disc_reward(self, logit, r, n, scale):
         L.check(self.lib.ase_hip_disc_reward(_ptr(logit), _ld(logit), _ptr(r), n, float(scale), self._stream()),

@@ -1,0 +1,114 @@
+// Loss scaler of the half-storage engine: what torch.cuda.amp.GradScaler does around the optimizer step in the reference's
+// mixed_precision path (learning/ase_agent.py:271-288, learning/amp_agent.py:354-371, learning/common_agent.py:417-418) -
+// found_inf over everything the scaled backward produced, and a SKIPPED optimizer step when it fired.
+//   The engine's conversions into half storage saturate at +-65504 (common.h from_f32<f16_t>: an overflowing scaled gradient must
+// not become inf -> NaN inside the matrix launches that follow), so "overflow" here = an element that is not finite OR sits at
+// half's saturation value.  The scale itself is a launch argument of the loss heads (a power of two, baked into recorded launch
+// programs): the host moves it between updates from the counters this file keeps (UpdateEngine.scaler_update).
+// Own translation unit: nothing of the static-scale path links against it.
+#include "common.h"
+
+namespace {
+
+// scaler (f64[8]): {found (elements / workgroups that overflowed since the last scaler_step), skipped steps (total), clean steps in
+//                   a row (GradScaler's growth tracker), steps seen (total), unused x4}
+enum { SC_FOUND = 0, SC_SKIPPED = 1, SC_CLEAN = 2, SC_STEPS = 3 };
+
+template <typename T> __device__ __forceinline__ bool overflowed(T x);
+template <> __device__ __forceinline__ bool overflowed<float>(float x) { return !(fabsf(x) <= 3.402823466e38f); }      // NaN, +-inf
+template <> __device__ __forceinline__ bool overflowed<bf16_t>(bf16_t x) { return !(fabsf((float)x) <= 3.402823466e38f); }
+template <> __device__ __forceinline__ bool overflowed<f16_t>(f16_t x) { return !(fabsf((float)x) < 65504.f); }        // + saturated
+
+// 16-byte loads over the aligned body, scalar loads over head and tail; one f64 atomic per workgroup that found something
+template <typename T>
+__global__ __launch_bounds__(256) void scaler_check_kernel(const T* __restrict__ x, int64_t n, double* __restrict__ scaler) {
+    constexpr int V = 16 / (int)sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(V)));
+    __shared__ int any;
+    if (threadIdx.x == 0) any = 0;
+    __syncthreads();
+    // elements in front of the first 16-byte boundary (buffers of the engine start aligned: head = 0 there)
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(x);
+    int64_t head = (int64_t)(((16 - (addr & 15)) & 15) / sizeof(T));
+    if (head > n) head = n;
+    const int64_t nvec = (n - head) / V;
+    const vec_t* xv = reinterpret_cast<const vec_t*>(x + head);
+    bool bad = false;
+    const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = tid; i < nvec; i += nthr) {
+        const vec_t v = xv[i];
+#pragma unroll
+        for (int c = 0; c < V; ++c) bad |= overflowed<T>(v[c]);
+    }
+    for (int64_t i = tid; i < head; i += nthr) bad |= overflowed<T>(x[i]);
+    for (int64_t i = head + nvec * V + tid; i < n; i += nthr) bad |= overflowed<T>(x[i]);
+    if (bad) any = 1;                          // (every writer stores the same value)
+    __syncthreads();
+    if (threadIdx.x == 0 && any) atomic_add_f64(scaler + SC_FOUND, 1.0);
+}
+
+// found: the step's gradient is dropped (the optimizer launch behind this one then runs the identity step scaler_book writes)
+__global__ __launch_bounds__(256) void scaler_guard_kernel(float* __restrict__ g, int64_t n, const double* __restrict__ scaler) {
+    if (scaler[SC_FOUND] == 0.0) return;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) g[i] = 0.f;
+}
+
+// opt_state (f64[8]): {step, lr, beta1, beta2, eps, bias_corr1, bias_corr2, unused} (optim.hip)
+__global__ void scaler_book_kernel(double* __restrict__ scaler, double* __restrict__ opt_state, double* __restrict__ opt_eff) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const bool found = scaler[SC_FOUND] != 0.0;
+    if (found) {
+        // GradScaler.step does not call optimizer.step(): the step counter begin_step advanced goes back (its bias corrections
+        // are recomputed from the counter by the next begin_step), and the optimizer launch gets the identity step -
+        // exp_avg.lerp_(g, 0), exp_avg_sq * 1 + 0 * g^2, param - 0 * (...) - on the zeroed gradient
+        opt_state[0] -= 1.0;
+        opt_eff[0] = opt_state[0];
+        opt_eff[1] = 0.0;                      // lr
+        opt_eff[2] = 1.0;                      // beta1
+        opt_eff[3] = 1.0;                      // beta2
+        opt_eff[4] = opt_state[4];             // eps (> 0 keeps the quotient finite)
+        opt_eff[5] = 1.0;
+        opt_eff[6] = 1.0;
+        opt_eff[7] = opt_state[7];
+        scaler[SC_SKIPPED] += 1.0;
+        scaler[SC_CLEAN] = 0.0;
+    } else {
+        for (int i = 0; i < 8; ++i) opt_eff[i] = opt_state[i];
+        scaler[SC_CLEAN] += 1.0;
+    }
+    scaler[SC_STEPS] += 1.0;
+    scaler[SC_FOUND] = 0.0;
+}
+
+inline int check_grid(int64_t n, int elem) {
+    const int64_t per_wg = 256 * (16 / elem) * 4;          // four 16-byte loads per thread
+    int64_t g = (n + per_wg - 1) / per_wg;
+    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+}  // namespace
+
+extern "C" int ase_hip_scaler_check(const void* buf, int64_t n, int dtype, double* scaler, void* stream) {
+    ASE_CHECK_ARG(buf && scaler && n > 0, "scaler_check: null/empty operand");
+    ASE_CHECK_ARG(dtype == ASE_F32 || dtype == ASE_BF16 || dtype == ASE_F16, "scaler_check: bad dtype %d", dtype);
+    ASE_CHECK_ARG((reinterpret_cast<uintptr_t>(buf) % ase_elem_size(dtype)) == 0, "scaler_check: misaligned buffer");
+    const int rc = ase_dispatch_storage(dtype, [&](auto tag) {
+        typedef typename decltype(tag)::type T;
+        ASE_LAUNCH(scaler_check_kernel<T>, dim3(check_grid(n, (int)sizeof(T))), dim3(256), 0, (hipStream_t)stream,
+                   static_cast<const T*>(buf), n, scaler);
+        return ASE_OK;
+    });
+    ASE_CHECK_ARG(rc == ASE_OK, "scaler_check: bad dtype %d", dtype);
+    ASE_CHECK_LAUNCH("scaler_check");
+    return ASE_OK;
+}
+
+extern "C" int ase_hip_scaler_step(double* scaler, double* opt_state, double* opt_eff, float* grads, int64_t n, void* stream) {
+    ASE_CHECK_ARG(scaler && opt_state && opt_eff && grads && n > 0 && opt_eff != opt_state, "scaler_step: null/empty/aliased operand");
+    int64_t g = (n + 1023) / 1024;
+    g = g < 1 ? 1 : (g > 4096 ? 4096 : g);
+    ASE_LAUNCH(scaler_guard_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, grads, n, (const double*)scaler);
+    ASE_LAUNCH(scaler_book_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scaler, opt_state, opt_eff);
+    ASE_CHECK_LAUNCH("scaler_step");
+    return ASE_OK;
+}

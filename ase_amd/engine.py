@@ -91,9 +91,35 @@ class UpdateEngine:
         # gradients are O(1/minibatch): S = the power of two nearest minibatch/4 puts them near 1 and leaves ~2^13 of
         # headroom up to half's largest finite value and ~2^10 down to its subnormals for the deeper layers' gradients.
         # Conversions saturate (no inf), S is a power of two (exact), so unlike GradScaler nothing is skipped or adapted.
+        scale_given = grad_scale is not None
         if grad_scale is None:
             grad_scale = 2.0 ** max(0, round(math.log2(max(minibatch, 4) / 4.0))) if dtype == torch.float16 else 1.0
+        # loss_scale: 'static' (above) | 'dynamic' = torch.cuda.amp.GradScaler's behaviour (learning/ase_agent.py:271-288): overflow
+        # detection over everything the scaled backward wrote, a SKIPPED optimizer step when it fires (device side, csrc/scaler.hip),
+        # backoff / growth of the scale (host side, between updates: scaler_update).  Default: dynamic when the configuration sets the
+        # reference's own flag (mixed_precision: True), static for an explicitly named precision mode.  cfg['loss_scaler']: GradScaler's
+        # constructor arguments {init_scale 65536, growth_factor 2, backoff_factor 0.5, growth_interval 2000} (powers of two).
+        ls = cfg.get('loss_scale', None)
+        if ls is None:
+            ls = 'dynamic' if (cfg.get('mixed_precision', False) and dtype == torch.float16 and not scale_given) else 'static'
+        assert ls in ('static', 'dynamic'), ls
+        self.dyn_scale = ls == 'dynamic'
+        if self.dyn_scale:
+            assert dtype == torch.float16, "loss_scale: dynamic belongs to half storage (precision f16 / f16gp32 / f16gpx3)"
+            assert not (cfg.get('graph_capture') == 'hipgraph' and (world_size > 1 or cfg.get('force_dist', False))), \
+                "loss_scale: dynamic exchanges its overflow flag inside the optimizer phase: not capturable as a hipGraph"
+            sc = dict(init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000)
+            unknown = set(cfg.get('loss_scaler', {}) or {}) - set(sc)
+            assert not unknown, f"unknown loss_scaler keys {sorted(unknown)}"
+            sc.update(cfg.get('loss_scaler', {}) or {})
+            for k in ('init_scale', 'growth_factor', 'backoff_factor'):
+                assert sc[k] > 0 and math.log2(sc[k]) == round(math.log2(sc[k])), f"loss_scaler.{k} must be a power of two"
+            assert sc['growth_factor'] >= 1.0 and sc['backoff_factor'] <= 1.0 and int(sc['growth_interval']) >= 1
+            self.loss_scaler = sc
+            if not scale_given:
+                grad_scale = float(sc['init_scale'])
         self.gs = float(grad_scale)
+        self._scaler_skipped_seen = 0.0
         # flags resolved once (rl_games defaults: normalize_value False, bounds_loss_coef None = no bound loss)
         # truncate_grads: global-norm clip of the whole gradient before Adam (learning/ase_agent.py:273-288): the norm needs every
         # gradient (weight-only loss terms included), so the per-branch optimizer steps give way to the end-of-step form
@@ -264,6 +290,11 @@ class UpdateEngine:
         self.n_train = net.trainable_numel           # trainable tensors come first in the flat buffer
         lr = float(self.cfg['learning_rate'])
         self.opt_state = torch.tensor([0.0, lr, 0.9, 0.999, 1e-8, 1.0, 1.0, 0.0], dtype=torch.float64, device=dev)
+        # dynamic loss scale (csrc/scaler.hip): {found, skipped, clean, steps, ...} and the optimizer state the Adam launch reads
+        # (opt_state, or the identity step of a skipped step)
+        self.scaler = torch.zeros(8, dtype=torch.float64, device=dev)
+        self.opt_eff = self.opt_state.clone()
+        self._scaler_list = None
         for d in self.layers:
             d.Ws = torch.zeros(d.n_pad, d.k_pad, dtype=T, device=dev)
             d.Wts = torch.zeros(d.k_pad, d.n_pad, dtype=T, device=dev)
@@ -683,7 +714,7 @@ class UpdateEngine:
         its bucket, optimizer step of its parameters - so the discriminator's tail overlaps the policy's backward.
         fence=False: the caller has ordered the branch streams behind its own writes (fence_side_streams) - required while a
         launch program is being recorded (a torch-level stream wait is not a recordable entry)."""
-        inline = apply and self._fused_apply and not self.truncate
+        inline = apply and self._fused_apply and not self.truncate and not self.dyn_scale
         # cross-step schedule: single GPU, streams, every branch finishing by itself (its own optimizer step)
         self._xs = bool(self._xstep and inline and self.has_disc and self._short_prologue and self._disc_early
                         and self._amp_stats_in_branch())
@@ -1198,7 +1229,7 @@ class UpdateEngine:
     # ---- phase C (end-of-step form): weight-only loss terms, optimizer, shadows, reported scalars ------
     def phase_apply(self, apply=True):
         be, c = self.be, self.cfg
-        if apply and self._fused_apply and not self.truncate:
+        if apply and self._fused_apply and not self.truncate and not self.dyn_scale:
             # weight-only loss terms + their reported norms + Adam + shadow refresh of every layer: ONE launch
             self._build_apply_desc()
             be.apply_multi(self._apply_desc, self._apply_items, self.dtype, self.opt_state, self.acc)
@@ -1218,18 +1249,84 @@ class UpdateEngine:
                     for W, gW, coef, slot in self.l2_terms:
                         if slot == L.ACC_ENC_W2:
                             be.reduce_sum(W.view(-1), W.numel(), True, self.acc, L.ACC_ENC_W2)
+            if apply and self.dyn_scale:
+                # GradScaler (learning/ase_agent.py:271-288): found_inf over the scaled backward (every half buffer a launch of the
+                # step wrote + the f32 gradient), one flag for all ranks, then the decision - a found overflow zeroes the gradient
+                # and the optimizer launch below runs the identity step (weights, moments, step counter stay what they are)
+                g = self.grads[:self.n_train]
+                for t in self._scaler_bufs():
+                    be.scaler_check(t, self.scaler)
+                be.scaler_check(g, self.scaler)
+                if self._dist_on():
+                    self._ar(self.scaler[:1])
+                be.scaler_step(self.scaler, self.opt_state, self.opt_eff, g)
             if apply and self.truncate:
                 g = self.grads[:self.n_train]
                 be.reduce_sum(g, g.numel(), True, self.acc, L.ACC_GRAD_SQ)
                 be.clip_scale(g, self.acc, L.ACC_GRAD_SQ, self.grad_norm)
             if apply:
                 be.adam(self.params[:self.n_train], self.grads[:self.n_train], self.adam_m[:self.n_train],
-                        self.adam_v[:self.n_train], self.opt_state)
+                        self.adam_v[:self.n_train], self.opt_eff if self.dyn_scale else self.opt_state)
                 self.refresh_shadows()
         self._average_kl()
         be.finalize_scalars(self.acc, self.res, self.Mg if self.shard else self.M, self.AMBg if self.shard else self.AMB,
                             self.masked, self.has_disc, self.has_enc, self.div_on, c,
                             opt_state=self.opt_state if (self.adaptive_lr and apply) else None, kl_threshold=self.kl_threshold)
+
+    # ---- dynamic loss scale (cfg loss_scale = 'dynamic') ---------------------------------------------------------------
+    def _scaler_bufs(self):
+        """Every buffer of the step a conversion into half storage writes (forward activations included: under autocast an
+        overflowing activation is inf, the loss NaN, and GradScaler skips that step too) + the f32 chain of a gp_f32 engine."""
+        if self._scaler_list is None:
+            out = []
+
+            def add(x):
+                for t in (x if isinstance(x, (list, tuple)) else [x]):
+                    if t is not None and t.numel():
+                        assert t.is_contiguous()
+                        out.append(t)
+            for name in ('Ha', 'dZa', 'Hc', 'dZc', 'dMU', 'dV', 'Hs', 'dZs', 'dStyle', 'Hd4', 'dZd4', 'dHD', 'GpTop', 'He', 'dZe',
+                         'dE', 'Ue', 'Re', 'Ge', 'Qe'):
+                add(getattr(self, name, None))
+            g = getattr(self, '_gp32', None)
+            if g is not None:
+                add(g.H)
+                add(g.Gp)
+                add(g.G0)
+            self._scaler_list = out
+        return self._scaler_list
+
+    def set_grad_scale(self, s):
+        """A new gradient scale (a power of two).  The scale is a launch ARGUMENT of the loss heads and the weight-gradient
+        launches: recorded launch programs / captured graphs of the step hold the old one and must be dropped by their owner."""
+        assert s > 0 and math.log2(s) == round(math.log2(s)), s
+        self.gs = float(s)
+
+    def scaler_state(self):
+        """{'scale', 'skipped', 'clean', 'steps'} - reads the device counters (synchronises)."""
+        f, sk, cl, st = self.scaler[:4].tolist()
+        return {'scale': self.gs, 'skipped': int(sk), 'clean': int(cl), 'steps': int(st)}
+
+    def scaler_update(self):
+        """GradScaler.update() (torch/amp/grad_scaler.py: scale *= backoff_factor after a step with found_inf, *= growth_factor
+        after growth_interval clean steps in a row) at UPDATE granularity: the scale is baked into the step's launches, so it
+        moves between updates - once down for an update in which any step was skipped (one cause: the scale of that update),
+        once up when the device's clean-step counter has reached the interval.  Call between updates; reads four doubles back.
+        Returns True when the scale changed (recorded programs of the step are stale then)."""
+        assert self.dyn_scale
+        sc = self.loss_scaler
+        st = self.scaler_state()
+        new = self.gs
+        if st['skipped'] > self._scaler_skipped_seen:
+            self._scaler_skipped_seen = st['skipped']
+            new = self.gs * sc['backoff_factor']
+        elif st['clean'] >= int(sc['growth_interval']):
+            new = self.gs * sc['growth_factor']
+            self.scaler[2:3].zero_()
+        if new != self.gs and new < 2.0 ** 100 and new > 2.0 ** -100:
+            self.set_grad_scale(new)
+            return True
+        return False
 
     def _enc_grad_penalty(self, h_top):
         """Encoder gradient penalty  c * mean_rows |d err / d x|^2,  err = -<normalize(e), z>  (learning/ase_agent.py:431-441,

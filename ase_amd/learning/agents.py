@@ -123,7 +123,9 @@ class CommonAgent:
         self.truncate_grads = config.get('truncate_grads', False)       # global-norm clip (UpdateEngine.truncate)
         self.grad_norm = config.get('grad_norm', 1.0)
         # mixed_precision (rl_games: torch.cuda.amp autocast = half arithmetic + GradScaler, learning/ase_agent.py:216,271-288)
-        # selects the half-storage mode: 'f16' below, with a static power-of-two gradient scale in the GradScaler's place
+        # selects the half-storage mode 'f16' below WITH the GradScaler's behaviour (config loss_scale: 'dynamic' - overflow
+        # detection, skipped steps, backoff / growth of the scale: UpdateEngine.scaler_update); an explicitly named precision mode
+        # ('precision': 'f16' / 'f16gp32' / 'f16gpx3') keeps the static power-of-two scale unless loss_scale says otherwise
         # lr_schedule: constant | adaptive (rl_games AdaptiveScheduler on every step's kl, schedule_type 'legacy' - the default;
         # learning/common_agent.py:204-208).  The per-mini-epoch / per-epoch variants ('standard', 'standard_epoch') are not built.
         assert config.get('lr_schedule', 'constant') in ('constant', 'adaptive', None)
@@ -664,6 +666,7 @@ class CommonAgent:
         ds = {k: v for k, v in input_dict.items() if v is not None}
         self.engine.step(ds, idx, (0, 0), streams, new_z=input_dict.get('_new_z'))
         self.train_result = self._collect_result()
+        self._scaler_update()
         if self._snapshot_stream is not None:          # single-step callers read the result right away
             torch.cuda.current_stream().wait_stream(self._snapshot_stream)
             self._snapshot_stream = None
@@ -886,7 +889,15 @@ class CommonAgent:
             self.train_result = {k: v[-1] for k, v in train_info.items()} if step else None
         self._post_update(batch_dict)
         self._lr_stale = self.engine.adaptive_lr      # (the host mirror `last_lr` is refreshed lazily: no read-back here)
+        self._scaler_update()
         return train_info
+
+    def _scaler_update(self):
+        """mixed_precision with the dynamic loss scale (GradScaler.update(), learning/ase_agent.py:280,285,288): the scale moves
+        between updates from the device's skipped / clean step counters - the one read-back of such an update - and a new scale
+        invalidates the recorded launch programs of the step (it is an argument of their launches)."""
+        if self.engine.dyn_scale and self.engine.scaler_update():
+            self._drop_graphs()
 
     def _ring_results(self, n):
         """train_info of an update from the engine's result rings: ONE copy of the n result vectors (+ one of the n logit

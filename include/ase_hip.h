@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ASE_HIP_ABI_VERSION 4
+#define ASE_HIP_ABI_VERSION 5
 
 enum { ASE_F32 = 0, ASE_BF16 = 1, ASE_F32X3 = 2 /* f32 storage, products as 3 bf16 MFMAs on a hi/lo split (GEMMs only) */,
        ASE_F32H3 = 4 /* 4-byte storage, products as 3 f16 MFMAs on hi/lo splits of operands scaled by 2^ea / 2^eb (the exponents ride in
@@ -342,6 +342,22 @@ int ase_hip_adam(float* w, const float* g, float* m, float* v, int64_t n, const 
                  void* stream);
 /* g[i] += c * w[i]  (the weight-only loss terms: learning/amp_agent.py:449-466) */
 int ase_hip_axpy(float* g, const float* w, int64_t n, float c, void* stream);
+
+/* Loss scaler of the half-storage engine = torch.cuda.amp.GradScaler around the optimizer step of the reference's mixed_precision
+ * path (learning/ase_agent.py:271-288, learning/amp_agent.py:354-371: scaler.scale(loss).backward(); scaler.unscale_; scaler.step;
+ * scaler.update).  ABI 5.  scaler: DEVICE f64[8] = {found, skipped steps (total), clean steps in a row (the growth tracker),
+ * steps (total), _ x4}.
+ * ase_hip_scaler_check = the found_inf test over ONE buffer the scaled backward wrote (dtype ASE_F32 / ASE_BF16 / ASE_F16):
+ * scaler[found] += number of workgroups that met an element that is not finite or - ASE_F16, whose conversions saturate instead
+ * of producing inf - sits at +-65504. */
+int ase_hip_scaler_check(const void* buf, int64_t n, int dtype, double* scaler, void* stream);
+/* ase_hip_scaler_step = GradScaler.step's decision, between the checks and the optimizer launch (ase_hip_adam reads opt_eff):
+ *   found != 0: grads[0..n) = 0, opt_eff = the identity step {lr 0, beta1 = beta2 = 1, bias corrections 1} (w, m, v stay what they
+ *               are), opt_state.step -= 1 (a skipped step is no optimizer step), skipped += 1, clean = 0
+ *   found == 0: opt_eff = opt_state, clean += 1
+ * then steps += 1, found = 0.  The scale itself is a launch argument of the loss heads (a power of two): the host moves it between
+ * updates from {skipped, clean} (backoff / growth: UpdateEngine.scaler_update). */
+int ase_hip_scaler_step(double* scaler, double* opt_state, double* opt_eff, float* grads, int64_t n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Once-per-epoch rollout tail.

@@ -491,6 +491,33 @@ class EmuBackend:
     def axpy(self, g, w, c):
         g.add_(c * w)
 
+    def scaler_check(self, buf, scaler):
+        """csrc/scaler.hip: not finite, or (half storage, whose conversions saturate) at +-65504."""
+        x = buf.float()
+        bad = ~torch.isfinite(x)
+        if buf.dtype == torch.float16:
+            bad |= x.abs() >= 65504.0
+        if bool(bad.any()):
+            scaler[0] += 1.0
+
+    def scaler_step(self, scaler, opt_state, opt_eff, grads):
+        if float(scaler[0]) != 0.0:
+            grads.zero_()
+            opt_state[0] -= 1.0
+            opt_eff.copy_(opt_state)
+            opt_eff[1] = 0.0
+            opt_eff[2] = 1.0
+            opt_eff[3] = 1.0
+            opt_eff[5] = 1.0
+            opt_eff[6] = 1.0
+            scaler[1] += 1.0
+            scaler[2] = 0.0
+        else:
+            opt_eff.copy_(opt_state)
+            scaler[2] += 1.0
+        scaler[3] += 1.0
+        scaler[0] = 0.0
+
     # ------------------------------------------------------------------ rollout tail
     def disc_reward(self, logit, r, n, scale):
         l = logit.reshape(-1, logit.shape[-1])[:n, 0]

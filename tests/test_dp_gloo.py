@@ -207,3 +207,50 @@ def test_horovod_adaptive_lr_is_the_same_on_every_rank(tmp_path):
     assert torch.equal(r['kls'][0], r['kls'][1])                          # the reported kl is the rank average
     assert torch.equal(r['flats'][0], r['flats'][1])                      # replicas identical
     assert float(r['lrs'][0]) != r['lr0']                                 # (the schedule did move in this run)
+
+
+# ------------------------------------------------------------------------------------------------ dynamic loss scale
+def _worker_scaler(rank, world, port, name, out):
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    G = torch.load(os.path.join(GOLDEN, name + '.pt'), weights_only=False)
+    be = EmuBackend()
+    ag = make_agent(G, be, precision='f16', world_size=world, rank=rank, loss_scale='dynamic', loss_scaler={'init_scale': 16.0})
+    assert ag.engine.dyn_scale and ag.engine.gs == 16.0
+    if rank == 1:            # an overflow only THIS rank sees, in the very first step
+        orig, n = be.scaler_check, [0]
+
+        def check(buf, scaler):
+            if n[0] == 0:
+                scaler[0] += 1.0
+            n[0] += 1
+            orig(buf, scaler)
+        be.scaler_check = check
+    replay_epochs(G, ag, rtol=1.0, wtol=1.0, check=False, max_steps=2)
+    flat = ag.model.a2c_network.flat_params.clone()
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    st = ag.engine.scaler_state()
+    states = [None] * world
+    dist.all_gather_object(states, st)
+    if rank == 0:
+        torch.save({'flats': gathered, 'states': states, 'opt_step': float(ag.engine.opt_state[0])}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_skip_the_same_step(tmp_path):
+    """loss_scale: dynamic under data parallelism: the overflow flag is exchanged (SUM) before the decision, so a step one rank
+    found an overflow in is skipped by BOTH, the weights stay identical across the ranks and the scale moves on both."""
+    out = str(tmp_path / 'sc.pt')
+    mp.spawn(_worker_scaler, args=(2, _free_port(), 'ase_tiny', out), nprocs=2, join=True)
+    r = torch.load(out, weights_only=False)
+    assert torch.equal(r['flats'][0], r['flats'][1])
+    s0, s1 = r['states']
+    assert s0 == s1, (s0, s1)
+    G = torch.load(os.path.join(GOLDEN, 'ase_tiny.pt'), weights_only=False)
+    n_upd = len(G['epochs'])
+    assert s0['steps'] == 2 * n_upd and s0['skipped'] == 1 and s0['scale'] == 8.0       # one backoff, after the first update
+    assert r['opt_step'] == 2 * n_upd - 1                                                # the skipped step was no optimizer step
