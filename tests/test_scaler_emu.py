@@ -2,7 +2,7 @@
 reference's mixed_precision path, learning/ase_agent.py:271-288): overflow detection over the scaled backward, the skipped
 optimizer step, backoff / growth of the scale between updates.  Host logic + op semantics on the CPU emulator; the scale
 trajectory of the host-side update rule is pinned against torch's own GradScaler.  check_dynamic_loss_scale is shared with the
-GPU test (tests/gpu_scaler_checks.py)."""
+GPU test (tests/test_gpu_scaler.py)."""
 import copy
 import math
 import os
