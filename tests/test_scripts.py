@@ -135,3 +135,34 @@ def test_round5_bench_line_headline_holds_the_bar():
     for st in ('fresh', 'stress'):
         lr = full['parity'][st]['loss_rel']
         assert lr['disc_grad_penalty'] <= 1e-5, (st, lr['disc_grad_penalty'])
+
+
+def test_isa_report_parses_a_kernel_and_its_metadata():
+    """scripts/isa_report.py on a canned piece of gfx950 assembly: the kernel's resource block, the basic block with the most MFMAs
+    and its instruction classes, the kernel-symbol prettifier (binutils' c++filt does not know _Float16's mangling)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('isa_report', os.path.join(ROOT, 'scripts', 'isa_report.py'))
+    R = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(R)
+    sym = '_ZN12_GLOBAL__N_115gemm_nt8_kernelIDF16_Lb1ELi256EEEvN6ase_nt8NTParamsE'
+    asm = '\n'.join([
+        '\t.text', sym + ':', '\ts_load_dwordx4 s[0:3], s[4:5], 0x0', '\tv_mov_b32_e32 v0, 0',
+        '.LBB0_1:', '\tds_read_b128 v[2:5], v1', '\tv_mfma_f32_32x32x16_f16 v[10:25], v[2:5], v[6:9], v[10:25]',
+        '\tv_mfma_f32_32x32x16_f16 v[10:25], v[2:5], v[6:9], v[10:25]', '\tglobal_load_lds_dwordx4 v[30:31], off', '\ts_barrier',
+        '\ts_waitcnt vmcnt(3)', '\ts_setprio 1', '\tv_add_u32_e32 v1, 64, v1', '\ts_cbranch_scc1 .LBB0_1',
+        '.LBB0_2:', '\tv_mfma_f32_32x32x16_f16 v[10:25], v[2:5], v[6:9], v[10:25]', '\tglobal_store_dwordx4 v[30:31], v[10:13], off',
+        '\ts_endpgm', '\t.amdhsa_kernel ' + sym, '\t.end_amdhsa_kernel',
+        'amdhsa.kernels:', '  - .agpr_count:     0', '    .group_segment_fixed_size: 0', '    .max_flat_workgroup_size: 512',
+        '    .name:           ' + sym, '    .private_segment_fixed_size: 0', '    .sgpr_count:     77', '    .sgpr_spill_count: 0',
+        '    .symbol:         ' + sym + '.kd', '    .vgpr_count:     238', '    .vgpr_spill_count: 0', ''])
+    k = {n: v for n, v in R.parse(asm).items() if v['meta']}          # (report() keeps the symbols that own a metadata entry)
+    assert list(k) == [sym]
+    assert k[sym]['meta']['vgpr_count'] == 238 and k[sym]['meta']['sgpr_count'] == 77 and k[sym]['meta']['max_flat_workgroup_size'] == 512
+    assert R.waves_per_simd(k[sym]['meta']) == 2
+    best = max(k[sym]['blocks'], key=lambda b: sum(1 for op in b if R.classify(op) == 'mfma'))
+    import collections
+    c = collections.Counter(R.classify(op) for op in best)
+    assert (c['mfma'], c['lds_read'], c['lds_dma'], c['barrier'], c['waitcnt'], c['sched'], c['valu'], c['branch']) == (2, 1, 1, 1, 1, 1, 1, 1)
+    assert R.demangle([sym, '_ZN12_GLOBAL__N_114gemm_nt_kernelI6f32h_tLi2ELi2ELi1ELi2ELi128ELi2ELi2ELb0EEEvN6ase_nt8NTParamsE',
+                       '_ZN12_GLOBAL__N_116tn_reduce_kernelEPKlPKiPKf']) == \
+        ['gemm_nt8_kernel<f16, true, 256>', 'gemm_nt_kernel<f32h_t, 2, 2, 1, 2, 128, 2, 2, false>', 'tn_reduce_kernel']
