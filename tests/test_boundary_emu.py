@@ -13,7 +13,7 @@ import torch
 from ase_amd.learning import agents, models, players
 from ase_amd.synthetic import EnvSpec, SyntheticVecEnv
 from tests.emu_backend import EmuBackend
-from tests.helpers import BUILDERS
+from tests.helpers import BUILDERS, close
 
 MODELS = {'ase': models.ModelASEContinuous, 'amp': models.ModelAMPContinuous, 'ppo': models.ModelHRLContinuous}
 AGENTS = {'ase': agents.ASEAgent, 'amp': agents.AMPAgent, 'ppo': agents.CommonAgent}
@@ -382,3 +382,36 @@ def test_precision_resolver_is_shared_by_trainer_and_player():
     from ase_amd.learning import agents, players
     assert 'resolve_precision' in inspect.getsource(agents.CommonAgent.__init__)
     assert 'resolve_precision' in inspect.getsource(players)
+
+
+@pytest.mark.parametrize('name', ['ase_tiny', 'amp_tiny', 'ppo_tiny'])
+def test_model_wrapper_forward_matches_the_reference(name, golden_dir):
+    """learning/models.py `Network.forward` against the REFERENCE'S OWN model wrappers (learning/ase_models.py:19-29,
+    amp_models.py:20-38, hrl_models.py; tests/golden/model_forward.pt from oracle/make_golden_model.py): same result keys, train
+    mode - prev_neglogp, values, entropy, mus, sigmas, the three discriminator logits, enc_pred - and play mode - mus / sigmas /
+    values, and the returned neglogpacs are those of the returned actions."""
+    import math
+    from tests.test_agent_emu import make_agent
+    G = torch.load(os.path.join(golden_dir, name + '.pt'), weights_only=False)
+    M = torch.load(os.path.join(golden_dir, 'model_forward.pt'), weights_only=False)[name]
+    ag = make_agent(G, EmuBackend(), precision='f32')
+    model = ag.model
+    out = model(dict(M['inputs'], is_train=True))
+    assert set(out) == set(M['train']), (sorted(out), sorted(M['train']))
+    for k, ref in M['train'].items():
+        if ref is None:
+            assert out[k] is None, k
+            continue
+        assert out[k].shape == ref.shape, (k, out[k].shape, ref.shape)
+        close(out[k], ref, 2e-5, 2e-5 * max(1.0, float(ref.abs().max())), 'train ' + k)
+    torch.manual_seed(M['play_seed'])
+    play = model(dict(M['inputs'], is_train=False))
+    assert set(play) == set(M['play'])
+    for k in ('mus', 'sigmas', 'values'):
+        close(play[k], M['play'][k], 2e-5, 2e-5 * max(1.0, float(M['play'][k].abs().max())), 'play ' + k)
+    a, mu, sg = play['actions'], play['mus'], play['sigmas']
+    nlp = 0.5 * (((a - mu) / sg) ** 2).sum(-1) + 0.5 * math.log(2 * math.pi) * a.shape[-1] + sg.log().sum(-1)
+    close(play['neglogpacs'], nlp, 1e-5, 1e-5, 'play neglogpacs of the returned actions')
+    assert play['neglogpacs'].shape == M['play']['neglogpacs'].shape and a.shape == M['play']['actions'].shape
+    # the draw itself: mu + sigma * N(0, 1) from torch's generator, like Normal(mu, sigma).sample() - same seed, same actions
+    close(a, M['play']['actions'], 2e-5, 2e-5 * max(1.0, float(M['play']['actions'].abs().max())), 'play actions (seeded)')
