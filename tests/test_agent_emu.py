@@ -411,3 +411,61 @@ def test_result_rings_equal_per_step_snapshots(golden_dir):
             for x, y in zip(a[k], b[k]):
                 x, y = torch.as_tensor(x), torch.as_tensor(y)
                 assert x.shape == y.shape and torch.equal(x.float(), y.float()), k
+
+
+# ------------------------------------------------------------------------------------------------ reference-named single calls
+@pytest.mark.parametrize('name', ['ase_tiny', 'amp_tiny', 'ppo_tiny'])
+def test_calc_gradients_on_a_gathered_minibatch(name, golden_dir):
+    """The reference's single-step entry points on an already gathered minibatch dict (`calc_gradients(input_dict)` /
+    `train_actor_critic`, learning/ase_agent.py:159-308, amp_agent.py:266-390, common_agent.py:353-435): `train_result` of the
+    golden's first step, its gradients, and the weights after the optimizer step."""
+    from tests.helpers import set_rms
+    from tests.test_engine_emu import SCALARS
+    G = torch.load(os.path.join(golden_dir, name + '.pt'), weights_only=False)
+    E = G['epochs'][0]
+    ag = make_agent(G, EmuBackend(), precision='f32')
+    set_rms(ag.engine.obs_state, E['rms_step0_before']['obs'])
+    if G['kind'] != 'ppo':
+        set_rms(ag.engine.amp_state, E['rms_step0_before']['amp'])
+    inp = {k: v.clone() for k, v in E['first_minibatch'].items()}
+    if E['new_zs']:
+        inp['_new_z'] = E['new_zs'][0].clone()             # (the latents _diversity_loss draws: injected, as in every golden replay)
+    res = ag.train_actor_critic(inp)
+    assert res is ag.train_result
+    ref = E['steps'][0]
+    for k in SCALARS:
+        if k in ref:
+            close(res[k], ref[k], 2e-5, 2e-6, k)
+    close(res['critic_loss'], ref['critic_loss'].mean(), 2e-5, 1e-6, 'critic_loss')
+    assert float(res['last_lr']) == G['cfg']['learning_rate'] and res['lr_mul'] == 1.0
+    grads = ag.engine.export_grads()
+    for k, g in E['first_grads'].items():
+        close(grads[k], g, 2e-4, 2e-4 * float(g.abs().max()) + 1e-12, 'grad ' + k)
+    sd = ag.model.a2c_network.state_dict()
+    moved = max(float((sd[k] - v).abs().max()) for k, v in golden_init_sd(G).items() if k in G['trainable'])
+    assert 0.5 * G['cfg']['learning_rate'] < moved < 1.5 * G['cfg']['learning_rate']      # one Adam step was taken
+
+
+def test_discount_values_and_preproc_obs_keep_the_reference_signatures(golden_dir):
+    """`discount_values(mb_fdones, mb_values, mb_rewards, mb_next_values)` (learning/common_agent.py:437-449) and
+    `_preproc_obs(obs_batch)` (rl_games A2CBase: uint8 -> / 255, eval-mode normaliser with its clamp) as stand-alone calls."""
+    G = torch.load(os.path.join(golden_dir, 'ase_tiny.pt'), weights_only=False)
+    ag = make_agent(G, EmuBackend(), precision='f32')
+    H, N = ag.horizon_length, ag.num_actors
+    g = torch.Generator().manual_seed(11)
+    fd = (torch.rand(H, N, generator=g) < 0.2).float()
+    v, nv, r = torch.randn(H, N, 1, generator=g), torch.randn(H, N, 1, generator=g), torch.randn(H, N, 1, generator=g)
+    advs = ag.discount_values(fd, v, r, nv)
+    ref = R.discount_values(fd, v, r, nv, ag.gamma, ag.tau)
+    close(advs, ref, 1e-5, 1e-6, 'discount_values')
+    # the observation normaliser in eval mode: (x - mean) / sqrt(var + 1e-5), clamped to +-5; uint8 observations are scaled first
+    D = ag.obs_shape[0]
+    ag.engine.obs_state[:D] = torch.linspace(-1, 1, D, dtype=torch.float64)
+    ag.engine.obs_state[D:2 * D] = torch.linspace(0.5, 2.0, D, dtype=torch.float64)
+    ag.engine.obs_state[2 * D] = 100.0
+    x = torch.randn(7, D, generator=g) * 4
+    mean, var = ag.engine.obs_state[:D].float(), ag.engine.obs_state[D:2 * D].float()
+    close(ag._preproc_obs(x), ((x - mean) / torch.sqrt(var + 1e-5)).clamp(-5, 5), 1e-5, 1e-5, '_preproc_obs')
+    xb = torch.randint(0, 256, (5, D), generator=g, dtype=torch.uint8)
+    close(ag._preproc_obs(xb), ((xb.float() / 255.0 - mean) / torch.sqrt(var + 1e-5)).clamp(-5, 5), 1e-5, 1e-5, '_preproc_obs uint8')
+    assert ag._preproc_obs(x.view(7, 1, D)).shape == (7, 1, D)
