@@ -415,3 +415,42 @@ def test_model_wrapper_forward_matches_the_reference(name, golden_dir):
     assert play['neglogpacs'].shape == M['play']['neglogpacs'].shape and a.shape == M['play']['actions'].shape
     # the draw itself: mu + sigma * N(0, 1) from torch's generator, like Normal(mu, sigma).sample() - same seed, same actions
     close(a, M['play']['actions'], 2e-5, 2e-5 * max(1.0, float(M['play']['actions'].abs().max())), 'play actions (seeded)')
+
+
+@pytest.mark.parametrize('kind', ['ase', 'amp'])
+def test_player_reward_helpers_match_the_oracle(kind, golden_dir, tmp_path):
+    """The players' stand-alone discriminator / encoder helpers (learning/amp_players.py:60-110 `_preproc_amp_obs`, `_eval_disc`,
+    `_calc_disc_rewards`, `_calc_amp_rewards`; learning/ase_players.py `_eval_enc`, `_calc_enc_rewards`) on a restored checkpoint
+    against oracle/restated.py's `calc_disc_rewards` / `calc_enc_rewards` with the checkpoint's weights and AMP statistics."""
+    from oracle import restated as R
+    from tests.helpers import get_rms
+    G = _load(golden_dir, kind)
+    env = _env(G)
+    ag, cfg = _agent(G, env, max_epochs=1, train_dir=str(tmp_path), name='q')
+    ag.train()
+    pcfg = dict(cfg)
+    pcfg.update(vec_env=_env(G, seed=9), env_info=None, backend=_BE(), player={'games_num': 1, 'print_stats': False})
+    pl = PLAYERS[kind](pcfg)
+    pl.restore(os.path.join(str(tmp_path), 'q.pth'))
+    sd = R.canonical_sd({k: v.detach().cpu() for k, v in pl.model.state_dict().items()}, False)
+    rms = get_rms(pl.engine.amp_state)
+    rms = {'mean': rms['mean'].float(), 'var': rms['var'].float(), 'count': rms['count']}
+    amp = env.fetch_amp_obs_demo(12)
+    amp_c = amp.cpu()
+    # the eval-mode AMP normaliser on its own
+    x = pl._preproc_amp_obs(amp)
+    assert torch.allclose(x.cpu(), R.rms_normalize(rms, amp_c), rtol=1e-5, atol=1e-5)
+    ref_d = R.calc_disc_rewards(sd, rms, amp_c, G['cfg']['disc_reward_scale'])
+    out = pl._calc_amp_rewards(amp) if kind == 'amp' else None
+    if kind == 'amp':
+        assert set(out) == {'disc_rewards'}
+        assert torch.allclose(out['disc_rewards'].cpu(), ref_d, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(pl._eval_disc(amp).cpu(), R.eval_disc(sd, R.rms_normalize(rms, amp_c)), rtol=1e-5, atol=1e-5)
+        return
+    g = torch.Generator().manual_seed(2)
+    z = torch.nn.functional.normalize(torch.randn(12, G['cfg']['latent_dim'], generator=g), dim=-1)
+    out = pl._calc_amp_rewards(amp, z.to(amp.device))
+    assert set(out) == {'disc_rewards', 'enc_rewards'}
+    assert torch.allclose(out['disc_rewards'].cpu(), ref_d, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(out['enc_rewards'].cpu(), R.calc_enc_rewards(sd, rms, amp_c, z, G['cfg']['enc_reward_scale']), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(pl._eval_enc(amp).cpu(), R.eval_enc(sd, R.rms_normalize(rms, amp_c)), rtol=1e-5, atol=1e-5)
