@@ -219,3 +219,33 @@ def test_mixed_precision_flag_selects_the_dynamic_scale(golden_dir):
     assert st['steps'] == 2 * n_updates and st['skipped'] >= 2             # the first update at 2^40: every step skipped
     assert ag.engine.gs == 2.0 ** (40 - min(n_updates, 2)) or ag.engine.gs < 2.0 ** 40
     assert len(dropped) >= 1
+
+
+def test_dynamic_loss_scale_with_truncate_grads(golden_dir):
+    """scaler.unscale_ -> clip_grad_norm_ -> scaler.step (learning/ase_agent.py:273-285): with the clip active a clean step of the
+    dynamic engine is the static engine's clipped step; an overflowing one clips nothing (zero gradient) and moves nothing."""
+    G = torch.load(os.path.join(golden_dir, 'ase_tiny.pt'), weights_only=False)
+    E = G['epochs'][0]
+    total0 = float(torch.sqrt(sum((g.double() ** 2).sum() for g in E['first_grads'].values())))
+    Gs = copy.deepcopy(G)
+    Gs['cfg'].update(truncate_grads=True, grad_norm=0.5 * total0)
+    net_s, eng_s = first_step(Gs, EmuBackend(), torch.float16)
+    assert eng_s.truncate and not eng_s.dyn_scale
+    for init, skipped in ((eng_s.gs, 0), (eng_s.gs * 2.0 ** 30, 1)):
+        Gd = copy.deepcopy(Gs)
+        Gd['cfg'].update(loss_scale='dynamic', loss_scaler={'init_scale': init})
+        net_d, eng_d = first_step(Gd, EmuBackend(), torch.float16)
+        assert eng_d.truncate and eng_d.dyn_scale and eng_d.scaler_state()['skipped'] == skipped
+        gd = eng_d.export_grads()
+        if skipped:
+            assert all(float(v.abs().max()) == 0.0 for v in gd.values()) and float(eng_d.opt_state[0]) == 0.0
+            for k, v in G['init_sd'].items():
+                assert torch.equal(net_d.state_dict()[k], v), k
+        else:
+            gs_ = eng_s.export_grads()
+            tot = float(torch.sqrt(sum((g.double() ** 2).sum() for g in gd.values())))
+            assert abs(tot - 0.5 * total0) <= 2e-2 * total0                  # clipped to grad_norm (half storage: the golden's norm +- 2 %)
+            for k, g in gs_.items():
+                close(gd[k], g, 2e-5, 2e-5 * float(g.abs().max()) + 1e-12, 'clipped grad ' + k)
+            for k in G['trainable']:
+                close(net_d.state_dict()[k], net_s.state_dict()[k], 1e-6, G['cfg']['learning_rate'] * 0.25, 'weight ' + k)
