@@ -166,3 +166,47 @@ def test_isa_report_parses_a_kernel_and_its_metadata():
     assert R.demangle([sym, '_ZN12_GLOBAL__N_114gemm_nt_kernelI6f32h_tLi2ELi2ELi1ELi2ELi128ELi2ELi2ELb0EEEvN6ase_nt8NTParamsE',
                        '_ZN12_GLOBAL__N_116tn_reduce_kernelEPKlPKiPKf']) == \
         ['gemm_nt8_kernel<f16, true, 256>', 'gemm_nt_kernel<f32h_t, 2, 2, 1, 2, 128, 2, 2, false>', 'tn_reduce_kernel']
+
+
+def test_configure_sets_the_queue_count_once_and_respects_the_user(monkeypatch):
+    """ase_amd.configure(): importing the package changes nothing; configure() exports GPU_MAX_HW_QUEUES before HIP
+    initialises, leaves a user's value alone, and says what happened in the note the bench line carries."""
+    import importlib
+    import ase_amd
+    monkeypatch.delenv('GPU_MAX_HW_QUEUES', raising=False)
+    importlib.reload(ase_amd)
+    assert 'GPU_MAX_HW_QUEUES' not in os.environ and not ase_amd.hw_queues_applied and 'not called' in ase_amd.hw_queue_note
+    assert ase_amd.configure() is True
+    assert os.environ['GPU_MAX_HW_QUEUES'] == '4' and ase_amd.hw_queues_applied and 'set by ase_amd.configure()' in ase_amd.hw_queue_note
+    monkeypatch.setenv('GPU_MAX_HW_QUEUES', '6')
+    assert ase_amd.configure(hw_queues='3') is True
+    assert os.environ['GPU_MAX_HW_QUEUES'] == '6' and 'set by the user' in ase_amd.hw_queue_note
+    import torch
+    n = torch.get_num_threads()
+    ase_amd.configure(cpu_threads=1)
+    assert torch.get_num_threads() == 1
+    torch.set_num_threads(n)
+
+
+def test_cfg_tables_follow_the_reference_yaml():
+    """ase_amd/cfg: the hyper-parameter tables are the reference's yaml files (read here when /root/reference is mounted; the
+    GPU box compares nothing), numeric strings of PyYAML ('2e-5') normalised."""
+    from ase_amd import cfg as C
+    net, conf = C.get('ase')
+    assert isinstance(conf['learning_rate'], float) and net['mlp']['units'] == [1024, 1024, 512]
+    assert C.normalize({'learning_rate': '2e-5', 'disc_weight_decay': '0.0001'}) == {'learning_rate': 2e-5, 'disc_weight_decay': 1e-4}
+    ref_dir = '/root/reference/ase/data/cfg/train/rlg'
+    if not os.path.isdir(ref_dir):
+        return
+    import yaml
+    for kind, fn in (('ase', 'ase_humanoid.yaml'), ('amp', 'amp_humanoid.yaml'), ('hrl', 'hrl_humanoid.yaml')):
+        ref = yaml.safe_load(open(os.path.join(ref_dir, fn)))['params']
+        net, conf = C.get(kind)
+        for part in ('mlp', 'disc', 'enc'):
+            if part in ref['network']:
+                assert net[part]['units'] == ref['network'][part]['units'], (kind, part)
+                assert net[part]['activation'] == ref['network'][part]['activation'], (kind, part)
+        rc = C.normalize(ref['config'])
+        for k, v in rc.items():
+            if k in conf and isinstance(v, (int, float, bool, str)) and k not in ('name', 'llc_config'):
+                assert conf[k] == v, (kind, k, conf[k], v)
