@@ -454,3 +454,48 @@ def test_player_reward_helpers_match_the_oracle(kind, golden_dir, tmp_path):
     assert torch.allclose(out['disc_rewards'].cpu(), ref_d, rtol=1e-5, atol=1e-6)
     assert torch.allclose(out['enc_rewards'].cpu(), R.calc_enc_rewards(sd, rms, amp_c, z, G['cfg']['enc_reward_scale']), rtol=1e-5, atol=1e-6)
     assert torch.allclose(pl._eval_enc(amp).cpu(), R.eval_enc(sd, R.rms_normalize(rms, amp_c)), rtol=1e-5, atol=1e-5)
+
+
+def test_network_weight_getters_and_initialisers(golden_dir):
+    """The network-level helpers the reference's losses call (learning/amp_network_builder.py:86-96 `get_disc_logit_weights`,
+    `get_disc_weights`; learning/ase_network_builder.py `get_enc_weights`) return the same tensors in the same order, a FRESH
+    network starts where the reference's initialisers put it (zero biases; logit / encoder / style-dense weights uniform within
+    the reference's constants), and the flat parameter buffer refuses to move once an engine has bound it."""
+    G = _load(golden_dir, 'ase')
+    b = BUILDERS['ase']()
+    b.load(G['net'])
+    s = G['spec']
+    torch.manual_seed(0)
+    net = b.build('ase', actions_num=s['act_size'], input_shape=(s['obs_size'],), num_seqs=s['num_envs'], value_size=1,
+                  amp_input_shape=(s['amp_obs_size'],), ase_latent_shape=(G['cfg']['latent_dim'],), device='cpu')
+    sd = net.state_dict()
+    disc_keys = sorted(k for k in sd if k.startswith('_disc_mlp.') and k.endswith('.weight'))
+    ws = net.get_disc_weights()
+    assert len(ws) == len(disc_keys) + 1
+    for w, k in zip(ws, disc_keys + ['_disc_logits.weight']):
+        assert torch.equal(w, sd[k].reshape(-1)), k
+    assert torch.equal(net.get_disc_logit_weights(), sd['_disc_logits.weight'].reshape(-1))
+    enc_keys = sorted(k for k in sd if k.startswith('_enc_mlp.') and k.endswith('.weight'))
+    we = net.get_enc_weights()
+    assert len(we) == len(enc_keys) + 1 and torch.equal(we[-1], sd['_enc.weight'].reshape(-1))
+    for w, k in zip(we, enc_keys):
+        assert torch.equal(w, sd[k].reshape(-1)), k
+    # shared trunk: the encoder's trunk IS the discriminator's (checkpoint aliases, learning/ase_network_builder.py:202-203)
+    assert all(torch.equal(sd[k], sd[k.replace('_enc_mlp.', '_disc_mlp.')]) for k in enc_keys)
+    # initialisers
+    from ase_amd.learning import network_builder as NB
+    assert all(float(v.abs().max()) == 0.0 for k, v in sd.items() if k.endswith('.bias'))
+    assert float(sd['_disc_logits.weight'].abs().max()) <= NB.DISC_LOGIT_INIT_SCALE
+    assert float(sd['_enc.weight'].abs().max()) <= NB.ENC_LOGIT_INIT_SCALE < 0.5
+    assert 0.5 < float(sd['actor_mlp._style_dense.weight'].abs().max()) <= NB.STYLE_INIT_RANGE
+    assert abs(float(sd['sigma'][0]) - G['net']['space']['continuous']['sigma_init']['val']) < 1e-6 and not net.sigma.requires_grad
+    if os.path.isdir('/root/reference/ase/learning'):            # the constants, read from the reference's own sources
+        import re
+        src = lambda f: open(os.path.join('/root/reference/ase/learning', f)).read()
+        assert NB.DISC_LOGIT_INIT_SCALE == float(re.search(r'^DISC_LOGIT_INIT_SCALE\s*=\s*([0-9.]+)', src('amp_network_builder.py'), re.M).group(1))
+        assert NB.ENC_LOGIT_INIT_SCALE == float(re.search(r'^ENC_LOGIT_INIT_SCALE\s*=\s*([0-9.]+)', src('ase_network_builder.py'), re.M).group(1))
+        assert NB.STYLE_INIT_RANGE == float(re.search(r'scale_init_range\s*=\s*([0-9.]+)', src('ase_network_builder.py')).group(1))
+    # an engine binds the flat buffer: .to() / .double() afterwards must fail loudly instead of orphaning its shadows
+    ag, _ = _agent(G, _env(G))
+    with pytest.raises((RuntimeError, TypeError)):
+        ag.model.a2c_network.double()
