@@ -148,3 +148,37 @@ def test_motion_state_restatement_matches_reference(golden_dir):
     for k, o in zip(G['outputs'], out):
         assert o.shape == G['outputs'][k].shape
         assert float((o - G['outputs'][k]).abs().max()) <= 1e-6, k
+
+
+def test_rl_games_restatements_against_closed_forms():
+    """The rl_games 1.1.4 pieces the reference calls (absent from /root/reference: parity unpinned at that boundary) anchored to
+    what CAN be checked here - torch.distributions' closed forms and the algebra of the running-statistics merge:
+      neglogp            = -Normal(mu, sigma).log_prob(x).sum(-1)                                  (exact)
+      policy_kl          = KL(N(mu0, s0) || N(mu1, s1)).sum(-1).mean() up to its two 1e-5 guards   (sigma ~ 1: 1e-4)
+      RunningMeanStd     mean after k merges = (the pseudo-sample 0 of the initial count 1 + every row) / (1 + rows); the
+                         normaliser clamps to +-5 and un-normalise inverts normalise inside the clamp."""
+    g = torch.Generator().manual_seed(7)
+    mu, mu1 = torch.randn(64, 31, generator=g), torch.randn(64, 31, generator=g)
+    ls, ls1 = torch.randn(31, generator=g) * 0.2, torch.randn(31, generator=g) * 0.2
+    s, s1 = torch.exp(ls).expand(64, 31), torch.exp(ls1).expand(64, 31)
+    x = mu + s * torch.randn(64, 31, generator=g)
+    N = torch.distributions.Normal
+    assert torch.allclose(R.neglogp(x, mu, s, ls.expand(64, 31)), -N(mu, s).log_prob(x).sum(-1), rtol=1e-6, atol=1e-5)
+    kl_ref = torch.distributions.kl_divergence(N(mu, s), N(mu1, s1)).sum(-1).mean()
+    assert abs(float(R.policy_kl(mu, s, mu1, s1)) - float(kl_ref)) <= 1e-4 * abs(float(kl_ref))
+    assert abs(float(R.policy_kl(mu, s, mu, s))) <= 31 * 2e-5                       # (KL of a policy with itself: the guards' size)
+    st = R.rms_new(5)
+    rows = [torch.randn(n, 5, generator=g, dtype=torch.float64) * 3 + 1 for n in (7, 1000, 33)]
+    for b in rows:
+        R.rms_update(st, b)
+    allx = torch.cat(rows)
+    assert float(st['count']) == 1 + allx.shape[0]
+    assert torch.allclose(st['mean'], allx.sum(0) / (1 + allx.shape[0]), rtol=1e-12, atol=1e-12)
+    # variance: the merge treats every batch's UNBIASED variance as if it were its population variance (rl_games): between the two
+    pop = ((torch.cat([torch.zeros(1, 5, dtype=torch.float64), allx]) - st['mean']) ** 2).mean(0)
+    assert torch.all((st['var'] - pop).abs() <= 0.02 * pop + 1.0 / allx.shape[0])
+    y = torch.randn(200, 5, generator=g, dtype=torch.float64) * 3 + 1
+    z = R.rms_normalize(st, y)
+    assert float(z.abs().max()) <= 5.0
+    inside = z.abs() < 5.0
+    assert torch.allclose(R.rms_unnormalize(st, z)[inside], y[inside], rtol=1e-9, atol=1e-9)
