@@ -200,3 +200,18 @@ def test_every_entry_point_is_documented():
     for name in _header_decls():
         stem, last = name.rsplit('_', 1)
         assert name in doc or (stem in doc and re.search(r'[/ ]\s*' + re.escape(last) + r'\b', doc)), f'{name} is not mentioned in INTEGRATION.md'
+
+
+def test_scaler_entry_points_validate_on_the_host():
+    """ase_hip_scaler_check / ase_hip_scaler_step reject null, empty, misaligned, badly typed and aliased operands before any
+    launch (so this runs without a GPU), with the message naming the entry point."""
+    lib = L.load()
+    buf = (ctypes.c_double * 8)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.ase_hip_scaler_check(None, 8, L.F16, p, None) == -1 and b'scaler_check' in lib.ase_hip_last_error()
+    assert lib.ase_hip_scaler_check(p, 0, L.F16, p, None) == -1
+    assert lib.ase_hip_scaler_check(p, 8, L.F32X3, p, None) == -1 and b'dtype' in lib.ase_hip_last_error()
+    assert lib.ase_hip_scaler_check(ctypes.c_void_p(p.value + 1), 4, L.F16, p, None) == -1 and b'misaligned' in lib.ase_hip_last_error()
+    assert lib.ase_hip_scaler_step(p, p, p, p, 8, None) == -1 and b'scaler_step' in lib.ase_hip_last_error()      # opt_eff aliases opt_state
+    assert lib.ase_hip_scaler_step(None, p, p, p, 8, None) == -1
+    assert lib.ase_hip_scaler_step(p, p, ctypes.c_void_p(p.value + 8), p, 0, None) == -1
