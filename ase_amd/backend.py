@@ -127,7 +127,9 @@ class HipBackend:
 
     # ------------------------------------------------------------------ GEMMs
     def gemm_nt(self, A, B, Cm, M, N, K, bias=None, aux=None, aux_mode=L.AUX_NONE, colsum=None, colsum_n=0,
-                act=L.ACT_NONE, alpha=1.0, aux_split=0, aux_delta=0, mask_out=None, x3_exps=None):
+                act=L.ACT_NONE, alpha=1.0, aux_split=0, aux_delta=0, mask_out=None, x3_exps=None, alpha_dev=None):
+        """alpha_dev (all `*_dev` / `dyn` arguments of this class): a device f32 scalar the launch multiplies its scale by when it
+        RUNS - an entry of the dynamic loss scale's table (UpdateEngine.scale_tab: S, 1 / S, 1 / S^2)."""
         dt = self._gemm_code(A.dtype, x3_exps)
         assert B.dtype == A.dtype
         if aux_mode == L.AUX_RELU_BITS:
@@ -140,12 +142,13 @@ class HipBackend:
         L.check(self.lib.ase_hip_gemm_nt(_ptr(A), _ld(A), _ptr(B), _ld(B), _ptr(Cm), _ld(Cm), _ptr(bias), _ptr(aux),
                                          _ld(aux), int(aux_split), int(aux_delta), _ptr(colsum), int(colsum_n),
                                          _ptr(mask_out), _ld(mask_out), M, N, K, act, aux_mode, out_f32,
-                                         float(alpha), dt, self._stream()), "gemm_nt")
+                                         float(alpha), _ptr(alpha_dev), dt, self._stream()), "gemm_nt")
 
-    def gemm_tn(self, A, B, G, M, N, K, n_real, k_real, split_src, split_dst, alpha=1.0, gbias=None, bias_rows=0):
+    def gemm_tn(self, A, B, G, M, N, K, n_real, k_real, split_src, split_dst, alpha=1.0, gbias=None, bias_rows=0, alpha_dev=None):
         L.check(self.lib.ase_hip_gemm_tn(_ptr(A), _ld(A), _ptr(B), _ld(B), _ptr(G), _ptr(gbias), int(bias_rows), M, N, K,
                                          n_real, k_real,
-                                         split_src, split_dst, float(alpha), self._gemm_code(A.dtype), self._stream()), "gemm_tn")
+                                         split_src, split_dst, float(alpha), _ptr(alpha_dev), self._gemm_code(A.dtype), self._stream()),
+                "gemm_tn")
 
     # grouped weight gradients: one launch for every (eligible) dense layer of a step
     def grouped_tn_ok(self, dtype, M, n_real, K, bias_rows):
@@ -158,7 +161,7 @@ class HipBackend:
         #  against 156 us as seven launches of the 128 x 128 kernel)
         return dtype in (torch.bfloat16, torch.float16) and M % 64 == 0 and bias_rows % 64 == 0
 
-    def make_tn_plan(self, problems, target_wg=0):
+    def make_tn_plan(self, problems, target_wg=0, alpha_dev=None):
         """problems: [(A, B, G, gbias|None, bias_rows, M, N, K, n_real, k_real, split_src, split_dst, alpha)] -> plan
         (device tables + the tensors they point to, kept alive)."""
         import struct
@@ -183,11 +186,12 @@ class HipBackend:
         # partial-sum workspace of this launch (plans of different branches run side by side: one each)
         ws = torch.empty(nw * L.TN_SLAB, dtype=torch.float32, device=self.device) if self.tn_workspace else None
         return {'problems': dev_tab, 'work': dev_work, 'n_work': nw, 'red': dev_red, 'n_red': nr, 'ws': ws, 'keep': problems,
-                'dtype': _code(problems[0][0].dtype)}
+                'dtype': _code(problems[0][0].dtype), 'alpha_dev': alpha_dev}
 
     def gemm_tn_grouped(self, plan):
         L.check(self.lib.ase_hip_gemm_tn_grouped(_ptr(plan['problems']), _ptr(plan['work']), plan['n_work'], _ptr(plan['red']),
-                                                 plan['n_red'], _ptr(plan['ws']), plan['dtype'], self._stream()),
+                                                 plan['n_red'], _ptr(plan['ws']), _ptr(plan.get('alpha_dev')), plan['dtype'],
+                                                 self._stream()),
                 "gemm_tn_grouped")
 
     def refresh_shadow(self, W, Ws, Wts, split_src, split_dst, x3_exp=None):
@@ -303,7 +307,7 @@ class HipBackend:
 
     def ppo_head(self, mu, value, mb, new_z, logstd, d_mu, d_value, db_mu, db_value, acc, M, m_global, act_dim,
                  z_dim, masked, div_on, mu_tanh, clip_value, e_clip, critic_coef, bounds_coef, div_coef, div_tar,
-                 mu_out=None, grad_scale=1.0):
+                 mu_out=None, grad_scale=1.0, dyn=None):
         L.check(self.lib.ase_hip_ppo_head(
             _ptr(mu), _ld(mu), _ptr(value), _ld(value), _ptr(mb['actions']), _ptr(mb['mu']), _ptr(mb['sigma']),
             _ptr(mb['old_logp_actions']), _ptr(mb['advantages']), _ptr(mb.get('old_values')), _ptr(mb['returns']),
@@ -312,17 +316,17 @@ class HipBackend:
             _ptr(self._head_scratch),
             M, m_global, act_dim, z_dim, int(masked), int(div_on), int(mu_tanh), int(clip_value),
             float(e_clip), float(critic_coef), float(bounds_coef), float(div_coef), float(div_tar), float(grad_scale),
-            _code(d_mu.dtype), self._stream()), "ppo_head")
+            _ptr(dyn), _code(d_mu.dtype), self._stream()), "ppo_head")
 
-    def disc_head(self, logit, d_logit, db_logit, acc, amb, amb_global, disc_coef, grad_scale=1.0):
+    def disc_head(self, logit, d_logit, db_logit, acc, amb, amb_global, disc_coef, grad_scale=1.0, dyn=None):
         L.check(self.lib.ase_hip_disc_head(_ptr(logit), _ld(logit), _ptr(d_logit), _ld(d_logit), _ptr(db_logit),
-                                           _ptr(acc), amb, amb_global, float(disc_coef), float(grad_scale), _code(d_logit.dtype),
-                                           self._stream()), "disc_head")
+                                           _ptr(acc), amb, amb_global, float(disc_coef), float(grad_scale), _ptr(dyn),
+                                           _code(d_logit.dtype), self._stream()), "disc_head")
 
-    def enc_head(self, e, z, d_e, db_enc, enc_out, acc, amb, amb_global, z_dim, enc_coef, grad_scale=1.0):
+    def enc_head(self, e, z, d_e, db_enc, enc_out, acc, amb, amb_global, z_dim, enc_coef, grad_scale=1.0, dyn=None):
         L.check(self.lib.ase_hip_enc_head(_ptr(e), _ld(e), _ptr(z), _ld(z), _ptr(d_e), _ld(d_e), _ptr(db_enc),
                                           _ptr(enc_out), _ptr(acc), amb, amb_global, z_dim, float(enc_coef), float(grad_scale),
-                                          _code(d_e.dtype), self._stream()), "enc_head")
+                                          _ptr(dyn), _code(d_e.dtype), self._stream()), "enc_head")
 
     def enc_gp_seed(self, e, z, u, rows, z_dim, scale=1.0):
         """u[:rows, :z_dim] = scale * d enc_err / d e (learning/ase_agent.py:431-434; e f32 pre-normalisation output)."""
@@ -330,12 +334,12 @@ class HipBackend:
         L.check(self.lib.ase_hip_enc_gp_seed(_ptr(e), _ld(e), _ptr(z), _ld(z), _ptr(u), _ld(u), rows, z_dim, float(scale),
                                              _code(u.dtype), self._stream()), "enc_gp_seed")
 
-    def enc_gp_back(self, e, z, du, d_e, db_enc, rows, z_dim, grad_scale=1.0):
+    def enc_gp_back(self, e, z, du, d_e, db_enc, rows, z_dim, grad_scale=1.0, dyn=None):
         """d_e[:rows, :z_dim] += (d u / d e) du, the bias gradient follows the stored values."""
         assert e.dtype == torch.float32 and z.dtype == torch.float32 and du.dtype == torch.float32
         L.check(self.lib.ase_hip_enc_gp_back(_ptr(e), _ld(e), _ptr(z), _ld(z), _ptr(du), _ld(du), _ptr(d_e), _ld(d_e),
-                                             _ptr(db_enc), rows, z_dim, float(grad_scale), _code(d_e.dtype), self._stream()),
-                "enc_gp_back")
+                                             _ptr(db_enc), rows, z_dim, float(grad_scale), _ptr(dyn), _code(d_e.dtype),
+                                             self._stream()), "enc_gp_back")
 
     def gp_seed(self, h, w, g, rows, width, scale=1.0, act=L.ACT_RELU):
         L.check(self.lib.ase_hip_gp_seed(_ptr(h), _ld(h), _ptr(w), _ptr(g), _ld(g), rows, width, float(scale), int(act),
@@ -350,8 +354,8 @@ class HipBackend:
         assert x.dtype == torch.float32 and out.dtype == torch.float32
         L.check(self.lib.ase_hip_colsum(_ptr(x), _ld(x), rows, cols, float(scale), _ptr(out), self._stream()), "colsum")
 
-    def sqnorm(self, x, rows, cols, acc, slot, scale=1.0):
-        L.check(self.lib.ase_hip_sqnorm(_ptr(x), _ld(x), rows, cols, _ptr(acc), slot, float(scale), _code(x.dtype),
+    def sqnorm(self, x, rows, cols, acc, slot, scale=1.0, dyn=None):
+        L.check(self.lib.ase_hip_sqnorm(_ptr(x), _ld(x), rows, cols, _ptr(acc), slot, float(scale), _ptr(dyn), _code(x.dtype),
                                         self._stream()),
                 "sqnorm")
 
@@ -385,10 +389,11 @@ class HipBackend:
         L.check(self.lib.ase_hip_scaler_check(_ptr(buf), buf.numel(), _code(buf.dtype), _ptr(scaler), self._stream()),
                 "scaler_check")
 
-    def scaler_step(self, scaler, opt_state, opt_eff, grads):
-        """GradScaler.step's decision: a found overflow zeroes the gradient and hands the optimizer launch the identity step."""
+    def scaler_step(self, scaler, opt_state, opt_eff, grads, scale_tab=None):
+        """GradScaler.step's decision - a found overflow zeroes the gradient and hands the optimizer launch the identity step - and
+        (scale_tab given) GradScaler.update(): backoff / growth of the device-resident scale and its table, every step."""
         L.check(self.lib.ase_hip_scaler_step(_ptr(scaler), _ptr(opt_state), _ptr(opt_eff), _ptr(grads), grads.numel(),
-                                             self._stream()), "scaler_step")
+                                             _ptr(scale_tab), self._stream()), "scaler_step")
 
     # ------------------------------------------------------------------ rollout tail
     def disc_reward(self, logit, r, n, scale):

@@ -40,6 +40,7 @@ struct NTParams {
     int M, N, K;                    // K in elements (multiple of 128/sizeof(T))
     int act, aux_mode, out_f32;
     float alpha;
+    const float* alpha_dev;         // nullable: device factor multiplied into alpha when the launch runs (the dynamic loss scale)
     float sa;                       // f32h_t storage: power-of-two scale of the A operand before its half split (B arrives pre-split and
                                     // pre-scaled; alpha undoes both scales)
     int tiles_m, tiles_n;
@@ -69,22 +70,80 @@ __device__ __forceinline__ f32x16 nt8_mfma(const i32x4& a, const i32x4& b, const
     } while (0)
 
 
-// ---- epilogue of the phased kernel with swapped MFMA operands.  acc[i][j] holds the transposed 32 x 32 block: lane
-// (r = lane & 31, h = lane >> 5) owns output row i*32 + r and the columns j*32 + 8 g + 4 h + q (g = e >> 2, q = e & 3):
-// four runs of 4 consecutive columns.  bias + activation + mask in registers, bf16 packing, then v_permlane32_swap
-// between the column groups (g, g + 1) of the two half-waves gives every lane 8 consecutive columns = ONE 16-byte store
-// (lanes 0-31: columns 8 g .., lanes 32-63: columns 8 (g + 1) ..): 16 global_store_dwordx4 per wave for its 128 x 64
-// outputs instead of 256 ds_write_b32 + 64 ds_read_b128 + 64 global_store_dwordx2 through an LDS slab (the epilogue was
-// bound by store ISSUE, not by bandwidth).  Mask words: one 32-bit word per (row, 32-column fragment) per lane - all 8 of
-// a wave tile are fetched before the main loop (bits[]); the forward's mask_out word is assembled from the two
-// half-waves' 16 bits each with one more swap.  Needs whole 64-column wave tiles (N % 64 == 0) and a bf16 output.
+// ---- row-per-lane epilogues (swapped MFMA operands): one 32 x 32 accumulator fragment of a lane = 16 outputs of ONE row, the columns
+// 8 g + 4 h + q (g = e >> 2, q = e & 3, h = lane >> 5).  Two outputs at a time on the packed instructions of gfx950:
+//     v_pk_fma_f32 (alpha * acc + bias) -> [bit-mask operand: v_bfe_i32 + v_and per output] -> v_cvt_pk_{bf16,f16}_f32 ->
+//     v_pk_max_i16 (ReLU on the packed 16-bit patterns: sign-magnitude formats order like integers, -0 included) ->
+//     [mask_out: v_pk_min_i16 with 1 = "stored value > 0", v_pk_lshlrev_b16 to its bit, v_or]
+// i.e. ~3 VALU operations per output where the scalar form of rounds 2-5 (per output: fma, max, select on the runtime activation
+// code, a one-sided cvt_pk + shift + or to pack, compare + select + shift-or for the mask bit) cost 8-10 - with ONE wave per SIMD
+// (or two in lock-step) nothing overlaps the epilogue, and at 256 outputs per lane it was 5-6 us of a 35-us launch (round 6).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+template <typename T> __device__ __forceinline__ uint32_t cvt_pk16(f32x2 v);
+template <> __device__ __forceinline__ uint32_t cvt_pk16<bf16_t>(f32x2 v) {      // RNE
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+template <> __device__ __forceinline__ uint32_t cvt_pk16<f16_t>(f32x2 v) {       // RNE, saturating like from_f32<f16_t>
+    const f32x2 c = {__builtin_amdgcn_fmed3f(v[0], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v[1], -65504.f, 65504.f)};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(c, f16x2));
+}
+
+// bias: the lane's 16 bias values of the fragment as 4 x f32x4 (columns 8 g + 4 h ..); w: the fragment's mask word >> 4 h (AUXK = 2);
+// relu_lo: packed lower bound of v_pk_max_i16 (0 = ReLU, -32768 = none); pk[g][0 / 1]: the packed outputs q = 0, 1 / 2, 3;
+// returns (MASK) the lane's 16 "stored > 0" bits at their places 8 g + 4 h + q of the fragment's 32-bit mask word
+template <typename T, int AUXK, bool MASK>
+__device__ __forceinline__ uint32_t rows_frag(const f32x16& c, const f32x4 (&bias)[4], uint32_t w, f32x2 al, i16x2 relu_lo, int h,
+                                              uint32_t (&pk)[4][2]) {
+    uint32_t mlo = 0, mhi = 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            f32x2 v = {c[g * 4 + 2 * pr], c[g * 4 + 2 * pr + 1]};
+            const f32x2 b = {bias[g][2 * pr], bias[g][2 * pr + 1]};
+            v = v * al + b;
+            if constexpr (AUXK == 2) {
+                // (as ONE vector AND: written per element - v[0] = ..., v[1] = ... - hipcc 7.2 folded the two ANDs into a v_bitop3 that
+                //  multiplied element 0 into element 1; caught by the bit-mask tests of round 6)
+                const i32x2 keep = {(int)__builtin_amdgcn_sbfe(w, 8 * g + 2 * pr, 1), (int)__builtin_amdgcn_sbfe(w, 8 * g + 2 * pr + 1, 1)};
+                v = __builtin_bit_cast(f32x2, __builtin_bit_cast(i32x2, v) & keep);
+            }
+            const i16x2 o = __builtin_elementwise_max(__builtin_bit_cast(i16x2, cvt_pk16<T>(v)), relu_lo);
+            pk[g][pr] = __builtin_bit_cast(uint32_t, o);
+            if constexpr (MASK) {
+                const i16x2 one = {1, 1};
+                const u16x2 t = __builtin_bit_cast(u16x2, __builtin_elementwise_min(o, one));      // 1 where the stored value is > 0
+                const u16x2 sh = {(unsigned short)((g & 1) * 8 + 2 * pr), (unsigned short)((g & 1) * 8 + 2 * pr + 1)};
+                const uint32_t m = __builtin_bit_cast(uint32_t, t << sh);
+                if (g < 2) mlo |= m; else mhi |= m;
+            }
+        }
+    if constexpr (MASK) return ((((mlo | (mlo >> 16)) & 0xFFFFu) | ((mhi | (mhi >> 16)) << 16))) << (4 * h);
+    else return 0u;
+}
+
+// ---- epilogue of the phased kernels with swapped MFMA operands.  acc[i][j] holds the transposed 32 x 32 block: lane
+// (r = lane & 31, h = lane >> 5) owns output row i*32 + r and the columns j*32 + 8 g + 4 h + q: four runs of 4 consecutive columns.
+// bias + activation + mask in registers (rows_frag), then v_permlane32_swap between the column groups (g, g + 1) of the two half-waves
+// gives every lane 8 consecutive columns = ONE 16-byte store (lanes 0-31: columns 8 g .., lanes 32-63: columns 8 (g + 1) ..).
+// Mask words: one 32-bit word per (row, 32-column fragment) per lane - fetched by the caller before / during the main loop (bits[]);
+// the forward's mask_out word is assembled from the two half-waves' 16 bits each with one more swap.  Needs whole 64-column wave
+// tiles (N % 64 == 0), a 16-bit output and act <= ASE_ACT_RELU.
 // NJ: 32-column fragments of the wave tile (2: the 8-wave kernel's 128 x 64, 4: the 4-wave kernel's 128 x 128).
 // NI: 32-row blocks of the wave tile (4: the 256 x 256 tiles' 128 rows per wave row, 3: the 192 x 256 tile's 96).
-template <typename T, int AUXK, int NJ = 2, int NI = 4>
-__device__ __forceinline__ void nt8_epilogue_rows(const NTParams& p, f32x16 (&acc)[NI][NJ], int lane, int mrow0, int ncol0,
-                                                  const uint32_t (&bits)[NI][NJ]) {
-    if (ncol0 >= p.N) return;                                   // wave-uniform: N is a multiple of the wave tile's width
+template <typename T, int AUXK, bool MASK, int NJ, int NI>
+__device__ __forceinline__ void nt8_epilogue_rows_impl(const NTParams& p, f32x16 (&acc)[NI][NJ], int lane, int mrow0, int ncol0,
+                                                       const uint32_t (&bits)[NI][NJ]) {
     const int r = lane & 31, h = lane >> 5;
+    const f32x2 al = {p.alpha, p.alpha};
+    const short lo = (p.act == ASE_ACT_RELU) ? (short)0 : (short)-32768;
+    const i16x2 relu_lo = {lo, lo};
     f32x4 bias[NJ][4];
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
@@ -99,37 +158,26 @@ __device__ __forceinline__ void nt8_epilogue_rows(const NTParams& p, f32x16 (&ac
         const bool row_ok = m < p.M;
         char* crow = p.C + (int64_t)m * p.ldc + (int64_t)ncol0 * 2 + h * 16;
         uint32_t mword[NJ];
+        uint4 out[NJ][2];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             uint32_t pk[4][2];
-            uint32_t mb = 0;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                T o[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float v = p.alpha * acc[i][j][g * 4 + q] + bias[j][g][q];
-                    if (p.act == ASE_ACT_RELU) v = fmaxf(v, 0.f);
-                    if constexpr (AUXK == 2) v = ((bits[i][j] >> (8 * g + 4 * h + q)) & 1u) ? v : 0.f;
-                    o[q] = from_f32<T>(v);
-                    mb |= ((float)o[q] > 0.f ? 1u : 0u) << (8 * g + 4 * h + q);
-                }
-                pk[g][0] = (uint32_t)__builtin_bit_cast(uint16_t, o[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, o[1]) << 16);
-                pk[g][1] = (uint32_t)__builtin_bit_cast(uint16_t, o[2]) | ((uint32_t)__builtin_bit_cast(uint16_t, o[3]) << 16);
-            }
+            mword[j] = rows_frag<T, AUXK, MASK>(acc[i][j], bias[j], AUXK == 2 ? bits[i][j] >> (4 * h) : 0u, al, relu_lo, h, pk);
 #pragma unroll
             for (int g = 0; g < 4; g += 2) {
                 const auto s0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
                 const auto s1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
                 // lanes 0-31: [own g | upper's g] = columns 8 g .. 8 g + 7; lanes 32-63: [lower's g + 1 | own g + 1]
-                if (row_ok) {
-                    const uint4 out = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-                    *reinterpret_cast<uint4*>(crow + (j * 32 + 8 * g) * 2) = out;
-                }
+                out[j][g >> 1] = make_uint4(s0[0], s1[0], s0[1], s1[1]);
             }
-            mword[j] = mb;
         }
-        if (p.mask_out) {
+        if (row_ok) {                           // (one predicated block per row block: the swaps above need every lane)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; g += 2) *reinterpret_cast<uint4*>(crow + (j * 32 + 8 * g) * 2) = out[j][g >> 1];
+        }
+        if constexpr (MASK) {
 #pragma unroll
             for (int jp = 0; jp < NJ; jp += 2) {
                 // word j of this row = own 16 bits | the other half-wave's 16 bits
@@ -140,6 +188,14 @@ __device__ __forceinline__ void nt8_epilogue_rows(const NTParams& p, f32x16 (&ac
             }
         }
     }
+}
+
+template <typename T, int AUXK, int NJ = 2, int NI = 4>
+__device__ __forceinline__ void nt8_epilogue_rows(const NTParams& p, f32x16 (&acc)[NI][NJ], int lane, int mrow0, int ncol0,
+                                                  const uint32_t (&bits)[NI][NJ]) {
+    if (ncol0 >= p.N) return;                                   // wave-uniform: N is a multiple of the wave tile's width
+    if (p.mask_out) nt8_epilogue_rows_impl<T, AUXK, true, NJ, NI>(p, acc, lane, mrow0, ncol0, bits);
+    else nt8_epilogue_rows_impl<T, AUXK, false, NJ, NI>(p, acc, lane, mrow0, ncol0, bits);
 }
 
 

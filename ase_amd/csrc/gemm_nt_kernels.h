@@ -369,11 +369,13 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x16 (&acc)[FM]
 // ---- row-per-lane epilogue of the lock-step kernels (bf16, swapped MFMA operands): the general FM x FN form of
 // nt8_epilogue_rows further down - see there.  acc[i][j]: lane (r = lane & 31, h = lane >> 5) owns output row i*32 + r
 // and the columns j*32 + 8 g + 4 h + q.  bits[i][j]: the ReLU mask word of (row, 32-column fragment), loaded by the caller.
-template <typename T, int FM, int FN, int AUXK>
-__device__ __forceinline__ void nt_epilogue_rows(const NTParams& p, f32x16 (&acc)[FM][FN], int lane, int mrow0, int ncol0,
-                                                 const uint32_t (&bits)[FM][FN]) {
-    if (ncol0 >= p.N) return;                                   // wave-uniform: N is a multiple of the wave tile's width
+template <typename T, int FM, int FN, int AUXK, bool MASK>
+__device__ __forceinline__ void nt_epilogue_rows_impl(const NTParams& p, f32x16 (&acc)[FM][FN], int lane, int mrow0, int ncol0,
+                                                      const uint32_t (&bits)[FM][FN]) {
     const int r = lane & 31, h = lane >> 5;
+    const f32x2 al = {p.alpha, p.alpha};
+    const short lo = (p.act == ASE_ACT_RELU) ? (short)0 : (short)-32768;
+    const i16x2 relu_lo = {lo, lo};
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
         f32x4 bias[4];
@@ -388,33 +390,27 @@ __device__ __forceinline__ void nt_epilogue_rows(const NTParams& p, f32x16 (&acc
             const bool row_ok = m < p.M;
             char* crow = p.C + (int64_t)m * p.ldc + (int64_t)(ncol0 + j * 32) * 2 + h * 16;
             uint32_t pk[4][2];
-            uint32_t mb = 0;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                T o[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float v = p.alpha * acc[i][j][g * 4 + q] + bias[g][q];
-                    if (p.act == ASE_ACT_RELU) v = fmaxf(v, 0.f);
-                    if constexpr (AUXK == 2) v = ((bits[i][j] >> (8 * g + 4 * h + q)) & 1u) ? v : 0.f;
-                    o[q] = from_f32<T>(v);
-                    mb |= ((float)o[q] > 0.f ? 1u : 0u) << (8 * g + 4 * h + q);
-                }
-                pk[g][0] = (uint32_t)__builtin_bit_cast(uint16_t, o[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, o[1]) << 16);
-                pk[g][1] = (uint32_t)__builtin_bit_cast(uint16_t, o[2]) | ((uint32_t)__builtin_bit_cast(uint16_t, o[3]) << 16);
-            }
+            const uint32_t mb = rows_frag<T, AUXK, MASK>(acc[i][j], bias, AUXK == 2 ? bits[i][j] >> (4 * h) : 0u, al, relu_lo, h, pk);
 #pragma unroll
             for (int g = 0; g < 4; g += 2) {
                 const auto s0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
                 const auto s1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
                 if (row_ok) *reinterpret_cast<uint4*>(crow + 8 * g * 2) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
             }
-            if (p.mask_out) {
+            if constexpr (MASK) {
                 const auto w = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);   // own 16 bits | the other half-wave's
                 if (row_ok && h == 0) p.mask_out[(int64_t)m * p.ldmask + ((ncol0 + j * 32) >> 5)] = w[0] | w[1];
             }
         }
     }
+}
+
+template <typename T, int FM, int FN, int AUXK>
+__device__ __forceinline__ void nt_epilogue_rows(const NTParams& p, f32x16 (&acc)[FM][FN], int lane, int mrow0, int ncol0,
+                                                 const uint32_t (&bits)[FM][FN]) {
+    if (ncol0 >= p.N) return;                                   // wave-uniform: N is a multiple of the wave tile's width
+    if (p.mask_out) nt_epilogue_rows_impl<T, FM, FN, AUXK, true>(p, acc, lane, mrow0, ncol0, bits);
+    else nt_epilogue_rows_impl<T, FM, FN, AUXK, false>(p, acc, lane, mrow0, ncol0, bits);
 }
 
 // WPE = minimum waves per SIMD the register allocation must leave room for (k workgroups of T threads per CU <=> k T / 256)
@@ -431,6 +427,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, WPE) void gemm_nt_kernel(NTParams p
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the rows staged per pass");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int kBuf = (BM + BN) * RB;
+    if (p.alpha_dev) p.alpha *= *p.alpha_dev;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WGN, wn = wid % WGN;
@@ -705,6 +702,7 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(NTParams p) {
     constexpr int RB = 128, BN = 256, BK = 64, WM = BM / 2, NI = WM / 32;
     constexpr int kBuf = 512 * RB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (p.alpha_dev) p.alpha *= *p.alpha_dev;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -855,6 +853,10 @@ template <typename T, bool SW = false, int BM = 256> int launch_nt8(const NTPara
     return ASE_OK;
 }
 
+}  // namespace
+#include "gemm_nt4.h"
+namespace {
+
 // row-per-lane epilogue (swapped MFMA operands): 16-bit output in whole wave-tile column blocks, no column sums, no tanh,
 // mask operand absent or a bit matrix
 inline bool rows_epi(const NTParams& p, int wave_cols) {
@@ -873,6 +875,9 @@ template <typename T> int dispatch_nt(const NTParams& p, hipStream_t s) {
             if constexpr (sizeof(T) == 2) {
                 // row-per-lane epilogue (swapped MFMA operands): 16-bit output in whole 64-column wave tiles, no column sums,
                 // mask operand absent or a bit matrix; otherwise the LDS-slab epilogue
+                // whole 128-column wave tiles and operands a 32-bit byte offset reaches: the 4-wave kernel (gemm_nt4.h)
+                if (rows_epi(p, 128) && (int64_t)p.M * p.lda < (int64_t)0x7FFFFFFF && (int64_t)p.N * p.ldb < (int64_t)0x7FFFFFFF)
+                    return launch_nt4<T>(p, s);
                 if (rows_epi(p, 64)) return launch_nt8<T, true>(p, s);
                 return launch_nt8<T, false>(p, s);
             }

@@ -41,6 +41,7 @@ struct TNParams {
     int M, N, K;                  // padded widths N (of A), K (of B), in elements
     int n_real, k_real, split_src, split_dst;
     float alpha;
+    const float* alpha_dev;       // nullable: device factor multiplied into alpha when the launch runs (1 / the dynamic loss scale)
     int tiles_n, tiles_k, m_chunk;
     unsigned long long* prof;     // debug stamps (ase_hip_debug_nt_profile), else null
 };
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(TNParams p) {
     constexpr int LOADS = BKM * CPR / kThreads;          // 16-B chunks per thread per operand
     constexpr int kOp = BKM * STRIDE;                    // bytes per operand tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (p.alpha_dev) p.alpha *= *p.alpha_dev;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wi = wid >> 1, wj = wid & 1;               // wave position in the 128x128 output tile
@@ -545,6 +547,7 @@ __device__ __forceinline__ void tn8_body(const TNParams& p, char* smem, int bn0,
 template <typename T>
 __global__ __launch_bounds__(512) void gemm_tn8_kernel(TNParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (p.alpha_dev) p.alpha *= *p.alpha_dev;
     const int nwg = p.tiles_n * p.tiles_k;
     const int tile = xcd_remap(blockIdx.x, nwg);
     const int m_begin = blockIdx.z * p.m_chunk;
@@ -560,7 +563,8 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(TNParams p) {
 template <typename T>
 __global__ __launch_bounds__(512) void gemm_tn8g_kernel(const int64_t* __restrict__ problems,
                                                         const int32_t* __restrict__ work, int n_work,
-                                                        unsigned long long* prof, float* __restrict__ ws) {
+                                                        unsigned long long* prof, float* __restrict__ ws,
+                                                        const float* __restrict__ alpha_dev) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int item = xcd_remap(blockIdx.x, n_work);             // neighbours in the work list share operand panels
     const int32_t* w = work + 4 * item;
@@ -575,7 +579,8 @@ __global__ __launch_bounds__(512) void gemm_tn8g_kernel(const int64_t* __restric
     p.G = reinterpret_cast<float*>(d[4]); p.gbias = reinterpret_cast<float*>(d[5]);
     p.bias_rows = (int)d[6]; p.M = (int)d[7]; p.N = (int)d[8]; p.K = (int)d[9];
     p.n_real = (int)d[10]; p.k_real = (int)d[11]; p.split_src = (int)d[12]; p.split_dst = (int)d[13];
-    p.alpha = __builtin_bit_cast(float, (int)d[14]);
+    p.alpha = __builtin_bit_cast(float, (int)d[14]) * (alpha_dev ? *alpha_dev : 1.f);
+    p.alpha_dev = nullptr;
     p.tiles_k = (int)(d[15] & 0xFFFF);
     tn8_body<T>(p, smem, (tile / p.tiles_k) * 256, (tile % p.tiles_k) * 256, m_begin, nk,
                    prof ? prof + blockIdx.x * 4 : nullptr, ws ? ws + (int64_t)slab * kTnSlab : nullptr,
@@ -588,14 +593,14 @@ __global__ __launch_bounds__(512) void gemm_tn8g_kernel(const int64_t* __restric
 // exactly one owner; problems that share a gradient buffer with another one (field 15 bit 30 set by the planner: the
 // gradient-penalty terms of the encoder land on the discriminator's weights) use atomics.
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const int64_t* __restrict__ problems, const int32_t* __restrict__ red,
-                                                        const float* __restrict__ ws) {
+                                                        const float* __restrict__ ws, const float* __restrict__ alpha_dev) {
     const int32_t* r = red + 4 * blockIdx.x;
     const int pi = r[0], tile = r[1], first = r[2], splits = r[3], q = blockIdx.y;
     const int64_t* d = problems + 16 * pi;
     float* G = reinterpret_cast<float*>(d[4]);
     float* gbias = reinterpret_cast<float*>(d[5]);
     const int n_real = (int)d[10], k_real = (int)d[11], split_src = (int)d[12], gap = (int)d[13] - (int)d[12];
-    const float alpha = __builtin_bit_cast(float, (int)d[14]);
+    const float alpha = __builtin_bit_cast(float, (int)d[14]) * (alpha_dev ? *alpha_dev : 1.f);
     const int tiles_k = (int)(d[15] & 0xFFFF), shared = (int)((d[15] >> 30) & 1);
     const int64_t stride = (int64_t)(((n_real + 255) / 256) * tiles_k) * kTnSlab;
     const int bn0 = (tile / tiles_k) * 256, bk0 = (tile % tiles_k) * 256;
@@ -690,7 +695,7 @@ template <typename T> int launch_tn8(TNParams p, hipStream_t stream) {
 }
 
 template <typename T> int launch_tn8g(const int64_t* problems, const int32_t* work, int n_work, const int32_t* red,
-                                             int n_red, float* ws, hipStream_t stream) {
+                                             int n_red, float* ws, const float* alpha_dev, hipStream_t stream) {
     constexpr int lds = 2 * 65536;
     static bool attr_done = false;
     auto kern = gemm_tn8g_kernel<T>;
@@ -703,8 +708,8 @@ template <typename T> int launch_tn8g(const int64_t* problems, const int32_t* wo
         }
         attr_done = true;
     }
-    ASE_LAUNCH(kern, dim3(n_work), dim3(512), lds, stream, problems, work, n_work, g_nt_prof, ws);
-    if (ws) ASE_LAUNCH(tn_reduce_kernel, dim3(n_red, 16), dim3(256), 0, stream, problems, red, (const float*)ws);
+    ASE_LAUNCH(kern, dim3(n_work), dim3(512), lds, stream, problems, work, n_work, g_nt_prof, ws, alpha_dev);
+    if (ws) ASE_LAUNCH(tn_reduce_kernel, dim3(n_red, 16), dim3(256), 0, stream, problems, red, (const float*)ws, alpha_dev);
     ASE_CHECK_LAUNCH("gemm_tn_grouped");
     return ASE_OK;
 }
@@ -871,8 +876,8 @@ extern "C" int ase_hip_refresh_shadow_multi(const int64_t* desc, int n_layers, i
 }
 
 extern "C" int ase_hip_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* G, float* gbias,
-                               int bias_rows, int M, int N, int K, int n_real, int k_real, int split_src, int split_dst, float alpha, int dtype,
-                               void* stream) {
+                               int bias_rows, int M, int N, int K, int n_real, int k_real, int split_src, int split_dst, float alpha,
+                               const float* alpha_dev, int dtype, void* stream) {
     const int es = ase_elem_size(dtype);
     ASE_CHECK_ARG(dtype == ASE_F32 || dtype == ASE_BF16 || dtype == ASE_F32X3 || dtype == ASE_F16, "gemm_tn: bad dtype %d", dtype);
     ASE_CHECK_ARG(A && B && G && M > 0 && N > 0 && K > 0, "gemm_tn: null/empty operand");
@@ -885,7 +890,7 @@ extern "C" int ase_hip_gemm_tn(const void* A, int64_t lda, const void* B, int64_
     TNParams p;
     p.A = (const char*)A; p.lda = lda * es; p.B = (const char*)B; p.ldb = ldb * es; p.G = G; p.gbias = gbias; p.bias_rows = bias_rows > 0 ? bias_rows : M;
     p.M = M; p.N = N; p.K = K; p.n_real = n_real; p.k_real = k_real; p.split_src = split_src; p.split_dst = split_dst;
-    p.alpha = alpha; p.tiles_n = p.tiles_k = p.m_chunk = 0; p.prof = nullptr;
+    p.alpha = alpha; p.alpha_dev = alpha_dev; p.tiles_n = p.tiles_k = p.m_chunk = 0; p.prof = nullptr;
     if (es == 2) {
         // Single-problem launches take the phased 256 x 256 kernel only when few M-splits fill the chip (its split
         // reduction costs 256 KB of memory-side atomics per workgroup; see the grouped launch): whole 64-row K-tiles,
@@ -1041,13 +1046,13 @@ extern "C" int ase_hip_gemm_tn_grouped_plan(int64_t* problems, int n_problems, i
 }
 
 extern "C" int ase_hip_gemm_tn_grouped(const int64_t* problems, const int32_t* work, int n_work, const int32_t* red, int n_red,
-                                       float* workspace, int dtype, void* stream) {
+                                       float* workspace, const float* alpha_dev, int dtype, void* stream) {
     ASE_CHECK_ARG(problems && work && n_work > 0, "gemm_tn_grouped: null/empty argument");
     ASE_CHECK_ARG(dtype == ASE_BF16 || dtype == ASE_F16, "gemm_tn_grouped: 16-bit storage types only (dtype %d)", dtype);
     ASE_CHECK_ARG(workspace == nullptr || (red && n_red > 0 && ((uintptr_t)workspace % 16) == 0),
                   "gemm_tn_grouped: a workspace needs the reduce table of the plan (and 16-byte alignment)");
-    if (dtype == ASE_F16) return launch_tn8g<f16_t>(problems, work, n_work, red, n_red, workspace, (hipStream_t)stream);
-    return launch_tn8g<bf16_t>(problems, work, n_work, red, n_red, workspace, (hipStream_t)stream);
+    if (dtype == ASE_F16) return launch_tn8g<f16_t>(problems, work, n_work, red, n_red, workspace, alpha_dev, (hipStream_t)stream);
+    return launch_tn8g<bf16_t>(problems, work, n_work, red, n_red, workspace, alpha_dev, (hipStream_t)stream);
 }
 
 extern "C" int ase_hip_refresh_shadow(const float* W, int n_real, int k_real, void* Ws, int64_t ldws, void* Wts,

@@ -30,7 +30,8 @@ struct PpoArgs {
     double* scratch;              // [8 spare] then [gridDim.x][kPpoSlots] per-workgroup partial sums (no contended atomics)
     int M, m_global, act_dim, z_dim, masked, div_on, mu_tanh, clip_value;
     float e_clip, critic_coef, bounds_coef, div_coef, div_tar;
-    float gs, inv_gs;             // the stored head gradients carry the static gradient scale (f16 storage), the bias gradients do not
+    float gs, inv_gs;             // the stored head gradients carry the gradient scale (f16 storage), the bias gradients do not
+    const float* gs_dev;          // nullable: device factor on top of gs (the dynamic loss scale), read when the launch runs
 };
 
 // per-workgroup partials: 7 loss sums, then 64 + 1 head-bias column sums (mu columns, value)
@@ -46,6 +47,10 @@ __global__ __launch_bounds__(256) void ppo_head_kernel(PpoArgs p) {
     const int lane = threadIdx.x & (LPR - 1), rib = threadIdx.x / LPR;
     float gm_out = 0.f, gm2_out = 0.f, dv_out = 0.f;
     const int D = p.act_dim;
+    if (p.gs_dev) {
+        p.gs *= *p.gs_dev;
+        p.inv_gs = 1.f / p.gs;
+    }
     double part[7] = {0, 0, 0, 0, 0, 0, 0};  // a_loss, b_loss, entropy, clipped, c_loss, kl, div
 
     // grid-stride over rows: few workgroups => few contended f64 atomics on the 7 accumulators
@@ -222,8 +227,10 @@ __global__ __launch_bounds__(256) void ppo_head_fold_kernel(const double* __rest
 template <typename T>
 __global__ __launch_bounds__(256) void disc_head_kernel(const float* __restrict__ logit, int64_t ld_l, T* __restrict__ d_logit,
                                                         int64_t ld_d, float* __restrict__ db_logit, double* __restrict__ acc,
-                                                        int amb, int amb_global, float disc_coef, float gs) {
+                                                        int amb, int amb_global, float disc_coef, float gs,
+                                                        const float* __restrict__ gs_dev) {
     __shared__ double sm[5 * 16];
+    if (gs_dev) gs *= *gs_dev;
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     double part[5] = {0, 0, 0, 0, 0};  // bce agent, bce demo, agent acc, demo acc, sum of d_logit
     if (r < 3 * amb) {
@@ -261,8 +268,9 @@ __global__ __launch_bounds__(256) void enc_head_kernel(const float* __restrict__
                                                        int64_t ld_z, T* __restrict__ d_e, int64_t ld_de,
                                                        float* __restrict__ db_enc, float* __restrict__ enc_out,
                                                        double* __restrict__ acc, int amb, int amb_global, int z_dim,
-                                                       float enc_coef, float gs) {
+                                                       float enc_coef, float gs, const float* __restrict__ gs_dev) {
     __shared__ double sm[16];
+    if (gs_dev) gs *= *gs_dev;
     __shared__ float sdb[4][128];
     float dbv[2] = {0.f, 0.f};
     const int lane = threadIdx.x & 63;
@@ -320,8 +328,9 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(256) void enc_gp_kernel(const float* __restrict__ e, int64_t ld_e, const float* __restrict__ z,
                                                      int64_t ld_z, const float* __restrict__ du, int64_t ld_du,
                                                      T* __restrict__ out, int64_t ld_out, float* __restrict__ db_enc,
-                                                     int rows, int z_dim, float scale) {
+                                                     int rows, int z_dim, float scale, const float* __restrict__ scale_dev) {
     __shared__ float sdb[4][128];
+    if (scale_dev) scale *= *scale_dev;
     float dbv[2] = {0.f, 0.f};
     const int lane = threadIdx.x & 63;
     for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += gridDim.x * 4) {
@@ -425,8 +434,9 @@ __global__ __launch_bounds__(256) void gp_second_kernel(const T* __restrict__ t,
 // (the host falls back to VEC = 1 otherwise)
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void sqnorm_kernel(const T* __restrict__ x, int64_t ld, int rows, int cols,
-                                                     double* __restrict__ acc, double scale) {
+                                                     double* __restrict__ acc, double scale, const float* __restrict__ scale_dev) {
     __shared__ double sm[16];
+    if (scale_dev) scale *= (double)*scale_dev;
     const int cpr = cols / VEC;                            // chunks per row
     const int64_t n = (int64_t)rows * cpr;
     double v[1] = {0.0};
@@ -559,7 +569,8 @@ extern "C" int ase_hip_ppo_head(const float* mu, int64_t ld_mu, const float* val
                                 const float* logstd, void* d_mu, int64_t ld_dmu, void* d_value, int64_t ld_dv,
                                 float* db_mu, float* db_value, float* mu_out, double* acc, double* scratch, int M, int m_global, int act_dim, int z_dim, int masked,
                                 int div_on, int mu_tanh, int clip_value, float e_clip, float critic_coef,
-                                float bounds_coef, float div_coef, float div_tar, float grad_scale, int dtype, void* stream) {
+                                float bounds_coef, float div_coef, float div_tar, float grad_scale, const float* grad_scale_dev, int dtype,
+                                void* stream) {
     ASE_CHECK_ARG(mu && value && mb_actions && mb_old_mu && mb_old_sigma && mb_old_logp && mb_adv && mb_return &&
                       logstd && d_mu && d_value && acc && scratch && M > 0 && m_global >= M,
                   "ppo_head: null/empty operand");
@@ -575,7 +586,7 @@ extern "C" int ase_hip_ppo_head(const float* mu, int64_t ld_mu, const float* val
     p.logstd = logstd; p.d_mu = d_mu; p.ld_dmu = ld_dmu; p.d_value = d_value; p.ld_dv = ld_dv; p.db_mu = db_mu; p.db_value = db_value; p.mu_out = mu_out;
     p.acc = acc; p.scratch = scratch; p.M = M; p.m_global = m_global; p.act_dim = act_dim; p.z_dim = z_dim; p.masked = masked;
     p.div_on = div_on; p.mu_tanh = mu_tanh; p.clip_value = clip_value; p.e_clip = e_clip; p.critic_coef = critic_coef;
-    p.bounds_coef = bounds_coef; p.div_coef = div_coef; p.div_tar = div_tar; p.gs = grad_scale; p.inv_gs = 1.f / grad_scale;
+    p.bounds_coef = bounds_coef; p.div_coef = div_coef; p.div_tar = div_tar; p.gs = grad_scale; p.inv_gs = 1.f / grad_scale; p.gs_dev = grad_scale_dev;
     const int rows = act_dim <= 32 ? 8 : 4;         // rows per workgroup (32 / 64 lanes per row)
     const dim3 grid(min((M + rows - 1) / rows, 1024));       // scratch: (1024 x 72 + 1) doubles, the ticket word zero between launches
     const int rc = ase_dispatch_storage(dtype, [&](auto tag) {
@@ -592,14 +603,14 @@ extern "C" int ase_hip_ppo_head(const float* mu, int64_t ld_mu, const float* val
 }
 
 extern "C" int ase_hip_disc_head(const float* logit, int64_t ld_l, void* d_logit, int64_t ld_d, float* db_logit,
-                                 double* acc, int amb, int amb_global, float disc_coef, float grad_scale, int dtype,
-                                 void* stream) {
+                                 double* acc, int amb, int amb_global, float disc_coef, float grad_scale,
+                                 const float* grad_scale_dev, int dtype, void* stream) {
     ASE_CHECK_ARG(logit && d_logit && acc && amb > 0 && amb_global >= amb && grad_scale > 0.f, "disc_head: null/empty operand");
     const dim3 grid((3 * amb + 255) / 256);
     const int rc = ase_dispatch_storage(dtype, [&](auto tag) {
         typedef typename decltype(tag)::type T;
         ASE_LAUNCH(disc_head_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, logit, ld_l, (T*)d_logit, ld_d, db_logit, acc, amb,
-                   amb_global, disc_coef, grad_scale);
+                   amb_global, disc_coef, grad_scale, grad_scale_dev);
         return ASE_OK;
     });
     ASE_CHECK_ARG(rc == ASE_OK, "disc_head: bad dtype %d", dtype);
@@ -609,14 +620,14 @@ extern "C" int ase_hip_disc_head(const float* logit, int64_t ld_l, void* d_logit
 
 extern "C" int ase_hip_enc_head(const float* e, int64_t ld_e, const float* z, int64_t ld_z, void* d_e, int64_t ld_de,
                                 float* db_enc, float* enc_out, double* acc, int amb, int amb_global, int z_dim, float enc_coef,
-                                float grad_scale, int dtype, void* stream) {
+                                float grad_scale, const float* grad_scale_dev, int dtype, void* stream) {
     ASE_CHECK_ARG(e && z && d_e && acc && amb > 0 && amb_global >= amb && grad_scale > 0.f, "enc_head: null/empty operand");
     ASE_CHECK_ARG(z_dim >= 1 && z_dim <= 128, "enc_head: z_dim %d not in [1,128]", z_dim);
     const dim3 grid(min((amb + 3) / 4, 128));
     const int rc = ase_dispatch_storage(dtype, [&](auto tag) {
         typedef typename decltype(tag)::type T;
         ASE_LAUNCH(enc_head_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, e, ld_e, z, ld_z, (T*)d_e, ld_de, db_enc, enc_out, acc,
-                   amb, amb_global, z_dim, enc_coef, grad_scale);
+                   amb, amb_global, z_dim, enc_coef, grad_scale, grad_scale_dev);
         return ASE_OK;
     });
     ASE_CHECK_ARG(rc == ASE_OK, "enc_head: bad dtype %d", dtype);
@@ -632,7 +643,7 @@ extern "C" int ase_hip_enc_gp_seed(const float* e, int64_t ld_e, const float* z,
     const int rc = ase_dispatch_storage(dtype, [&](auto tag) {
         typedef typename decltype(tag)::type T;
         ASE_LAUNCH((enc_gp_kernel<T, 0>), grid, dim3(256), 0, (hipStream_t)stream, e, ld_e, z, ld_z, (const float*)nullptr,
-                   (int64_t)0, (T*)u, ld_u, (float*)nullptr, rows, z_dim, scale);
+                   (int64_t)0, (T*)u, ld_u, (float*)nullptr, rows, z_dim, scale, (const float*)nullptr);
         return ASE_OK;
     });
     ASE_CHECK_ARG(rc == ASE_OK, "enc_gp_seed: bad dtype %d", dtype);
@@ -641,15 +652,15 @@ extern "C" int ase_hip_enc_gp_seed(const float* e, int64_t ld_e, const float* z,
 }
 
 extern "C" int ase_hip_enc_gp_back(const float* e, int64_t ld_e, const float* z, int64_t ld_z, const float* du, int64_t ld_du,
-                                   void* d_e, int64_t ld_de, float* db_enc, int rows, int z_dim, float grad_scale, int dtype,
-                                   void* stream) {
+                                   void* d_e, int64_t ld_de, float* db_enc, int rows, int z_dim, float grad_scale,
+                                   const float* grad_scale_dev, int dtype, void* stream) {
     ASE_CHECK_ARG(e && z && du && d_e && rows > 0 && grad_scale > 0.f, "enc_gp_back: null/empty operand");
     ASE_CHECK_ARG(z_dim >= 1 && z_dim <= 128, "enc_gp_back: z_dim %d not in [1,128]", z_dim);
     const dim3 grid(min((rows + 3) / 4, 128));          // <= 128 workgroups on the bias-gradient atomics (see enc_head)
     const int rc = ase_dispatch_storage(dtype, [&](auto tag) {
         typedef typename decltype(tag)::type T;
         ASE_LAUNCH((enc_gp_kernel<T, 1>), grid, dim3(256), 0, (hipStream_t)stream, e, ld_e, z, ld_z, du, ld_du, (T*)d_e, ld_de,
-                   db_enc, rows, z_dim, grad_scale);
+                   db_enc, rows, z_dim, grad_scale, grad_scale_dev);
         return ASE_OK;
     });
     ASE_CHECK_ARG(rc == ASE_OK, "enc_gp_back: bad dtype %d", dtype);
@@ -690,7 +701,7 @@ extern "C" int ase_hip_gp_second(const void* twin, int64_t ld_t, const void* g, 
 }
 
 extern "C" int ase_hip_sqnorm(const void* x, int64_t ld, int rows, int cols, double* acc, int slot, double scale,
-                              int dtype, void* stream) {
+                              const float* scale_dev, int dtype, void* stream) {
     ASE_CHECK_ARG(x && acc && rows > 0 && cols > 0 && slot >= 0, "sqnorm: null/empty operand");
     const int es = ase_elem_size(dtype), vec = 16 / es;
     const bool wide = cols % vec == 0 && (ld * es) % 16 == 0 && ((uintptr_t)x % 16) == 0;
@@ -698,8 +709,8 @@ extern "C" int ase_hip_sqnorm(const void* x, int64_t ld, int rows, int cols, dou
     const int rc = ase_dispatch_storage(dtype, [&](auto tag) {
         typedef typename decltype(tag)::type T;
         constexpr int VEC = 16 / (int)sizeof(T);
-        if (wide) ASE_LAUNCH((sqnorm_kernel<T, VEC>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, ld, rows, cols, acc + slot, scale);
-        else ASE_LAUNCH((sqnorm_kernel<T, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, ld, rows, cols, acc + slot, scale);
+        if (wide) ASE_LAUNCH((sqnorm_kernel<T, VEC>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, ld, rows, cols, acc + slot, scale, scale_dev);
+        else ASE_LAUNCH((sqnorm_kernel<T, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, ld, rows, cols, acc + slot, scale, scale_dev);
         return ASE_OK;
     });
     ASE_CHECK_ARG(rc == ASE_OK, "sqnorm: bad dtype %d", dtype);

@@ -1,18 +1,21 @@
 // Loss scaler of the half-storage engine: what torch.cuda.amp.GradScaler does around the optimizer step in the reference's
 // mixed_precision path (learning/ase_agent.py:271-288, learning/amp_agent.py:354-371, learning/common_agent.py:417-418) -
-// found_inf over everything the scaled backward produced, and a SKIPPED optimizer step when it fired.
+// found_inf over everything the scaled backward produced, a SKIPPED optimizer step when it fired, and GradScaler.update() - backoff
+// after a skipped step, growth after growth_interval clean ones - once per optimisation step, on the device (ABI 6).
 //   The engine's conversions into half storage saturate at +-65504 (common.h from_f32<f16_t>: an overflowing scaled gradient must
 // not become inf -> NaN inside the matrix launches that follow), so "overflow" here = an element that is not finite OR sits at
-// half's saturation value.  The scale itself is a launch argument of the loss heads (a power of two, baked into recorded launch
-// programs): the host moves it between updates from the counters this file keeps (UpdateEngine.scaler_update).
+// half's saturation value.  The scale lives in the scaler state; scaler_book_kernel rewrites the table {S, 1 / S, 1 / S^2} the loss
+// heads, the weight-gradient launches and the penalty's norm read through their `*_dev` arguments, so recorded launch programs survive
+// every change of the scale.  (scale_tab NULL: the ABI-5 form - the scale as a launch argument the host moves between updates.)
 // Own translation unit: nothing of the static-scale path links against it.
 #include "common.h"
 
 namespace {
 
-// scaler (f64[8]): {found (elements / workgroups that overflowed since the last scaler_step), skipped steps (total), clean steps in
-//                   a row (GradScaler's growth tracker), steps seen (total), unused x4}
-enum { SC_FOUND = 0, SC_SKIPPED = 1, SC_CLEAN = 2, SC_STEPS = 3 };
+// scaler (f64[8]): {found (elements / workgroups that overflowed since the last scaler_step), skipped steps (total), GradScaler's
+//                   growth tracker (clean steps since the scale last moved), steps seen (total), scale, growth_factor, backoff_factor,
+//                   growth_interval}
+enum { SC_FOUND = 0, SC_SKIPPED = 1, SC_CLEAN = 2, SC_STEPS = 3, SC_SCALE = 4, SC_GROWTH = 5, SC_BACKOFF = 6, SC_INTERVAL = 7 };
 
 template <typename T> __device__ __forceinline__ bool overflowed(T x);
 template <> __device__ __forceinline__ bool overflowed<float>(float x) { return !(fabsf(x) <= 3.402823466e38f); }      // NaN, +-inf
@@ -54,7 +57,8 @@ __global__ __launch_bounds__(256) void scaler_guard_kernel(float* __restrict__ g
 }
 
 // opt_state (f64[8]): {step, lr, beta1, beta2, eps, bias_corr1, bias_corr2, unused} (optim.hip)
-__global__ void scaler_book_kernel(double* __restrict__ scaler, double* __restrict__ opt_state, double* __restrict__ opt_eff) {
+__global__ void scaler_book_kernel(double* __restrict__ scaler, double* __restrict__ opt_state, double* __restrict__ opt_eff,
+                                   float* __restrict__ scale_tab) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const bool found = scaler[SC_FOUND] != 0.0;
     if (found) {
@@ -78,6 +82,21 @@ __global__ void scaler_book_kernel(double* __restrict__ scaler, double* __restri
     }
     scaler[SC_STEPS] += 1.0;
     scaler[SC_FOUND] = 0.0;
+    if (scale_tab) {
+        // torch/amp/grad_scaler.py _amp_update_scale_: found -> scale *= backoff_factor, tracker = 0; else tracker += 1 (above) and at
+        // growth_interval: scale *= growth_factor, tracker = 0
+        double s = scaler[SC_SCALE];
+        if (found) s *= scaler[SC_BACKOFF];
+        else if (scaler[SC_CLEAN] >= scaler[SC_INTERVAL]) {
+            s *= scaler[SC_GROWTH];
+            scaler[SC_CLEAN] = 0.0;
+        }
+        scaler[SC_SCALE] = s;
+        scale_tab[0] = (float)s;
+        scale_tab[1] = (float)(1.0 / s);
+        scale_tab[2] = (float)(1.0 / (s * s));
+        scale_tab[3] = 0.f;
+    }
 }
 
 inline int check_grid(int64_t n, int elem) {
@@ -103,12 +122,13 @@ extern "C" int ase_hip_scaler_check(const void* buf, int64_t n, int dtype, doubl
     return ASE_OK;
 }
 
-extern "C" int ase_hip_scaler_step(double* scaler, double* opt_state, double* opt_eff, float* grads, int64_t n, void* stream) {
+extern "C" int ase_hip_scaler_step(double* scaler, double* opt_state, double* opt_eff, float* grads, int64_t n, float* scale_tab,
+                                   void* stream) {
     ASE_CHECK_ARG(scaler && opt_state && opt_eff && grads && n > 0 && opt_eff != opt_state, "scaler_step: null/empty/aliased operand");
     int64_t g = (n + 1023) / 1024;
     g = g < 1 ? 1 : (g > 4096 ? 4096 : g);
     ASE_LAUNCH(scaler_guard_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, grads, n, (const double*)scaler);
-    ASE_LAUNCH(scaler_book_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scaler, opt_state, opt_eff);
+    ASE_LAUNCH(scaler_book_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scaler, opt_state, opt_eff, scale_tab);
     ASE_CHECK_LAUNCH("scaler_step");
     return ASE_OK;
 }

@@ -95,10 +95,12 @@ class UpdateEngine:
         if grad_scale is None:
             grad_scale = 2.0 ** max(0, round(math.log2(max(minibatch, 4) / 4.0))) if dtype == torch.float16 else 1.0
         # loss_scale: 'static' (above) | 'dynamic' = torch.cuda.amp.GradScaler's behaviour (learning/ase_agent.py:271-288): overflow
-        # detection over everything the scaled backward wrote, a SKIPPED optimizer step when it fires (device side, csrc/scaler.hip),
-        # backoff / growth of the scale (host side, between updates: scaler_update).  Default: dynamic when the configuration sets the
-        # reference's own flag (mixed_precision: True), static for an explicitly named precision mode.  cfg['loss_scaler']: GradScaler's
-        # constructor arguments {init_scale 65536, growth_factor 2, backoff_factor 0.5, growth_interval 2000} (powers of two).
+        # detection over everything the scaled backward wrote, a SKIPPED optimizer step when it fires, backoff / growth of the scale
+        # after EVERY optimisation step - all on the device (csrc/scaler.hip): the scale lives in self.scaler / self.scale_tab and the
+        # launches that carry it read it there (their `*_dev` arguments), so recorded launch programs survive every change of it and
+        # nothing is read back.  Default: dynamic when the configuration sets the reference's own flag (mixed_precision: True), static
+        # for an explicitly named precision mode.  cfg['loss_scaler']: GradScaler's constructor arguments {init_scale 65536,
+        # growth_factor 2, backoff_factor 0.5, growth_interval 2000} (powers of two).
         ls = cfg.get('loss_scale', None)
         if ls is None:
             ls = 'dynamic' if (cfg.get('mixed_precision', False) and dtype == torch.float16 and not scale_given) else 'static'
@@ -118,8 +120,10 @@ class UpdateEngine:
             self.loss_scaler = sc
             if not scale_given:
                 grad_scale = float(sc['init_scale'])
-        self.gs = float(grad_scale)
-        self._scaler_skipped_seen = 0.0
+        # gs: the HOST-side (static) factor of the gradient scale, a launch argument.  Dynamic scale: 1 - the scale itself is the
+        # device factor the same launches multiply in (self.scale_tab, written by _bind_params / set_grad_scale / every scaler_step)
+        self._gs_init = float(grad_scale)
+        self.gs = 1.0 if self.dyn_scale else float(grad_scale)
         # flags resolved once (rl_games defaults: normalize_value False, bounds_loss_coef None = no bound loss)
         # truncate_grads: global-norm clip of the whole gradient before Adam (learning/ase_agent.py:273-288): the norm needs every
         # gradient (weight-only loss terms included), so the per-branch optimizer steps give way to the end-of-step form
@@ -290,9 +294,16 @@ class UpdateEngine:
         self.n_train = net.trainable_numel           # trainable tensors come first in the flat buffer
         lr = float(self.cfg['learning_rate'])
         self.opt_state = torch.tensor([0.0, lr, 0.9, 0.999, 1e-8, 1.0, 1.0, 0.0], dtype=torch.float64, device=dev)
-        # dynamic loss scale (csrc/scaler.hip): {found, skipped, clean, steps, ...} and the optimizer state the Adam launch reads
-        # (opt_state, or the identity step of a skipped step)
+        # dynamic loss scale (csrc/scaler.hip): {found, skipped, growth tracker, steps, scale, growth_factor, backoff_factor,
+        # growth_interval}, the table {S, 1 / S, 1 / S^2, 0} its launches read, and the optimizer state the Adam launch reads (opt_state,
+        # or the identity step of a skipped step)
         self.scaler = torch.zeros(8, dtype=torch.float64, device=dev)
+        self.scale_tab = torch.tensor([1.0, 1.0, 1.0, 0.0], dtype=torch.float32, device=dev)
+        if self.dyn_scale:
+            sc = self.loss_scaler
+            self.scaler[4:8] = torch.tensor([self._gs_init, sc['growth_factor'], sc['backoff_factor'], float(int(sc['growth_interval']))],
+                                            dtype=torch.float64)
+            self.set_grad_scale(self._gs_init)
         self.opt_eff = self.opt_state.clone()
         self._scaler_list = None
         for d in self.layers:
@@ -628,12 +639,12 @@ class UpdateEngine:
         the data-gradient chain never overwrites, so phase_main launches all of them as ONE grid at its end
         (ase_hip_gemm_tn_grouped: the split-M reduction is paid once per step instead of once per layer)."""
         br = bias_rows if bias_rows > 0 else M
-        alpha = alpha / self.gs              # the back-propagated operand carries the gradient scale
+        alpha = alpha / self.gs              # the back-propagated operand carries the gradient scale (dynamic scale: x *_dI on the device)
         if self._tn_defer and self.be.grouped_tn_ok(A.dtype, M, n_real, K, br):
             self._tn_queue.append((A, B, G, gbias, br, M, N, K, n_real, k_real, split_src, split_dst, alpha))
         else:
             self.be.gemm_tn(A, B, G, M, N, K, n_real, k_real, split_src, split_dst, alpha=alpha, gbias=gbias,
-                            bias_rows=bias_rows)
+                            bias_rows=bias_rows, alpha_dev=self._dI)
 
     def _flush_tn(self, target_wg=0):
         """ONE grouped launch for the weight gradients queued since the last flush (a branch of the step, or the whole step).
@@ -645,7 +656,7 @@ class UpdateEngine:
                                    for (a, b, g, gb, br, M, N, K, nr, kr, ss, sd, al) in q)
         plan = self._tn_plans.get(key)
         if plan is None:
-            plan = self._tn_plans[key] = self.be.make_tn_plan(q, target_wg)
+            plan = self._tn_plans[key] = self.be.make_tn_plan(q, target_wg, alpha_dev=self._dI)
         self.be.gemm_tn_grouped(plan)
 
     def _bwd_chain(self, chain, X0, H, dZ, rows):
@@ -1102,7 +1113,7 @@ class UpdateEngine:
                 elif not disc_early:
                     hd, he = self._disc_forward(amp_streams)
                 be.disc_head(self.HD, self.dHD, self.disc_head.gb[0], self.acc, AMB, amb_den, c['disc_coef'],
-                             grad_scale=self.gs)
+                             grad_scale=self.gs, dyn=self._dS)
                 if self.has_enc:
                     src, sidx, srm = amp_streams[0]   # enc_latents = ase_latents[0:amp_minibatch] (learning/ase_agent.py:247)
                     zsrc = ds['ase_latents'].view(ds['ase_latents'].shape[0], -1)
@@ -1110,11 +1121,11 @@ class UpdateEngine:
                         be.gather_rows(zsrc, self.z, sidx, srm, AMB, self.enc_z)
                     if self.enc_sep:
                         be.enc_head(self.E, self.enc_z, self.dE, self.enc_head.gb[0], None, self.acc, AMB, amb_den,
-                                    self.z, c['enc_coef'], grad_scale=self.gs)
+                                    self.z, c['enc_coef'], grad_scale=self.gs, dyn=self._dS)
                     else:
                         off = self.disc_head.parts[1][2]
                         be.enc_head(self.HD[:AMB, off:], self.enc_z, self.dHD[:AMB, off:], self.disc_head.gb[1], None,
-                                    self.acc, AMB, amb_den, self.z, c['enc_coef'], grad_scale=self.gs)
+                                    self.acc, AMB, amb_den, self.z, c['enc_coef'], grad_scale=self.gs, dyn=self._dS)
                 if self.enc_gp:
                     self._enc_grad_penalty(he if self.enc_chain else hd[:AMB])
                 self._wgrad(self.disc_head, self.dHD, hd, Rd)
@@ -1138,7 +1149,7 @@ class UpdateEngine:
         be.ppo_head(self.MU, self.V, self.mb, self.new_z if self.div_on else None, self.logstd, self.dMU, self.dV,
                     self.mu_head.gb[0], self.value_head.gb[0], self.acc, M, self.Mg if self.shard else self.M, self.act, self.z,
                     self.masked, self.div_on, self.mu_tanh, c['clip_value'], c['e_clip'], c['critic_coef'],
-                    self.bounds_coef, c.get('amp_diversity_bonus', 0.0), c.get('amp_diversity_tar', 0.0), grad_scale=self.gs)
+                    self.bounds_coef, c.get('amp_diversity_bonus', 0.0), c.get('amp_diversity_tar', 0.0), grad_scale=self.gs, dyn=self._dS)
         fork2 = self._mark()
 
         # -- actor backward on the main stream, critic backward beside it.  The wide layers' weight gradients of BOTH
@@ -1259,7 +1270,7 @@ class UpdateEngine:
                 be.scaler_check(g, self.scaler)
                 if self._dist_on():
                     self._ar(self.scaler[:1])
-                be.scaler_step(self.scaler, self.opt_state, self.opt_eff, g)
+                be.scaler_step(self.scaler, self.opt_state, self.opt_eff, g, scale_tab=self.scale_tab)
             if apply and self.truncate:
                 g = self.grads[:self.n_train]
                 be.reduce_sum(g, g.numel(), True, self.acc, L.ACC_GRAD_SQ)
@@ -1276,56 +1287,79 @@ class UpdateEngine:
     # ---- dynamic loss scale (cfg loss_scale = 'dynamic') ---------------------------------------------------------------
     def _scaler_bufs(self):
         """Every buffer of the step a conversion into half storage writes (forward activations included: under autocast an
-        overflowing activation is inf, the loss NaN, and GradScaler skips that step too) + the f32 chain of a gp_f32 engine."""
+        overflowing activation is inf, the loss NaN, and GradScaler skips that step too) + the f32 chain of a gp_f32 engine.
+        Built from the engine's structure - a buffer a feature allocates MUST be found (a renamed attribute is an assertion, not a
+        silently shorter list; round 5's list missed G0, the half copy of S s g_0 in the 4th row block of Xd4: the largest scaled
+        quantity of a gp_f32 step and the first to saturate as the scale grows) - and the half pre-activation twins of smooth layers."""
         if self._scaler_list is None:
             out = []
 
             def add(x):
                 for t in (x if isinstance(x, (list, tuple)) else [x]):
-                    if t is not None and t.numel():
+                    assert t is not None
+                    if t.numel():
                         assert t.is_contiguous()
                         out.append(t)
-            for name in ('Ha', 'dZa', 'Hc', 'dZc', 'dMU', 'dV', 'Hs', 'dZs', 'dStyle', 'Hd4', 'dZd4', 'dHD', 'GpTop', 'He', 'dZe',
-                         'dE', 'Ue', 'Re', 'Ge', 'Qe'):
-                add(getattr(self, name, None))
-            g = getattr(self, '_gp32', None)
-            if g is not None:
+            need = ['Ha', 'dZa', 'Hc', 'dZc', 'dMU', 'dV']
+            if self.style:
+                need += ['Hs', 'dZs', 'dStyle']
+            if self.has_disc:
+                need += ['Hd4', 'dZd4', 'dHD', 'GpTop', 'G0']
+            if self.has_disc and self.enc_chain:
+                need += ['He', 'dZe', 'dE']
+            if self.enc_gp:
+                need += ['Ue', 'Re', 'Ge', 'Qe']
+            for name in need:
+                assert hasattr(self, name), f"_scaler_bufs: the engine has no buffer '{name}' (renamed?)"
+                add(getattr(self, name))
+            for h, twin in self._bits.values():          # pre-activation twins of smooth activations (ReLU twins are bit words)
+                if twin.dtype == self.dtype:
+                    add(twin)
+            if self.gp32:
+                g = self._gp32
                 add(g.H)
                 add(g.Gp)
                 add(g.G0)
             self._scaler_list = out
         return self._scaler_list
 
+    @property
+    def _dS(self):
+        """Device factors of the dynamic loss scale for the `*_dev` arguments: S (loss heads), 1 / S (_dI: weight gradients, the top
+        of the penalty chain), 1 / S^2 (_dI2: the penalty's norm); None under the static scale, where self.gs carries it."""
+        return self.scale_tab[0:1] if self.dyn_scale else None
+
+    @property
+    def _dI(self):
+        return self.scale_tab[1:2] if self.dyn_scale else None
+
+    @property
+    def _dI2(self):
+        return self.scale_tab[2:3] if self.dyn_scale else None
+
     def set_grad_scale(self, s):
-        """A new gradient scale (a power of two).  The scale is a launch ARGUMENT of the loss heads and the weight-gradient
-        launches: recorded launch programs / captured graphs of the step hold the old one and must be dropped by their owner."""
+        """A new gradient scale (a power of two).  Static scale: a launch ARGUMENT of the loss heads and the weight-gradient launches -
+        recorded launch programs / captured graphs of the step hold the old one and must be dropped by their owner.  Dynamic scale:
+        written into the device state (GradScaler's `_scale`) and its table; recorded programs read it there and stay valid."""
         assert s > 0 and math.log2(s) == round(math.log2(s)), s
-        self.gs = float(s)
+        if self.dyn_scale:
+            s = float(s)
+            self.scaler[4:5] = torch.tensor([s], dtype=torch.float64)
+            self.scale_tab.copy_(torch.tensor([s, 1.0 / s, 1.0 / (s * s), 0.0], dtype=torch.float32))
+        else:
+            self.gs = float(s)
 
     def scaler_state(self):
-        """{'scale', 'skipped', 'clean', 'steps'} - reads the device counters (synchronises)."""
-        f, sk, cl, st = self.scaler[:4].tolist()
-        return {'scale': self.gs, 'skipped': int(sk), 'clean': int(cl), 'steps': int(st)}
+        """{'scale', 'skipped', 'clean' (the growth tracker), 'steps'} - reads the device state (synchronises)."""
+        f, sk, cl, st, sc = self.scaler[:5].tolist()
+        return {'scale': sc if self.dyn_scale else self.gs, 'skipped': int(sk), 'clean': int(cl), 'steps': int(st)}
 
     def scaler_update(self):
-        """GradScaler.update() (torch/amp/grad_scaler.py: scale *= backoff_factor after a step with found_inf, *= growth_factor
-        after growth_interval clean steps in a row) at UPDATE granularity: the scale is baked into the step's launches, so it
-        moves between updates - once down for an update in which any step was skipped (one cause: the scale of that update),
-        once up when the device's clean-step counter has reached the interval.  Call between updates; reads four doubles back.
-        Returns True when the scale changed (recorded programs of the step are stale then)."""
+        """GradScaler.update() (torch/amp/grad_scaler.py) happens on the DEVICE after every optimisation step (ase_hip_scaler_step:
+        scale *= backoff_factor after a step with found_inf, *= growth_factor after growth_interval clean steps in a row) - as the
+        reference calls scaler.update() behind every scaler.step() (learning/ase_agent.py:280,285,288).  Nothing is left for the host
+        to do between updates and no recorded program goes stale: kept for callers of the round-5 interface, returns False."""
         assert self.dyn_scale
-        sc = self.loss_scaler
-        st = self.scaler_state()
-        new = self.gs
-        if st['skipped'] > self._scaler_skipped_seen:
-            self._scaler_skipped_seen = st['skipped']
-            new = self.gs * sc['backoff_factor']
-        elif st['clean'] >= int(sc['growth_interval']):
-            new = self.gs * sc['growth_factor']
-            self.scaler[2:3].zero_()
-        if new != self.gs and new < 2.0 ** 100 and new > 2.0 ** -100:
-            self.set_grad_scale(new)
-            return True
         return False
 
     def _enc_grad_penalty(self, h_top):
@@ -1368,8 +1402,8 @@ class UpdateEngine:
         # (Ge and everything derived from it - the second operand of the weight-gradient pairs - carries the gradient
         #  scale S, like the back-propagated operand of every other weight gradient)
         S = self.gs
-        be.gemm_nt(self.Re[0], d0.Wts, self.Ge, AMB, d0.k_pad, d0.n_pad, alpha=S)         # S s * g
-        be.sqnorm(self.Ge, AMB, d0.k_pad, self.acc, L.ACC_ENC_GP, scale=1.0 / (cg * S * S))
+        be.gemm_nt(self.Re[0], d0.Wts, self.Ge, AMB, d0.k_pad, d0.n_pad, alpha=S, alpha_dev=self._dS)         # S s * g
+        be.sqnorm(self.Ge, AMB, d0.k_pad, self.acc, L.ACC_ENC_GP, scale=1.0 / (cg * S * S), dyn=self._dI2)
         # its backward: forward-shaped launches without bias, masked by the same activations
         x = self.Ge
         for l in range(nl):
@@ -1377,7 +1411,7 @@ class UpdateEngine:
             aux, mode = self._aux(H[l], L.AUX_RELU_MASK)
             be.gemm_nt(x, d.Ws, self.Qe[l], AMB, d.n_pad, d.k_pad, aux=aux, aux_mode=mode)
             x = self.Qe[l]
-        be.gemm_nt(x, head.Ws, self.DUe, AMB, head.n_pad, head.k_pad, alpha=s / S)        # du (unscaled)
+        be.gemm_nt(x, head.Ws, self.DUe, AMB, head.n_pad, head.k_pad, alpha=s / S, alpha_dev=self._dI)        # du (unscaled)
         # weight gradients (no bias terms: the chain has none)
         for l in range(nl):
             d = chain[l]
@@ -1386,11 +1420,17 @@ class UpdateEngine:
         for (name, nr, poff), gW in zip(head.parts, head.gW):
             if sep or poff == off:
                 self._tn(self.Ue[:, poff:], self.Qe[-1], gW, AMB, P(nr), head.k_pad, nr, head.K, head.split_src, head.split_dst)
-        be.enc_gp_back(e, self.enc_z, self.DUe[:, off:], d_e, db, AMB, self.z, grad_scale=S)
+        be.enc_gp_back(e, self.enc_z, self.DUe[:, off:], d_e, db, AMB, self.z, grad_scale=S, dyn=self._dS)
 
     def _gp_scales(self):
-        """(Sc, Sr): the gradient scale S = engine.gs (a power of two) split as evenly as powers of two allow."""
-        if not self.engine_opts.get('gp_scale_split', True):
+        """(Sc, Sr): the gradient scale S (a power of two) split between the two factors of the penalty chain's products, as evenly
+        as powers of two allow.  Dynamic scale: Sc stays put (2^6, the static mode's value at S = 4096) and Sr = S / Sc moves with the
+        scale - returned here is its HOST factor 1 / Sc, the launches multiply the device's S (_dS), 1 / S (_dI), 1 / S^2 (_dI2) in."""
+        split = self.engine_opts.get('gp_scale_split', True)
+        if self.dyn_scale:
+            sc = 64.0 if split else 1.0
+            return sc, 1.0 / sc
+        if not split:
             return 1.0, self.gs
         e = int(round(math.log2(self.gs)))
         sc = 2.0 ** ((e + 1) // 2)
@@ -1435,8 +1475,8 @@ class UpdateEngine:
         d0 = self.disc[0]
         # (the chain's second-operand side - G0 and the dJ/dU_l derived from it - carries Sr so that the stacked
         #  weight-gradient launches undo S = Sc Sr for both row blocks with one alpha)
-        be.gemm_nt(self.Gp[0], d0.Wts, self.G0, AMB, d0.k_pad, d0.n_pad, alpha=Sr / Sc)        # Sr s * g_0
-        be.sqnorm(self.G0, AMB, d0.k_pad, self.acc, L.ACC_GP, scale=1.0 / (cg * Sr * Sr))
+        be.gemm_nt(self.Gp[0], d0.Wts, self.G0, AMB, d0.k_pad, d0.n_pad, alpha=Sr / Sc, alpha_dev=self._dS)        # Sr s * g_0
+        be.sqnorm(self.G0, AMB, d0.k_pad, self.acc, L.ACC_GP, scale=1.0 / (cg * Sr * Sr), dyn=self._dI2)
         # backward of the chain (values scaled by s; see the docstring): dJ/dU_l, masked by the demo rows' ReLU masks
         aux, mode = self._aux(self.Hd[0][2 * AMB:], L.AUX_RELU_MASK)
         be.gemm_nt(self.G0, d0.Ws, self.dGp[0], AMB, d0.n_pad, d0.k_pad, aux=aux, aux_mode=mode)
@@ -1445,7 +1485,7 @@ class UpdateEngine:
             last = l == nl - 1
             aux, mode = self._aux(self.Hd[l][2 * AMB:], L.AUX_RELU_MASK)
             be.gemm_nt(self.dGp[l - 1], d.Ws, self.GpTop if last else self.dGp[l], AMB, d.n_pad, d.k_pad, aux=aux,
-                       aux_mode=mode, alpha=s / Sr if last else 1.0)
+                       aux_mode=mode, alpha=s / Sr if last else 1.0, alpha_dev=self._dI if last else None)
             if last:      # the penalty's gradient w.r.t. the logit weights: column sums of the top launch (f32, true scale)
                 be.colsum(self.GpTop, AMB, d.N, self.disc_head.gW[0].view(-1))
         # weight (+ bias) gradients: one launch per layer over the stacked rows
@@ -1496,7 +1536,7 @@ class UpdateEngine:
             d = self.disc[l]
             be.gemm_nt(g.Gp[l], g.Wts[l], g.Gp[l - 1], AMB, d.k_pad, d.n_pad, aux=g.bits[l - 1], aux_mode=bits, **ex(12))
         d0 = self.disc[0]
-        be.gemm_nt(g.Gp[0], g.Wts[0], g.G0, AMB, d0.k_pad, d0.n_pad, alpha=S, **ex(12))         # S s * g_0
+        be.gemm_nt(g.Gp[0], g.Wts[0], g.G0, AMB, d0.k_pad, d0.n_pad, alpha=S, alpha_dev=self._dS, **ex(12))         # S s * g_0
         if x3_prev is not None:
             be.x3 = x3_prev
 
@@ -1520,7 +1560,7 @@ class UpdateEngine:
         if self._gp_value_done is not None:
             self._join_branch(self._gp_value_done)
             self._gp_value_done = None
-        be.sqnorm(g.G0, AMB, d0.k_pad, self.acc, L.ACC_GP, scale=1.0 / (cg * S * S))
+        be.sqnorm(g.G0, AMB, d0.k_pad, self.acc, L.ACC_GP, scale=1.0 / (cg * S * S), dyn=self._dI2)
         # [dZ_l ; s g_l] and [X ; S s g_0]: the exact chain, rounded once, in the storage type
         if g.cast is None:
             code = {torch.bfloat16: L.BF16, torch.float16: L.F16}[self.dtype]
@@ -1537,7 +1577,7 @@ class UpdateEngine:
             d = self.disc[l]
             last = l == nl - 1
             be.gemm_nt(self.dGp[l - 1], d.Ws, self.GpTop if last else self.dGp[l], AMB, d.n_pad, d.k_pad, aux=g.bits[l],
-                       aux_mode=bits, alpha=s / S if last else 1.0)
+                       aux_mode=bits, alpha=s / S if last else 1.0, alpha_dev=self._dI if last else None)
             if last:
                 be.colsum(self.GpTop, AMB, d.N, self.disc_head.gW[0].view(-1))
         for l in range(nl):
@@ -1573,8 +1613,8 @@ class UpdateEngine:
             aux, mode = self._aux(self.Hd[l - 1][demo], _AUX[pl.act])
             be.gemm_nt(self.Gp[l], d.Wts, self.Gp[l - 1], AMB, d.k_pad, d.n_pad, aux=aux, aux_mode=mode)
         d0 = self.disc[0]
-        be.gemm_nt(self.Gp[0], d0.Wts, self.G0, AMB, d0.k_pad, d0.n_pad, alpha=Sr / Sc)        # Sr s * g_in
-        be.sqnorm(self.G0, AMB, d0.k_pad, self.acc, L.ACC_GP, scale=1.0 / (cg * Sr * Sr))
+        be.gemm_nt(self.Gp[0], d0.Wts, self.G0, AMB, d0.k_pad, d0.n_pad, alpha=Sr / Sc, alpha_dev=self._dS)        # Sr s * g_in
+        be.sqnorm(self.G0, AMB, d0.k_pad, self.acc, L.ACC_GP, scale=1.0 / (cg * Sr * Sr), dyn=self._dI2)
         # ---- its backward: dGp[l] = a'_l * (dGp[l-1] @ W_l^T), the last one only for the logit weights' gradient
         x = self.G0
         for l in range(nl):
@@ -1582,7 +1622,7 @@ class UpdateEngine:
             last = l == nl - 1
             aux, mode = self._aux(self.Hd[l][demo], _AUX[d.act])
             be.gemm_nt(x, d.Ws, self.GpTop if last else self.dGp[l], AMB, d.n_pad, d.k_pad, aux=aux, aux_mode=mode,
-                       alpha=s / Sr if last else 1.0)
+                       alpha=s / Sr if last else 1.0, alpha_dev=self._dI if last else None)
             if last:
                 be.colsum(self.GpTop, AMB, d.N, self.disc_head.gW[0].view(-1))
             if last:     # the top layer's dGp in storage type and S scale, for the second-order term below

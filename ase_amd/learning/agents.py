@@ -893,11 +893,11 @@ class CommonAgent:
         return train_info
 
     def _scaler_update(self):
-        """mixed_precision with the dynamic loss scale (GradScaler.update(), learning/ase_agent.py:280,285,288): the scale moves
-        between updates from the device's skipped / clean step counters - the one read-back of such an update - and a new scale
-        invalidates the recorded launch programs of the step (it is an argument of their launches)."""
-        if self.engine.dyn_scale and self.engine.scaler_update():
-            self._drop_graphs()
+        """mixed_precision with the dynamic loss scale: GradScaler.update() (learning/ase_agent.py:280,285,288) runs on the device
+        behind every optimisation step (csrc/scaler.hip) and the recorded launch programs read the scale there - nothing to do
+        between updates (round 5 moved the scale here, once per update, and dropped the programs)."""
+        if self.engine.dyn_scale:
+            self.engine.scaler_update()
 
     def _ring_results(self, n):
         """train_info of an update from the engine's result rings: ONE copy of the n result vectors (+ one of the n logit

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libase_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 PPO_SCRATCH = 1024 * 72 + 8       # ASE_PPO_SCRATCH: doubles of ase_hip_ppo_head's workspace
 TN_SLAB = 65536 + 256        # ASE_TN_SLAB: floats per work item in the grouped weight-gradient launch's workspace
 F32, BF16, F32X3, F16, F32H3 = 0, 1, 2, 3, 4
@@ -32,8 +32,8 @@ _p, _i, _i64, _f, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 # name -> argtypes; every function returns int.  Keep in lock-step with include/ase_hip.h
 # (tests/test_abi.py parses the header and checks names + arity against this table).
 SIGNATURES = {
-    "ase_hip_gemm_nt": [_p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _i, _i, _p, _i, _p, _i64, _i, _i, _i, _i, _i, _i, _f, _i, _p],
-    "ase_hip_gemm_tn": [_p, _i64, _p, _i64, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
+    "ase_hip_gemm_nt": [_p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _i, _i, _p, _i, _p, _i64, _i, _i, _i, _i, _i, _i, _f, _p, _i, _p],
+    "ase_hip_gemm_tn": [_p, _i64, _p, _i64, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p, _i, _p],
     "ase_hip_refresh_shadow": [_p, _i, _i, _p, _i64, _p, _i64, _i, _i, _i, _p],
     "ase_hip_refresh_shadow_multi": [_p, _i, _i, _p],
     "ase_hip_gather_multi": [_p, _i, _p, _i, _i, _i, _p],
@@ -43,22 +43,22 @@ SIGNATURES = {
     "ase_hip_rms_unnormalize": [_p, _p, _p, _i64, _p],
     "ase_hip_gather_rows": [_p, _i64, _i, _p, _i, _i, _i, _p, _i64, _i, _p],
     "ase_hip_reduce_sum": [_p, _i64, _i, _p, _i, _p],
-    "ase_hip_ppo_head": [_p, _i64, _p, _i64] + [_p] * 11 + [_p, _i64, _p, _i64, _p, _p, _p, _p, _p] + [_i] * 8 + [_f] * 6 + [_i, _p],
-    "ase_hip_disc_head": [_p, _i64, _p, _i64, _p, _p, _i, _i, _f, _f, _i, _p],
-    "ase_hip_enc_head": [_p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _i, _i, _i, _f, _f, _i, _p],
+    "ase_hip_ppo_head": [_p, _i64, _p, _i64] + [_p] * 11 + [_p, _i64, _p, _i64, _p, _p, _p, _p, _p] + [_i] * 8 + [_f] * 6 + [_p, _i, _p],
+    "ase_hip_disc_head": [_p, _i64, _p, _i64, _p, _p, _i, _i, _f, _f, _p, _i, _p],
+    "ase_hip_enc_head": [_p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _i, _i, _i, _f, _f, _p, _i, _p],
     "ase_hip_gp_seed": [_p, _i64, _p, _p, _i64, _i, _i, _f, _i, _i, _p],
     "ase_hip_gp_second": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i, _i, _i, _i, _p],
     "ase_hip_colsum": [_p, _i64, _i, _i, _f, _p, _p],
-    "ase_hip_sqnorm": [_p, _i64, _i, _i, _p, _i, _d, _i, _p],
+    "ase_hip_sqnorm": [_p, _i64, _i, _i, _p, _i, _d, _p, _i, _p],
     "ase_hip_finalize_scalars": [_p, _p, _i, _i, _i, _i, _i, _i] + [_f] * 11 + [_p, _f, _p],
     "ase_hip_enc_gp_seed": [_p, _i64, _p, _i64, _p, _i64, _i, _i, _f, _i, _p],
-    "ase_hip_enc_gp_back": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i, _i, _f, _i, _p],
+    "ase_hip_enc_gp_back": [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i, _i, _f, _p, _i, _p],
     "ase_hip_clip_scale": [_p, _i64, _p, _f, _p],
     "ase_hip_begin_step": [_p, _p, _i, _p, _i, _p, _p],
     "ase_hip_adam": [_p, _p, _p, _p, _i64, _p, _p],
     "ase_hip_axpy": [_p, _p, _i64, _f, _p],
     "ase_hip_scaler_check": [_p, _i64, _i, _p, _p],
-    "ase_hip_scaler_step": [_p, _p, _p, _p, _i64, _p],
+    "ase_hip_scaler_step": [_p, _p, _p, _p, _i64, _p, _p],
     "ase_hip_disc_reward": [_p, _i64, _p, _i64, _f, _p],
     "ase_hip_enc_reward": [_p, _i64, _p, _i64, _p, _i64, _i, _f, _p],
     "ase_hip_gae": [_p, _p, _p, _p, _p, _p, _f, _f, _f, _d, _d, _p, _p, _i, _i, _p],
@@ -87,7 +87,7 @@ SIGNATURES = {
     "ase_hip_wait": [_p, _i],
     "ase_hip_memset": [_p, _i, _i64, _p],
     "ase_hip_memcpy": [_p, _p, _i64, _p],
-    "ase_hip_gemm_tn_grouped": [_p, _p, _i, _p, _i, _p, _i, _p],
+    "ase_hip_gemm_tn_grouped": [_p, _p, _i, _p, _i, _p, _p, _i, _p],
 }
 
 

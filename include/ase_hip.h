@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ASE_HIP_ABI_VERSION 5
+#define ASE_HIP_ABI_VERSION 6
 
 enum { ASE_F32 = 0, ASE_BF16 = 1, ASE_F32X3 = 2 /* f32 storage, products as 3 bf16 MFMAs on a hi/lo split (GEMMs only) */,
        ASE_F32H3 = 4 /* 4-byte storage, products as 3 f16 MFMAs on hi/lo splits of operands scaled by 2^ea / 2^eb (the exponents ride in
@@ -84,6 +84,9 @@ int ase_hip_debug_nt_profile_clock(int shader_clock);
  *   act >= ASE_ACT_SILU: dtype [M, ldmask] (ldmask in ELEMENTS), the pre-activation z = alpha * A.B^T + bias - read back with
  *     ASE_AUX_PREACT (the derivative of a non-monotonic activation is not a function of its output; tanh keeps
  *     ASE_AUX_TANH_GRAD on the output itself).
+ *   alpha_dev (nullable, ABI 6): DEVICE f32 the launch multiplies alpha by when it RUNS - how the factors of the dynamic loss scale
+ *   (ase_hip_scaler_step's scale table: S, 1 / S, 1 / S^2) reach launches recorded once and replayed across scale changes; the same
+ *   convention for every `*_dev` argument below (weight gradients, loss heads, ase_hip_sqnorm).
  * Replaces: nn.Linear + activation forward  (learning/ase_network_builder.py:255-259,305-324,
  *   learning/amp_network_builder.py:81-84), and autograd's data-gradient of the same layers
  *   (B = the transposed weight shadow; mask = derivative of the previous activation), and the
@@ -91,7 +94,7 @@ int ase_hip_debug_nt_profile_clock(int shader_clock);
 int ase_hip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                     const float* bias, const void* aux, int64_t ldaux, int aux_split, int aux_delta,
                     float* colsum, int colsum_n, void* mask_out, int64_t ldmask, int M, int N, int K, int act,
-                    int aux_mode, int out_f32, float alpha, int dtype, void* stream);
+                    int aux_mode, int out_f32, float alpha, const float* alpha_dev, int dtype, void* stream);
 
 /* G[n, kmap(k)] += alpha * sum_m A[m,n] * B[m,k]   for n < n_real, kmap(k) valid     "TN" GEMM
  *   A [M,N] dtype (output gradients), B [M,K] dtype (layer inputs), G f32 [n_real, k_real]
@@ -105,7 +108,7 @@ int ase_hip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void
  *   (learning/ase_agent.py:271). */
 int ase_hip_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* G, float* gbias,
                     int bias_rows, int M, int N, int K, int n_real, int k_real, int split_src, int split_dst,
-                    float alpha, int dtype, void* stream);
+                    float alpha, const float* alpha_dev, int dtype, void* stream);
 
 /* All weight gradients of one branch of an optimisation step in ONE grouped launch (16-bit storage).  They only depend on
  * buffers the data-gradient chain has already written, and one grid of ~256 long contractions pays the split-M reduction once
@@ -131,7 +134,7 @@ int ase_hip_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, floa
 int ase_hip_gemm_tn_grouped_plan(int64_t* problems, int n_problems, int target_wg, int32_t* work, int max_work,
                                  int* n_work, int32_t* red, int max_red, int* n_red);
 int ase_hip_gemm_tn_grouped(const int64_t* problems, const int32_t* work, int n_work, const int32_t* red, int n_red,
-                            float* workspace, int dtype, void* stream);
+                            float* workspace, const float* alpha_dev, int dtype, void* stream);
 
 /* Shadow copies of one weight matrix for the matrix cores: W_s [n_pad,k_pad] and its transpose
  * Wt_s [k_pad,n_pad] (both dtype, zero padded, concat columns moved to split_dst).  Run after
@@ -241,6 +244,8 @@ int ase_hip_reduce_sum(const float* x, int64_t n, int square, double* acc, int s
  *            scalars are not) - the static loss scale of ASE_F16 storage, whose back-propagated gradients would
  *            otherwise fall into half's subnormal range; the weight-gradient launches undo it through their alpha.
  *            The counterpart of the reference's GradScaler (learning/ase_agent.py:216,271-288).  1 for bf16 / f32.
+ *            grad_scale_dev (nullable, ABI 6): a DEVICE f32 factor on top - the DYNAMIC loss scale (ase_hip_scaler_step keeps it),
+ *            read when the launch runs.
  *   scratch: device f64[ASE_PPO_SCRATCH] workspace, private to one launch at a time: per-workgroup partial sums (loss
  *            scalars, head-bias column sums), folded into acc / db_* by a second one-workgroup kernel of the same call (no
  *            contended atomics; a kernel boundary instead of per-workgroup fences). */
@@ -254,19 +259,20 @@ int ase_hip_ppo_head(const float* mu, int64_t ld_mu, const float* value, int64_t
                      float* db_mu, float* db_value, float* mu_out, double* acc, double* scratch,
                      int M, int m_global, int act_dim, int z_dim, int masked, int div_on, int mu_tanh,
                      int clip_value, float e_clip, float critic_coef, float bounds_coef,
-                     float div_coef, float div_tar, float grad_scale, int dtype, void* stream);
+                     float div_coef, float div_tar, float grad_scale, const float* grad_scale_dev, int dtype, void* stream);
 
 /* Discriminator logit losses (learning/amp_agent.py:442-447,481-496): rows [0,2*amb) agent+replay
  * (target 0), rows [2*amb,3*amb) demo (target 1).  d_logit dtype [3*amb, ld_d] column 0. */
 int ase_hip_disc_head(const float* logit, int64_t ld_l, void* d_logit, int64_t ld_d, float* db_logit,
-                      double* acc, int amb, int amb_global, float disc_coef, float grad_scale, int dtype, void* stream);
+                      double* acc, int amb, int amb_global, float disc_coef, float grad_scale, const float* grad_scale_dev, int dtype,
+                      void* stream);
 
 /* Encoder head (learning/ase_network_builder.py:217, learning/ase_agent.py:413-418,469-472):
  * e f32 [amb, ld_e] pre-normalisation output, z f32 [amb, z_dim]; d_e dtype [amb, ld_de].
  * enc_out (nullable) f32 [amb, z_dim] receives normalize(e). */
 int ase_hip_enc_head(const float* e, int64_t ld_e, const float* z, int64_t ld_z, void* d_e,
                      int64_t ld_de, float* db_enc, float* enc_out, double* acc, int amb, int amb_global,
-                     int z_dim, float enc_coef, float grad_scale, int dtype, void* stream);
+                     int z_dim, float enc_coef, float grad_scale, const float* grad_scale_dev, int dtype, void* stream);
 
 /* Encoder gradient penalty (learning/ase_agent.py:431-441: mean_rows |d enc_err / d amp_obs|^2 with enc_err = -<normalize(e), z>),
  * the two per-row pieces around the GEMM chain.  e f32 [rows, ld_e] pre-normalisation encoder output, z f32 [rows, ld_z].
@@ -277,8 +283,8 @@ int ase_hip_enc_head(const float* e, int64_t ld_e, const float* z, int64_t ld_z,
 int ase_hip_enc_gp_seed(const float* e, int64_t ld_e, const float* z, int64_t ld_z, void* u, int64_t ld_u, int rows,
                         int z_dim, float scale, int dtype, void* stream);
 int ase_hip_enc_gp_back(const float* e, int64_t ld_e, const float* z, int64_t ld_z, const float* du, int64_t ld_du,
-                        void* d_e, int64_t ld_de, float* db_enc, int rows, int z_dim, float grad_scale, int dtype,
-                        void* stream);
+                        void* d_e, int64_t ld_de, float* db_enc, int rows, int z_dim, float grad_scale, const float* grad_scale_dev,
+                        int dtype, void* stream);
 
 /* Gradient-penalty seed (learning/amp_agent.py:453-459): g[r,j] = scale * w[j] * act'  (d logit / d pre-activation of the last
  * hidden layer).  h = that layer's TWIN: its output for ReLU (act' = [h > 0]) and tanh (1 - h^2), its pre-activation z for
@@ -297,8 +303,8 @@ int ase_hip_gp_second(const void* twin, int64_t ld_t, const void* g, int64_t ld_
  * stream instead of column sums inside that launch's store-bound epilogue. */
 int ase_hip_colsum(const float* x, int64_t ld, int rows, int cols, float scale, float* out, void* stream);
 
-/* acc[slot] += scale * sum_{r,j} x[r,j]^2 over a dtype matrix [rows, cols]. */
-int ase_hip_sqnorm(const void* x, int64_t ld, int rows, int cols, double* acc, int slot, double scale,
+/* acc[slot] += scale * sum_{r,j} x[r,j]^2 over a dtype matrix [rows, cols]; scale_dev (nullable): a DEVICE f32 factor on top. */
+int ase_hip_sqnorm(const void* x, int64_t ld, int rows, int cols, double* acc, int slot, double scale, const float* scale_dev,
                    int dtype, void* stream);
 
 /* train_result scalars from the accumulators (same keys as learning/ase_agent.py:296-306).
@@ -345,19 +351,26 @@ int ase_hip_axpy(float* g, const float* w, int64_t n, float c, void* stream);
 
 /* Loss scaler of the half-storage engine = torch.cuda.amp.GradScaler around the optimizer step of the reference's mixed_precision
  * path (learning/ase_agent.py:271-288, learning/amp_agent.py:354-371: scaler.scale(loss).backward(); scaler.unscale_; scaler.step;
- * scaler.update).  ABI 5.  scaler: DEVICE f64[8] = {found, skipped steps (total), clean steps in a row (the growth tracker),
- * steps (total), _ x4}.
+ * scaler.update - after EVERY optimisation step).  ABI 5; ABI 6: the scale lives on the device.
+ *   scaler: DEVICE f64[8] = {found, skipped steps (total), growth tracker = clean steps since the scale last moved, steps (total),
+ *           scale, growth_factor, backoff_factor, growth_interval}  (GradScaler's state and constructor arguments; the host writes
+ *           slots 4-7 once)
+ *   scale_tab: DEVICE f32[4] = {S, 1 / S, 1 / S^2, 0}: what the `*_dev` arguments of the loss heads (S), the weight-gradient launches
+ *           (1 / S) and the penalty's norm (1 / S^2) point at - launches recorded once keep working when the scale moves.
  * ase_hip_scaler_check = the found_inf test over ONE buffer the scaled backward wrote (dtype ASE_F32 / ASE_BF16 / ASE_F16):
  * scaler[found] += number of workgroups that met an element that is not finite or - ASE_F16, whose conversions saturate instead
  * of producing inf - sits at +-65504. */
 int ase_hip_scaler_check(const void* buf, int64_t n, int dtype, double* scaler, void* stream);
-/* ase_hip_scaler_step = GradScaler.step's decision, between the checks and the optimizer launch (ase_hip_adam reads opt_eff):
+/* ase_hip_scaler_step = GradScaler.step + GradScaler.update, between the checks and the optimizer launch (ase_hip_adam reads opt_eff):
  *   found != 0: grads[0..n) = 0, opt_eff = the identity step {lr 0, beta1 = beta2 = 1, bias corrections 1} (w, m, v stay what they
- *               are), opt_state.step -= 1 (a skipped step is no optimizer step), skipped += 1, clean = 0
- *   found == 0: opt_eff = opt_state, clean += 1
- * then steps += 1, found = 0.  The scale itself is a launch argument of the loss heads (a power of two): the host moves it between
- * updates from {skipped, clean} (backoff / growth: UpdateEngine.scaler_update). */
-int ase_hip_scaler_step(double* scaler, double* opt_state, double* opt_eff, float* grads, int64_t n, void* stream);
+ *               are), opt_state.step -= 1 (a skipped step is no optimizer step), skipped += 1;
+ *               scale *= backoff_factor, growth tracker = 0
+ *   found == 0: opt_eff = opt_state; growth tracker += 1, and when it reaches growth_interval: scale *= growth_factor, tracker = 0
+ * then steps += 1, found = 0 and (scale_tab non-null) scale_tab = {scale, 1 / scale, 1 / scale^2, 0} - exactly
+ * torch/amp/grad_scaler.py's _amp_update_scale_, once per optimisation step.  scale_tab NULL (ABI 5 behaviour): the scale is a
+ * launch argument the host moves between updates; slots 4-7 are not touched. */
+int ase_hip_scaler_step(double* scaler, double* opt_state, double* opt_eff, float* grads, int64_t n, float* scale_tab,
+                        void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Once-per-epoch rollout tail.

@@ -134,11 +134,11 @@ static int run_grouped(int reps) {
     // LAB_TNG_WS=0: f32 atomics into G; default: partial tiles in a workspace + the reduce kernel
     if (!getenv("LAB_TNG_WS") || atoi(getenv("LAB_TNG_WS"))) CK(hipMalloc(&ws, (size_t)nw * ASE_TN_SLAB * 4));
     printf("reduce entries %d, workspace %s\n", nr, ws ? "on" : "off (atomics)");
-    auto grouped = [&]() { if (ase_hip_gemm_tn_grouped(dprob, dwork, nw, dred, nr, ws, ASE_BF16, st)) { printf("grouped failed: %s\n", ase_hip_last_error()); exit(3); } };
+    auto grouped = [&]() { if (ase_hip_gemm_tn_grouped(dprob, dwork, nw, dred, nr, ws, nullptr, ASE_BF16, st)) { printf("grouped failed: %s\n", ase_hip_last_error()); exit(3); } };
     auto single = [&]() {
         for (int i = 0; i < P; ++i) {
             const Shape& h = shapes[i];
-            if (ase_hip_gemm_tn(A[i], h.N, B[i], h.K, G[i], gb[i], (int)prob[16 * i + 6] == h.M ? 0 : (int)prob[16 * i + 6], h.M, h.N, h.K, h.N, h.K, h.K, h.K, 1.0f, ASE_BF16, st)) { printf("tn failed: %s\n", ase_hip_last_error()); exit(3); }
+            if (ase_hip_gemm_tn(A[i], h.N, B[i], h.K, G[i], gb[i], (int)prob[16 * i + 6] == h.M ? 0 : (int)prob[16 * i + 6], h.M, h.N, h.K, h.N, h.K, h.K, h.K, 1.0f, nullptr, ASE_BF16, st)) { printf("tn failed: %s\n", ase_hip_last_error()); exit(3); }
         }
     };
     grouped();
@@ -222,7 +222,7 @@ int main(int argc, char** argv) {
         auto run = [&]() {
             int rc = ase_hip_gemm_nt(A, K, B, K, C, N, bias, use_aux == 2 ? (void*)bitsbuf : (void*)aux, use_aux == 2 ? (N + 31) / 32 : N, 0, 0, nullptr, 0,
                                      use_aux == 3 ? bitsbuf : nullptr, (N + 31) / 32, M, N, K, relu ? ASE_ACT_RELU : ASE_ACT_NONE,
-                                     use_aux == 2 ? ASE_AUX_RELU_BITS : (use_aux == 1 ? ASE_AUX_RELU_MASK : ASE_AUX_NONE), 0, 1.0f, ASE_BF16, st);
+                                     use_aux == 2 ? ASE_AUX_RELU_BITS : (use_aux == 1 ? ASE_AUX_RELU_MASK : ASE_AUX_NONE), 0, 1.0f, nullptr, ASE_BF16, st);
             if (rc) { printf("gemm_nt failed: %s\n", ase_hip_last_error()); exit(3); }
         };
         run();
@@ -275,7 +275,7 @@ int main(int argc, char** argv) {
         fill_kernel<<<1024, 256, 0, st>>>(B, (int64_t)M * K, 2, 0.05f);
         CK(hipMemsetAsync(G, 0, (int64_t)N * K * 4, st));
         auto run = [&]() {
-            int rc = ase_hip_gemm_tn(A, N, B, K, G, use_aux ? gb : nullptr, 0, M, N, K, N, K, K, K, 1.0f, ASE_BF16, st);
+            int rc = ase_hip_gemm_tn(A, N, B, K, G, use_aux ? gb : nullptr, 0, M, N, K, N, K, K, K, 1.0f, nullptr, ASE_BF16, st);
             if (rc) { printf("gemm_tn failed: %s\n", ase_hip_last_error()); exit(3); }
         };
         run();

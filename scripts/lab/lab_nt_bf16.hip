@@ -4,6 +4,7 @@
 //   ASE_NT_VARIANT=n   force one of the co-resident / skinny tilings below for every bf16 launch
 //   ASE_NT_TILE=128|256, ASE_NT_PHASED=0   force the tile class / keep the phased kernel out
 //   ASE_NT4R=1         the 4-wave register-staged 256 x 256 kernel (gemm_nt4r_variant.hip) where its epilogue applies
+//   ASE_NT4V=<bits>    the 4-wave LDS-DMA kernel with the half-K-tile pipeline (gemm_nt4v_variant.hip; bits = its ablation switches)
 // The schedule ablations of the phased kernel (no DMA / no reads / no MFMAs / 16x16x32 MFMA shape / DMA in the read half: timing
 // only, wrong results) lived behind `#ifdef ASE_LAB` in the product's gemm.hip up to commit 9f99095 and were removed with it;
 // their results are kept in profiles/r03_lab_*.log and profiles/r04_lab_mfma_shape.txt.
@@ -11,6 +12,7 @@
 
 namespace ase_nt {
 template <typename T> int launch_nt4r(const NTParams& p, unsigned long long* prof, hipStream_t stream);      // gemm_nt4r_variant.hip
+template <typename T> int launch_nt4v(const NTParams& p, unsigned long long* prof, int variant, hipStream_t stream);   // gemm_nt4v_variant.hip
 }
 
 static int lab_knob(const char* name, int dflt) {
@@ -22,7 +24,7 @@ int ase_nt::dispatch_nt_bf16(const NTParams& p, hipStream_t s) {
     typedef bf16_t T;
     const bool k128 = (p.K * (int)sizeof(T)) % 128 == 0;
     static const int variant = lab_knob("ASE_NT_VARIANT", 0), force = lab_knob("ASE_NT_TILE", 0), phased = lab_knob("ASE_NT_PHASED", 1),
-                     nt4r = lab_knob("ASE_NT4R", 0);
+                     nt4r = lab_knob("ASE_NT4R", 0), nt4v = lab_knob("ASE_NT4V", -1);
     switch (variant) {
         case 10: return launch_nt<T, 2, 2, 2, 4, 64, 3, 2>(p, s);    // 128 x 256, 4 waves (64 x 128 each), 72 KB
         case 11: return launch_nt<T, 2, 2, 4, 2, 64, 3, 2>(p, s);    // 256 x 128, 4 waves (128 x 64 each), 72 KB
@@ -50,6 +52,7 @@ int ase_nt::dispatch_nt_bf16(const NTParams& p, hipStream_t s) {
     if (force == 256 && p.N > 64) choice = k128 ? 2 : 3;
     if (force == 128 && p.N > 64) choice = 1;
     if (choice == 2 && !phased) choice = 3;
+    if ((choice == 2 || choice == 6) && nt4v >= 0 && rows_epi(p, 128) && p.pre_out == nullptr) return launch_nt4v<T>(p, g_nt_prof, nt4v, s);
     if (choice == 2 && nt4r && rows_epi(p, 128) && p.pre_out == nullptr) return launch_nt4r<T>(p, g_nt_prof, s);
     if (choice == 2) return rows_epi(p, 64) ? launch_nt8<T, true>(p, s) : launch_nt8<T, false>(p, s);
     if (choice == 3) return k128 ? launch_nt<T, 4, 2, 2, 4, 128, 2>(p, s) : launch_nt<T, 4, 2, 2, 4, 64, 4>(p, s);

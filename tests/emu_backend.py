@@ -13,6 +13,11 @@ import torch
 from ase_amd import lib as L
 
 
+def _dyn(t):
+    """Value of a `*_dev` / dyn argument (a device f32 scalar the HIP launch multiplies its scale by), 1 when absent."""
+    return 1.0 if t is None else float(t.reshape(-1)[0])
+
+
 def _rows(idx, remap, M):
     p = torch.arange(M) if idx is None else idx[:M].long()
     if remap[0] > 0:
@@ -115,7 +120,8 @@ class EmuBackend:
 
     # ------------------------------------------------------------------ GEMMs
     def gemm_nt(self, A, B, Cm, M, N, K, bias=None, aux=None, aux_mode=L.AUX_NONE, colsum=None, colsum_n=0,
-                act=L.ACT_NONE, alpha=1.0, aux_split=0, aux_delta=0, mask_out=None, x3_exps=None):
+                act=L.ACT_NONE, alpha=1.0, aux_split=0, aux_delta=0, mask_out=None, x3_exps=None, alpha_dev=None):
+        alpha = alpha * _dyn(alpha_dev)
         if aux is not None and aux_split > 0:
             rows = torch.arange(M)
             rows = torch.where(rows >= aux_split, rows - aux_delta, rows)
@@ -159,7 +165,8 @@ class EmuBackend:
         if colsum is not None and colsum_n > 0:
             colsum[:colsum_n] += out.float().sum(0)[:colsum_n]
 
-    def gemm_tn(self, A, B, G, M, N, K, n_real, k_real, split_src, split_dst, alpha=1.0, gbias=None, bias_rows=0):
+    def gemm_tn(self, A, B, G, M, N, K, n_real, k_real, split_src, split_dst, alpha=1.0, gbias=None, bias_rows=0, alpha_dev=None):
+        alpha = alpha * _dyn(alpha_dev)
         if gbias is not None:
             br = bias_rows if bias_rows > 0 else M
             gbias[:n_real] += alpha * A[:br, :n_real].float().sum(0)
@@ -173,13 +180,13 @@ class EmuBackend:
             return True
         return M % 64 == 0 and bias_rows % 64 == 0 and n_real >= 128 and K >= 128      # any dtype: exercises the deferral on CPU
 
-    def make_tn_plan(self, problems, target_wg=0):
-        return {'keep': problems}
+    def make_tn_plan(self, problems, target_wg=0, alpha_dev=None):
+        return {'keep': problems, 'alpha_dev': alpha_dev}
 
     def gemm_tn_grouped(self, plan):
         self.grouped_launches += 1
         for (A, B, G, gb, br, M, N, K, nr, kr, ss, sd, alpha) in plan['keep']:
-            self.gemm_tn(A, B, G, M, N, K, nr, kr, ss, sd, alpha=alpha, gbias=gb, bias_rows=br)
+            self.gemm_tn(A, B, G, M, N, K, nr, kr, ss, sd, alpha=alpha, gbias=gb, bias_rows=br, alpha_dev=plan.get('alpha_dev'))
 
     def refresh_shadow(self, W, Ws, Wts, split_src, split_dst, x3_exp=None):
         # (x3_exp: the HIP backend packs half splits there; the emulator keeps plain f32 shadows - its x3 products are formed
@@ -274,8 +281,8 @@ class EmuBackend:
 
     def ppo_head(self, mu, value, mb, new_z, logstd, d_mu, d_value, db_mu, db_value, acc, M, m_global, act_dim,
                  z_dim, masked, div_on, mu_tanh, clip_value, e_clip, critic_coef, bounds_coef, div_coef, div_tar,
-                 mu_out=None, grad_scale=1.0):
-        D, gs = act_dim, float(grad_scale)
+                 mu_out=None, grad_scale=1.0, dyn=None):
+        D, gs = act_dim, float(grad_scale) * _dyn(dyn)
         raw = mu[:M, :D]
         m = torch.tanh(raw) if mu_tanh else raw
         a, omu, osg = mb['actions'], mb['mu'], mb['sigma']
@@ -354,7 +361,8 @@ class EmuBackend:
         if div_on:
             acc[L.ACC_DIV] += (mk * div_row).double().sum()
 
-    def disc_head(self, logit, d_logit, db_logit, acc, amb, amb_global, disc_coef, grad_scale=1.0):
+    def disc_head(self, logit, d_logit, db_logit, acc, amb, amb_global, disc_coef, grad_scale=1.0, dyn=None):
+        grad_scale = grad_scale * _dyn(dyn)
         l = logit[:3 * amb, 0]
         la, ld = l[:2 * amb], l[2 * amb:]
         sp = lambda x: torch.clamp_min(x, 0) + torch.log1p(torch.exp(-x.abs()))
@@ -369,7 +377,8 @@ class EmuBackend:
         if db_logit is not None:
             db_logit[0] += o.float().sum() / grad_scale
 
-    def enc_head(self, e, z, d_e, db_enc, enc_out, acc, amb, amb_global, z_dim, enc_coef, grad_scale=1.0):
+    def enc_head(self, e, z, d_e, db_enc, enc_out, acc, amb, amb_global, z_dim, enc_coef, grad_scale=1.0, dyn=None):
+        grad_scale = grad_scale * _dyn(dyn)
         ev, zv = e[:amb, :z_dim], z[:amb, :z_dim]
         nrm = ev.norm(dim=-1, keepdim=True).clamp_min(1e-12)
         h = ev / nrm
@@ -389,7 +398,8 @@ class EmuBackend:
         a = (h * zv).sum(-1, keepdim=True)
         u[:rows, :z_dim] = (-scale * (zv - h * a) / nrm).to(u.dtype)
 
-    def enc_gp_back(self, e, z, du, d_e, db_enc, rows, z_dim, grad_scale=1.0):
+    def enc_gp_back(self, e, z, du, d_e, db_enc, rows, z_dim, grad_scale=1.0, dyn=None):
+        grad_scale = grad_scale * _dyn(dyn)
         ev, zv, r = e[:rows, :z_dim], z[:rows, :z_dim], du[:rows, :z_dim]
         nrm = ev.norm(dim=-1, keepdim=True).clamp_min(1e-12)
         h = ev / nrm
@@ -417,8 +427,8 @@ class EmuBackend:
     def colsum(self, x, rows, cols, out, scale=1.0):
         out[:cols] += scale * x[:rows, :cols].float().sum(0)
 
-    def sqnorm(self, x, rows, cols, acc, slot, scale=1.0):
-        acc[slot] += scale * (x[:rows, :cols].double() ** 2).sum()
+    def sqnorm(self, x, rows, cols, acc, slot, scale=1.0, dyn=None):
+        acc[slot] += scale * _dyn(dyn) * (x[:rows, :cols].double() ** 2).sum()
 
     def finalize_scalars(self, acc, out, m_global, amb_global, masked, has_disc, has_enc, has_div, c, opt_state=None, kl_threshold=0.0):
         a = acc.tolist()
@@ -500,7 +510,8 @@ class EmuBackend:
         if bool(bad.any()):
             scaler[0] += 1.0
 
-    def scaler_step(self, scaler, opt_state, opt_eff, grads):
+    def scaler_step(self, scaler, opt_state, opt_eff, grads, scale_tab=None):
+        found = float(scaler[0]) != 0.0
         if float(scaler[0]) != 0.0:
             grads.zero_()
             opt_state[0] -= 1.0
@@ -517,6 +528,15 @@ class EmuBackend:
             scaler[2] += 1.0
         scaler[3] += 1.0
         scaler[0] = 0.0
+        if scale_tab is not None:          # GradScaler.update(), every step (csrc/scaler.hip scaler_book_kernel)
+            s = float(scaler[4])
+            if found:
+                s *= float(scaler[6])
+            elif float(scaler[2]) >= float(scaler[7]):
+                s *= float(scaler[5])
+                scaler[2] = 0.0
+            scaler[4] = s
+            scale_tab[0], scale_tab[1], scale_tab[2], scale_tab[3] = s, 1.0 / s, 1.0 / (s * s), 0.0
 
     # ------------------------------------------------------------------ rollout tail
     def disc_reward(self, logit, r, n, scale):

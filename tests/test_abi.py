@@ -46,7 +46,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 def test_argument_validation_fails_loudly_without_gpu():
     """Null operands are rejected by the host-side checks before any launch (works without a GPU)."""
     lib = L.load()
-    rc = lib.ase_hip_gemm_nt(None, 0, None, 0, None, 0, None, None, 0, 0, 0, None, 0, None, 0, 0, 0, 0, 0, 0, 0, 1.0, L.BF16, None)
+    rc = lib.ase_hip_gemm_nt(None, 0, None, 0, None, 0, None, None, 0, 0, 0, None, 0, None, 0, 0, 0, 0, 0, 0, 0, 1.0, None, L.BF16, None)
     assert rc == -1 and b'gemm_nt' in lib.ase_hip_last_error()
     with pytest.raises(L.AseHipError):
         L.check(rc, 'gemm_nt')
@@ -212,6 +212,6 @@ def test_scaler_entry_points_validate_on_the_host():
     assert lib.ase_hip_scaler_check(p, 0, L.F16, p, None) == -1
     assert lib.ase_hip_scaler_check(p, 8, L.F32X3, p, None) == -1 and b'dtype' in lib.ase_hip_last_error()
     assert lib.ase_hip_scaler_check(ctypes.c_void_p(p.value + 1), 4, L.F16, p, None) == -1 and b'misaligned' in lib.ase_hip_last_error()
-    assert lib.ase_hip_scaler_step(p, p, p, p, 8, None) == -1 and b'scaler_step' in lib.ase_hip_last_error()      # opt_eff aliases opt_state
-    assert lib.ase_hip_scaler_step(None, p, p, p, 8, None) == -1
-    assert lib.ase_hip_scaler_step(p, p, ctypes.c_void_p(p.value + 8), p, 0, None) == -1
+    assert lib.ase_hip_scaler_step(p, p, p, p, 8, None, None) == -1 and b'scaler_step' in lib.ase_hip_last_error()      # opt_eff aliases opt_state
+    assert lib.ase_hip_scaler_step(None, p, p, p, 8, None, None) == -1
+    assert lib.ase_hip_scaler_step(p, p, ctypes.c_void_p(p.value + 8), p, 0, None, None) == -1

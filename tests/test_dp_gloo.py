@@ -217,7 +217,7 @@ def _worker_scaler(rank, world, port, name, out):
     G = torch.load(os.path.join(GOLDEN, name + '.pt'), weights_only=False)
     be = EmuBackend()
     ag = make_agent(G, be, precision='f16', world_size=world, rank=rank, loss_scale='dynamic', loss_scaler={'init_scale': 16.0})
-    assert ag.engine.dyn_scale and ag.engine.gs == 16.0
+    assert ag.engine.dyn_scale and ag.engine.gs == 1.0 and ag.engine.scaler_state()['scale'] == 16.0
     if rank == 1:            # an overflow only THIS rank sees, in the very first step
         orig, n = be.scaler_check, [0]
 
@@ -252,5 +252,5 @@ def test_two_ranks_skip_the_same_step(tmp_path):
     assert s0 == s1, (s0, s1)
     G = torch.load(os.path.join(GOLDEN, 'ase_tiny.pt'), weights_only=False)
     n_upd = len(G['epochs'])
-    assert s0['steps'] == 2 * n_upd and s0['skipped'] == 1 and s0['scale'] == 8.0       # one backoff, after the first update
+    assert s0['steps'] == 2 * n_upd and s0['skipped'] == 1 and s0['scale'] == 8.0       # one backoff, right behind the skipped step
     assert r['opt_step'] == 2 * n_upd - 1                                                # the skipped step was no optimizer step

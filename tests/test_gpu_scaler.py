@@ -1,6 +1,7 @@
 """GPU tests of the dynamic loss scale (csrc/scaler.hip behind config loss_scale: 'dynamic' - torch.cuda.amp.GradScaler's
 found_inf / skipped step of the reference's mixed_precision path, learning/ase_agent.py:271-288): the two entry points against
-the emulator's semantics, and the engine's skip -> backoff -> clean step -> growth cycle against the static-scale engine
+the emulator's semantics (incl. the per-step backoff / growth of the device-resident scale, ABI 6), and the engine's skip -> backoff
+-> clean step -> growth cycle against the static-scale engine
 (tests/test_scaler_emu.py::check_dynamic_loss_scale, the same check the emulator passes on the CPU)."""
 import os
 
@@ -65,17 +66,21 @@ def test_scaler_step_and_the_identity_optimizer_step(be):
         eff = torch.zeros(8, dtype=torch.float64)
         d = lambda t: t.clone().to(dev)
         opt_d, sc_d, eff_d, g_d, w_d, m_d, v_d = d(opt), d(sc), d(eff), d(gr), d(w0), d(m0), d(v0)
-        be.scaler_step(sc_d, opt_d, eff_d, g_d)
+        sc[4:8] = torch.tensor([4096.0, 2.0, 0.5, 6.0], dtype=torch.float64)        # scale, growth, backoff, interval (tracker at 5)
+        sc_d = d(sc)
+        tab_d, tab = torch.zeros(4, device=dev), torch.zeros(4)
+        be.scaler_step(sc_d, opt_d, eff_d, g_d, scale_tab=tab_d)
         be.adam(w_d, g_d, m_d, v_d, eff_d)
         g_e, w_e, m_e, v_e = gr.clone(), w0.clone(), m0.clone(), v0.clone()
-        emu.scaler_step(sc, opt, eff, g_e)
+        emu.scaler_step(sc, opt, eff, g_e, scale_tab=tab)
+        assert torch.equal(tab_d.cpu(), tab) and float(tab[0]) == (2048.0 if found else 8192.0)      # backoff | growth at the interval
         emu.adam(w_e, g_e, m_e, v_e, eff)
         torch.cuda.synchronize()
         assert torch.equal(sc_d.cpu(), sc) and torch.equal(opt_d.cpu(), opt) and torch.equal(eff_d.cpu(), eff)
         assert torch.equal(g_d.cpu(), g_e)
         if found:
             assert torch.equal(w_d.cpu(), w0) and torch.equal(m_d.cpu(), m0) and torch.equal(v_d.cpu(), v0)
-            assert sc.tolist()[:4] == [0.0, 3.0, 0.0, 10.0] and float(opt[0]) == 3.0
+            assert sc.tolist()[:5] == [0.0, 3.0, 0.0, 10.0, 2048.0] and float(opt[0]) == 3.0
         else:
             assert torch.allclose(w_d.cpu(), w_e, rtol=1e-6, atol=1e-9) and torch.allclose(m_d.cpu(), m_e, rtol=1e-6, atol=1e-12)
             assert torch.allclose(v_d.cpu(), v_e, rtol=1e-6, atol=1e-15) and not torch.equal(w_d.cpu(), w0)
@@ -90,9 +95,9 @@ def test_dynamic_loss_scale_on_gpu(be, name, gp_f32, golden_dir):
 
 
 def test_mixed_precision_update_replays_programs_across_a_scale_change(golden_dir):
-    """The agent under the reference's flag (mixed_precision: True) with recorded launch programs: an update at an overflowing
-    scale skips its steps, the scale backs off, the stale programs are dropped and re-recorded, and the following updates take
-    optimizer steps again."""
+    """The agent under the reference's flag (mixed_precision: True) with recorded launch programs, from an overflowing initial scale:
+    ONE step is skipped per backoff (here one backoff of 2^-36), the very next step of the same update runs at the new scale, and the
+    recorded programs - which read the scale on the device - are replayed across the change without being dropped."""
     import copy
     from tests.test_agent_emu import replay_epochs
     from tests.test_scaler_emu import _agent_without_precision_key
@@ -103,12 +108,15 @@ def test_mixed_precision_update_replays_programs_across_a_scale_change(golden_di
     ag = _agent_without_precision_key(Gm, device='cuda', backend=HipBackend())
     assert ag.engine.dyn_scale and ag.use_graph
     w0 = ag.model.a2c_network.flat_params.clone()
-    Gm['epochs'] = Gm['epochs'] + copy.deepcopy(Gm['epochs'])               # four updates: skip | record | replay | replay
+    Gm['epochs'] = Gm['epochs'] + copy.deepcopy(Gm['epochs'])               # four updates: (skip, then eager) | record | replay | replay
+    dropped = []
+    drop = ag._drop_graphs
+    ag._drop_graphs = lambda: (dropped.append(1), drop())
     replay_epochs(Gm, ag, rtol=1.0, wtol=1.0, check=False)
     torch.cuda.synchronize()
     st = ag.engine.scaler_state()
-    per_update = st['steps'] // len(Gm['epochs'])
-    assert st['skipped'] == per_update and ag.engine.gs == 16.0, st          # the whole first update, and only that one
-    assert float(ag.engine.opt_state[0]) == st['steps'] - st['skipped']
+    assert st['skipped'] == 1 and st['scale'] == 16.0, st                    # one step lost, not an update's worth
+    assert float(ag.engine.opt_state[0]) == st['steps'] - 1
+    assert not dropped
     w1 = ag.model.a2c_network.flat_params
     assert bool(torch.isfinite(w1).all()) and not torch.equal(w0, w1)

@@ -1,8 +1,9 @@
 """The dynamic loss scale of the half-storage engine (config loss_scale: 'dynamic' = what torch.cuda.amp.GradScaler does in the
 reference's mixed_precision path, learning/ase_agent.py:271-288): overflow detection over the scaled backward, the skipped
-optimizer step, backoff / growth of the scale between updates.  Host logic + op semantics on the CPU emulator; the scale
-trajectory of the host-side update rule is pinned against torch's own GradScaler.  check_dynamic_loss_scale is shared with the
-GPU test (tests/test_gpu_scaler.py)."""
+optimizer step, backoff / growth of the DEVICE-resident scale after every optimisation step (ABI 6; round 5 moved the scale on the
+host, once per update).  Host logic + op semantics on the CPU emulator; the scale trajectory of the per-step rule is pinned
+against torch's own GradScaler over two 48-step updates.  check_dynamic_loss_scale is shared with the GPU test
+(tests/test_gpu_scaler.py)."""
 import copy
 import math
 import os
@@ -34,21 +35,29 @@ def _reset_rms(G, eng):
         set_rms(eng.amp_state, E['rms_step0_before']['amp'])
 
 
+def _scale_of(eng):
+    tab = eng.scale_tab.tolist()
+    s = float(eng.scaler[4])
+    assert tab[0] == s and abs(tab[1] * s - 1.0) < 1e-6 and abs(tab[2] * s * s - 1.0) < 1e-6, (tab, s)      # table follows the state
+    return s
+
+
 def check_dynamic_loss_scale(G, make_backend, device='cpu', gp_f32=False):
-    """One minibatch of a golden, three calls of the dynamic engine against the static-scale engine:
+    """One minibatch of a golden, two calls of the dynamic engine against the static-scale engine:
       1. at a scale 2^30 above the static choice the scaled backward saturates half storage: the step is SKIPPED - weights, Adam
          moments and the optimizer's step counter are bit-for-bit what they were, the exported gradient is zero, the loss scalars
-         of the forward (formed in f32) are those of the static engine;
-      2. scaler_update() backs the scale off (here in one move, backoff_factor 2^-30) and the same minibatch again is a CLEAN step
-         that equals the static engine's step: gradients, post-Adam weights, step counter 1;
-      3. growth after growth_interval (= 1) clean steps; no move without news."""
+         of the forward (formed in f32) are those of the static engine - and the scale has ALREADY backed off on the device
+         (here in one move, backoff_factor 2^-30): no host decision, nothing to re-record;
+      2. the same minibatch again, same engine object, same launches, is a CLEAN step at the new scale that equals the static engine's
+         step: gradients, post-Adam weights, step counter 1; growth_interval = 1: the scale has grown behind it and the tracker
+         starts over."""
     f16 = torch.float16
     lr = G['cfg']['learning_rate']
     sync = torch.cuda.synchronize if str(device) != 'cpu' else (lambda: None)
     # the static-scale engine: the reference point
     net_s, eng_s = first_step(G, make_backend(), f16, device=device, gp_f32=gp_f32)
     sync()
-    assert not eng_s.dyn_scale
+    assert not eng_s.dyn_scale and eng_s._dS is None
     S0 = eng_s.gs
     init_sd = {k: v.detach().clone() for k, v in first_step.__globals__['build_net'](G, device).state_dict().items()}
     Gd = copy.deepcopy(G)
@@ -56,10 +65,11 @@ def check_dynamic_loss_scale(G, make_backend, device='cpu', gp_f32=False):
                                                         'growth_factor': 2.0, 'growth_interval': 1})
     net_d, eng_d = first_step(Gd, make_backend(), f16, device=device, gp_f32=gp_f32)
     sync()
-    assert eng_d.dyn_scale and eng_d.gs == S0 * 2.0 ** 30
-    # ---- 1. the skipped step
+    assert eng_d.dyn_scale and eng_d.gs == 1.0                             # (the host factor: the scale itself lives on the device)
+    # ---- 1. the skipped step, and the backoff behind it
     st = eng_d.scaler_state()
     assert (st['skipped'], st['clean'], st['steps']) == (1, 0, 1), st
+    assert _scale_of(eng_d) == S0 and st['scale'] == S0
     assert float(eng_d.scaler[0]) == 0.0                                   # the flag is consumed
     assert float(eng_d.opt_state[0]) == 0.0                                # no optimizer step happened
     sd = net_d.state_dict()
@@ -71,16 +81,15 @@ def check_dynamic_loss_scale(G, make_backend, device='cpu', gp_f32=False):
     for k in ('actor_loss', 'critic_loss', 'kl'):        # (not the penalties: their values come out of the scaled chains)
         if k in rs:
             close(rd[k], rs[k], 1e-5, 1e-6, k + ' (skipped step)')
-    # ---- 2. backoff, then the same minibatch as a clean step
-    assert eng_d.scaler_update() is True
-    assert eng_d.gs == S0
-    assert eng_d.scaler_update() is False                                  # nothing new: no move
+    assert eng_d.scaler_update() is False                                  # (round-5 interface: nothing left for the host)
+    # ---- 2. the same minibatch as a clean step at the backed-off scale
     _reset_rms(G, eng_d)
     mb, idx, streams, z = _step_inputs(G, device)
     eng_d.step(mb, idx, (0, 0), streams, new_z=z)
     sync()
     st = eng_d.scaler_state()
-    assert (st['skipped'], st['clean'], st['steps']) == (1, 1, 2), st
+    assert (st['skipped'], st['clean'], st['steps']) == (1, 0, 2), st       # clean step -> growth (interval 1) -> tracker starts over
+    assert _scale_of(eng_d) == 2.0 * S0
     assert float(eng_d.opt_state[0]) == 1.0
     gs_, gd_ = eng_s.export_grads(), eng_d.export_grads()
     for k, g in gs_.items():
@@ -95,11 +104,6 @@ def check_dynamic_loss_scale(G, make_backend, device='cpu', gp_f32=False):
     for k in ('actor_loss', 'critic_loss', 'kl', 'disc_loss', 'disc_grad_penalty', 'enc_loss'):
         if k in rs:
             close(rd[k], rs[k], 1e-5, 1e-6, k + ' (clean step)')
-    # ---- 3. growth after growth_interval clean steps, and the tracker starts over
-    assert eng_d.scaler_update() is True
-    assert eng_d.gs == 2.0 * S0
-    assert eng_d.scaler_state()['clean'] == 0
-    assert eng_d.scaler_update() is False
     return eng_d
 
 
@@ -137,7 +141,20 @@ def test_scaler_ops_emulated():
     be.scaler_step(sc, opt, eff, g)                                         # overflow
     assert float(g.abs().sum()) == 0.0 and float(opt[0]) == 2.0
     assert eff.tolist() == [2.0, 0.0, 1.0, 1.0, 1e-8, 1.0, 1.0, 0.0] and sc.tolist()[:4] == [0.0, 1.0, 0.0, 2.0]
+    # GradScaler.update() on the device state (scale_tab given): backoff at once, growth when the tracker reaches the interval
+    sc = torch.tensor([1.0, 0, 0, 0, 1024.0, 2.0, 0.5, 2.0], dtype=torch.float64)
+    tab = torch.zeros(4)
+    be.scaler_step(sc, opt, eff, g, scale_tab=tab)                          # overflow: 1024 -> 512
+    assert sc.tolist() == [0.0, 1.0, 0.0, 1.0, 512.0, 2.0, 0.5, 2.0] and tab.tolist() == [512.0, 1 / 512.0, 1 / 512.0 ** 2, 0.0]
+    be.scaler_step(sc, opt, eff, g, scale_tab=tab)                          # clean 1 of 2
+    assert sc.tolist()[:5] == [0.0, 1.0, 1.0, 2.0, 512.0]
+    be.scaler_step(sc, opt, eff, g, scale_tab=tab)                          # clean 2 of 2: growth, tracker starts over
+    assert sc.tolist()[:5] == [0.0, 1.0, 0.0, 3.0, 1024.0] and tab.tolist()[:2] == [1024.0, 1 / 1024.0]
     # the identity step through the optimizer op: nothing moves, even with moments in place
+    opt = torch.tensor([3.0, 2e-5, 0.9, 0.999, 1e-8, 0.271, 0.003, 0.0], dtype=torch.float64)
+    sc = torch.zeros(8, dtype=torch.float64)
+    sc[0] = 2.0
+    be.scaler_step(sc, opt, eff, g)
     w, m, v = torch.randn(10), torch.randn(10) * 1e-3, torch.rand(10) * 1e-6
     w0, m0, v0 = w.clone(), m.clone(), v.clone()
     be.adam(w, g, m, v, eff)
@@ -145,20 +162,22 @@ def test_scaler_ops_emulated():
 
 
 def test_scale_trajectory_matches_torch_gradscaler(golden_dir):
-    """UpdateEngine.scaler_update against torch.amp.GradScaler on the same found_inf sequence, one optimisation step per
-    update (the granularity at which the two rules coincide): the scale after every step, the number of optimizer steps
-    taken."""
+    """The device-side rule (scaler_step with the engine's state and table) against torch.amp.GradScaler on the same found_inf
+    sequence over TWO UPDATES OF 48 OPTIMISATION STEPS: the scale after every step (the reference calls scaler.update() behind every
+    scaler.step(), learning/ase_agent.py:280,285,288), the number of optimizer steps taken, the skipped count - one step lost per
+    backoff, not the rest of the update (round 5: 36 skipped steps for two backoffs)."""
     G = torch.load(os.path.join(golden_dir, 'ppo_tiny.pt'), weights_only=False)
     Gd = copy.deepcopy(G)
-    Gd['cfg'].update(loss_scale='dynamic', loss_scaler={'init_scale': 2.0 ** 10, 'growth_interval': 3})
+    Gd['cfg'].update(loss_scale='dynamic', loss_scaler={'init_scale': 2.0 ** 16, 'growth_interval': 7})
     _, eng = first_step(Gd, EmuBackend(), torch.float16)
-    eng.scaler.zero_()
-    eng._scaler_skipped_seen = 0.0
-    eng.set_grad_scale(2.0 ** 10)
+    eng.scaler[:4] = 0.0
+    eng.set_grad_scale(2.0 ** 16)
     p = torch.nn.Parameter(torch.zeros(4))
     opt = torch.optim.SGD([p], lr=0.1)
-    ref = torch.amp.GradScaler('cpu', init_scale=2.0 ** 10, growth_factor=2.0, backoff_factor=0.5, growth_interval=3)
-    pattern = [0, 0, 0, 1, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0]
+    ref = torch.amp.GradScaler('cpu', init_scale=2.0 ** 16, growth_factor=2.0, backoff_factor=0.5, growth_interval=7)
+    g = torch.Generator().manual_seed(11)
+    pattern = [1, 1] + [int(x) for x in (torch.rand(94, generator=g) < 0.08)]       # two backoffs at the start (65536 -> 16384), then rare ones
+    assert len(pattern) == 2 * 48 and 2 < sum(pattern) < 20
     taken_ref = taken = 0
     for bad in pattern:
         # torch: a scaled backward whose gradient is inf when `bad`
@@ -169,15 +188,15 @@ def test_scale_trajectory_matches_torch_gradscaler(golden_dir):
         ref.step(opt)
         ref.update()
         taken_ref += int(not torch.equal(before, p.detach()))
-        # here: the device-side decision on the same flag, then the host-side move
+        # here: the device-side decision and update on the same flag
         eng.scaler[0] = float(bad)
-        g = torch.ones(4)
-        eng.be.scaler_step(eng.scaler, eng.opt_state, eng.opt_eff, g)
+        gr = torch.ones(4)
+        eng.be.scaler_step(eng.scaler, eng.opt_state, eng.opt_eff, gr, scale_tab=eng.scale_tab)
         taken += int(float(eng.opt_eff[1]) != 0.0)
-        eng.scaler_update()
-        assert eng.gs == ref.get_scale(), (eng.gs, ref.get_scale())
+        assert _scale_of(eng) == ref.get_scale(), (_scale_of(eng), ref.get_scale())
     assert taken == taken_ref == pattern.count(0)
-    assert eng.scaler_state()['skipped'] == pattern.count(1)
+    st = eng.scaler_state()
+    assert st['skipped'] == pattern.count(1) and st['steps'] == 96 and st['scale'] == ref.get_scale()
 
 
 def _agent_without_precision_key(G, device='cpu', backend=None):
@@ -202,7 +221,8 @@ def _agent_without_precision_key(G, device='cpu', backend=None):
 
 def test_mixed_precision_flag_selects_the_dynamic_scale(golden_dir):
     """The reference's own flag (mixed_precision: True, no precision key) = half storage WITH the GradScaler's behaviour; a named
-    precision mode keeps the static scale; an update whose scale moved drops the recorded launch programs."""
+    precision mode keeps the static scale; the scale moves per optimisation step on the device and NO recorded launch program is
+    dropped for it."""
     from tests.test_agent_emu import make_agent, replay_epochs
     G = torch.load(os.path.join(golden_dir, 'ase_tiny.pt'), weights_only=False)
     ag = make_agent(copy.deepcopy(G), EmuBackend(), precision='f16')
@@ -210,15 +230,16 @@ def test_mixed_precision_flag_selects_the_dynamic_scale(golden_dir):
     Gm = copy.deepcopy(G)
     Gm['cfg'].update(mixed_precision=True, loss_scaler={'init_scale': 2.0 ** 40})
     ag = _agent_without_precision_key(Gm)
-    assert ag.precision == 'f16' and ag.engine.dyn_scale and ag.engine.gs == 2.0 ** 40
+    assert ag.precision == 'f16' and ag.engine.dyn_scale and ag.engine.gs == 1.0 and ag.engine.scaler_state()['scale'] == 2.0 ** 40
     dropped = []
-    ag._drop_graphs = lambda: dropped.append(1)
+    drop = ag._drop_graphs
+    ag._drop_graphs = lambda: (dropped.append(1), drop())
     replay_epochs(Gm, ag, rtol=1.0, wtol=1.0, check=False, max_steps=2)
     st = ag.engine.scaler_state()
     n_updates = len(Gm['epochs'])
-    assert st['steps'] == 2 * n_updates and st['skipped'] >= 2             # the first update at 2^40: every step skipped
-    assert ag.engine.gs == 2.0 ** (40 - min(n_updates, 2)) or ag.engine.gs < 2.0 ** 40
-    assert len(dropped) >= 1
+    assert st['steps'] == 2 * n_updates and st['skipped'] >= 2             # at 2^40 every step overflows: each one skipped, each one halves
+    assert st['scale'] == 2.0 ** 40 * 0.5 ** st['skipped']
+    assert not dropped
 
 
 def test_dynamic_loss_scale_with_truncate_grads(golden_dir):
