@@ -578,20 +578,32 @@ int launch_nt(const NTParams& p0, hipStream_t stream) {
 //   behind a lab switch in this file up to commit 9f99095; their results are in profiles/r03_lab_*.log, r04_lab_mfma_shape.txt.)
 // ------------------------------------------------------------------------------------------------
 
+// DMA pieces go out as `buffer_load_dwordx4 ... lds` (round 6, like gemm_nt4.h): an SGPR buffer descriptor per operand, ONE 32-bit
+// offset register per piece (the 64-bit per-lane addresses of global_load_lds cost 16 registers and two VALU adds per piece), the
+// K-tile's byte offset as the instruction's SGPR offset, M0 = LDS destination.  What it buys is REGISTERS: the kernel's allocation
+// decides how many of the 512 registers per SIMD its two waves leave to the small HBM-bound kernels of the step's other branches,
+// which run in exactly that space (profiles/r06_nt_policy_ab.txt: a matrix kernel that owns the whole file costs the update 2.2 %).
 struct NT8Lane {
-    const char* src[4][2];     // per-lane DMA source (row base + swizzled chunk) of unit kind x piece
-    int dst[4][2];             // wave-uniform LDS byte offset of the piece inside a K-tile buffer
+    uint32_t voff[4][2];       // per-lane byte offset (row * ld + swizzled chunk) of unit kind x piece from its operand's base
+    uint32_t dst[4][2];        // wave-uniform LDS byte ADDRESS of the piece in K-tile buffer 0 (buffer 1: + 65536)
     int roff[4];               // per-lane fragment read offsets (row * 128 + swizzled chunk) for the 4 k-steps
+    i32x4 rsA, rsB;            // raw buffer descriptors of the two operands (SGPRs)
 };
+
+__device__ __forceinline__ void nt8_dma(uint32_t lds_s, uint32_t voff, i32x4 rs, uint32_t soff) {
+    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(lds_s), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+template <int KIND>
+__device__ __forceinline__ void nt8_piece(const NT8Lane& L, int g, int tile) {
+    constexpr bool isB = (KIND == 1 || KIND == 2);
+    nt8_dma(__builtin_amdgcn_readfirstlane(L.dst[KIND][g] + (uint32_t)(tile & 1) * 65536u), L.voff[KIND][g], isB ? L.rsB : L.rsA,
+            (uint32_t)tile * 128u);
+}
 
 template <int KIND>
 __device__ __forceinline__ void nt8_issue(const NT8Lane& L, char* smem, int tile) {
-    constexpr int kBuf = 512 * 128;
-    char* buf = smem + (tile & 1) * kBuf;
-    const int64_t koff = (int64_t)tile * 128;
 #pragma unroll
-    for (int g = 0; g < 2; ++g)
-        __builtin_amdgcn_global_load_lds((gptr_t*)(L.src[KIND][g] + koff), (lptr_t*)(buf + L.dst[KIND][g]), 16, 0, 0);
+    for (int g = 0; g < 2; ++g) nt8_piece<KIND>(L, g, tile);
 }
 
 // fragment registers of one 32-row operand block: 4 k-steps x 16 bytes
@@ -609,9 +621,6 @@ __device__ __forceinline__ void nt8_read(i32x4 (&f)[4], const char* base, const 
 template <typename T, int KIND, bool SW>
 __device__ __forceinline__ void nt8_mma_issue(f32x16& c0, f32x16& c1, const i32x4 (&a0)[4], const i32x4 (&a1)[4],
                                               const i32x4 (&b)[4], const NT8Lane& L, char* smem, int tile, bool live) {
-    constexpr int kBuf = 512 * 128;
-    char* buf = smem + (tile & 1) * kBuf;
-    const int64_t koff = (int64_t)tile * 128;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         if (ks == 3) NT8_BARRIER();                       // (closes the phase: see above)
@@ -619,8 +628,7 @@ __device__ __forceinline__ void nt8_mma_issue(f32x16& c0, f32x16& c1, const i32x
         c1 = nt8_mfma<T, SW>(a1[ks], b[ks], c1);
         if (ks == 0 || ks == 2) {
             __builtin_amdgcn_sched_barrier(0);
-            if (live)
-                __builtin_amdgcn_global_load_lds((gptr_t*)(L.src[KIND][ks >> 1] + koff), (lptr_t*)(buf + L.dst[KIND][ks >> 1]), 16, 0, 0);
+            if (live) nt8_piece<KIND>(L, ks >> 1, tile);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -633,17 +641,13 @@ __device__ __forceinline__ void nt8_mma_issue(f32x16& c0, f32x16& c1, const i32x
 template <typename T, int KIND, bool SW>
 __device__ __forceinline__ void nt8_mma_issue1(f32x16& c0, const i32x4 (&a0)[4], const i32x4 (&b)[4], const NT8Lane& L, char* smem,
                                                int tile, bool live) {
-    constexpr int kBuf = 512 * 128;
-    char* buf = smem + (tile & 1) * kBuf;
-    const int64_t koff = (int64_t)tile * 128;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         if (ks == 3) NT8_BARRIER();
         c0 = nt8_mfma<T, SW>(a0[ks], b[ks], c0);
         if (ks == 0 || ks == 2) {
             __builtin_amdgcn_sched_barrier(0);
-            if (live)
-                __builtin_amdgcn_global_load_lds((gptr_t*)(L.src[KIND][ks >> 1] + koff), (lptr_t*)(buf + L.dst[KIND][ks >> 1]), 16, 0, 0);
+            if (live) nt8_piece<KIND>(L, ks >> 1, tile);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -726,13 +730,17 @@ __global__ __launch_bounds__(512) void gemm_nt8_kernel(NTParams p) {
                 const int r = rows[kind] + lr;
                 const bool isB = (kind == 1 || kind == 2);
                 const int64_t grow = isB ? min(bn0 + r, p.N - 1) : min(bm0 + r, p.M - 1);
-                L.src[kind][g] = (isB ? p.B + grow * p.ldb : p.A + grow * p.lda) + ((slot ^ lds_swz<RB>(r)) << 4);
-                L.dst[kind][g] = (isB ? BM * RB : 0) + rows[kind] * RB;
+                L.voff[kind][g] = (uint32_t)(grow * (isB ? p.ldb : p.lda)) + (uint32_t)((slot ^ lds_swz<RB>(r)) << 4);
+                L.dst[kind][g] = (uint32_t)(uintptr_t)smem + (isB ? BM * RB : 0) + rows[kind] * RB;
             }
         }
         const int r = lane & 31, h = lane >> 5, sw = lds_swz<RB>(r);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) L.roff[ks] = r * RB + (((ks * 2 + h) ^ sw) << 4);
+        // whole operands as raw buffers (rows past M / N are clamped in the per-lane offsets above)
+        const uint64_t a = (uint64_t)(uintptr_t)p.A, b = (uint64_t)(uintptr_t)p.B;
+        L.rsA = i32x4{(int)(uint32_t)a, (int)(uint32_t)(a >> 32), (int)0x7FFFFFFF, 0x00020000};
+        L.rsB = i32x4{(int)(uint32_t)b, (int)(uint32_t)(b >> 32), (int)0x7FFFFFFF, 0x00020000};
     }
 
     f32x16 acc[NI][2];
@@ -866,7 +874,11 @@ inline bool rows_epi(const NTParams& p, int wave_cols) {
 
 template <typename T> int dispatch_nt(const NTParams& p, hipStream_t s) {
     const bool k128 = (p.K * (int)sizeof(T)) % 128 == 0;       // 128-byte staged rows need K in whole 128-byte steps
-    switch (nt_choice(p.M, p.N, p.K, (int)sizeof(T), sizeof(T) == 2)) {
+    // (the phased kernels and the 4-wave kernel address their operands with 32-bit byte offsets from the base: < 2 GiB each)
+    const bool fits32 = (int64_t)p.M * p.lda < (int64_t)0x7FFFFFFF && (int64_t)p.N * p.ldb < (int64_t)0x7FFFFFFF;
+    int choice = nt_choice(p.M, p.N, p.K, (int)sizeof(T), sizeof(T) == 2);
+    if ((choice == 2 || choice == 6) && !fits32) choice = 3;
+    switch (choice) {
         case 0: return launch_nt<T, 2, 2, 1, 1, 64, 4>(p, s);
         case 6:
             if constexpr (sizeof(T) == 2) if (rows_epi(p, 64)) return launch_nt8<T, true, 192>(p, s);
@@ -875,9 +887,14 @@ template <typename T> int dispatch_nt(const NTParams& p, hipStream_t s) {
             if constexpr (sizeof(T) == 2) {
                 // row-per-lane epilogue (swapped MFMA operands): 16-bit output in whole 64-column wave tiles, no column sums,
                 // mask operand absent or a bit matrix; otherwise the LDS-slab epilogue
-                // whole 128-column wave tiles and operands a 32-bit byte offset reaches: the 4-wave kernel (gemm_nt4.h)
-                if (rows_epi(p, 128) && (int64_t)p.M * p.lda < (int64_t)0x7FFFFFFF && (int64_t)p.N * p.ldb < (int64_t)0x7FFFFFFF)
-                    return launch_nt4<T>(p, s);
+                // The 4-wave kernel (gemm_nt4.h: whole 128-column wave tiles, operands a 32-bit byte offset reaches) takes the launches of
+                // MANY rounds that run with nothing beside them - the epoch tail's reward inference over the whole experience buffer
+                // (131072 rows: 324 vs 344 us).  Inside an optimisation step it stays out although it is 4-8 % faster launch by launch
+                // (profiles/r06_nt4_lab.txt): its workgroup owns the CU's whole register file (4 waves x 512), the 8-wave kernel leaves
+                // 32 registers per SIMD, and in the four-stream step the small HBM-bound kernels of the other branches (<= 32 VGPRs:
+                // gathers, conversions, loss heads) run in exactly that space - same-box A/B of the update: 77.5 ms with the 8-wave
+                // kernel, 79.3 ms with this one (profiles/r06_nt_policy_ab.txt).
+                if (p.M >= 65536 && rows_epi(p, 128)) return launch_nt4<T>(p, s);
                 if (rows_epi(p, 64)) return launch_nt8<T, true>(p, s);
                 return launch_nt8<T, false>(p, s);
             }

@@ -277,21 +277,31 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(TNParams p) {
 // ------------------------------------------------------------------------------------------------
 constexpr int kTnSlab = 65536 + 256;       // floats per work item in the partial-sum workspace: 256 x 256 tile + 256 bias sums
 
+// (DMA pieces as `buffer_load_dwordx4 ... lds`, round 6 - see NT8Lane in gemm_nt_kernels.h: one 32-bit offset register per piece
+//  instead of a 64-bit address, the K-tile's byte offset as the instruction's SGPR offset; the registers it frees are what the
+//  small kernels of the step's other branches co-reside in.)
 struct TN8Lane {
-    const char* src[4][2];     // per-lane DMA source of unit kind (B-lo, A-lo, B-hi, A-hi) x piece, at K-tile 0
-    int dst[4][2];             // wave-uniform LDS byte offset of the piece inside a K-tile buffer
+    uint32_t voff[4][2];       // per-lane byte offset of unit kind (B-lo, A-lo, B-hi, A-hi) x piece from its operand's base, at K-tile 0
+    uint32_t dst[4][2];        // wave-uniform LDS byte ADDRESS of the piece in K-tile buffer 0 (buffer 1: + 65536)
     int rbase;                 // per-lane tr-read base: row, 16-byte sub-chunk and half of the lane
     int foffA[4], foffB[2];    // swizzled 64-byte fragment-column offsets
-    int64_t kstep[2];          // bytes per K-tile (64 rows) of B / A
+    uint32_t kstep[2];         // bytes per K-tile (64 rows) of B / A
+    i32x4 rs[2];               // raw buffer descriptors of B / A (SGPRs)
 };
 
 template <int KIND>
+__device__ __forceinline__ void tn8_piece(const TN8Lane& L, int g, int tile) {
+    const uint32_t lds_s = __builtin_amdgcn_readfirstlane(L.dst[KIND][g] + (uint32_t)(tile & 1) * 65536u);
+    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :
+                 : "s"(lds_s), "v"(L.voff[KIND][g]), "s"(L.rs[KIND & 1]), "s"((uint32_t)tile * L.kstep[KIND & 1])
+                 : "memory");
+}
+
+template <int KIND>
 __device__ __forceinline__ void tn8_issue(const TN8Lane& L, char* smem, int tile) {
-    char* buf = smem + (tile & 1) * 65536;
-    const int64_t koff = (int64_t)tile * L.kstep[KIND & 1];
 #pragma unroll
-    for (int g = 0; g < 2; ++g)
-        __builtin_amdgcn_global_load_lds((gptr_t*)(L.src[KIND][g] + koff), (lptr_t*)(buf + L.dst[KIND][g]), 16, 0, 0);
+    for (int g = 0; g < 2; ++g) tn8_piece<KIND>(L, g, tile);
 }
 
 // fragment (32 columns) x k-step (16 rows): two transposed 8-byte reads = the lane's 8 consecutive m of its column.
@@ -317,8 +327,6 @@ __device__ __forceinline__ void tn8_mma(f32x16& c00, f32x16& c01, f32x16& c10, f
                                         typename V16<T>::x8 bvec, const TN8Lane& L, char* smem, int tile, bool live) {
     typedef typename V16<T>::x8 x8;
     x8 a0[2], a1[2];
-    char* buf = smem + (tile & 1) * 65536;
-    const int64_t koff = (int64_t)tile * L.kstep[(KIND < 0 ? 0 : KIND) & 1];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         a0[ks] = tn8_join<T>(a[0][ks]);
@@ -328,8 +336,7 @@ __device__ __forceinline__ void tn8_mma(f32x16& c00, f32x16& c01, f32x16& c10, f
         c10 = mfma16<T>(a1[ks], b0, c10);
         if constexpr (KIND >= 0) {
             __builtin_amdgcn_sched_barrier(0);
-            if (live)
-                __builtin_amdgcn_global_load_lds((gptr_t*)(L.src[KIND][ks] + koff), (lptr_t*)(buf + L.dst[KIND][ks]), 16, 0, 0);
+            if (live) tn8_piece<KIND>(L, ks, tile);
             __builtin_amdgcn_sched_barrier(0);
         }
         c01 = mfma16<T>(a0[ks], b1, c01);
@@ -427,14 +434,16 @@ __device__ __forceinline__ void tn8_body(const TNParams& p, char* smem, int bn0,
                 int chunk = slot ^ ((row & 3) << 2);
                 const int col0 = isA ? bn0 : bk0, width = isA ? p.N : p.K;
                 if (col0 + chunk * 8 >= width) chunk = 0;            // columns past the operand: products only reach unstored outputs
-                const char* base = isA ? p.A : p.B;
                 const int64_t ld = isA ? p.lda : p.ldb;
-                L.src[kind][g] = base + (int64_t)(m_begin + row) * ld + (int64_t)col0 * 2 + chunk * 16;
-                L.dst[kind][g] = (isA ? 0 : 32768) + row0 * 512;
+                L.voff[kind][g] = (uint32_t)((int64_t)(m_begin + row) * ld + (int64_t)col0 * 2 + chunk * 16);
+                L.dst[kind][g] = (uint32_t)(uintptr_t)smem + (isA ? 0 : 32768) + row0 * 512;
             }
         }
-        L.kstep[0] = 64 * p.ldb;
-        L.kstep[1] = 64 * p.lda;
+        L.kstep[0] = (uint32_t)(64 * p.ldb);
+        L.kstep[1] = (uint32_t)(64 * p.lda);
+        const uint64_t pa_ = (uint64_t)(uintptr_t)p.A, pb_ = (uint64_t)(uintptr_t)p.B;
+        L.rs[0] = i32x4{(int)(uint32_t)pb_, (int)(uint32_t)(pb_ >> 32), (int)0x7FFFFFFF, 0x00020000};
+        L.rs[1] = i32x4{(int)(uint32_t)pa_, (int)(uint32_t)(pa_ >> 32), (int)0x7FFFFFFF, 0x00020000};
         const int t = lane & 15, g4 = lane >> 4, h = g4 >> 1, cg = g4 & 1, s2 = (t >> 2) & 3;
         L.rbase = (h * 8 + (t >> 2)) * 512 + (cg * 2 + ((t & 3) >> 1)) * 16 + (t & 1) * 8;
 #pragma unroll
@@ -786,7 +795,10 @@ __global__ void refresh_shadow_kernel(const float* __restrict__ W, int n_real, i
 // the contracted (contiguous) dimension - k for W_s, n for W_s^T; 4 bytes per element, leading dimensions in 4-byte units like the
 // f32 shadows they replace.  (See Mma<f32h_t> in gemm_nt_kernels.h.)
 __device__ __forceinline__ void store_split(char* row, int col, float v, float scale) {
-    const float s = v * scale;
+    // (saturating, like every other conversion into half storage: a weight beyond +-32 at the scale 2^11 must not become inf and
+    //  then NaN in every product - advisor, round 5; once per weight and step, free.  The A operand's split stays a plain cast in
+    //  the kernel's loop: its inputs are bounded by construction - observations clamped to +-5 at 2^12, see _gp_value)
+    const float s = __builtin_amdgcn_fmed3f(v * scale, -65504.f, 65504.f);
     const f16_t hi = (f16_t)s, lo = (f16_t)(s - (float)hi);
     char* g = row + (col >> 3) * 32 + (col & 7) * 2;
     *reinterpret_cast<f16_t*>(g) = hi;
@@ -896,7 +908,9 @@ extern "C" int ase_hip_gemm_tn(const void* A, int64_t lda, const void* B, int64_
         // reduction costs 256 KB of memory-side atomics per workgroup; see the grouped launch): whole 64-row K-tiles,
         // whole bias tiles, >= 32 K-tiles per split.
         const int t256 = ((n_real + 255) / 256) * ((K + 255) / 256);
-        const bool phased = M % 64 == 0 && p.bias_rows % 64 == 0 && n_real >= 128 && K >= 128 && (int64_t)M * t256 >= 256 * 2048;
+        // (the phased kernel reaches its operands through 32-bit byte offsets: < 2 GiB each)
+        const bool fits32 = (int64_t)M * p.lda < (int64_t)0x7FFFFFFF && (int64_t)M * p.ldb < (int64_t)0x7FFFFFFF;
+        const bool phased = M % 64 == 0 && p.bias_rows % 64 == 0 && n_real >= 128 && K >= 128 && (int64_t)M * t256 >= 256 * 2048 && fits32;
         if (dtype == ASE_BF16) return phased ? launch_tn8<bf16_t>(p, (hipStream_t)stream) : launch_tn<bf16_t>(p, (hipStream_t)stream);
         return phased ? launch_tn8<f16_t>(p, (hipStream_t)stream) : launch_tn<f16_t>(p, (hipStream_t)stream);
     }
@@ -916,6 +930,8 @@ static int tn_problem_check(const int64_t* d, int i) {
                   "gemm_tn_grouped: problem %d: operands must be 16-byte aligned with whole 16-byte chunks per row", i);
     ASE_CHECK_ARG(n_real > 0 && n_real <= N && k_real > 0 && d[12] <= d[13] && d[12] <= k_real,
                   "gemm_tn_grouped: problem %d: bad real dims / split", i);
+    ASE_CHECK_ARG(M * lda * 2 < (int64_t)0x7FFFFFFF && M * ldb * 2 < (int64_t)0x7FFFFFFF,
+                  "gemm_tn_grouped: problem %d: operands beyond 2 GiB (the kernel addresses them with 32-bit byte offsets)", i);
     return ASE_OK;
 }
 

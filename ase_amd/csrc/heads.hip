@@ -39,8 +39,11 @@ constexpr int kPpoSlots = 72;
 
 // LPR lanes per row (act_dim <= LPR: 32 for the humanoid's 28 / 31 actions, 64 for the HRL high-level policy whose action
 // is the 64-d latent), 256 / LPR rows per 256-thread block.
+// (8 waves per SIMD = at most 64 registers, at the price of ~10 spilled dwords per lane: a latency-bound kernel on the step's critical
+//  path that starts while other branches' matrix kernels hold every CU - their two waves per SIMD leave 64 registers (round 6), and at
+//  72 this kernel waited for a CU to drain: 18 us alone, 111 us behind a resident grid)
 template <typename T, int LPR>
-__global__ __launch_bounds__(256) void ppo_head_kernel(PpoArgs p) {
+__global__ __launch_bounds__(256, 8) void ppo_head_kernel(PpoArgs p) {
     constexpr int ROWS = 256 / LPR;
     __shared__ double sm[7 * 16];
     __shared__ float sdb[ROWS][LPR + 1];

@@ -228,6 +228,16 @@ class UpdateEngine:
         self._apply_wide = bool(o['apply_wide'])
         self._apply_desc = self._apply_items = None
         self.force_dist = bool(cfg.get('force_dist', False))   # exercise the collectives with a 1-rank group
+        # Gradient exchange of the data-parallel step: payload type of the two gradient buckets - 'f32' (exact: the R-rank
+        # update equals the 1-rank update) or 'bf16' (half the bytes on the links: converted, summed and converted back inside the
+        # exchange's host callback; the sum of R bf16-rounded partial gradients carries ~2^-9 relative error per element, which Adam's
+        # normalised step tolerates and the equality tests do not - so it is an option, not the default)
+        self.dp_grad_dtype = cfg.get('dp_grad_dtype', 'f32')
+        assert self.dp_grad_dtype in ('f32', 'bf16'), self.dp_grad_dtype
+        self._xbuf = {}
+        self._disc_acc_mark = None
+        self._merged_stats = False       # this step exchanges [amp sums | obs sums | mask sum] as ONE collective (phase_stats)
+        self._acc_in_bucket = False      # ... and the loss partial sums inside the policy bucket's exchange (_finish_branch)
         self._refresh_desc = None
         self._mb_desc = None
         self._mb_desc_key = None
@@ -775,6 +785,24 @@ class UpdateEngine:
         be, c, M, AMB = self.be, self.cfg, self.M, self.AMB
         self._disc_fwd_out = None
         self._stats_exchanged = False
+        pf = self._xs and self._prefetch and len(self._Xa2) == 2
+        # Sharded data parallel under the cross-step schedule: ONE statistics collective per step.  The policy prologue (critic's
+        # stream) forms the observation sums and the mask sum, the discriminator's head (its own stream) the amp sums; the head waits
+        # for the prologue's mark, exchanges the whole buffer [amp sums x3 | obs sums | mask sum] and the prologue waits for that -
+        # every running statistic stays on the stream that owns it (round 5: three small collectives from three streams, which the
+        # process group's single stream serialised anyway).
+        merged = self._merged_stats = bool(pf and self._dist_shard() and self.has_disc and self.masked)
+        pre_a = None
+        if merged:
+            self._build_apply_desc()
+            with self._Branch(self, self._side(0), nowait=True):
+                be.begin_step(None, None, zero2=self.stats_flat, rng_bump=self.div_rng if self.div_on else None)
+                self.gather_minibatch(ds, idx, remap, part=1)            # (the fields first: the mask sum needs the gathered mask)
+                be.reduce_sum(self.mb['rand_action_mask'], M, False, self.stats_flat, self.stats_flat.numel() - 1)
+                if c.get('normalize_input', True):
+                    be.rms_moments(ds['obs'], self.obs, idx, remap, M, self.obs_state, self.obs_sums)
+                pre_a = self._mark()
+        self._stats_mark_a, self._stats_mark_b = pre_a, None
         if self._xs:
             # Cross-step schedule: the head of the discriminator branch goes FIRST into the step's launch sequence and waits
             # for nothing on the main stream.  On its own stream it follows the branch's optimizer step of the previous
@@ -790,13 +818,13 @@ class UpdateEngine:
             self._disc_split = bool(self._disc_after_style and self.style)
             with self._Branch(self, self._side(1), nowait=True):
                 be.zero_(self.grads[lo:hi])
-                be.zero_(self.amp_sums)
+                if not merged:                   # (merged: the prologue's begin_step zeroed the whole statistics buffer)
+                    be.zero_(self.amp_sums)
                 if self._disc_split:
                     self._disc_inputs(amp_streams, ds)
                     self._disc_fwd_out = 'split'
                 else:
                     self._disc_fwd_out = self._disc_forward(amp_streams, ds)
-        pf = self._xs and self._prefetch and len(self._Xa2) == 2
         pre = None
         if pf:
             # The weight-independent prologue, un-chained like the discriminator's head: on the critic's stream it follows that
@@ -805,11 +833,15 @@ class UpdateEngine:
             # (one begin_step launch without optimizer state); the accumulators are not touched before the step's real
             # begin_step below (the mask sum follows it).
             with self._Branch(self, self._side(0), nowait=True) as pre:
-                be.begin_step(None, None, zero2=self.obs_sums, rng_bump=self.div_rng if self.div_on else None)
+                if merged:
+                    be.wait(self._stats_mark_b)          # the one statistics collective of the step (discriminator's head) is through
+                else:
+                    be.begin_step(None, None, zero2=self.obs_sums, rng_bump=self.div_rng if self.div_on else None)
                 if c.get('normalize_input', True):
-                    be.rms_moments(ds['obs'], self.obs, idx, remap, M, self.obs_state, self.obs_sums)
-                    if self._dist_shard():
-                        self._ar(self.obs_sums)          # (sharded data parallel: the ranks' partial sums, on this stream)
+                    if not merged:
+                        be.rms_moments(ds['obs'], self.obs, idx, remap, M, self.obs_state, self.obs_sums)
+                        if self._dist_shard():
+                            self._ar(self.obs_sums)          # (sharded data parallel: the ranks' partial sums, on this stream)
                     be.rms_finalize(self.obs_state, self.obs, self.obs_sums, self.Mg if self.shard else self.M, 1, self.obs_mean,
                                     self.obs_std)
                 else:
@@ -822,7 +854,8 @@ class UpdateEngine:
                 if self.div_on:
                     self._draw_new_latents(new_z)
                 self._lat_ready = self._mark()        # everything the style MLP / the first actor layer read is in place
-                self.gather_minibatch(ds, idx, remap, part=1)
+                if not merged:
+                    self.gather_minibatch(ds, idx, remap, part=1)
         self._pre_done = pre
         if pf:
             # begin_step leaves the main stream: nothing in front of the loss heads reads the accumulators or the optimizer
@@ -834,7 +867,9 @@ class UpdateEngine:
                 be.begin_step(self.opt_state if advance else None, self.acc, zero2=None, rng_bump=None)
                 self._early_fork = self._mark()
                 be.zero_(self.grads[plo:phi])
-                if self.masked:
+                if merged:                               # (the global mask sum came with the statistics collective)
+                    be.copy_(self.acc[L.ACC_MASK_SUM:L.ACC_MASK_SUM + 1], self.stats_flat[-1:])
+                elif self.masked:
                     be.reduce_sum(self.mb['rand_action_mask'], M, False, self.acc, L.ACC_MASK_SUM)
                     if self._dist_shard():
                         self._ar(self.acc[L.ACC_MASK_SUM:L.ACC_MASK_SUM + 1])
@@ -899,7 +934,13 @@ class UpdateEngine:
         return self._dist_on() and self.shard
 
     def _exchange_amp_sums(self):
-        if self._dist_shard():
+        if self._merged_stats:
+            # the step's ONE statistics collective: behind the policy prologue's sums (mark A), in front of everything that reads a
+            # global statistic on either stream (mark B)
+            self.be.wait(self._stats_mark_a)
+            self._ar(self.stats_flat)
+            self._stats_mark_b = self._mark()
+        elif self._dist_shard():
             self._ar(self.amp_sums_flat)
 
     def _amp_moments(self, amp_streams):
@@ -975,7 +1016,14 @@ class UpdateEngine:
         if inline_apply:
             a, b, lo, hi = self._apply_groups[group]
             if self._dist_on():
-                self._ar(self.grads[lo:hi])
+                # the LAST bucket of a sharded step (the policy's, on the main stream) carries the loss partial sums of the whole step
+                # with it: one collective less (round 5: a 100-byte all-reduce of its own in phase_finish).  The discriminator branch's
+                # contributions to them are complete at its mark (_disc_acc_mark), long before this point.
+                with_acc = bool(last and self.shard and self.dp_grad_dtype == 'f32')
+                if with_acc and self._disc_acc_mark is not None:
+                    self.be.wait(self._disc_acc_mark)
+                self._exchange_bucket(group, lo, hi, with_acc)
+                self._acc_in_bucket = with_acc
                 if not self.shard:
                     self._host(lambda: self.grads[lo:hi].mul_(1.0 / self.R))
             self.be.apply_multi(self._apply_desc[a:b], self._apply_items[a:b], self.dtype, self.opt_state, self.acc)
@@ -1137,6 +1185,8 @@ class UpdateEngine:
                     last = self.enc_chain[-1]
                     self._dgrad(self.enc_head, self.dE, self.dZe[-1], AMB, self.He[-1], last.act)
                     self._bwd_chain(self.enc_chain, self.Xd[:AMB], self.He, self.dZe, AMB)
+                # (every contribution of this branch to the loss partial sums - logit losses, penalties, encoder loss - is launched)
+                self._disc_acc_mark = self._mark()
                 self._finish_branch('disc', inline_apply)
             self._tn_queue = tnq
         self._join_branch(br_critic)
@@ -1230,8 +1280,9 @@ class UpdateEngine:
         """After the inline per-branch optimizer steps: loss partial sums over the ranks (weight-norm slots are local),
         reported scalars."""
         c = self.cfg
-        if self._dist_on() and self.shard:
+        if self._dist_on() and self.shard and not self._acc_in_bucket:
             self._ar(self.acc[1:L.ACC_LOGIT_W2])
+        self._acc_in_bucket = False
         self._average_kl()
         self.be.finalize_scalars(self.acc, self.res, self.Mg if self.shard else self.M, self.AMBg if self.shard else self.AMB,
                                  self.masked, self.has_disc, self.has_enc, self.div_on, c,
@@ -1670,6 +1721,41 @@ class UpdateEngine:
                 dist.all_reduce(t)
         self._host(run)
 
+    def _exchange_bucket(self, group, lo, hi, with_acc=False):
+        """SUM exchange of one gradient bucket (+ with_acc: the step's loss partial sums acc[1 : ACC_LOGIT_W2], f64, travelling as
+        (hi, lo) f32 pairs - their sums are exact to f64 rounding) as ONE collective.  f32 payload without the sums: in place, no copy.
+        Otherwise through a persistent exchange buffer inside the host callback: pack (+ convert: dp_grad_dtype 'bf16' halves the
+        bytes on the links) -> all-reduce -> unpack; two device copies of the bucket against an xGMI ring pass of it."""
+        g = self.grads[lo:hi]
+        if self.dp_grad_dtype == 'f32' and not with_acc:
+            self._ar(g)
+            return
+        n, k = g.numel(), (L.ACC_LOGIT_W2 - 1) if with_acc else 0
+        dt = torch.float32 if self.dp_grad_dtype == 'f32' else torch.bfloat16
+        key = (group, dt, k)
+        if key not in self._xbuf:
+            self._xbuf[key] = torch.zeros(n + 2 * k, dtype=dt, device=self.dev)
+        xb, acc = self._xbuf[key], self.acc
+        import torch.distributed as dist
+
+        def run():
+            xb[:n].copy_(g)
+            if k:
+                a = acc[1:1 + k]
+                hi_ = a.float()
+                xb[n:n + k].copy_(hi_)
+                xb[n + k:].copy_((a - hi_.double()).float())
+            if xb.is_cuda and dist.get_backend() == 'gloo':
+                h = xb.cpu()
+                dist.all_reduce(h)
+                xb.copy_(h)
+            else:
+                dist.all_reduce(xb)
+            g.copy_(xb[:n])
+            if k:
+                acc[1:1 + k] = xb[n:n + k].double() + xb[n + k:].double()
+        self._host(run)
+
     def _dist_on(self):
         return self.R > 1 or self.force_dist
 
@@ -1689,7 +1775,7 @@ class UpdateEngine:
 
     def _allreduce_grads(self):
         if self._dist_on():
-            self._ar(self.grads[:self.n_train])     # SUM of per-rank partials (global denominators inside)
+            self._exchange_bucket('all', 0, self.n_train)     # SUM of per-rank partials (global denominators inside)
             if self.shard:
                 self._ar(self.acc[1:])              # slot 0 (mask sum) is already global
             else:

@@ -20,6 +20,15 @@ the CUDA (= HIP) dispatch key only: on CPU tensors PyTorch itself raises ``NotIm
   normalize_rows(x) -> y                             torch.nn.functional.normalize(x, dim=-1)
   sample_latents(n, dim, rng_state) -> z             ASEBuilder.Network.sample_latents (Philox stream {seed, offset}, advanced)
   fused_adam_(w, g, m, v, opt_state)                 torch.optim.Adam.step on flat buffers (in place)
+  ppo_loss_head(mu, value, actions, old_mu, old_sigma, old_neglogp, advantages, old_values, returns, mask, logstd, ...)
+      -> (stats [6], d_mu, d_value)                   CommonAgent._actor_loss / _critic_loss / bound_loss + entropy, clip fraction, kl
+                                                      (learning/common_agent.py:456-464,505-534) with the gradient of
+                                                      actor_loss + bounds_coef bound_loss w.r.t. mu and of critic_coef critic_loss w.r.t. value
+  disc_loss_gp(logits, grad_demo, disc_coef) -> (stats [4], d_logits)
+                                                      AMPAgent._disc_loss' data terms (learning/amp_agent.py:442-459,481-496): BCE halves,
+                                                      accuracies, the gradient penalty mean |d logit / d obs|^2, d loss / d logits
+  enc_div_loss(enc_pred, enc_z, mu, mu_div, z, z_new, enc_coef, div_coef, div_tar)
+      -> (stats [2], d_enc, d_mu, d_mu_div)            ASEAgent._enc_loss + _diversity_loss (learning/ase_agent.py:413-418,445-467)
 
 ``HipLinear`` is an ``nn.Linear`` whose forward is ``linear_act`` (optionally with a fused ReLU / tanh).
 """
@@ -334,3 +343,110 @@ def fused_adam_(w: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tens
     be = _backend()
     be.begin_step(opt_state, None)
     be.adam(w.view(-1), g.view(-1), m.view(-1), v.view(-1), opt_state)
+
+
+# ------------------------------------------------------------------------------------------------ loss heads
+def _f32c(t, name, cols=None):
+    _check(t.dtype == torch.float32 and t.is_cuda, f'{name}: f32 device tensor expected')
+    t = t.contiguous()
+    _check(cols is None or (t.dim() == 2 and t.shape[1] == cols), f'{name}: expected [rows, {cols}], got {tuple(t.shape)}')
+    return t
+
+
+@torch.library.custom_op('ase_hip::ppo_loss_head', mutates_args=(), device_types='cuda')
+def ppo_loss_head(mu: torch.Tensor, value: torch.Tensor, actions: torch.Tensor, old_mu: torch.Tensor, old_sigma: torch.Tensor,
+                  old_neglogp: torch.Tensor, advantages: torch.Tensor, old_values: torch.Tensor, returns: torch.Tensor,
+                  mask: torch.Tensor, logstd: torch.Tensor, e_clip: float, critic_coef: float, bounds_coef: float,
+                  clip_value: bool) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """PPO loss head of one minibatch (learning/common_agent.py:505-534,456-464; rl_games neglogp / policy_kl):
+    stats = [actor_loss, critic_loss, bound_loss, entropy, clip_fraction, kl] as the reference reports them (mask: an EMPTY tensor ->
+    plain means; else the AMP / ASE masked means sum(mask x) / sum(mask) of learning/amp_agent.py:316-324), d_mu = d (actor_loss +
+    bounds_coef bound_loss) / d mu, d_value = d (critic_coef critic_loss) / d value.  One launch of ase_hip_ppo_head; nothing
+    synchronises (the statistics are formed from the device accumulators by tensor operations)."""
+    M, A = mu.shape
+    _check(mu.dim() == 2 and 1 <= A <= 64, 'ppo_loss_head: mu [M, actions <= 64]')
+    be, dev = _backend(), mu.device
+    mu, value = _f32c(mu, 'mu'), _f32c(value.reshape(M, 1), 'value')
+    masked = mask.numel() > 0
+    mb = {'actions': _f32c(actions, 'actions', A), 'mu': _f32c(old_mu, 'old_mu', A), 'sigma': _f32c(old_sigma, 'old_sigma', A),
+          'old_logp_actions': _f32c(old_neglogp.reshape(M, 1), 'old_neglogp'), 'advantages': _f32c(advantages.reshape(M, 1), 'advantages'),
+          'old_values': _f32c(old_values.reshape(M, 1), 'old_values'), 'returns': _f32c(returns.reshape(M, 1), 'returns')}
+    acc = torch.zeros(L.ACC_COUNT, dtype=torch.float64, device=dev)
+    if masked:
+        mb['rand_action_mask'] = _f32c(mask.reshape(M, 1).float(), 'mask')
+        be.reduce_sum(mb['rand_action_mask'], M, False, acc, L.ACC_MASK_SUM)
+    d_mu, d_value = torch.zeros(M, A, dtype=torch.float32, device=dev), torch.zeros(M, 1, dtype=torch.float32, device=dev)
+    be.ppo_head(mu, value, mb, None, _f32c(logstd.reshape(-1), 'logstd'), d_mu, d_value, None, None, acc, M, M, A, 0, masked, False,
+                False, bool(clip_value), e_clip, critic_coef, bounds_coef, 0.0, 0.0)
+    den = acc[L.ACC_MASK_SUM] if masked else float(M)
+    stats = torch.stack([acc[L.ACC_A_LOSS] / den, acc[L.ACC_C_LOSS] / M, acc[L.ACC_B_LOSS] / den, acc[L.ACC_ENTROPY] / den,
+                         acc[L.ACC_CLIPPED] / den, acc[L.ACC_KL] / M]).float()
+    return stats, d_mu, d_value
+
+
+@ppo_loss_head.register_fake
+def _(mu, value, actions, old_mu, old_sigma, old_neglogp, advantages, old_values, returns, mask, logstd, e_clip, critic_coef,
+      bounds_coef, clip_value):
+    return mu.new_empty(6), torch.empty_like(mu), mu.new_empty(mu.shape[0], 1)
+
+
+@torch.library.custom_op('ase_hip::disc_loss_gp', mutates_args=(), device_types='cuda')
+def disc_loss_gp(logits: torch.Tensor, grad_demo: torch.Tensor, disc_coef: float) -> tuple[torch.Tensor, torch.Tensor]:
+    """Discriminator loss head (learning/amp_agent.py:442-459,481-496).  logits [3 n, 1]: rows [0, 2 n) agent + replay (target 0),
+    rows [2 n, 3 n) demo (target 1); grad_demo [n, D] = d logit / d (demo observation), from autograd or the engine's chain (an EMPTY
+    tensor skips the penalty).  stats = [0.5 (BCE_agent + BCE_demo), gradient penalty = mean_rows |grad|^2, agent accuracy, demo
+    accuracy]; d_logits = disc_coef x d (0.5 (BCE_agent + BCE_demo)) / d logits."""
+    R = logits.shape[0]
+    _check(logits.dim() == 2 and logits.shape[1] == 1 and R % 3 == 0, 'disc_loss_gp: logits [3 n, 1]')
+    n, dev, be = R // 3, logits.device, _backend()
+    lg = _f32c(logits, 'logits')
+    acc = torch.zeros(L.ACC_COUNT, dtype=torch.float64, device=dev)
+    d_logit = torch.zeros(R, 1, dtype=torch.float32, device=dev)
+    be.disc_head(lg, d_logit, None, acc, n, n, disc_coef)
+    if grad_demo.numel():
+        g = _f32c(grad_demo, 'grad_demo')
+        _check(g.dim() == 2 and g.shape[0] == n, 'disc_loss_gp: grad_demo [n, D]')
+        be.sqnorm(g, n, g.shape[1], acc, L.ACC_GP, scale=1.0)
+    stats = torch.stack([0.5 * (acc[L.ACC_BCE_AGENT] / (2 * n) + acc[L.ACC_BCE_DEMO] / n), acc[L.ACC_GP] / n,
+                         acc[L.ACC_AGENT_ACC] / (2 * n), acc[L.ACC_DEMO_ACC] / n]).float()
+    return stats, d_logit
+
+
+@disc_loss_gp.register_fake
+def _(logits, grad_demo, disc_coef):
+    return logits.new_empty(4), torch.empty_like(logits)
+
+
+@torch.library.custom_op('ase_hip::enc_div_loss', mutates_args=(), device_types='cuda')
+def enc_div_loss(enc_pred: torch.Tensor, enc_z: torch.Tensor, mu: torch.Tensor, mu_div: torch.Tensor, z: torch.Tensor,
+                 z_new: torch.Tensor, enc_coef: float, div_coef: float,
+                 div_tar: float) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """ASE's two extra loss heads (learning/ase_agent.py:413-418,445-467).  enc_pred [n, Z] = the encoder's PRE-normalisation output,
+    enc_z [n, Z] the latents of those rows: enc_loss = mean(-<normalize(enc_pred), enc_z>), d_enc = enc_coef x its gradient.
+    mu / mu_div [M, A] = the actor's means under the rollout's latents z [M, Z] and under fresh ones z_new [M, Z]:
+    diversity loss = mean((div_tar - |clamp(mu) - clamp(mu_div)|^2 / A / (0.5 - 0.5 <z_new, z> + 1e-5))^2), d_mu / d_mu_div =
+    div_coef x its gradients.  stats = [enc_loss, diversity_loss]."""
+    n, Z = enc_pred.shape
+    M, A = mu.shape
+    _check(enc_z.shape == enc_pred.shape and Z <= 128, 'enc_div_loss: enc_pred / enc_z [n, Z <= 128]')
+    _check(mu_div.shape == mu.shape and z.shape == (M, Z) and z_new.shape == (M, Z) and A <= 64, 'enc_div_loss: mu / mu_div [M, A], z / z_new [M, Z]')
+    be, dev = _backend(), mu.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    acc = torch.zeros(L.ACC_COUNT, dtype=torch.float64, device=dev)
+    d_enc = torch.zeros(n, Z, **f32)
+    be.enc_head(_f32c(enc_pred, 'enc_pred'), _f32c(enc_z, 'enc_z'), d_enc, None, None, acc, n, n, Z, enc_coef)
+    # the diversity term rides in ase_hip_ppo_head's launch: with zero advantages, zero critic / bound coefficients its other terms vanish
+    mu2 = torch.cat([_f32c(mu, 'mu'), _f32c(mu_div, 'mu_div')])
+    zeros1, ones = torch.zeros(M, 1, **f32), torch.ones(M, A, **f32)
+    mb = {'actions': mu2[:M], 'mu': mu2[:M], 'sigma': ones, 'old_logp_actions': zeros1, 'advantages': zeros1, 'old_values': zeros1,
+          'returns': zeros1, 'ase_latents': _f32c(z, 'z')}
+    d_mu2, d_v = torch.zeros(2 * M, A, **f32), torch.zeros(M, 1, **f32)
+    be.ppo_head(mu2, zeros1, mb, _f32c(z_new, 'z_new'), torch.zeros(A, **f32), d_mu2, d_v, None, None, acc, M, M, A, Z, False, True,
+                False, False, 0.2, 0.0, 0.0, div_coef, div_tar)
+    stats = torch.stack([acc[L.ACC_ENC] / n, acc[L.ACC_DIV] / M]).float()
+    return stats, d_enc, d_mu2[:M].clone(), d_mu2[M:].clone()          # (clones: a custom operator's outputs must not alias each other)
+
+
+@enc_div_loss.register_fake
+def _(enc_pred, enc_z, mu, mu_div, z, z_new, enc_coef, div_coef, div_tar):
+    return mu.new_empty(2), torch.empty_like(enc_pred), torch.empty_like(mu), torch.empty_like(mu)

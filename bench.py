@@ -821,13 +821,22 @@ def measure_mode(args, precision, device, world, rank, use_graph):
     achieved = dv['flops'] / (dv['ms'] * 1e-3) / 1e12
     # HBM traffic of that kernel per launch: PMC measurement committed under profiles/ (rocprofv3 --pmc FETCH_SIZE /
     # WRITE_SIZE in separate passes, FETCH doubled per the gfx950 note); bench cannot profile itself
+    # ... and only a measurement of THIS build is quoted: the file carries the sha256 of the library its passes ran
+    # (scripts/make_pmc_json.py --lib), compared with the library loaded here; a profile of another build gives traffic = null
     traffic, traffic_src = None, None
     pmc = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_pmc.json')) \
         if os.path.isdir(os.path.join(ROOT, 'profiles')) else []
     if pmc and precision in ('bf16', 'f16', 'f16gp32', 'f16gpx3'):
-        j = json.load(open(os.path.join(ROOT, 'profiles', pmc[-1])))
-        if j.get('kernel_class') == dom:
-            traffic, traffic_src = j['hbm_bytes_per_launch'], 'profiles/' + pmc[-1]
+        from scripts.make_pmc_json import lib_sha256
+        from ase_amd import lib as _L
+        sha = lib_sha256(_L.LIB_PATH)
+        for name in reversed(pmc):
+            j = json.load(open(os.path.join(ROOT, 'profiles', name)))
+            if j.get('kernel_class') == dom and j.get('lib_sha256') == sha:
+                traffic, traffic_src = j['hbm_bytes_per_launch'], 'profiles/' + name
+                break
+        if traffic is None:
+            traffic_src = 'none: no profiles/*_pmc.json was measured on the loaded build (sha256 %s...)' % sha[:12]
     clk = sustained_clock(eng.be, device, eng.dtype) if (dom == 'nt8' and rank == 0) else None
     roof = {'bound': 'mfma', 'kernel': dname,
             'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),

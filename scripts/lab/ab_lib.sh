@@ -3,7 +3,7 @@
 # libase_hip.so): every build twice, interleaved, on (1) the carrying NT shapes in f16 (back-to-back launches, HIP events) and
 # (2) the benchmark update.  The build is chosen by patching ase_amd.lib.LIB_PATH in the driver process - the product has no
 # environment switch for it.
-#   bash scripts/lab/ab_lib.sh libase_hip.so libase_hip_eb.so [more builds ...] [precision]
+#   bash scripts/lab/ab_lib.sh libase_hip.so libase_hip_eb.so [more builds ...] [precision]      (AB_EXTRA='--no-multi-stream': more bench.py arguments)
 cd "$(dirname "$0")/../.."
 LIBS=(); P=f16gpx3
 for a in "$@"; do case "$a" in *.so) LIBS+=("$a");; *) P="$a";; esac; done      # any number of builds, then (optionally) the precision
@@ -35,7 +35,7 @@ for M, N, K in [(16384, 1024, 1024), (32768, 1024, 1024), (32768, 1024, 320), (1
     out.append(f'{M}x{N}x{K} {ms * 1e3:.1f}us {2 * M * N * K / ms / 1e9:.0f}TF')
 print(sys.argv[1], 'NT f16:', ' | '.join(out), flush=True)
 sys.argv = ['bench.py', '--gpus', '1', '--steps', '20', '--warmup', '3', '--precision', sys.argv[2], '--no-cpu-baseline', '--no-config5',
-            '--throughput-mode', 'none', '--detail', '']
+            '--throughput-mode', 'none', '--detail', ''] + os.environ.get('AB_EXTRA', '').split()
 buf = io.StringIO()
 with contextlib.redirect_stdout(buf):          # (stderr stays a real file: bench.py enables faulthandler on it)
     runpy.run_path('bench.py', run_name='__main__')

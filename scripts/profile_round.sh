@@ -30,4 +30,5 @@ done
 grep -h "^{\"metric\"" $OUT/bench_replay.log > $OUT/bench_replay.json
 grep -h "^{\"metric\"" $OUT/bench_serial.log > $OUT/bench_serial.json
 # the per-launch HBM traffic file bench.py quotes (copy to profiles/rNN_pmc.json together with the summaries)
-python scripts/make_pmc_json.py $OUT/pmc_summary.txt $OUT/pmc.json $OUT/kernel_stats_serial.txt > $OUT/pmc_json.log 2>&1
+python scripts/make_pmc_json.py $OUT/pmc_summary.txt $OUT/pmc.json $OUT/kernel_stats_serial.txt --lib ase_amd/csrc/libase_hip.so > $OUT/pmc_json.log 2>&1
+sha256sum ase_amd/csrc/libase_hip.so > $OUT/lib_sha256.txt

@@ -254,3 +254,52 @@ def test_two_ranks_skip_the_same_step(tmp_path):
     n_upd = len(G['epochs'])
     assert s0['steps'] == 2 * n_upd and s0['skipped'] == 1 and s0['scale'] == 8.0       # one backoff, right behind the skipped step
     assert r['opt_step'] == 2 * n_upd - 1                                                # the skipped step was no optimizer step
+
+
+# ------------------------------------------------------------------------------------------------ round 6: the exchange itself
+def _worker_exchange(rank, world, port, name, out, grad_dtype):
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    G = torch.load(os.path.join(GOLDEN, name + '.pt'), weights_only=False)
+    ag = make_agent(G, EmuBackend(), world_size=world, rank=rank, dp_grad_dtype=grad_dtype)
+    calls = []
+    orig = dist.all_reduce
+
+    def counted(t, *a, **kw):
+        calls.append(t.numel() * t.element_size())
+        return orig(t, *a, **kw)
+    dist.all_reduce = counted
+    tol = dict(rtol=3e-4, wtol=G['cfg']['learning_rate'] * 0.25) if grad_dtype == 'f32' else dict(rtol=5e-2, wtol=G['cfg']['learning_rate'] * 2.2)
+    infos = replay_epochs(G, ag, check=grad_dtype == 'f32', **tol)
+    dist.all_reduce = orig
+    steps = sum(len(i['kl']) for i in infos)
+    if rank == 0:
+        torch.save({'flat': ag.model.a2c_network.flat_params.clone(), 'calls': calls, 'steps': steps,
+                    'bucket_bytes': 4 * ag.engine.n_train}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_three_collectives_per_step_and_the_bf16_payload(tmp_path):
+    """The sharded step's exchange: ONE statistics collective [amp sums | obs sums | mask sum], the discriminator's gradient
+    bucket, the policy's gradient bucket carrying the loss partial sums as (hi, lo) f32 pairs - three collectives per optimisation
+    step (round 5: six) and still the reference's result; dp_grad_dtype = 'bf16' sends half the gradient bytes and stays within
+    Adam's +-lr of the f32 exchange."""
+    G = torch.load(os.path.join(GOLDEN, 'ase_tiny.pt'), weights_only=False)
+    res = {}
+    for dt in ('f32', 'bf16'):
+        out = str(tmp_path / (dt + '.pt'))
+        mp.spawn(_worker_exchange, args=(2, _free_port(), 'ase_tiny', out, dt), nprocs=2, join=True)
+        res[dt] = torch.load(out, weights_only=False)
+    f, b = res['f32'], res['bf16']
+    per_epoch_extra = 4          # once per epoch: the sharded reward inference + statistics of the tail (not per step)
+    assert len(f['calls']) <= 3 * f['steps'] + per_epoch_extra * len(G['epochs']), (len(f['calls']), f['steps'])
+    assert len(b['calls']) <= 4 * b['steps'] + per_epoch_extra * len(G['epochs'])        # (bf16 payload: the f64 partial sums travel apart)
+    grad_f = sum(x for x in f['calls'] if x > 0.2 * f['bucket_bytes'])
+    grad_b = sum(x for x in b['calls'] if x > 0.1 * b['bucket_bytes'])
+    assert 0.45 * grad_f < grad_b < 0.55 * grad_f, (grad_f, grad_b)                         # half the bytes on the links
+    lr = G['cfg']['learning_rate']
+    d = (f['flat'] - b['flat']).abs()
+    assert float(d.max()) <= 2.2 * lr * len(G['epochs']) * 8 and float((d > 0.5 * lr).float().mean()) < 0.2

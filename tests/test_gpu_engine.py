@@ -365,10 +365,12 @@ def test_parity_at_16384_envs(mode, loss_tol, grad_tol):
     torch.cuda.empty_cache()
 
 
-# (f32 bounds: twice what the schedules measure against each other - worst element 10.0 ... 19.5 lr over 12 comparisons, mean
-#  0.053 ... 0.059 lr, scalars <= 3e-4 (profiles/r05_schedule_drift.txt, scripts/lab/schedule_drift.py); at 20 lr the case failed
-#  once in ~8 runs of the round on an unchanged build.  A race shows as hundreds of lr / non-finite scalars.)
-@pytest.mark.parametrize('precision,w_max,w_mean,s_rtol', [('f32', 40, 0.2, 1e-2), ('f16gpx3', 80, 0.5, 5e-2), ('bf16', 120, 1.0, 0.25)])
+# (f32: what the schedules measure against each other - worst element 10.0 ... 19.5 lr over 12 comparisons, mean 0.053 ... 0.059 lr,
+#  scalars <= 3e-4 (profiles/r05_schedule_drift.txt, scripts/lab/schedule_drift.py).  Round 5 doubled the bound on the single WORST
+#  element because 20 lr failed once in ~8 runs; the advisor's point stands - a maximum over 7 M elements is the wrong statistic for
+#  "no race".  Round 6: the MEAN keeps round 4's bound (0.1 lr), the TAIL is a count - at most 2e-5 of the elements further than
+#  5 lr apart (a race moves whole tiles: thousands of elements by hundreds of lr) - and the maximum is only a gross bound.)
+@pytest.mark.parametrize('precision,w_max,w_mean,s_rtol', [('f32', 40, 0.1, 5e-3), ('f16gpx3', 80, 0.5, 5e-2), ('bf16', 120, 1.0, 0.25)])
 def test_schedule_variants_agree_config2(precision, w_max, w_mean, s_rtol):
     """The round-4 schedule (discriminator head and prologue un-chained from the main stream, penalty value path on its own
     stream, result rings, per-step launch programs, the agent's own high-priority stream) changes WHEN kernels run, never what
@@ -404,8 +406,10 @@ def _schedule_pair_agrees(w0, o0, a0, r0, w1, o1, a1, r1, w_max, w_mean, s_rtol)
     lr = 2e-5
     # weights: after 144 Adam steps two runs differ by a few lr where a gradient's sign is rounding noise (measured: mean
     # 0.08 lr; worst single element of the 7 M: f32 < 20 lr, 16-bit modes 20-25 lr of the 288 lr two runs could drift apart)
-    assert float((w0 - w1).abs().max()) <= w_max * lr, float((w0 - w1).abs().max())
-    assert float((w0 - w1).abs().mean()) <= w_mean * lr, float((w0 - w1).abs().mean())
+    d = (w0 - w1).abs()
+    assert float(d.max()) <= w_max * lr, float(d.max())
+    assert float(d.mean()) <= w_mean * lr, float(d.mean())
+    assert float((d > 0.125 * w_max * lr).float().mean()) <= 2e-5, float((d > 0.125 * w_max * lr).float().mean())     # the tail, as a count
     close(o1, o0, 1e-6, 1e-6, 'obs running statistics')
     close(a1, a0, 1e-6, 1e-6, 'amp running statistics')
     for k in r0:

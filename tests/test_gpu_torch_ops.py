@@ -131,3 +131,82 @@ def test_small_ops():
     assert int(st[1]) == 1 and torch.allclose(z.norm(dim=-1), torch.ones(1000, device=DEV), atol=1e-5)
     with pytest.raises(RuntimeError):
         torch.ops.ase_hip.linear_act(torch.zeros(4, 8, device=DEV, dtype=torch.float64), torch.zeros(3, 8, device=DEV), torch.zeros(3, device=DEV), 'relu')
+
+
+def _neglogp(a, mu, logstd):
+    return 0.5 * (((a - mu) / torch.exp(logstd)) ** 2).sum(-1) + 0.5 * math.log(2 * math.pi) * a.shape[-1] + logstd.sum(-1)
+
+
+@pytest.mark.parametrize('masked,clip_value', [(True, False), (False, True)])
+def test_ppo_loss_head_op_against_autograd(masked, clip_value):
+    """ase_hip::ppo_loss_head against the reference's formulas written in plain PyTorch (learning/common_agent.py:456-464,505-534,
+    learning/amp_agent.py:316-324; rl_games neglogp / policy_kl) and autograd's gradients of them."""
+    _ops()
+    g = torch.Generator().manual_seed(5)
+    M, A, e_clip, cc, bc = 1000, 31, 0.2, 5.0, 10.0
+    r = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    mu = (r(M, A) * 0.8).requires_grad_()
+    value = r(M, 1).requires_grad_()
+    old_mu = mu.detach() + 0.05 * r(M, A)
+    logstd = torch.full((A,), -2.9, device=DEV)
+    sigma = torch.exp(logstd).expand(M, A).contiguous()
+    actions = old_mu + sigma * r(M, A)
+    old_nlp = _neglogp(actions, old_mu, logstd)
+    adv, old_v, ret = r(M), value.detach().view(-1) + 0.3 * r(M), r(M)
+    mask = (torch.rand(M, generator=g) < 0.7).float().to(DEV) if masked else torch.empty(0, device=DEV)
+    stats, d_mu, d_v = torch.ops.ase_hip.ppo_loss_head(mu.detach(), value.detach(), actions, old_mu, sigma, old_nlp, adv, old_v, ret,
+                                                       mask, logstd, e_clip, cc, bc, clip_value)
+    w = mask if masked else torch.ones(M, device=DEV)
+    mean = lambda x: (x * w).sum() / w.sum()
+    ratio = torch.exp(old_nlp - _neglogp(actions, mu, logstd))
+    a_loss = mean(torch.max(-adv * ratio, -adv * torch.clamp(ratio, 1 - e_clip, 1 + e_clip)))
+    b_loss = mean((torch.clamp_min(mu - 1.0, 0) ** 2 + torch.clamp_max(mu + 1.0, 0) ** 2).sum(-1))
+    v = value.view(-1)
+    if clip_value:
+        vpc = old_v + (v - old_v).clamp(-e_clip, e_clip)
+        c_loss = torch.max((v - ret) ** 2, (vpc - ret) ** 2).mean()
+    else:
+        c_loss = ((ret - v) ** 2).mean()
+    ent = mean((0.5 + 0.5 * math.log(2 * math.pi) + logstd).sum().expand(M))
+    kl = (torch.log(sigma / sigma + 1e-5) + (sigma ** 2 + (old_mu - mu.detach()) ** 2) / (2 * (sigma ** 2 + 1e-5)) - 0.5).sum(-1).mean()
+    clipf = mean(((ratio.detach() - 1).abs() > e_clip).float())
+    ref = torch.stack([a_loss, c_loss, b_loss, ent, clipf, kl]).detach()
+    assert torch.allclose(stats, ref, rtol=2e-5, atol=1e-6), (stats, ref)
+    gm, gv = torch.autograd.grad(a_loss + bc * b_loss + cc * c_loss, [mu, value])
+    assert torch.allclose(d_mu, gm, rtol=1e-4, atol=1e-7 * float(gm.abs().max()) + 1e-10)
+    assert torch.allclose(d_v, gv, rtol=1e-4, atol=1e-9)
+
+
+def test_disc_and_enc_div_loss_ops_against_autograd():
+    """ase_hip::disc_loss_gp and ase_hip::enc_div_loss against learning/amp_agent.py:442-459,481-496 and
+    learning/ase_agent.py:413-418,445-467 in plain PyTorch."""
+    _ops()
+    g = torch.Generator().manual_seed(9)
+    r = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    n, D, dc = 512, 140, 5.0
+    logits = r(3 * n, 1).requires_grad_()
+    grad_demo = 0.1 * r(n, D)
+    stats, d_l = torch.ops.ase_hip.disc_loss_gp(logits.detach(), grad_demo, dc)
+    bce = torch.nn.functional.binary_cross_entropy_with_logits
+    la, ld = logits[:2 * n], logits[2 * n:]
+    loss = 0.5 * (bce(la, torch.zeros_like(la)) + bce(ld, torch.ones_like(ld)))
+    ref = torch.stack([loss.detach(), (grad_demo ** 2).sum(-1).mean(), (la < 0).float().mean(), (ld > 0).float().mean()])
+    assert torch.allclose(stats, ref, rtol=2e-5, atol=1e-6), (stats, ref)
+    assert torch.allclose(d_l, torch.autograd.grad(dc * loss, logits)[0], rtol=1e-4, atol=1e-9)
+    stats0, _ = torch.ops.ase_hip.disc_loss_gp(logits.detach(), torch.empty(0, device=DEV), dc)
+    assert float(stats0[1]) == 0.0
+    # encoder + diversity
+    M, A, Z, ec, dvc, tar = 768, 31, 64, 5.0, 0.01, 1.0
+    e = r(n, Z).requires_grad_()
+    ez = torch.nn.functional.normalize(r(n, Z), dim=-1)
+    mu, mu2 = (1.2 * r(M, A)).requires_grad_(), (1.2 * r(M, A)).requires_grad_()
+    z, zn = torch.nn.functional.normalize(r(M, Z), dim=-1), torch.nn.functional.normalize(r(M, Z), dim=-1)
+    st, d_e, d_mu, d_mu2 = torch.ops.ase_hip.enc_div_loss(e.detach(), ez, mu.detach(), mu2.detach(), z, zn, ec, dvc, tar)
+    enc_loss = (-(torch.nn.functional.normalize(e, dim=-1) * ez).sum(-1)).mean()
+    a_diff = ((mu.clamp(-1, 1) - mu2.clamp(-1, 1)) ** 2).mean(-1)
+    z_diff = 0.5 - 0.5 * (zn * z).sum(-1)
+    div_loss = ((tar - a_diff / (z_diff + 1e-5)) ** 2).mean()
+    assert torch.allclose(st, torch.stack([enc_loss, div_loss]).detach(), rtol=2e-5, atol=1e-6), st
+    assert torch.allclose(d_e, torch.autograd.grad(ec * enc_loss, e)[0], rtol=1e-4, atol=1e-9)
+    gm, gm2 = torch.autograd.grad(dvc * div_loss, [mu, mu2])
+    assert torch.allclose(d_mu, gm, rtol=1e-4, atol=1e-9) and torch.allclose(d_mu2, gm2, rtol=1e-4, atol=1e-9)
