@@ -601,7 +601,9 @@ __global__ __launch_bounds__(512) void gemm_tn8g_kernel(const int64_t* __restric
 // problem` items further (ase_hip_gemm_tn_grouped_plan's order).  Plain read-modify-write: every (n, k) of a problem has
 // exactly one owner; problems that share a gradient buffer with another one (field 15 bit 30 set by the planner: the
 // gradient-penalty terms of the encoder land on the discriminator's weights) use atomics.
-__global__ __launch_bounds__(256) void tn_reduce_kernel(const int64_t* __restrict__ problems, const int32_t* __restrict__ red,
+// (at most 64 registers - it needed 65: what the phased NT kernel's two waves per SIMD leave free, so that this HBM-bound fold of one
+//  branch runs beside the other branches' matrix launches instead of waiting for a CU to drain)
+__global__ __launch_bounds__(256, 8) void tn_reduce_kernel(const int64_t* __restrict__ problems, const int32_t* __restrict__ red,
                                                         const float* __restrict__ ws, const float* __restrict__ alpha_dev) {
     const int32_t* r = red + 4 * blockIdx.x;
     const int pi = r[0], tile = r[1], first = r[2], splits = r[3], q = blockIdx.y;
