@@ -128,8 +128,9 @@ class HipBackend:
     # ------------------------------------------------------------------ GEMMs
     def gemm_nt(self, A, B, Cm, M, N, K, bias=None, aux=None, aux_mode=L.AUX_NONE, colsum=None, colsum_n=0,
                 act=L.ACT_NONE, alpha=1.0, aux_split=0, aux_delta=0, mask_out=None, x3_exps=None, alpha_dev=None):
-        """alpha_dev (all `*_dev` / `dyn` arguments of this class): a device f32 scalar the launch multiplies its scale by when it
-        RUNS - an entry of the dynamic loss scale's table (UpdateEngine.scale_tab: S, 1 / S, 1 / S^2)."""
+        """alpha_dev (all `*_dev` / `dyn` arguments of this class): a scale RECORD on the device, f32 {factor, overflow count} - an
+        entry of the dynamic loss scale's table (UpdateEngine.scale_tab: S, 1 / S, 1 / S^2, 1).  The launch multiplies its scale by the
+        factor when it RUNS and adds to the count when an element it stored overflowed (include/ase_hip.h, ABI 7)."""
         dt = self._gemm_code(A.dtype, x3_exps)
         assert B.dtype == A.dtype
         if aux_mode == L.AUX_RELU_BITS:
@@ -388,6 +389,26 @@ class HipBackend:
         assert buf.is_contiguous()
         L.check(self.lib.ase_hip_scaler_check(_ptr(buf), buf.numel(), _code(buf.dtype), _ptr(scaler), self._stream()),
                 "scaler_check")
+
+    def scaler_check_multi(self, bufs, scaler, table=None):
+        """The same test over a list of buffers in ONE launch; `table` = what make_check_table(bufs) returned (built once)."""
+        if table is None:
+            table = self.make_check_table(bufs)
+        L.check(self.lib.ase_hip_scaler_check_multi(_ptr(table['rows']), table['n'], table['wg'], _ptr(scaler), self._stream()),
+                "scaler_check_multi")
+
+    def make_check_table(self, bufs):
+        rows = []
+        for t in bufs:
+            assert t.is_contiguous() and t.numel() > 0
+            rows.append([t.data_ptr(), t.numel(), _code(t.dtype)])
+        big = max(t.numel() * t.element_size() for t in bufs)
+        wg = max(1, min(1024, (big + 16383) // 16384))             # four 16-byte loads per thread of the largest buffer
+        return {'rows': torch.tensor(rows, dtype=torch.int64, device=self.device), 'n': len(rows), 'wg': int(wg), 'keep': list(bufs)}
+
+    def scaler_fold(self, scaler, scale_tab):
+        """Overflow counts of the scale records -> scaler[found] (in front of the ranks' exchange of that flag)."""
+        L.check(self.lib.ase_hip_scaler_fold(_ptr(scaler), _ptr(scale_tab), self._stream()), "scaler_fold")
 
     def scaler_step(self, scaler, opt_state, opt_eff, grads, scale_tab=None):
         """GradScaler.step's decision - a found overflow zeroes the gradient and hands the optimizer launch the identity step - and

@@ -140,3 +140,19 @@ template <int NV> __device__ __forceinline__ void block_sum(double (&v)[NV], dou
 
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
+
+// ---- scale records of the dynamic loss scale (ase_hip.h): {factor, overflow count} ---------------------------------------------------
+// A launch that was given a record multiplies `factor` into its scale and reports what it STORED: an element that is non-finite or sits at
+// the storage type's saturation value (the f16 conversions above saturate at +-65504 where autocast would produce inf; bf16 goes to
+// inf; f32 storage: NaN / inf).  |x| of a 16-bit pattern orders like an unsigned integer.
+template <typename T> __device__ __forceinline__ constexpr uint32_t ovf_threshold() { return 0x7F80u; }      // the first non-finite bf16
+template <> __device__ __forceinline__ constexpr uint32_t ovf_threshold<f16_t>() { return 0x7BFFu; }          // |65504| in IEEE half
+__device__ __forceinline__ bool ovf_hit1(f16_t x) { return (uint32_t)(__builtin_bit_cast(unsigned short, x) & 0x7FFFu) >= 0x7BFFu; }
+__device__ __forceinline__ bool ovf_hit1(bf16_t x) { return (uint32_t)(__builtin_bit_cast(unsigned short, x) & 0x7FFFu) >= 0x7F80u; }
+__device__ __forceinline__ bool ovf_hit1(float x) { return !(__builtin_fabsf(x) <= 3.402823466e38f); }
+// one atomic per wave that saw one, from its first active lane (the count's value is unspecified beyond zero / non-zero)
+__device__ __forceinline__ void ovf_report(float* rec, bool bad) {
+    if (rec && __builtin_amdgcn_ballot_w64(bad) != 0 &&
+        (int)(threadIdx.x & 63) == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true)))
+        atomic_add_f32(rec + 1, 1.f);
+}

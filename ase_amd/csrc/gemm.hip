@@ -51,7 +51,7 @@ extern "C" int ase_hip_gemm_nt_kernel_id(int M, int N, int K, int dtype) {
 extern "C" int ase_hip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                                const float* bias, const void* aux, int64_t ldaux, int aux_split, int aux_delta,
                                float* colsum, int colsum_n, void* mask_out, int64_t ldmask, int M, int N, int K, int act,
-                               int aux_mode, int out_f32, float alpha, const float* alpha_dev, int dtype_word, void* stream) {
+                               int aux_mode, int out_f32, float alpha, float* alpha_dev, int dtype_word, void* stream) {
     const int dtype = dtype_word & 0xFF, ea = (dtype_word >> 8) & 0xFF, eb = (dtype_word >> 16) & 0xFF;
     const int es = ase_elem_size(dtype);
     ASE_CHECK_ARG(dtype == ASE_F32 || dtype == ASE_BF16 || dtype == ASE_F32X3 || dtype == ASE_F16 || dtype == ASE_F32H3,

@@ -40,7 +40,9 @@ struct NTParams {
     int M, N, K;                    // K in elements (multiple of 128/sizeof(T))
     int act, aux_mode, out_f32;
     float alpha;
-    const float* alpha_dev;         // nullable: device factor multiplied into alpha when the launch runs (the dynamic loss scale)
+    float* alpha_dev;               // nullable: device record {factor, overflow count} (ase_hip.h "scale records"): factor is multiplied into
+                                    // alpha when the launch runs (the dynamic loss scale), and the launch adds to the count when an
+                                    // element it stored was non-finite or sat at the storage type's saturation value
     float sa;                       // f32h_t storage: power-of-two scale of the A operand before its half split (B arrives pre-split and
                                     // pre-scaled; alpha undoes both scales)
     int tiles_m, tiles_n;
@@ -94,6 +96,22 @@ template <> __device__ __forceinline__ uint32_t cvt_pk16<f16_t>(f32x2 v) {      
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(c, f16x2));
 }
 
+// ---- overflow detection of the dynamic loss scale, fused into the producers (round 6; rounds 4-5 re-read every half buffer of the step,
+// 0.82 GB, with ase_hip_scaler_check): a launch that was given a scale record reports an element it STORED that is non-finite or sits at
+// the storage type's saturation value (f16 conversions saturate at +-65504 where autocast would produce inf; bf16 goes to inf).  On the
+// packed 16-bit patterns: |x| as an unsigned integer orders like the magnitude, so one v_and + one v_pk_max_u16 per two outputs keep a
+// running maximum and ONE comparison per lane at the end of the epilogue decides.
+// (as an asm statement: written with __builtin_elementwise_max hipcc re-associated the running maximum of an epilogue into a tree over
+//  all of a row block's outputs - 33 more live registers in a kernel whose 217 leave the 64 its co-resident neighbours run in)
+__device__ __forceinline__ uint32_t ovf_fold(uint32_t run, uint32_t packed) {
+    const uint32_t mag = packed & 0x7FFF7FFFu;
+    asm("v_pk_max_u16 %0, %0, %1" : "+v"(run) : "v"(mag));
+    return run;
+}
+template <typename T> __device__ __forceinline__ bool ovf_hit(uint32_t run) {
+    return (run & 0xFFFFu) >= ovf_threshold<T>() || (run >> 16) >= ovf_threshold<T>();
+}
+
 // bias: the lane's 16 bias values of the fragment as 4 x f32x4 (columns 8 g + 4 h ..); w: the fragment's mask word >> 4 h (AUXK = 2);
 // relu_lo: packed lower bound of v_pk_max_i16 (0 = ReLU, -32768 = none); pk[g][0 / 1]: the packed outputs q = 0, 1 / 2, 3;
 // returns (MASK) the lane's 16 "stored > 0" bits at their places 8 g + 4 h + q of the fragment's 32-bit mask word
@@ -144,6 +162,7 @@ __device__ __forceinline__ void nt8_epilogue_rows_impl(const NTParams& p, f32x16
     const f32x2 al = {p.alpha, p.alpha};
     const short lo = (p.act == ASE_ACT_RELU) ? (short)0 : (short)-32768;
     const i16x2 relu_lo = {lo, lo};
+    uint32_t ovf = 0;
     f32x4 bias[NJ][4];
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
@@ -169,6 +188,8 @@ __device__ __forceinline__ void nt8_epilogue_rows_impl(const NTParams& p, f32x16
                 const auto s1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
                 // lanes 0-31: [own g | upper's g] = columns 8 g .. 8 g + 7; lanes 32-63: [lower's g + 1 | own g + 1]
                 out[j][g >> 1] = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                // (on the swapped words: they are live until the store anyway - folding pk[] in rows_frag cost 33 registers)
+                ovf = ovf_fold(ovf_fold(ovf_fold(ovf_fold(ovf, s0[0]), s1[0]), s0[1]), s1[1]);
             }
         }
         if (row_ok) {                           // (one predicated block per row block: the swaps above need every lane)
@@ -188,6 +209,8 @@ __device__ __forceinline__ void nt8_epilogue_rows_impl(const NTParams& p, f32x16
             }
         }
     }
+    // (rows past M are clamped copies of the last valid row, see the kernels' DMA addressing: they cannot report what a stored row does not)
+    ovf_report(p.alpha_dev, ovf_hit<T>(ovf));
 }
 
 template <typename T, int AUXK, int NJ = 2, int NI = 4>

@@ -246,6 +246,7 @@ __device__ __forceinline__ void nt_epilogue_impl(const NTParams& p, f32x16 (&acc
     constexpr bool AHEAD = AUXK != 0 && sizeof(AuxReg<T, AUXK>) <= 8;   // 16-byte f32 masks: current chunk only
     const int c4 = lane % ELPR, rsub = lane / ELPR;
     AuxReg<T, AUXK> areg[AHEAD ? 2 : 1][NIT];
+    bool bad = false;                              // an element this lane stored overflowed (scale records, common.h)
 
     auto load_aux = [&](int ch, AuxReg<T, AUXK> (&dst)[NIT]) {
         nt_aux_load<T, FM, FN, FMC, FNC, AUXK>(p, ch, lane, mrow0, ncol0, dst);
@@ -296,9 +297,14 @@ __device__ __forceinline__ void nt_epilogue_impl(const NTParams& p, f32x16 (&acc
                         if constexpr (sizeof(T) == 2) {
                             typename V16<T>::x4 zt;
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) zt[q] = from_f32<T>(v[q]);
+                            for (int q = 0; q < 4; ++q) {
+                                zt[q] = from_f32<T>(v[q]);
+                                bad |= ovf_hit1(zt[q]);
+                            }
                             *reinterpret_cast<typename V16<T>::x4*>(p.pre_out + (int64_t)m * p.ldpre + (int64_t)n0 * 2) = zt;
                         } else {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) bad |= ovf_hit1(v[q]);
                             *reinterpret_cast<f32x4*>(p.pre_out + (int64_t)m * p.ldpre + (int64_t)n0 * 4) = v;
                         }
                     }
@@ -319,6 +325,8 @@ __device__ __forceinline__ void nt_epilogue_impl(const NTParams& p, f32x16 (&acc
                     }
                 }
                 if (p.out_f32 || sizeof(T) == 4) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bad |= ovf_hit1(v[q]);
                     *reinterpret_cast<f32x4*>(p.C + (int64_t)m * p.ldc + (int64_t)n0 * 4) = v;
                 } else {
                     typedef typename std::conditional<sizeof(T) == 2, T, bf16_t>::type S;     // (4-byte T: dead branch)
@@ -326,6 +334,7 @@ __device__ __forceinline__ void nt_epilogue_impl(const NTParams& p, f32x16 (&acc
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         o[q] = from_f32<S>(v[q]);
+                        bad |= ovf_hit1(o[q]);
                         v[q] = (float)o[q];
                     }
                     *reinterpret_cast<typename V16<S>::x4*>(p.C + (int64_t)m * p.ldc + (int64_t)n0 * 2) = o;
@@ -356,6 +365,7 @@ __device__ __forceinline__ void nt_epilogue_impl(const NTParams& p, f32x16 (&acc
             }
         }
     }
+    ovf_report(p.alpha_dev, bad);
 }
 
 template <typename T, int FM, int FN, int FMC, int FNC>
@@ -376,6 +386,7 @@ __device__ __forceinline__ void nt_epilogue_rows_impl(const NTParams& p, f32x16 
     const f32x2 al = {p.alpha, p.alpha};
     const short lo = (p.act == ASE_ACT_RELU) ? (short)0 : (short)-32768;
     const i16x2 relu_lo = {lo, lo};
+    uint32_t ovf = 0;
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
         f32x4 bias[4];
@@ -396,6 +407,7 @@ __device__ __forceinline__ void nt_epilogue_rows_impl(const NTParams& p, f32x16 
                 const auto s0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
                 const auto s1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
                 if (row_ok) *reinterpret_cast<uint4*>(crow + 8 * g * 2) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                ovf = ovf_fold(ovf_fold(ovf_fold(ovf_fold(ovf, s0[0]), s1[0]), s0[1]), s1[1]);
             }
             if constexpr (MASK) {
                 const auto w = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);   // own 16 bits | the other half-wave's
@@ -403,6 +415,7 @@ __device__ __forceinline__ void nt_epilogue_rows_impl(const NTParams& p, f32x16 
             }
         }
     }
+    ovf_report(p.alpha_dev, ovf_hit<T>(ovf));
 }
 
 template <typename T, int FM, int FN, int AUXK>

@@ -31,7 +31,7 @@ struct PpoArgs {
     int M, m_global, act_dim, z_dim, masked, div_on, mu_tanh, clip_value;
     float e_clip, critic_coef, bounds_coef, div_coef, div_tar;
     float gs, inv_gs;             // the stored head gradients carry the gradient scale (f16 storage), the bias gradients do not
-    const float* gs_dev;          // nullable: device factor on top of gs (the dynamic loss scale), read when the launch runs
+    float* gs_dev;                // nullable: scale record {factor on top of gs, overflow count} (the dynamic loss scale, common.h)
 };
 
 // per-workgroup partials: 7 loss sums, then 64 + 1 head-bias column sums (mu columns, value)
@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256, 8) void ppo_head_kernel(PpoArgs p) {
         p.inv_gs = 1.f / p.gs;
     }
     double part[7] = {0, 0, 0, 0, 0, 0, 0};  // a_loss, b_loss, entropy, clipped, c_loss, kl, div
+    bool bad = false;                        // a stored head gradient overflowed
 
     // grid-stride over rows: few workgroups => few contended f64 atomics on the 7 accumulators
     for (int i = blockIdx.x * ROWS + rib; i < p.M; i += gridDim.x * ROWS) {
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(256, 8) void ppo_head_kernel(PpoArgs p) {
             const T o1 = from_f32<T>(p.gs * gm), o2 = from_f32<T>(p.gs * gm2);
             reinterpret_cast<T*>(p.d_mu)[(int64_t)i * p.ld_dmu + lane] = o1;
             if (p.div_on) reinterpret_cast<T*>(p.d_mu)[(int64_t)(p.M + i) * p.ld_dmu + lane] = o2;
+            bad |= ovf_hit1(o1) || (p.div_on && ovf_hit1(o2));
             gm_out += p.inv_gs * to_f32(o1);
             gm2_out += p.div_on ? p.inv_gs * to_f32(o2) : 0.f;
         }
@@ -160,6 +162,7 @@ __global__ __launch_bounds__(256, 8) void ppo_head_kernel(PpoArgs p) {
             }
             const T ov = from_f32<T>(p.gs * (p.critic_coef * dv / (float)p.m_global));
             reinterpret_cast<T*>(p.d_value)[(int64_t)i * p.ld_dv] = ov;
+            bad |= ovf_hit1(ov);
             dv_out += p.inv_gs * to_f32(ov);
             part[0] += (double)(mk * a_loss);
             part[1] += (double)(mk * b_row);
@@ -170,6 +173,7 @@ __global__ __launch_bounds__(256, 8) void ppo_head_kernel(PpoArgs p) {
             part[6] += (double)(mk * div_row);
         }
     }
+    ovf_report(p.gs_dev, bad);
     // Every workgroup leaves its partial sums (7 loss sums in f64, the head-bias column sums of its rows) in its scratch
     // slab - 1024 workgroups adding to the same 40 addresses with atomics cost ~20 us of this kernel; ppo_head_fold_kernel
     // folds the slabs.
@@ -231,11 +235,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void disc_head_kernel(const float* __restrict__ logit, int64_t ld_l, T* __restrict__ d_logit,
                                                         int64_t ld_d, float* __restrict__ db_logit, double* __restrict__ acc,
                                                         int amb, int amb_global, float disc_coef, float gs,
-                                                        const float* __restrict__ gs_dev) {
+                                                        float* __restrict__ gs_dev) {
     __shared__ double sm[5 * 16];
     if (gs_dev) gs *= *gs_dev;
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     double part[5] = {0, 0, 0, 0, 0};  // bce agent, bce demo, agent acc, demo acc, sum of d_logit
+    bool bad = false;
     if (r < 3 * amb) {
         const float l = logit[(int64_t)r * ld_l];
         const float sp_abs = log1pf(expf(-fabsf(l)));
@@ -253,8 +258,10 @@ __global__ __launch_bounds__(256) void disc_head_kernel(const float* __restrict_
         }
         const T o = from_f32<T>(gs * g);
         d_logit[(int64_t)r * ld_d] = o;
+        bad = ovf_hit1(o);
         part[4] = (double)(to_f32(o) / gs);
     }
+    ovf_report(gs_dev, bad);
     block_sum<5>(part, sm);
     if (threadIdx.x == 0) {
         if (db_logit) atomic_add_f32(db_logit, (float)part[4]);
@@ -271,13 +278,14 @@ __global__ __launch_bounds__(256) void enc_head_kernel(const float* __restrict__
                                                        int64_t ld_z, T* __restrict__ d_e, int64_t ld_de,
                                                        float* __restrict__ db_enc, float* __restrict__ enc_out,
                                                        double* __restrict__ acc, int amb, int amb_global, int z_dim,
-                                                       float enc_coef, float gs, const float* __restrict__ gs_dev) {
+                                                       float enc_coef, float gs, float* __restrict__ gs_dev) {
     __shared__ double sm[16];
     if (gs_dev) gs *= *gs_dev;
     __shared__ float sdb[4][128];
     float dbv[2] = {0.f, 0.f};
     const int lane = threadIdx.x & 63;
     double part[1] = {0.0};
+    bool bad = false;
     // grid-stride over rows: <= 128 workgroups, so the 64 bias-gradient addresses and the loss accumulator see <= 128
     // atomics each (one workgroup per 4 rows = 1024 contended atomics per address: 22 us for 4096 rows)
     for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < amb; r += gridDim.x * 4) {
@@ -302,12 +310,14 @@ __global__ __launch_bounds__(256) void enc_head_kernel(const float* __restrict__
                 const float h = q ? h1 : h0;
                 const T o = from_f32<T>(gs * (-sc * (zv[q] - h * dot) / nrm));
                 d_e[(int64_t)r * ld_de + j] = o;
+                bad |= ovf_hit1(o);
                 dbv[q] += to_f32(o) / gs;
                 if (enc_out) enc_out[(int64_t)r * z_dim + j] = h;
             }
         }
         if (lane == 0) part[0] += (double)(-dot);
     }
+    ovf_report(gs_dev, bad);
     if (db_enc) {
         sdb[threadIdx.x >> 6][lane] = dbv[0];
         sdb[threadIdx.x >> 6][lane + 64] = dbv[1];
@@ -331,10 +341,11 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(256) void enc_gp_kernel(const float* __restrict__ e, int64_t ld_e, const float* __restrict__ z,
                                                      int64_t ld_z, const float* __restrict__ du, int64_t ld_du,
                                                      T* __restrict__ out, int64_t ld_out, float* __restrict__ db_enc,
-                                                     int rows, int z_dim, float scale, const float* __restrict__ scale_dev) {
+                                                     int rows, int z_dim, float scale, float* __restrict__ scale_dev) {
     __shared__ float sdb[4][128];
     if (scale_dev) scale *= *scale_dev;
     float dbv[2] = {0.f, 0.f};
+    bool bad = false;
     const int lane = threadIdx.x & 63;
     for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += gridDim.x * 4) {
         float ev[2] = {0.f, 0.f}, zv[2] = {0.f, 0.f}, dv[2] = {0.f, 0.f};
@@ -361,17 +372,21 @@ __global__ __launch_bounds__(256) void enc_gp_kernel(const float* __restrict__ e
             if (j < z_dim) {
                 const float h = q ? h1 : h0;
                 if (MODE == 0) {
-                    out[(int64_t)r * ld_out + j] = from_f32<T>(-scale * (zv[q] - h * a) / nrm);
+                    const T o = from_f32<T>(-scale * (zv[q] - h * a) / nrm);
+                    out[(int64_t)r * ld_out + j] = o;
+                    bad |= ovf_hit1(o);
                 } else {
                     const float jr = (zv[q] * hr + h * zr + a * dv[q] - 3.f * a * h * hr) / (nrm * nrm);
                     const float old = to_f32(out[(int64_t)r * ld_out + j]);      // (carries the gradient scale)
                     const T nw = from_f32<T>(old + scale * jr);
                     out[(int64_t)r * ld_out + j] = nw;
+                    bad |= ovf_hit1(nw);
                     dbv[q] += (to_f32(nw) - old) / scale;
                 }
             }
         }
     }
+    ovf_report(scale_dev, bad);
     if (MODE == 1 && db_enc) {
         sdb[threadIdx.x >> 6][lane] = dbv[0];
         sdb[threadIdx.x >> 6][lane + 64] = dbv[1];
@@ -572,7 +587,7 @@ extern "C" int ase_hip_ppo_head(const float* mu, int64_t ld_mu, const float* val
                                 const float* logstd, void* d_mu, int64_t ld_dmu, void* d_value, int64_t ld_dv,
                                 float* db_mu, float* db_value, float* mu_out, double* acc, double* scratch, int M, int m_global, int act_dim, int z_dim, int masked,
                                 int div_on, int mu_tanh, int clip_value, float e_clip, float critic_coef,
-                                float bounds_coef, float div_coef, float div_tar, float grad_scale, const float* grad_scale_dev, int dtype,
+                                float bounds_coef, float div_coef, float div_tar, float grad_scale, float* grad_scale_dev, int dtype,
                                 void* stream) {
     ASE_CHECK_ARG(mu && value && mb_actions && mb_old_mu && mb_old_sigma && mb_old_logp && mb_adv && mb_return &&
                       logstd && d_mu && d_value && acc && scratch && M > 0 && m_global >= M,
@@ -607,7 +622,7 @@ extern "C" int ase_hip_ppo_head(const float* mu, int64_t ld_mu, const float* val
 
 extern "C" int ase_hip_disc_head(const float* logit, int64_t ld_l, void* d_logit, int64_t ld_d, float* db_logit,
                                  double* acc, int amb, int amb_global, float disc_coef, float grad_scale,
-                                 const float* grad_scale_dev, int dtype, void* stream) {
+                                 float* grad_scale_dev, int dtype, void* stream) {
     ASE_CHECK_ARG(logit && d_logit && acc && amb > 0 && amb_global >= amb && grad_scale > 0.f, "disc_head: null/empty operand");
     const dim3 grid((3 * amb + 255) / 256);
     const int rc = ase_dispatch_storage(dtype, [&](auto tag) {
@@ -623,7 +638,7 @@ extern "C" int ase_hip_disc_head(const float* logit, int64_t ld_l, void* d_logit
 
 extern "C" int ase_hip_enc_head(const float* e, int64_t ld_e, const float* z, int64_t ld_z, void* d_e, int64_t ld_de,
                                 float* db_enc, float* enc_out, double* acc, int amb, int amb_global, int z_dim, float enc_coef,
-                                float grad_scale, const float* grad_scale_dev, int dtype, void* stream) {
+                                float grad_scale, float* grad_scale_dev, int dtype, void* stream) {
     ASE_CHECK_ARG(e && z && d_e && acc && amb > 0 && amb_global >= amb && grad_scale > 0.f, "enc_head: null/empty operand");
     ASE_CHECK_ARG(z_dim >= 1 && z_dim <= 128, "enc_head: z_dim %d not in [1,128]", z_dim);
     const dim3 grid(min((amb + 3) / 4, 128));
@@ -646,7 +661,7 @@ extern "C" int ase_hip_enc_gp_seed(const float* e, int64_t ld_e, const float* z,
     const int rc = ase_dispatch_storage(dtype, [&](auto tag) {
         typedef typename decltype(tag)::type T;
         ASE_LAUNCH((enc_gp_kernel<T, 0>), grid, dim3(256), 0, (hipStream_t)stream, e, ld_e, z, ld_z, (const float*)nullptr,
-                   (int64_t)0, (T*)u, ld_u, (float*)nullptr, rows, z_dim, scale, (const float*)nullptr);
+                   (int64_t)0, (T*)u, ld_u, (float*)nullptr, rows, z_dim, scale, (float*)nullptr);
         return ASE_OK;
     });
     ASE_CHECK_ARG(rc == ASE_OK, "enc_gp_seed: bad dtype %d", dtype);
@@ -656,7 +671,7 @@ extern "C" int ase_hip_enc_gp_seed(const float* e, int64_t ld_e, const float* z,
 
 extern "C" int ase_hip_enc_gp_back(const float* e, int64_t ld_e, const float* z, int64_t ld_z, const float* du, int64_t ld_du,
                                    void* d_e, int64_t ld_de, float* db_enc, int rows, int z_dim, float grad_scale,
-                                   const float* grad_scale_dev, int dtype, void* stream) {
+                                   float* grad_scale_dev, int dtype, void* stream) {
     ASE_CHECK_ARG(e && z && du && d_e && rows > 0 && grad_scale > 0.f, "enc_gp_back: null/empty operand");
     ASE_CHECK_ARG(z_dim >= 1 && z_dim <= 128, "enc_gp_back: z_dim %d not in [1,128]", z_dim);
     const dim3 grid(min((rows + 3) / 4, 128));          // <= 128 workgroups on the bias-gradient atomics (see enc_head)

@@ -308,7 +308,7 @@ class UpdateEngine:
         # growth_interval}, the table {S, 1 / S, 1 / S^2, 0} its launches read, and the optimizer state the Adam launch reads (opt_state,
         # or the identity step of a skipped step)
         self.scaler = torch.zeros(8, dtype=torch.float64, device=dev)
-        self.scale_tab = torch.tensor([1.0, 1.0, 1.0, 0.0], dtype=torch.float32, device=dev)
+        self.scale_tab = torch.tensor([1.0, 0.0, 1.0, 0.0, 1.0, 0.0, 1.0, 0.0], dtype=torch.float32, device=dev)   # four {factor, count} records
         if self.dyn_scale:
             sc = self.loss_scaler
             self.scaler[4:8] = torch.tensor([self._gs_init, sc['growth_factor'], sc['backoff_factor'], float(int(sc['growth_interval']))],
@@ -316,6 +316,7 @@ class UpdateEngine:
             self.set_grad_scale(self._gs_init)
         self.opt_eff = self.opt_state.clone()
         self._scaler_list = None
+        self._check_tabs = {}
         for d in self.layers:
             d.Ws = torch.zeros(d.n_pad, d.k_pad, dtype=T, device=dev)
             d.Wts = torch.zeros(d.k_pad, d.n_pad, dtype=T, device=dev)
@@ -587,7 +588,7 @@ class UpdateEngine:
     # ------------------------------------------------------------------ primitive layer ops
     def _fwd(self, d, X, Y, rows, act=None):
         act = d.act if act is None else act
-        self.be.gemm_nt(X, d.Ws, Y, rows, d.n_pad, d.k_pad, bias=d.bs, act=act,
+        self._nt(X, d.Ws, Y, rows, d.n_pad, d.k_pad, bias=d.bs, act=act,
                         mask_out=self._mask_of(Y) if (act == L.ACT_RELU or act >= L.ACT_SILU) else None)
 
     def _aux(self, aux, mode):
@@ -634,7 +635,7 @@ class UpdateEngine:
         wts = d.Wts if wts is None else wts
         n_out = d.k_pad if n_out is None else n_out
         aux, mode = self._aux(aux, _AUX[aux_act])
-        self.be.gemm_nt(dY, wts, dX, rows, n_out, d.n_pad, aux=aux, aux_mode=mode, alpha=alpha)
+        self._nt(dY, wts, dX, rows, n_out, d.n_pad, aux=aux, aux_mode=mode, alpha=alpha)
 
     def _wgrad(self, d, dY, X, rows, alpha=1.0, bias=True):
         """gW += dY^T X and (bias) gb += colsum(dY) from the same staged tiles.  Head groups computed their bias
@@ -735,7 +736,7 @@ class UpdateEngine:
         its bucket, optimizer step of its parameters - so the discriminator's tail overlaps the policy's backward.
         fence=False: the caller has ordered the branch streams behind its own writes (fence_side_streams) - required while a
         launch program is being recorded (a torch-level stream wait is not a recordable entry)."""
-        inline = apply and self._fused_apply and not self.truncate and not self.dyn_scale
+        inline = apply and self._fused_apply and not self.truncate
         # cross-step schedule: single GPU, streams, every branch finishing by itself (its own optimizer step)
         self._xs = bool(self._xstep and inline and self.has_disc and self._short_prologue and self._disc_early
                         and self._amp_stats_in_branch())
@@ -1026,7 +1027,15 @@ class UpdateEngine:
                 self._acc_in_bucket = with_acc
                 if not self.shard:
                     self._host(lambda: self.grads[lo:hi].mul_(1.0 / self.R))
-            self.be.apply_multi(self._apply_desc[a:b], self._apply_items[a:b], self.dtype, self.opt_state, self.acc)
+            if self.dyn_scale:
+                # GradScaler's decision is ONE per step (learning/ase_agent.py:271-288: one optimizer over every parameter): the
+                # branch checks what its launches could not report themselves and its (exchanged) f32 gradient, here on its own
+                # stream; the optimizer step of BOTH buckets follows the last branch (_dyn_apply)
+                self._dyn_check(group, lo, hi)
+                if last:
+                    self._dyn_apply()
+            else:
+                self.be.apply_multi(self._apply_desc[a:b], self._apply_items[a:b], self.dtype, self.opt_state, self.acc)
 
     def _disc_forward(self, amp_streams, ds=None):
         """Head of the discriminator (+ encoder) branch: AMP-observation moments -> running statistics -> normalised rows
@@ -1291,7 +1300,7 @@ class UpdateEngine:
     # ---- phase C (end-of-step form): weight-only loss terms, optimizer, shadows, reported scalars ------
     def phase_apply(self, apply=True):
         be, c = self.be, self.cfg
-        if apply and self._fused_apply and not self.truncate and not self.dyn_scale:
+        if apply and self._fused_apply and not self.truncate and not self.dyn_scale:      # (dynamic scale + fused: step() took the inline form)
             # weight-only loss terms + their reported norms + Adam + shadow refresh of every layer: ONE launch
             self._build_apply_desc()
             be.apply_multi(self._apply_desc, self._apply_items, self.dtype, self.opt_state, self.acc)
@@ -1316,12 +1325,15 @@ class UpdateEngine:
                 # step wrote + the f32 gradient), one flag for all ranks, then the decision - a found overflow zeroes the gradient
                 # and the optimizer launch below runs the identity step (weights, moments, step counter stay what they are)
                 g = self.grads[:self.n_train]
-                for t in self._scaler_bufs():
-                    be.scaler_check(t, self.scaler)
-                be.scaler_check(g, self.scaler)
+                self._dyn_check('all', 0, self.n_train)
                 if self._dist_on():
+                    be.scaler_fold(self.scaler, self.scale_tab)
                     self._ar(self.scaler[:1])
                 be.scaler_step(self.scaler, self.opt_state, self.opt_eff, g, scale_tab=self.scale_tab)
+            elif self.dyn_scale:
+                # a step without the optimizer (calc_gradients-style calls): GradScaler sees nothing of it - what its launches
+                # reported is dropped
+                self._host(lambda: self.scale_tab[1::2].zero_())
             if apply and self.truncate:
                 g = self.grads[:self.n_train]
                 be.reduce_sum(g, g.numel(), True, self.acc, L.ACC_GRAD_SQ)
@@ -1337,11 +1349,12 @@ class UpdateEngine:
 
     # ---- dynamic loss scale (cfg loss_scale = 'dynamic') ---------------------------------------------------------------
     def _scaler_bufs(self):
-        """Every buffer of the step a conversion into half storage writes (forward activations included: under autocast an
-        overflowing activation is inf, the loss NaN, and GradScaler skips that step too) + the f32 chain of a gp_f32 engine.
-        Built from the engine's structure - a buffer a feature allocates MUST be found (a renamed attribute is an assertion, not a
-        silently shorter list; round 5's list missed G0, the half copy of S s g_0 in the 4th row block of Xd4: the largest scaled
-        quantity of a gp_f32 step and the first to saturate as the scale grows) - and the half pre-activation twins of smooth layers."""
+        """Buffers of the step that half conversions write and whose writers carry NO scale record, by branch - the few the
+        producers' own reports (ABI 7: every NT matrix launch and every loss head of a dynamic-scale step is given a record, _nt)
+        leave over: seeds and second-order terms of the penalty chains (ase_hip_gp_seed / gp_second / enc_gp_seed) and the one
+        conversion launch of a gp_f32 engine.  Rounds 4-5 listed every half buffer here and re-read 0.82 GB per step.
+        Built from the engine's structure: a buffer a feature allocates MUST be found (a renamed attribute is an assertion, not a
+        silently shorter list)."""
         if self._scaler_list is None:
             out = []
 
@@ -1351,42 +1364,80 @@ class UpdateEngine:
                     if t.numel():
                         assert t.is_contiguous()
                         out.append(t)
-            need = ['Ha', 'dZa', 'Hc', 'dZc', 'dMU', 'dV']
-            if self.style:
-                need += ['Hs', 'dZs', 'dStyle']
-            if self.has_disc:
-                need += ['Hd4', 'dZd4', 'dHD', 'GpTop', 'G0']
-            if self.has_disc and self.enc_chain:
-                need += ['He', 'dZe', 'dE']
+            c = self.cfg
+            need = []
+            gp_on = self.has_disc and c['disc_coef'] * c['disc_grad_penalty'] != 0
+            if gp_on and self.gp32:
+                need += ['Gp', 'G0']                      # the conversion launch's outputs (16-bit copies of the exact chain)
+            elif gp_on:
+                need += ['Gp']                            # gp_seed writes the top of the chain (the rest: matrix launches)
+                if any(d.act != L.ACT_RELU for d in self.disc):
+                    need += ['dZd4']                      # gp_second adds the second-order terms into the demo rows
             if self.enc_gp:
-                need += ['Ue', 'Re', 'Ge', 'Qe']
+                need += ['Ue']                            # enc_gp_seed
             for name in need:
                 assert hasattr(self, name), f"_scaler_bufs: the engine has no buffer '{name}' (renamed?)"
                 add(getattr(self, name))
-            for h, twin in self._bits.values():          # pre-activation twins of smooth activations (ReLU twins are bit words)
-                if twin.dtype == self.dtype:
-                    add(twin)
-            if self.gp32:
-                g = self._gp32
-                add(g.H)
-                add(g.Gp)
-                add(g.G0)
-            self._scaler_list = out
+            if gp_on and self.gp32:
+                add(self._gp32.Gp[-1])                    # gp_seed's f32 output
+            self._scaler_list = {'disc': out, 'policy': []}
         return self._scaler_list
+
+    def _dyn_check(self, group, lo, hi):
+        """found_inf over what the launches of a branch ('disc' / 'policy'; 'all': the end-of-step form) did not report themselves
+        + the branch's f32 gradient bucket [lo, hi) (after its exchange: the same bits on every rank): ONE launch."""
+        bufs = self._scaler_bufs()
+        key = (group, lo, hi)
+        tab = self._check_tabs.get(key)
+        if tab is None:
+            lst = (bufs['disc'] + bufs['policy']) if group == 'all' else list(bufs[group])
+            lst.append(self.grads[lo:hi])
+            tab = self._check_tabs[key] = (lst, self.be.make_check_table(lst) if hasattr(self.be, 'make_check_table') else None)
+        self.be.scaler_check_multi(tab[0], self.scaler, table=tab[1])
+
+    def _dyn_apply(self):
+        """GradScaler.step + update + the optimizer step of EVERY parameter, after the last branch's checks.  With streams it is
+        submitted on the discriminator branch's stream - behind that branch's tail, waiting for the main stream's position - so
+        that the head of the NEXT step's discriminator branch (cross-step schedule: un-chained, same stream) follows the
+        optimizer step by stream order; the main stream joins it."""
+        be = self.be
+        g = self.grads[:self.n_train]
+        side = self._side(1) if (self.multi_stream and self.has_disc) else None
+        with self._Branch(self, side) as br:
+            if self._dist_on():
+                be.scaler_fold(self.scaler, self.scale_tab)       # the producers' reports -> one number, SUM over the ranks
+                self._ar(self.scaler[:1])
+            be.scaler_step(self.scaler, self.opt_state, self.opt_eff, g, scale_tab=self.scale_tab)
+            be.apply_multi(self._apply_desc, self._apply_items, self.dtype, self.opt_eff, self.acc)
+        self._join_branch(br)
 
     @property
     def _dS(self):
-        """Device factors of the dynamic loss scale for the `*_dev` arguments: S (loss heads), 1 / S (_dI: weight gradients, the top
-        of the penalty chain), 1 / S^2 (_dI2: the penalty's norm); None under the static scale, where self.gs carries it."""
-        return self.scale_tab[0:1] if self.dyn_scale else None
+        """Scale records of the dynamic loss scale for the `*_dev` arguments ({factor, overflow count}, include/ase_hip.h): S (loss
+        heads), 1 / S (_dI: weight gradients, the top of the penalty chain), 1 / S^2 (_dI2: the penalty's norm), 1 (_dOne: matrix
+        launches without a factor of their own - they still REPORT what they store); None under the static scale, where self.gs
+        carries it."""
+        return self.scale_tab[0:2] if self.dyn_scale else None
 
     @property
     def _dI(self):
-        return self.scale_tab[1:2] if self.dyn_scale else None
+        return self.scale_tab[2:4] if self.dyn_scale else None
 
     @property
     def _dI2(self):
-        return self.scale_tab[2:3] if self.dyn_scale else None
+        return self.scale_tab[4:6] if self.dyn_scale else None
+
+    @property
+    def _dOne(self):
+        return self.scale_tab[6:8] if self.dyn_scale else None
+
+    def _nt(self, *a, alpha_dev=None, **kw):
+        """Every NT matrix launch of the step: under the dynamic loss scale it carries a scale record - the factor it was given, or
+        the record of factor 1 - so that the launch itself reports an overflow it stores (GradScaler's found_inf without a pass over
+        the step's buffers; rounds 4-5 re-read 0.82 GB per step for it)."""
+        if alpha_dev is None and self.dyn_scale:
+            alpha_dev = self._dOne
+        self.be.gemm_nt(*a, alpha_dev=alpha_dev, **kw)
 
     def set_grad_scale(self, s):
         """A new gradient scale (a power of two).  Static scale: a launch ARGUMENT of the loss heads and the weight-gradient launches -
@@ -1396,7 +1447,7 @@ class UpdateEngine:
         if self.dyn_scale:
             s = float(s)
             self.scaler[4:5] = torch.tensor([s], dtype=torch.float64)
-            self.scale_tab.copy_(torch.tensor([s, 1.0 / s, 1.0 / (s * s), 0.0], dtype=torch.float32))
+            self.scale_tab.copy_(torch.tensor([s, 0.0, 1.0 / s, 0.0, 1.0 / (s * s), 0.0, 1.0, 0.0], dtype=torch.float32))
         else:
             self.gs = float(s)
 
@@ -1453,16 +1504,16 @@ class UpdateEngine:
         # (Ge and everything derived from it - the second operand of the weight-gradient pairs - carries the gradient
         #  scale S, like the back-propagated operand of every other weight gradient)
         S = self.gs
-        be.gemm_nt(self.Re[0], d0.Wts, self.Ge, AMB, d0.k_pad, d0.n_pad, alpha=S, alpha_dev=self._dS)         # S s * g
+        self._nt(self.Re[0], d0.Wts, self.Ge, AMB, d0.k_pad, d0.n_pad, alpha=S, alpha_dev=self._dS)         # S s * g
         be.sqnorm(self.Ge, AMB, d0.k_pad, self.acc, L.ACC_ENC_GP, scale=1.0 / (cg * S * S), dyn=self._dI2)
         # its backward: forward-shaped launches without bias, masked by the same activations
         x = self.Ge
         for l in range(nl):
             d = chain[l]
             aux, mode = self._aux(H[l], L.AUX_RELU_MASK)
-            be.gemm_nt(x, d.Ws, self.Qe[l], AMB, d.n_pad, d.k_pad, aux=aux, aux_mode=mode)
+            self._nt(x, d.Ws, self.Qe[l], AMB, d.n_pad, d.k_pad, aux=aux, aux_mode=mode)
             x = self.Qe[l]
-        be.gemm_nt(x, head.Ws, self.DUe, AMB, head.n_pad, head.k_pad, alpha=s / S, alpha_dev=self._dI)        # du (unscaled)
+        self._nt(x, head.Ws, self.DUe, AMB, head.n_pad, head.k_pad, alpha=s / S, alpha_dev=self._dI)        # du (unscaled)
         # weight gradients (no bias terms: the chain has none)
         for l in range(nl):
             d = chain[l]
@@ -1521,21 +1572,21 @@ class UpdateEngine:
         for l in range(nl - 1, 0, -1):
             d, pl = self.disc[l], self.disc[l - 1]
             aux, mode = self._aux(self.Hd4[l - 1], _AUX[pl.act])
-            be.gemm_nt(self.dZd4[l], d.Wts, self.dZd4[l - 1], 4 * AMB, d.k_pad, d.n_pad, aux=aux, aux_mode=mode,
+            self._nt(self.dZd4[l], d.Wts, self.dZd4[l - 1], 4 * AMB, d.k_pad, d.n_pad, aux=aux, aux_mode=mode,
                        aux_split=Rd, aux_delta=AMB)
         d0 = self.disc[0]
         # (the chain's second-operand side - G0 and the dJ/dU_l derived from it - carries Sr so that the stacked
         #  weight-gradient launches undo S = Sc Sr for both row blocks with one alpha)
-        be.gemm_nt(self.Gp[0], d0.Wts, self.G0, AMB, d0.k_pad, d0.n_pad, alpha=Sr / Sc, alpha_dev=self._dS)        # Sr s * g_0
+        self._nt(self.Gp[0], d0.Wts, self.G0, AMB, d0.k_pad, d0.n_pad, alpha=Sr / Sc, alpha_dev=self._dS)        # Sr s * g_0
         be.sqnorm(self.G0, AMB, d0.k_pad, self.acc, L.ACC_GP, scale=1.0 / (cg * Sr * Sr), dyn=self._dI2)
         # backward of the chain (values scaled by s; see the docstring): dJ/dU_l, masked by the demo rows' ReLU masks
         aux, mode = self._aux(self.Hd[0][2 * AMB:], L.AUX_RELU_MASK)
-        be.gemm_nt(self.G0, d0.Ws, self.dGp[0], AMB, d0.n_pad, d0.k_pad, aux=aux, aux_mode=mode)
+        self._nt(self.G0, d0.Ws, self.dGp[0], AMB, d0.n_pad, d0.k_pad, aux=aux, aux_mode=mode)
         for l in range(1, nl):
             d = self.disc[l]
             last = l == nl - 1
             aux, mode = self._aux(self.Hd[l][2 * AMB:], L.AUX_RELU_MASK)
-            be.gemm_nt(self.dGp[l - 1], d.Ws, self.GpTop if last else self.dGp[l], AMB, d.n_pad, d.k_pad, aux=aux,
+            self._nt(self.dGp[l - 1], d.Ws, self.GpTop if last else self.dGp[l], AMB, d.n_pad, d.k_pad, aux=aux,
                        aux_mode=mode, alpha=s / Sr if last else 1.0, alpha_dev=self._dI if last else None)
             if last:      # the penalty's gradient w.r.t. the logit weights: column sums of the top launch (f32, true scale)
                 be.colsum(self.GpTop, AMB, d.N, self.disc_head.gW[0].view(-1))
@@ -1578,16 +1629,16 @@ class UpdateEngine:
             be.refresh_shadow(d.W[0], g.Ws[l], g.Wts[l], d.split_src, d.split_dst, **({'x3_exp': 11} if half else {}))
         x = g.X
         for l, d in enumerate(self.disc):
-            be.gemm_nt(x, g.Ws[l], g.H[l], AMB, d.n_pad, d.k_pad, bias=d.bs, act=L.ACT_RELU, mask_out=g.bits[l],
+            self._nt(x, g.Ws[l], g.H[l], AMB, d.n_pad, d.k_pad, bias=d.bs, act=L.ACT_RELU, mask_out=g.bits[l],
                        **ex(12 if l == 0 else 6))
             x = g.H[l]
         top = self.disc[-1]
         be.gp_seed(g.H[-1], self.disc_head.W[0].view(-1), g.Gp[-1], AMB, top.N, scale=s)
         for l in range(nl - 1, 0, -1):
             d = self.disc[l]
-            be.gemm_nt(g.Gp[l], g.Wts[l], g.Gp[l - 1], AMB, d.k_pad, d.n_pad, aux=g.bits[l - 1], aux_mode=bits, **ex(12))
+            self._nt(g.Gp[l], g.Wts[l], g.Gp[l - 1], AMB, d.k_pad, d.n_pad, aux=g.bits[l - 1], aux_mode=bits, **ex(12))
         d0 = self.disc[0]
-        be.gemm_nt(g.Gp[0], g.Wts[0], g.G0, AMB, d0.k_pad, d0.n_pad, alpha=S, alpha_dev=self._dS, **ex(12))         # S s * g_0
+        self._nt(g.Gp[0], g.Wts[0], g.G0, AMB, d0.k_pad, d0.n_pad, alpha=S, alpha_dev=self._dS, **ex(12))         # S s * g_0
         if x3_prev is not None:
             be.x3 = x3_prev
 
@@ -1623,11 +1674,11 @@ class UpdateEngine:
         for l in range(nl - 1, 0, -1):
             self._dgrad(self.disc[l], self.dZd[l], self.dZd[l - 1], Rd, self.Hd[l - 1], self.disc[l - 1].act)
         # backward of the penalty chain (values carry s and the gradient scale S), through the EXACT masks
-        be.gemm_nt(self.G0, d0.Ws, self.dGp[0], AMB, d0.n_pad, d0.k_pad, aux=g.bits[0], aux_mode=bits)
+        self._nt(self.G0, d0.Ws, self.dGp[0], AMB, d0.n_pad, d0.k_pad, aux=g.bits[0], aux_mode=bits)
         for l in range(1, nl):
             d = self.disc[l]
             last = l == nl - 1
-            be.gemm_nt(self.dGp[l - 1], d.Ws, self.GpTop if last else self.dGp[l], AMB, d.n_pad, d.k_pad, aux=g.bits[l],
+            self._nt(self.dGp[l - 1], d.Ws, self.GpTop if last else self.dGp[l], AMB, d.n_pad, d.k_pad, aux=g.bits[l],
                        aux_mode=bits, alpha=s / S if last else 1.0, alpha_dev=self._dI if last else None)
             if last:
                 be.colsum(self.GpTop, AMB, d.N, self.disc_head.gW[0].view(-1))
@@ -1662,9 +1713,9 @@ class UpdateEngine:
         for l in range(nl - 1, 0, -1):
             d, pl = self.disc[l], self.disc[l - 1]
             aux, mode = self._aux(self.Hd[l - 1][demo], _AUX[pl.act])
-            be.gemm_nt(self.Gp[l], d.Wts, self.Gp[l - 1], AMB, d.k_pad, d.n_pad, aux=aux, aux_mode=mode)
+            self._nt(self.Gp[l], d.Wts, self.Gp[l - 1], AMB, d.k_pad, d.n_pad, aux=aux, aux_mode=mode)
         d0 = self.disc[0]
-        be.gemm_nt(self.Gp[0], d0.Wts, self.G0, AMB, d0.k_pad, d0.n_pad, alpha=Sr / Sc, alpha_dev=self._dS)        # Sr s * g_in
+        self._nt(self.Gp[0], d0.Wts, self.G0, AMB, d0.k_pad, d0.n_pad, alpha=Sr / Sc, alpha_dev=self._dS)        # Sr s * g_in
         be.sqnorm(self.G0, AMB, d0.k_pad, self.acc, L.ACC_GP, scale=1.0 / (cg * Sr * Sr), dyn=self._dI2)
         # ---- its backward: dGp[l] = a'_l * (dGp[l-1] @ W_l^T), the last one only for the logit weights' gradient
         x = self.G0
@@ -1672,12 +1723,12 @@ class UpdateEngine:
             d = self.disc[l]
             last = l == nl - 1
             aux, mode = self._aux(self.Hd[l][demo], _AUX[d.act])
-            be.gemm_nt(x, d.Ws, self.GpTop if last else self.dGp[l], AMB, d.n_pad, d.k_pad, aux=aux, aux_mode=mode,
+            self._nt(x, d.Ws, self.GpTop if last else self.dGp[l], AMB, d.n_pad, d.k_pad, aux=aux, aux_mode=mode,
                        alpha=s / Sr if last else 1.0, alpha_dev=self._dI if last else None)
             if last:
                 be.colsum(self.GpTop, AMB, d.N, self.disc_head.gW[0].view(-1))
             if last:     # the top layer's dGp in storage type and S scale, for the second-order term below
-                be.gemm_nt(x, d.Ws, self.dGp[l], AMB, d.n_pad, d.k_pad, aux=aux, aux_mode=mode)
+                self._nt(x, d.Ws, self.dGp[l], AMB, d.n_pad, d.k_pad, aux=aux, aux_mode=mode)
             x = self.dGp[l]
         # ---- ordinary backward, the second-order terms joining the demo rows layer by layer
         for l in range(nl - 1, -1, -1):

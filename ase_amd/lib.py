@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libase_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 PPO_SCRATCH = 1024 * 72 + 8       # ASE_PPO_SCRATCH: doubles of ase_hip_ppo_head's workspace
 TN_SLAB = 65536 + 256        # ASE_TN_SLAB: floats per work item in the grouped weight-gradient launch's workspace
 F32, BF16, F32X3, F16, F32H3 = 0, 1, 2, 3, 4
@@ -58,6 +58,8 @@ SIGNATURES = {
     "ase_hip_adam": [_p, _p, _p, _p, _i64, _p, _p],
     "ase_hip_axpy": [_p, _p, _i64, _f, _p],
     "ase_hip_scaler_check": [_p, _i64, _i, _p, _p],
+    "ase_hip_scaler_check_multi": [_p, _i, _i, _p, _p],
+    "ase_hip_scaler_fold": [_p, _p, _p],
     "ase_hip_scaler_step": [_p, _p, _p, _p, _i64, _p, _p],
     "ase_hip_disc_reward": [_p, _i64, _p, _i64, _f, _p],
     "ase_hip_enc_reward": [_p, _i64, _p, _i64, _p, _i64, _i, _f, _p],

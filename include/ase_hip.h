@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ASE_HIP_ABI_VERSION 6
+#define ASE_HIP_ABI_VERSION 7
 
 enum { ASE_F32 = 0, ASE_BF16 = 1, ASE_F32X3 = 2 /* f32 storage, products as 3 bf16 MFMAs on a hi/lo split (GEMMs only) */,
        ASE_F32H3 = 4 /* 4-byte storage, products as 3 f16 MFMAs on hi/lo splits of operands scaled by 2^ea / 2^eb (the exponents ride in
@@ -84,9 +84,13 @@ int ase_hip_debug_nt_profile_clock(int shader_clock);
  *   act >= ASE_ACT_SILU: dtype [M, ldmask] (ldmask in ELEMENTS), the pre-activation z = alpha * A.B^T + bias - read back with
  *     ASE_AUX_PREACT (the derivative of a non-monotonic activation is not a function of its output; tanh keeps
  *     ASE_AUX_TANH_GRAD on the output itself).
- *   alpha_dev (nullable, ABI 6): DEVICE f32 the launch multiplies alpha by when it RUNS - how the factors of the dynamic loss scale
- *   (ase_hip_scaler_step's scale table: S, 1 / S, 1 / S^2) reach launches recorded once and replayed across scale changes; the same
- *   convention for every `*_dev` argument below (weight gradients, loss heads, ase_hip_sqnorm).
+ *   alpha_dev (nullable; ABI 6, a RECORD since ABI 7): DEVICE f32[2] scale record {factor, overflow count}.  The launch multiplies
+ *   alpha by `factor` when it RUNS - how the factors of the dynamic loss scale (ase_hip_scaler_step's table: S, 1 / S, 1 / S^2, 1) reach
+ *   launches recorded once and replayed across scale changes - and ADDS to `count` (by an unspecified positive amount) when an element
+ *   it STORED into C / mask_out's pre-activation twin is not finite or sits at the storage type's saturation value (ASE_F16 conversions
+ *   saturate at +-65504 where autocast would produce inf): GradScaler's found_inf, detected by the producer instead of a pass that
+ *   re-reads every buffer of the step (ase_hip_scaler_check).  The same convention for every `*_dev` argument below; the loss heads
+ *   report their stored head gradients, ase_hip_gemm_tn(_grouped) and ase_hip_sqnorm only read the factor.
  * Replaces: nn.Linear + activation forward  (learning/ase_network_builder.py:255-259,305-324,
  *   learning/amp_network_builder.py:81-84), and autograd's data-gradient of the same layers
  *   (B = the transposed weight shadow; mask = derivative of the previous activation), and the
@@ -94,7 +98,7 @@ int ase_hip_debug_nt_profile_clock(int shader_clock);
 int ase_hip_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                     const float* bias, const void* aux, int64_t ldaux, int aux_split, int aux_delta,
                     float* colsum, int colsum_n, void* mask_out, int64_t ldmask, int M, int N, int K, int act,
-                    int aux_mode, int out_f32, float alpha, const float* alpha_dev, int dtype, void* stream);
+                    int aux_mode, int out_f32, float alpha, float* alpha_dev, int dtype, void* stream);
 
 /* G[n, kmap(k)] += alpha * sum_m A[m,n] * B[m,k]   for n < n_real, kmap(k) valid     "TN" GEMM
  *   A [M,N] dtype (output gradients), B [M,K] dtype (layer inputs), G f32 [n_real, k_real]
@@ -244,8 +248,8 @@ int ase_hip_reduce_sum(const float* x, int64_t n, int square, double* acc, int s
  *            scalars are not) - the static loss scale of ASE_F16 storage, whose back-propagated gradients would
  *            otherwise fall into half's subnormal range; the weight-gradient launches undo it through their alpha.
  *            The counterpart of the reference's GradScaler (learning/ase_agent.py:216,271-288).  1 for bf16 / f32.
- *            grad_scale_dev (nullable, ABI 6): a DEVICE f32 factor on top - the DYNAMIC loss scale (ase_hip_scaler_step keeps it),
- *            read when the launch runs.
+ *            grad_scale_dev (nullable, ABI 6 / 7): a DEVICE scale record {factor on top - the DYNAMIC loss scale (ase_hip_scaler_step
+ *            keeps it), read when the launch runs; overflow count, see ase_hip_gemm_nt's alpha_dev}.
  *   scratch: device f64[ASE_PPO_SCRATCH] workspace, private to one launch at a time: per-workgroup partial sums (loss
  *            scalars, head-bias column sums), folded into acc / db_* by a second one-workgroup kernel of the same call (no
  *            contended atomics; a kernel boundary instead of per-workgroup fences). */
@@ -259,12 +263,12 @@ int ase_hip_ppo_head(const float* mu, int64_t ld_mu, const float* value, int64_t
                      float* db_mu, float* db_value, float* mu_out, double* acc, double* scratch,
                      int M, int m_global, int act_dim, int z_dim, int masked, int div_on, int mu_tanh,
                      int clip_value, float e_clip, float critic_coef, float bounds_coef,
-                     float div_coef, float div_tar, float grad_scale, const float* grad_scale_dev, int dtype, void* stream);
+                     float div_coef, float div_tar, float grad_scale, float* grad_scale_dev, int dtype, void* stream);
 
 /* Discriminator logit losses (learning/amp_agent.py:442-447,481-496): rows [0,2*amb) agent+replay
  * (target 0), rows [2*amb,3*amb) demo (target 1).  d_logit dtype [3*amb, ld_d] column 0. */
 int ase_hip_disc_head(const float* logit, int64_t ld_l, void* d_logit, int64_t ld_d, float* db_logit,
-                      double* acc, int amb, int amb_global, float disc_coef, float grad_scale, const float* grad_scale_dev, int dtype,
+                      double* acc, int amb, int amb_global, float disc_coef, float grad_scale, float* grad_scale_dev, int dtype,
                       void* stream);
 
 /* Encoder head (learning/ase_network_builder.py:217, learning/ase_agent.py:413-418,469-472):
@@ -272,7 +276,7 @@ int ase_hip_disc_head(const float* logit, int64_t ld_l, void* d_logit, int64_t l
  * enc_out (nullable) f32 [amb, z_dim] receives normalize(e). */
 int ase_hip_enc_head(const float* e, int64_t ld_e, const float* z, int64_t ld_z, void* d_e,
                      int64_t ld_de, float* db_enc, float* enc_out, double* acc, int amb, int amb_global,
-                     int z_dim, float enc_coef, float grad_scale, const float* grad_scale_dev, int dtype, void* stream);
+                     int z_dim, float enc_coef, float grad_scale, float* grad_scale_dev, int dtype, void* stream);
 
 /* Encoder gradient penalty (learning/ase_agent.py:431-441: mean_rows |d enc_err / d amp_obs|^2 with enc_err = -<normalize(e), z>),
  * the two per-row pieces around the GEMM chain.  e f32 [rows, ld_e] pre-normalisation encoder output, z f32 [rows, ld_z].
@@ -283,7 +287,7 @@ int ase_hip_enc_head(const float* e, int64_t ld_e, const float* z, int64_t ld_z,
 int ase_hip_enc_gp_seed(const float* e, int64_t ld_e, const float* z, int64_t ld_z, void* u, int64_t ld_u, int rows,
                         int z_dim, float scale, int dtype, void* stream);
 int ase_hip_enc_gp_back(const float* e, int64_t ld_e, const float* z, int64_t ld_z, const float* du, int64_t ld_du,
-                        void* d_e, int64_t ld_de, float* db_enc, int rows, int z_dim, float grad_scale, const float* grad_scale_dev,
+                        void* d_e, int64_t ld_de, float* db_enc, int rows, int z_dim, float grad_scale, float* grad_scale_dev,
                         int dtype, void* stream);
 
 /* Gradient-penalty seed (learning/amp_agent.py:453-459): g[r,j] = scale * w[j] * act'  (d logit / d pre-activation of the last
@@ -355,18 +359,27 @@ int ase_hip_axpy(float* g, const float* w, int64_t n, float c, void* stream);
  *   scaler: DEVICE f64[8] = {found, skipped steps (total), growth tracker = clean steps since the scale last moved, steps (total),
  *           scale, growth_factor, backoff_factor, growth_interval}  (GradScaler's state and constructor arguments; the host writes
  *           slots 4-7 once)
- *   scale_tab: DEVICE f32[4] = {S, 1 / S, 1 / S^2, 0}: what the `*_dev` arguments of the loss heads (S), the weight-gradient launches
- *           (1 / S) and the penalty's norm (1 / S^2) point at - launches recorded once keep working when the scale moves.
+ *   scale_tab: DEVICE f32[8] = four scale records {S, n0}, {1 / S, n1}, {1 / S^2, n2}, {1, n3}: what the `*_dev` arguments of the loss
+ *           heads (S), the weight-gradient launches (1 / S), the penalty's norm (1 / S^2) and launches that carry no factor (1) point at
+ *           - launches recorded once keep working when the scale moves - and where those launches report an overflow they stored (the
+ *           counts n_k, ABI 7).
  * ase_hip_scaler_check = the found_inf test over ONE buffer the scaled backward wrote (dtype ASE_F32 / ASE_BF16 / ASE_F16):
  * scaler[found] += number of workgroups that met an element that is not finite or - ASE_F16, whose conversions saturate instead
- * of producing inf - sits at +-65504. */
+ * of producing inf - sits at +-65504.  For buffers whose producers were given no record, and for the f32 gradient.
+ * ase_hip_scaler_check_multi (ABI 7): the same over a DEVICE table int64[n_bufs][3] = {pointer, elements, dtype} in one launch,
+ * wg_per_buf workgroups per buffer.
+ * ase_hip_scaler_fold (ABI 7): scaler[found] += n0 + n1 + n2 + n3, counts = 0 - for a data-parallel step, whose ranks SUM-exchange
+ * scaler[found] between this launch and ase_hip_scaler_step (which otherwise reads the counts itself). */
 int ase_hip_scaler_check(const void* buf, int64_t n, int dtype, double* scaler, void* stream);
+int ase_hip_scaler_check_multi(const int64_t* table, int n_bufs, int wg_per_buf, double* scaler, void* stream);
+int ase_hip_scaler_fold(double* scaler, float* scale_tab, void* stream);
 /* ase_hip_scaler_step = GradScaler.step + GradScaler.update, between the checks and the optimizer launch (ase_hip_adam reads opt_eff):
+ *   found = scaler[found] != 0 or a non-zero count in scale_tab;
  *   found != 0: grads[0..n) = 0, opt_eff = the identity step {lr 0, beta1 = beta2 = 1, bias corrections 1} (w, m, v stay what they
  *               are), opt_state.step -= 1 (a skipped step is no optimizer step), skipped += 1;
  *               scale *= backoff_factor, growth tracker = 0
  *   found == 0: opt_eff = opt_state; growth tracker += 1, and when it reaches growth_interval: scale *= growth_factor, tracker = 0
- * then steps += 1, found = 0 and (scale_tab non-null) scale_tab = {scale, 1 / scale, 1 / scale^2, 0} - exactly
+ * then steps += 1, found = 0 and (scale_tab non-null) scale_tab = {scale, 0, 1 / scale, 0, 1 / scale^2, 0, 1, 0} - exactly
  * torch/amp/grad_scaler.py's _amp_update_scale_, once per optimisation step.  scale_tab NULL (ABI 5 behaviour): the scale is a
  * launch argument the host moves between updates; slots 4-7 are not touched. */
 int ase_hip_scaler_step(double* scaler, double* opt_state, double* opt_eff, float* grads, int64_t n, float* scale_tab,

@@ -8,6 +8,7 @@ rollout-time inference path.  One JSON line per measurement on stdout.
   ase16k: config 5's batch (16384 envs x 32 = 524288 samples, 192 optimisation steps), ASE nets
   ase-f32 / ase-bf16x3: config 2 in the parity / split precision modes
   ase-mixed: config 2 under the reference's `mixed_precision: True` (f16 + dynamic loss scale)
+  ase-dyn-gpx3: the headline mode (f16gpx3) with `loss_scale: dynamic` instead of its static gradient scale
   shard : ONE rank's share of the sharded data-parallel update (BASELINE configs[2]) on one GPU, for R = 2, 4, 8 ranks: the
           48 optimisation steps of an update at minibatch 16384 / R, amp minibatch 4096 / R (--shard-of R[,R...]); no collectives
           - the compute side of the scaling curve the driver's 8-GPU run would take, and the launch count it has to hide
@@ -58,6 +59,9 @@ def build(kind, num_envs, precision, graph=True, overrides=None, net_overrides=N
     if precision == 'mixed':          # the reference's own flag and nothing else: f16 storage + the dynamic loss scale (GradScaler)
         del cfg['precision']
         cfg['mixed_precision'] = True
+    elif precision.endswith('+dyn'):  # a named mode with GradScaler's dynamic scale instead of its static one
+        cfg['precision'] = precision[:-4]
+        cfg['loss_scale'] = 'dynamic'
     ag = A('extra', cfg)
     with torch.no_grad():
         ag.set_eval()
@@ -122,7 +126,7 @@ def main():
                 amp_obs_demo_buffer_size=512, amp_replay_buffer_size=2048)
     runs = [('amp', 'amp', 4096, 'bf16'), ('hrl', 'hrl', 4096, 'bf16'), ('ase16k', 'ase', 16384, 'bf16'),
             ('ase-f32', 'ase', 4096, 'f32'), ('ase-bf16x3', 'ase', 4096, 'bf16x3'), ('amp-cfg1', 'amp', 64, 'f32'),
-            ('amp-cfg1-bf16', 'amp', 64, 'bf16'), ('ase-mixed', 'ase', 4096, 'mixed')]
+            ('amp-cfg1-bf16', 'amp', 64, 'bf16'), ('ase-mixed', 'ase', 4096, 'mixed'), ('ase-dyn-gpx3', 'ase', 4096, 'f16gpx3+dyn')]
     for name, kind, envs, prec in runs:
         if args.only and name not in args.only.split(','):
             continue
@@ -130,15 +134,17 @@ def main():
             ag, cfg, spec = build(kind, envs, prec, overrides=cfg1, net_overrides={'mlp': [256, 128], 'disc': [256, 128]})
         else:
             ag, cfg, spec = build(kind, envs, prec)
-        dt = time_updates(ag, args.updates if prec in ('bf16', 'mixed') else 2)
+        dt = time_updates(ag, args.updates if (prec in ('bf16', 'mixed') or prec.endswith('+dyn')) else 2)
         B = ag.batch_size
         steps = cfg['mini_epochs'] * (B // cfg['minibatch_size'])
         print(json.dumps({'measurement': name, 'metric': 'PPO-update samples/sec', 'value': round(B / dt, 1), 'unit': 'samples/s',
                           'ms_per_update': round(dt * 1e3, 3), 'envs': envs, 'horizon': cfg['horizon_length'], 'batch': B,
                           'optimisation_steps': steps, 'precision': prec, 'params': int(ag.model.a2c_network.trainable_numel),
                           'replay': 'program', 'data': 'synthetic',
-                          **({'loss_scaler': ag.engine.scaler_state(), 'what': 'config 2 under `mixed_precision: True`: f16 storage, '
-                              'overflow checks + skipped steps on the device, end-of-step optimizer form, scale moved between updates'}
+                          **({'loss_scaler': ag.engine.scaler_state(), 'what': ('config 2 under `mixed_precision: True`: f16 storage' if prec == 'mixed'
+                              else 'config 2 in the headline mode with `loss_scale: dynamic`') + '; GradScaler on the device, per step: overflow '
+                              'reported by the producing launches (scale records), skipped step + backoff / growth in front of the fused '
+                              'optimizer launch, cross-step schedule kept'}
                              if ag.engine.dyn_scale else {})}), flush=True)
         del ag
         torch.cuda.empty_cache()

@@ -14,8 +14,25 @@ from ase_amd import lib as L
 
 
 def _dyn(t):
-    """Value of a `*_dev` / dyn argument (a device f32 scalar the HIP launch multiplies its scale by), 1 when absent."""
+    """Factor of a `*_dev` / dyn argument (a scale record {factor, overflow count} on the device - include/ase_hip.h, ABI 7 - or a
+    bare f32 factor), 1 when absent."""
     return 1.0 if t is None else float(t.reshape(-1)[0])
+
+
+def _overflowed(x):
+    """csrc/common.h ovf_hit1: a STORED element that is not finite or (IEEE half, whose conversions saturate) sits at +-65504."""
+    v = x.float()
+    bad = ~torch.isfinite(v)
+    if x.dtype == torch.float16:
+        bad |= v.abs() >= 65504.0
+    return bool(bad.any())
+
+
+def _report(rec, *stored):
+    """What a launch that was given a scale record does with what it stored: count += (something positive) on an overflow."""
+    if rec is not None and any(_overflowed(x) for x in stored):
+        assert rec.numel() >= 2, "a launch that may report needs a {factor, count} record"
+        rec.reshape(-1)[1] += 1.0
 
 
 def _rows(idx, remap, M):
@@ -154,8 +171,10 @@ class EmuBackend:
             v = v * (1 - x * x)
         out = _store(v, Cm.dtype)
         Cm[:M, :N] = out
+        _report(alpha_dev, out)
         if mask_out is not None and act >= L.ACT_SILU:        # twin of a smooth activation: the pre-activation itself
             mask_out[:M, :N] = _store(z_pre, mask_out.dtype)
+            _report(alpha_dev, mask_out[:M, :N])
         elif mask_out is not None:
             assert N % 32 == 0
             b = (out.float() > 0).to(torch.int64).reshape(M, N // 32, 32)
@@ -346,6 +365,7 @@ class EmuBackend:
             dv = 2 * (v - R)
         ov_ = _store(gs * (critic_coef * dv / m_global), d_value.dtype)
         d_value[:M, 0] = ov_
+        _report(dyn, ov_, d_mu[:2 * M if div_on else M, :D])
         if db_mu is not None:
             db_mu[:D] += dbm
             if db_value is not None:
@@ -374,6 +394,7 @@ class EmuBackend:
         gd = -disc_coef * 0.5 * torch.sigmoid(-ld) / amb_global
         o = _store(grad_scale * torch.cat([ga, gd]), d_logit.dtype)
         d_logit[:3 * amb, 0] = o
+        _report(dyn, o)
         if db_logit is not None:
             db_logit[0] += o.float().sum() / grad_scale
 
@@ -385,6 +406,7 @@ class EmuBackend:
         dot = (h * zv).sum(-1, keepdim=True)
         o = _store(grad_scale * (-(enc_coef / amb_global) * (zv - h * dot) / nrm), d_e.dtype)
         d_e[:amb, :z_dim] = o
+        _report(dyn, o)
         if db_enc is not None:
             db_enc[:z_dim] += o.float().sum(0) / grad_scale
         if enc_out is not None:
@@ -409,6 +431,7 @@ class EmuBackend:
         old = d_e[:rows, :z_dim].float().clone()
         new = _store(old + grad_scale * jr, d_e.dtype)
         d_e[:rows, :z_dim] = new
+        _report(dyn, new)
         if db_enc is not None:
             db_enc[:z_dim] += (new.float() - old).sum(0) / grad_scale
 
@@ -503,16 +526,20 @@ class EmuBackend:
 
     def scaler_check(self, buf, scaler):
         """csrc/scaler.hip: not finite, or (half storage, whose conversions saturate) at +-65504."""
-        x = buf.float()
-        bad = ~torch.isfinite(x)
-        if buf.dtype == torch.float16:
-            bad |= x.abs() >= 65504.0
-        if bool(bad.any()):
+        if _overflowed(buf):
             scaler[0] += 1.0
 
+    def scaler_check_multi(self, bufs, scaler, table=None):
+        for t in bufs:
+            self.scaler_check(t, scaler)
+
+    def scaler_fold(self, scaler, scale_tab):
+        scaler[0] += float(scale_tab[1::2].sum())
+        scale_tab[1::2] = 0.0
+
     def scaler_step(self, scaler, opt_state, opt_eff, grads, scale_tab=None):
-        found = float(scaler[0]) != 0.0
-        if float(scaler[0]) != 0.0:
+        found = float(scaler[0]) != 0.0 or (scale_tab is not None and float(scale_tab[1::2].sum()) != 0.0)
+        if found:
             grads.zero_()
             opt_state[0] -= 1.0
             opt_eff.copy_(opt_state)
@@ -536,7 +563,8 @@ class EmuBackend:
                 s *= float(scaler[5])
                 scaler[2] = 0.0
             scaler[4] = s
-            scale_tab[0], scale_tab[1], scale_tab[2], scale_tab[3] = s, 1.0 / s, 1.0 / (s * s), 0.0
+            scale_tab[0], scale_tab[2], scale_tab[4], scale_tab[6] = s, 1.0 / s, 1.0 / (s * s), 1.0
+            scale_tab[1::2] = 0.0
 
     # ------------------------------------------------------------------ rollout tail
     def disc_reward(self, logit, r, n, scale):

@@ -11,6 +11,7 @@ import os
 import pytest
 import torch
 
+from ase_amd import lib as L
 from tests.emu_backend import EmuBackend
 from tests.helpers import close, set_rms
 from tests.test_engine_emu import first_step
@@ -38,14 +39,16 @@ def _reset_rms(G, eng):
 def _scale_of(eng):
     tab = eng.scale_tab.tolist()
     s = float(eng.scaler[4])
-    assert tab[0] == s and abs(tab[1] * s - 1.0) < 1e-6 and abs(tab[2] * s * s - 1.0) < 1e-6, (tab, s)      # table follows the state
+    # the table of scale records {factor, overflow count} follows the state; the counts are consumed by the step
+    assert tab[0] == s and abs(tab[2] * s - 1.0) < 1e-6 and abs(tab[4] * s * s - 1.0) < 1e-6 and tab[6] == 1.0, (tab, s)
+    assert tab[1::2] == [0.0, 0.0, 0.0, 0.0], tab
     return s
 
 
 def check_dynamic_loss_scale(G, make_backend, device='cpu', gp_f32=False):
     """One minibatch of a golden, two calls of the dynamic engine against the static-scale engine:
       1. at a scale 2^30 above the static choice the scaled backward saturates half storage: the step is SKIPPED - weights, Adam
-         moments and the optimizer's step counter are bit-for-bit what they were, the exported gradient is zero, the loss scalars
+         moments and the optimizer's step counter are bit-for-bit what they were, the step's gradient is dropped, the loss scalars
          of the forward (formed in f32) are those of the static engine - and the scale has ALREADY backed off on the device
          (here in one move, backoff_factor 2^-30): no host decision, nothing to re-record;
       2. the same minibatch again, same engine object, same launches, is a CLEAN step at the new scale that equals the static engine's
@@ -76,7 +79,10 @@ def check_dynamic_loss_scale(G, make_backend, device='cpu', gp_f32=False):
     for k, v in init_sd.items():
         assert torch.equal(sd[k].detach().cpu(), v.cpu()), 'weight moved in a skipped step: ' + k
     assert float(eng_d.adam_m.abs().max()) == 0.0 and float(eng_d.adam_v.abs().max()) == 0.0
-    assert float(eng_d.grads[:eng_d.n_train].abs().max()) == 0.0
+    # the step's gradient was dropped: what the exported buffer holds afterwards is at most the weight-only loss terms c * W the fused
+    # optimizer launch adds behind the decision (the identity step ignores them) - nothing of the overflowed backward, nothing non-finite
+    gmax = float(eng_d.grads[:eng_d.n_train].abs().max())
+    assert math.isfinite(gmax) and gmax <= 0.25 * float(eng_d.params[:eng_d.n_train].abs().max()) + 1e-12, gmax
     rs, rd = eng_s.results(), eng_d.results()
     for k in ('actor_loss', 'critic_loss', 'kl'):        # (not the penalties: their values come out of the scaled chains)
         if k in rs:
@@ -143,13 +149,24 @@ def test_scaler_ops_emulated():
     assert eff.tolist() == [2.0, 0.0, 1.0, 1.0, 1e-8, 1.0, 1.0, 0.0] and sc.tolist()[:4] == [0.0, 1.0, 0.0, 2.0]
     # GradScaler.update() on the device state (scale_tab given): backoff at once, growth when the tracker reaches the interval
     sc = torch.tensor([1.0, 0, 0, 0, 1024.0, 2.0, 0.5, 2.0], dtype=torch.float64)
-    tab = torch.zeros(4)
+    tab = torch.zeros(8)
     be.scaler_step(sc, opt, eff, g, scale_tab=tab)                          # overflow: 1024 -> 512
-    assert sc.tolist() == [0.0, 1.0, 0.0, 1.0, 512.0, 2.0, 0.5, 2.0] and tab.tolist() == [512.0, 1 / 512.0, 1 / 512.0 ** 2, 0.0]
+    assert sc.tolist() == [0.0, 1.0, 0.0, 1.0, 512.0, 2.0, 0.5, 2.0]
+    assert tab.tolist() == [512.0, 0.0, 1 / 512.0, 0.0, 1 / 512.0 ** 2, 0.0, 1.0, 0.0]
     be.scaler_step(sc, opt, eff, g, scale_tab=tab)                          # clean 1 of 2
     assert sc.tolist()[:5] == [0.0, 1.0, 1.0, 2.0, 512.0]
     be.scaler_step(sc, opt, eff, g, scale_tab=tab)                          # clean 2 of 2: growth, tracker starts over
-    assert sc.tolist()[:5] == [0.0, 1.0, 0.0, 3.0, 1024.0] and tab.tolist()[:2] == [1024.0, 1 / 1024.0]
+    assert sc.tolist()[:5] == [0.0, 1.0, 0.0, 3.0, 1024.0] and tab.tolist()[:3] == [1024.0, 0.0, 1 / 1024.0]
+    # what the PRODUCERS reported into a record's count (ABI 7) decides like scaler[found]: skipped step, backoff, counts consumed
+    g = torch.ones(10)
+    tab[5] = 3.0
+    be.scaler_step(sc, opt, eff, g, scale_tab=tab)
+    assert float(g.abs().sum()) == 0.0 and sc.tolist()[:5] == [0.0, 2.0, 0.0, 4.0, 512.0] and tab.tolist()[1::2] == [0.0] * 4
+    # ... and scaler_fold moves the counts into scaler[found] (what a data-parallel step exchanges)
+    tab[1], tab[7] = 1.0, 2.0
+    be.scaler_fold(sc, tab)
+    assert float(sc[0]) == 3.0 and tab.tolist()[1::2] == [0.0] * 4
+    sc[0] = 0.0
     # the identity step through the optimizer op: nothing moves, even with moments in place
     opt = torch.tensor([3.0, 2e-5, 0.9, 0.999, 1e-8, 0.271, 0.003, 0.0], dtype=torch.float64)
     sc = torch.zeros(8, dtype=torch.float64)
@@ -159,6 +176,40 @@ def test_scaler_ops_emulated():
     w0, m0, v0 = w.clone(), m.clone(), v.clone()
     be.adam(w, g, m, v, eff)
     assert torch.equal(w, w0) and torch.equal(m, m0) and torch.equal(v, v0)
+
+
+def test_producers_report_into_their_record():
+    """A launch that is given a scale record {factor, count} multiplies the factor in and counts an overflow it STORED (csrc/common.h
+    ovf_report): matrix launch (output and pre-activation twin), the loss heads' stored gradients; nothing is counted for finite values,
+    for what a ReLU clips away, or without a record."""
+    be = EmuBackend()
+    f16 = torch.float16
+    A = torch.full((4, 64), 30.0, dtype=f16)
+    B = torch.full((32, 64), 40.0, dtype=f16)            # 64 * 1200 = 76800 > 65504
+    C = torch.zeros(4, 32, dtype=f16)
+    rec = torch.tensor([1.0, 0.0])
+    be.gemm_nt(A, B, C, 4, 32, 64, alpha_dev=rec)
+    assert float(rec[1]) > 0 and float(C.float().abs().max()) == 65504.0
+    rec = torch.tensor([0.5, 0.0])                        # the factor is applied first: 38400 fits
+    be.gemm_nt(A, B, C, 4, 32, 64, alpha_dev=rec)
+    assert float(rec[1]) == 0 and float(C[0, 0]) == 38400.0
+    rec = torch.tensor([-1.0, 0.0])                       # -76800 -> ReLU stores 0: nothing overflowed in storage
+    be.gemm_nt(A, B, C, 4, 32, 64, act=L.ACT_RELU, alpha_dev=rec)
+    assert float(rec[1]) == 0 and float(C.abs().max()) == 0.0
+    Cb = torch.zeros(4, 32, dtype=torch.bfloat16)         # bf16 storage does not saturate: finite stays finite
+    rec = torch.tensor([1.0, 0.0])
+    be.gemm_nt(A.to(torch.bfloat16), B.to(torch.bfloat16), Cb, 4, 32, 64, alpha_dev=rec)
+    assert float(rec[1]) == 0
+    be.gemm_nt(A, B, C, 4, 32, 64)                        # no record: nothing to write to
+    logit = torch.zeros(12, 1)
+    d = torch.zeros(12, 1, dtype=f16)
+    acc = torch.zeros(L.ACC_COUNT, dtype=torch.float64)
+    rec = torch.tensor([2.0 ** 40, 0.0])
+    be.disc_head(logit, d, None, acc, 4, 4, 5.0, grad_scale=1.0, dyn=rec)
+    assert float(rec[1]) > 0
+    rec = torch.tensor([2.0 ** 10, 0.0])
+    be.disc_head(logit, d, None, acc, 4, 4, 5.0, grad_scale=1.0, dyn=rec)
+    assert float(rec[1]) == 0
 
 
 def test_scale_trajectory_matches_torch_gradscaler(golden_dir):
