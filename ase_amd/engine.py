@@ -22,6 +22,7 @@ Data layout in HBM
     kernels, so neither swap_and_flatten01 nor the dataset gather materialise anything.
 """
 import math
+import os
 
 import torch
 
@@ -892,7 +893,10 @@ class UpdateEngine:
             # gradients goes to the discriminator's stream (that branch is their first user).
             m0 = self._mark()
             with self._Branch(self, self._side(1), m0):
-                be.zero_(self.grads[:self.n_train])
+                if os.environ.get('ASE_DEBUG_ZERO') == 'torch':
+                    self.grads[:self.n_train].zero_()
+                else:
+                    be.zero_(self.grads[:self.n_train])
                 self._fill_done = self._mark()
             self._early_fork = self._fill_done if self.has_disc else None
             with self._Branch(self, self._side(0), m0) as prep:
@@ -1195,7 +1199,7 @@ class UpdateEngine:
                     self._dgrad(self.enc_head, self.dE, self.dZe[-1], AMB, self.He[-1], last.act)
                     self._bwd_chain(self.enc_chain, self.Xd[:AMB], self.He, self.dZe, AMB)
                 # (every contribution of this branch to the loss partial sums - logit losses, penalties, encoder loss - is launched)
-                self._disc_acc_mark = self._mark()
+                self._disc_acc_mark = None if os.environ.get('ASE_DEBUG_NO_ACC_MARK') else self._mark()
                 self._finish_branch('disc', inline_apply)
             self._tn_queue = tnq
         self._join_branch(br_critic)
