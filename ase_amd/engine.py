@@ -22,7 +22,6 @@ Data layout in HBM
     kernels, so neither swap_and_flatten01 nor the dataset gather materialise anything.
 """
 import math
-import os
 
 import torch
 
@@ -198,7 +197,10 @@ class UpdateEngine:
         self._tn_early = bool(o['tn_early'])
         self._disc_early = bool(o['disc_early'])
         self._early_fork = None
-        self._short_prologue = bool(o['short_prologue'])
+        # (captured hipGraphs keep the serial prologue: at config-2 size torch's capture_end segfaults on the graph of a step whose
+        #  prologue is forked onto the side streams - every precision, ROCm 7.2; `profiles/r06_hipgraph_triage.txt`.  Launch programs,
+        #  the default replay form and 2x faster than the captured graph anyway, are not affected)
+        self._short_prologue = bool(o['short_prologue']) and cfg.get('graph_capture') != 'hipgraph'
         self._prep = self._lat_ready = self._fill_done = None
         self._style_early = bool(o['style_early'])
         self._n_side = max(1, min(int(o['side_streams']), 2))
@@ -207,7 +209,7 @@ class UpdateEngine:
         self._fused_apply = hasattr(backend, 'apply_multi') and bool(o['fused_apply'])
         # (a captured hipGraph forks every stream from the capturing one: an un-chained branch head cannot be captured)
         self._xstep = bool(o['xstep']) and cfg.get('graph_capture') != 'hipgraph'
-        self._gp_side = bool(o['gp_stream'])
+        self._gp_side = bool(o['gp_stream']) and cfg.get('graph_capture') != 'hipgraph'      # (a fork from a forked stream: same capture_end crash)
         self._style_side = int(o['style_side'])
         self._disc_after_style = bool(o['disc_after_style'])
         self._disc_split = False
@@ -893,10 +895,7 @@ class UpdateEngine:
             # gradients goes to the discriminator's stream (that branch is their first user).
             m0 = self._mark()
             with self._Branch(self, self._side(1), m0):
-                if os.environ.get('ASE_DEBUG_ZERO') == 'torch':
-                    self.grads[:self.n_train].zero_()
-                else:
-                    be.zero_(self.grads[:self.n_train])
+                be.zero_(self.grads[:self.n_train])
                 self._fill_done = self._mark()
             self._early_fork = self._fill_done if self.has_disc else None
             with self._Branch(self, self._side(0), m0) as prep:
@@ -1199,7 +1198,7 @@ class UpdateEngine:
                     self._dgrad(self.enc_head, self.dE, self.dZe[-1], AMB, self.He[-1], last.act)
                     self._bwd_chain(self.enc_chain, self.Xd[:AMB], self.He, self.dZe, AMB)
                 # (every contribution of this branch to the loss partial sums - logit losses, penalties, encoder loss - is launched)
-                self._disc_acc_mark = None if os.environ.get('ASE_DEBUG_NO_ACC_MARK') else self._mark()
+                self._disc_acc_mark = self._mark()
                 self._finish_branch('disc', inline_apply)
             self._tn_queue = tnq
         self._join_branch(br_critic)
