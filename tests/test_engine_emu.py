@@ -3,6 +3,7 @@ gradient-penalty chain, concat-column maps, Adam, running statistics) checked on
 drives tests/emu_backend.py (same op semantics as the HIP kernels) and must reproduce what the
 REFERENCE produced for the same minibatch (golden vectors): every loss scalar, every gradient
 tensor of the first step and the post-Adam weights."""
+import copy
 import os
 
 import pytest
@@ -188,3 +189,15 @@ def test_gradient_penalty_in_f32_inside_a_half_engine(name, golden_dir):
             e_16 = float((g16[k] - g).norm() / g.norm())
             e_32 = float((g32[k] - g).norm() / g.norm())
             assert e_32 <= e_16 * 1.05 + 1e-6, (k, e_16, e_32)
+
+
+def test_hipgraph_mode_runs_the_plain_schedule(golden_dir):
+    """graph_capture: 'hipgraph' switches off what torch's capture cannot hold at config-2 size on ROCm 7.2 (profiles/r06_hipgraph_triage.txt:
+    capture_end segfaults on a step whose prologue is forked onto the side streams, and on a fork from a forked stream): the cross-step
+    schedule, the short prologue, the penalty value path's own stream - whatever engine_opts asks for; the launch-program mode keeps all."""
+    G = torch.load(os.path.join(golden_dir, 'ase_tiny.pt'), weights_only=False)
+    for mode, plain in (('hipgraph', True), (True, False)):
+        Gm = copy.deepcopy(G)
+        Gm['cfg'].update(graph_capture=mode, engine_opts={'xstep': True, 'short_prologue': True, 'gp_stream': True})
+        _, eng = first_step(Gm, EmuBackend(), torch.float32)
+        assert (eng._xstep, eng._short_prologue, eng._gp_side) == ((False, False, False) if plain else (True, True, True)), mode

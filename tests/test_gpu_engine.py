@@ -368,8 +368,8 @@ def test_parity_at_16384_envs(mode, loss_tol, grad_tol):
 # (f32: what the schedules measure against each other - worst element 10.0 ... 19.5 lr over 12 comparisons, mean 0.053 ... 0.059 lr,
 #  scalars <= 3e-4 (profiles/r05_schedule_drift.txt, scripts/lab/schedule_drift.py).  Round 5 doubled the bound on the single WORST
 #  element because 20 lr failed once in ~8 runs; the advisor's point stands - a maximum over 7 M elements is the wrong statistic for
-#  "no race".  Round 6: the MEAN keeps round 4's bound (0.1 lr), the TAIL is a count - at most 2e-5 of the elements further than
-#  5 lr apart (a race moves whole tiles: thousands of elements by hundreds of lr) - and the maximum is only a gross bound.)
+#  "no race".  Round 6: the MEAN keeps round 4's bound (0.1 lr), the TAIL is a count - at most 1e-4 of the elements further than
+#  5 lr apart (measured <= 2.3e-5; a race moves whole tiles: percents of the elements by hundreds of lr) - and the maximum is only a gross bound.)
 @pytest.mark.parametrize('precision,w_max,w_mean,s_rtol', [('f32', 40, 0.1, 5e-3), ('f16gpx3', 80, 0.5, 5e-2), ('bf16', 120, 1.0, 0.25)])
 def test_schedule_variants_agree_config2(precision, w_max, w_mean, s_rtol):
     """The round-4 schedule (discriminator head and prologue un-chained from the main stream, penalty value path on its own
@@ -409,7 +409,10 @@ def _schedule_pair_agrees(w0, o0, a0, r0, w1, o1, a1, r1, w_max, w_mean, s_rtol)
     d = (w0 - w1).abs()
     assert float(d.max()) <= w_max * lr, float(d.max())
     assert float(d.mean()) <= w_mean * lr, float(d.mean())
-    assert float((d > 0.125 * w_max * lr).float().mean()) <= 2e-5, float((d > 0.125 * w_max * lr).float().mean())     # the tail, as a count
+    # the tail, as a count: benign drift (the order of f32 / f64 atomics) leaves <= 2.3e-5 of the weights further than an eighth of the
+    # max bound apart (five runs on five boxes of round 6: 4 x below 2e-5, once 2.26e-5); a race - a stale buffer read by a whole launch -
+    # moves percents of them
+    assert float((d > 0.125 * w_max * lr).float().mean()) <= 1e-4, float((d > 0.125 * w_max * lr).float().mean())
     close(o1, o0, 1e-6, 1e-6, 'obs running statistics')
     close(a1, a0, 1e-6, 1e-6, 'amp running statistics')
     for k in r0:
