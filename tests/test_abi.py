@@ -215,3 +215,10 @@ def test_scaler_entry_points_validate_on_the_host():
     assert lib.ase_hip_scaler_step(p, p, p, p, 8, None, None) == -1 and b'scaler_step' in lib.ase_hip_last_error()      # opt_eff aliases opt_state
     assert lib.ase_hip_scaler_step(None, p, p, p, 8, None, None) == -1
     assert lib.ase_hip_scaler_step(p, p, ctypes.c_void_p(p.value + 8), p, 0, None, None) == -1
+    # ABI 7: the table form of the check and the fold of the records' counts
+    assert lib.ase_hip_scaler_check_multi(None, 3, 64, p, None) == -1 and b'scaler_check_multi' in lib.ase_hip_last_error()
+    assert lib.ase_hip_scaler_check_multi(p, 0, 64, p, None) == -1
+    assert lib.ase_hip_scaler_check_multi(p, 3, 0, p, None) == -1 and b'wg_per_buf' in lib.ase_hip_last_error()
+    assert lib.ase_hip_scaler_check_multi(p, 3, 64, None, None) == -1
+    assert lib.ase_hip_scaler_fold(None, p, None) == -1 and b'scaler_fold' in lib.ase_hip_last_error()
+    assert lib.ase_hip_scaler_fold(p, None, None) == -1
