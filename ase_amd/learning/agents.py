@@ -601,7 +601,7 @@ class CommonAgent:
     def _graph_step(self, idx, streams):
         """Replay the optimisation step from a recorded launch sequence.  config['graph_capture']:
           True / 'program'  the library's own launch program (ase_hip_prog_*): the step's launches + fork / join points over
-                            the engine's streams, replayed with ~1 us of host work per launch, branch -> stream mapping
+                            the engine's streams, replayed with 4-5 us of host work per launch (measured, scripts/lab/host_vs_gpu.py), branch -> stream mapping
                             fixed by us;
           'hipgraph'        a captured hipGraph (torch.cuda.CUDAGraph): the runtime chooses how its branches map to queues.
         Launch programs: ONE program for the whole step, data parallel included - the collectives are host-callback entries

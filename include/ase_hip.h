@@ -473,7 +473,7 @@ int ase_hip_motion_state(const float* gts, const float* grs, const float* lrs, c
                          float* root_vel, float* root_ang_vel, float* dof_vel, float* key_pos, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Launch programs: record a sequence of the calls above ONCE (nothing is launched while recording), replay it with ~1 us
+ * Launch programs: record a sequence of the calls above ONCE (nothing is launched while recording), replay it with 4-5 us
  * of host work per launch on the same HIP streams - the optimisation step as one call, with OUR branch -> stream mapping
  * (a captured hipGraph picks its own; eager launches from Python fall behind the GPU).  Recording is per thread.
  * ase_hip_mark / ase_hip_wait are the fork / join points between streams (event record / stream-wait-event); outside a

@@ -945,6 +945,52 @@ def test_launch_program_replay(be):
     be.prog_destroy(prog)
 
 
+def test_launch_program_keeps_dependencies_and_callback_order(be):
+    """A chain of copies handed from stream to stream through marks (four streams, one stage recorded before the stage it depends on is
+    complete in program order) - a wait that does not see its record reads the previous replay's data - and host callbacks recorded on
+    different streams run in PROGRAM order (the collectives of a data-parallel step).  400 replays with new data each."""
+    n = 1 << 22
+    src, a, b, c, out = (torch.zeros(n, device='cuda') for _ in range(5))
+    s1, s2, s3 = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    order = []
+    prog = be.prog_create()
+    be.prog_begin(prog)
+    fork = be.mark()
+    with torch.cuda.stream(s1):
+        be.wait(fork)
+        be.host_call(lambda: order.append(0))
+        be.copy_(a, src)
+        m1 = be.mark()
+    with torch.cuda.stream(s3):                       # (recorded BEFORE the stage it depends on is complete in program order)
+        be.wait(fork)
+        be.zero_(c)
+        m0 = be.mark()
+    with torch.cuda.stream(s2):
+        be.wait(m1)
+        be.copy_(b, a)
+        be.host_call(lambda: order.append(1))
+        m2 = be.mark()
+    with torch.cuda.stream(s3):
+        be.wait(m2)
+        be.wait(m0)
+        be.copy_(c, b)
+        m3 = be.mark()
+    be.host_call(lambda: order.append(2))
+    be.wait(m3)
+    be.copy_(out, c)
+    be.prog_end(prog)
+    assert not order
+    for k in range(1, 401):
+        src.fill_(float(k))
+        torch.cuda.synchronize()
+        be.prog_launch(prog)
+        torch.cuda.synchronize()
+        assert float(out[0]) == k and float(out[-1]) == k and float(out.min()) == k, (k, float(out[0]), float(out[-1]))
+        assert order == [0, 1, 2], (k, order)
+        order.clear()
+    be.prog_destroy(prog)
+
+
 @pytest.mark.parametrize('kl,expect', [(0.05, 2e-5 / 1.5), (0.001, 2e-5 * 1.5), (0.01, 2e-5)])
 def test_finalize_scalars_adaptive_lr(be, kl, expect):
     """The rl_games AdaptiveScheduler branch of ase_hip_finalize_scalars (learning/common_agent.py:204-208): lr / 1.5 when the
