@@ -236,6 +236,54 @@ def test_two_ranks_sharded_update_matches_reference(name, graph):
     mp.spawn(_dp_worker, args=(2, port, name, 'f32', graph), nprocs=2, join=True)
 
 
+def _dp_scaler_worker(rank, world, port, name, out):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from ase_amd.backend import HipBackend
+    G = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', name + '.pt'), weights_only=False)
+    ag = make_agent(G, HipBackend('cuda:0'), device='cuda:0', precision='f16', world_size=world, rank=rank, graph_capture=True,
+                    loss_scale='dynamic', loss_scaler={'init_scale': 16.0})
+    eng = ag.engine
+    assert eng.dyn_scale and eng.scaler_state()['scale'] == 16.0
+    if rank == 1:            # an overflow only THIS rank's launches report, in the very first step: a count in its record of factor 1
+        eng.scale_tab[7] = 1.0
+    replay_epochs(G, ag, rtol=1.0, wtol=1.0, check=False, max_steps=2)
+    torch.cuda.synchronize()
+    flat = ag.model.a2c_network.flat_params.detach().cpu().clone()
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    states = [None] * world
+    dist.all_gather_object(states, eng.scaler_state())
+    if rank == 0:
+        torch.save({'flats': gathered, 'states': states, 'opt_step': float(eng.opt_state[0]), 'xs': bool(eng._xs)}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_skip_the_same_step(tmp_path, golden_dir):
+    """The dynamic loss scale under data parallelism on the HIP path, inside recorded launch programs: the producers' reports are folded
+    (ase_hip_scaler_fold), the flag is SUM-exchanged as a host-callback entry of the step's program in front of the ONE decision
+    (UpdateEngine._dyn_apply, on the discriminator's stream) - a step only rank 1 saw an overflow in is skipped by BOTH ranks, the
+    replicas stay bit-identical, the scale backs off once on both.  (CPU counterpart: tests/test_dp_gloo.py::test_two_ranks_skip_the_same_step.)"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / 'sc.pt')
+    mp.spawn(_dp_scaler_worker, args=(2, port, 'ase_tiny', out), nprocs=2, join=True)
+    r = torch.load(out, weights_only=False)
+    assert torch.equal(r['flats'][0], r['flats'][1])
+    s0, s1 = r['states']
+    assert s0 == s1, (s0, s1)
+    G = torch.load(os.path.join(golden_dir, 'ase_tiny.pt'), weights_only=False)
+    n_upd = len(G['epochs'])
+    assert s0['steps'] == 2 * n_upd and s0['skipped'] == 1 and s0['scale'] == 8.0, s0
+    assert r['opt_step'] == 2 * n_upd - 1
+
+
 @pytest.mark.parametrize('name', ['ase_tiny', 'amp_tiny', 'ppo_tiny'])
 @pytest.mark.parametrize('precision', ['f32', 'bf16'])
 def test_rollout_inference_matches_reference(be, name, precision, golden_dir):
