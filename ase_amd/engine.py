@@ -183,10 +183,14 @@ class UpdateEngine:
         #   gp_split        gp_f32 = 'x3': 'f16' = three f16 MFMAs per product on hi / lo splits of scaled operands (ASE_F32H3, ~2^-22),
         #                   'bf16' = round 4's bf16 split (ASE_F32X3, ~2^-17; penalty 1.08e-4 off in the driver's round-4 run)
         #   gp_stream       gp_f32 modes: the penalty's value path (f32 / bf16x3 forward of the demo rows + chain: independent of
-        #                   the loss rows until the conversion launch) on its own stream beside the discriminator branch
+        #                   the loss rows until the conversion launch) on its own stream beside the discriminator branch.  Round 4's
+        #                   A/B had it faster (with the bf16-split kernels of that round); on round 6's kernels it is SLOWER: f16gpx3
+        #                   76.29 vs 74.58 ms per update without it (four interleaved repetitions on one box, a second box 77.76 vs
+        #                   75.72; profiles/r06_schedule_options_ab.txt) - six more small-tile matrix launches in flight beside the
+        #                   256 x 256 kernels of three streams cost more CU fragmentation than their overlap buys.  Off since round 6
         o = dict(tn_grouped=True, tn_wg_side=64, tn_early=False, disc_early=True, short_prologue=True, style_early=False,
                  relu_bits=True, fused_apply=True, apply_wide=True, side_streams=2, gp_scale_split=True, xstep=True,
-                 gp_stream=True, style_side=0, style_wg=0, side_priority=None, prefetch=True, disc_after_style=False, gp_split='f16')
+                 gp_stream=False, style_side=0, style_wg=0, side_priority=None, prefetch=True, disc_after_style=False, gp_split='f16')
         unknown = set(cfg.get('engine_opts', {}) or {}) - set(o)
         assert not unknown, f"unknown engine_opts {sorted(unknown)}"
         o.update(cfg.get('engine_opts', {}) or {})

@@ -386,7 +386,7 @@ def test_schedule_variants_agree_config2(precision, w_max, w_mean, s_rtol):
     # third variant (round 5, advisor): the cross-step schedule WITHOUT result rings - the double-buffered prologue inputs
     # then follow the minibatch position's parity (engine.use_parity) instead of the ring slot's
     for opts, extra in (({'xstep': False, 'prefetch': False, 'gp_stream': False}, {'main_stream_priority': 0, 'result_rings': False}),
-                        ({}, {}), ({}, {'result_rings': False})):
+                        ({}, {}), ({'xstep': True, 'gp_stream': True}, {'result_rings': False})):   # (gp_stream: off by default since round 6, covered here)
         agent, cfg, spec = bench.make_agent('cuda:0', precision, 'program', 1, 0, engine_opts=opts or {'xstep': True}, extra_cfg=extra)
         bench.fill_rollout(agent, 'cuda:0')
         agent._init_amp_demo_buf()
