@@ -187,10 +187,14 @@ class UpdateEngine:
         #                   A/B had it faster (with the bf16-split kernels of that round); on round 6's kernels it is SLOWER: f16gpx3
         #                   76.29 vs 74.58 ms per update without it (four interleaved repetitions on one box, a second box 77.76 vs
         #                   75.72; profiles/r06_schedule_options_ab.txt) - six more small-tile matrix launches in flight beside the
-        #                   256 x 256 kernels of three streams cost more CU fragmentation than their overlap buys.  Off since round 6
+        #                   256 x 256 kernels of three streams cost more CU fragmentation than their overlap buys.  But where the
+        #                   discriminator branch IS the step's critical path the own stream wins clearly: one rank's share of a sharded
+        #                   step (4096 rows: 796 vs 1038 us, 2048 rows: 622 vs 919; 8192 rows: 1089 vs 1044 - off again) and under the
+        #                   dynamic loss scale (95.3 vs 115.2 ms).  'auto' (default) = on for minibatches below 8192 rows and under the
+        #                   dynamic loss scale, off otherwise; True / False force it
         o = dict(tn_grouped=True, tn_wg_side=64, tn_early=False, disc_early=True, short_prologue=True, style_early=False,
                  relu_bits=True, fused_apply=True, apply_wide=True, side_streams=2, gp_scale_split=True, xstep=True,
-                 gp_stream=False, style_side=0, style_wg=0, side_priority=None, prefetch=True, disc_after_style=False, gp_split='f16')
+                 gp_stream='auto', style_side=0, style_wg=0, side_priority=None, prefetch=True, disc_after_style=False, gp_split='f16')
         unknown = set(cfg.get('engine_opts', {}) or {}) - set(o)
         assert not unknown, f"unknown engine_opts {sorted(unknown)}"
         o.update(cfg.get('engine_opts', {}) or {})
@@ -213,7 +217,8 @@ class UpdateEngine:
         self._fused_apply = hasattr(backend, 'apply_multi') and bool(o['fused_apply'])
         # (a captured hipGraph forks every stream from the capturing one: an un-chained branch head cannot be captured)
         self._xstep = bool(o['xstep']) and cfg.get('graph_capture') != 'hipgraph'
-        self._gp_side = bool(o['gp_stream']) and cfg.get('graph_capture') != 'hipgraph'      # (a fork from a forked stream: same capture_end crash)
+        gp_side = (self.dyn_scale or minibatch < 8192) if o['gp_stream'] == 'auto' else bool(o['gp_stream'])
+        self._gp_side = gp_side and cfg.get('graph_capture') != 'hipgraph'      # (a fork from a forked stream: same capture_end crash)
         self._style_side = int(o['style_side'])
         self._disc_after_style = bool(o['disc_after_style'])
         self._disc_split = False
