@@ -217,7 +217,7 @@ class UpdateEngine:
         self._fused_apply = hasattr(backend, 'apply_multi') and bool(o['fused_apply'])
         # (a captured hipGraph forks every stream from the capturing one: an un-chained branch head cannot be captured)
         self._xstep = bool(o['xstep']) and cfg.get('graph_capture') != 'hipgraph'
-        gp_side = (self.dyn_scale or minibatch < 8192) if o['gp_stream'] == 'auto' else bool(o['gp_stream'])
+        gp_side = (self.dyn_scale or self.M < 8192) if o['gp_stream'] == 'auto' else bool(o['gp_stream'])      # (self.M: THIS rank's rows)
         self._gp_side = gp_side and cfg.get('graph_capture') != 'hipgraph'      # (a fork from a forked stream: same capture_end crash)
         self._style_side = int(o['style_side'])
         self._disc_after_style = bool(o['disc_after_style'])
@@ -968,6 +968,13 @@ class UpdateEngine:
             return None
         if self._side_streams is None:
             self._side_streams = [torch.cuda.Stream(device=self.dev, priority=self._side_prio[k % 3]) for k in range(self._n_side)]
+            if self.gp32 and not self._gp_side and self._gp_stream_obj is None:
+                # A gp_f32 engine takes its value-path stream from the pool even when it does not use it (gp_stream off): streams
+                # land on the hardware queues in creation order, and an engine that takes THREE streams shifts every later engine of
+                # the process by one place - the benchmark's later legs (bf16 throughput mode, the 16384-environment batch) then ran
+                # with two of their branch streams on one hardware queue: 82-85 ms instead of 62, 371-374 instead of 296-303
+                # (profiles/r06_bench_n1.json's history: calls AC / AE against I / M)
+                self._gp_stream_obj = torch.cuda.Stream(device=self.dev, priority=self._side_prio[2])
         return self._side_streams[k % len(self._side_streams)]
 
     def fence_side_streams(self):

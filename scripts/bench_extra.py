@@ -94,10 +94,14 @@ def main():
     ap.add_argument('--only', default='')
     ap.add_argument('--shard-of', default='', help='comma list of rank counts R: time one rank\'s share of the sharded update')
     ap.add_argument('--precision', default='bf16')
+    ap.add_argument('--engine-opts', default='', help='JSON dict of UpdateEngine.engine_opts overrides (the --shard-of runs)')
     args = ap.parse_args()
     if args.shard_of:
         for R in [int(x) for x in args.shard_of.split(',')]:
-            ag, cfg, spec = build('ase', 4096, args.precision, overrides={'minibatch_size': 16384 // R, 'amp_minibatch_size': 4096 // R})
+            ov = {'minibatch_size': 16384 // R, 'amp_minibatch_size': 4096 // R}
+            if args.engine_opts:
+                ov['engine_opts'] = json.loads(args.engine_opts)
+            ag, cfg, spec = build('ase', 4096, args.precision, overrides=ov)
 
             def one():
                 return ag.update(ag._play_steps_tail(), max_steps=48)
@@ -115,7 +119,7 @@ def main():
                               f'optimisation steps at minibatch {16384 // R} / amp {4096 // R} rows + the epoch tail (whole batch: the tail '
                               'is sharded too in the real run), no collectives', 'ranks': R, 'ms_per_update': round(dt * 1e3, 3),
                               'us_per_step': round(dt * 1e6 / 48, 1), 'program_entries_per_step': entries, 'precision': args.precision,
-                              'allreduce_bytes_per_step': int(ag.model.a2c_network.trainable_numel) * 4,
+                              'allreduce_bytes_per_step': int(ag.model.a2c_network.trainable_numel) * 4, 'gp_stream': bool(ag.engine._gp_side),
                               'ideal_us_per_step_from_1gpu': None}), flush=True)
             del ag
             torch.cuda.empty_cache()
