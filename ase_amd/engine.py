@@ -182,6 +182,8 @@ class UpdateEngine:
         #                   -1 = high; the main stream's priority is the caller's)
         #   gp_split        gp_f32 = 'x3': 'f16' = three f16 MFMAs per product on hi / lo splits of scaled operands (ASE_F32H3, ~2^-22),
         #                   'bf16' = round 4's bf16 split (ASE_F32X3, ~2^-17; penalty 1.08e-4 off in the driver's round-4 run)
+        #   stream_offset   (measurement aid) throw-away streams taken from the pool in front of the branch streams: streams land on the
+        #                   hardware queues in creation order, this shifts the engine's places
         #   gp_stream       gp_f32 modes: the penalty's value path (f32 / bf16x3 forward of the demo rows + chain: independent of
         #                   the loss rows until the conversion launch) on its own stream beside the discriminator branch.  Round 4's
         #                   A/B had it faster (with the bf16-split kernels of that round); on round 6's kernels it is SLOWER: f16gpx3
@@ -194,7 +196,8 @@ class UpdateEngine:
         #                   dynamic loss scale, off otherwise; True / False force it
         o = dict(tn_grouped=True, tn_wg_side=64, tn_early=False, disc_early=True, short_prologue=True, style_early=False,
                  relu_bits=True, fused_apply=True, apply_wide=True, side_streams=2, gp_scale_split=True, xstep=True,
-                 gp_stream='auto', style_side=0, style_wg=0, side_priority=None, prefetch=True, disc_after_style=False, gp_split='f16')
+                 gp_stream='auto', style_side=0, style_wg=0, side_priority=None, prefetch=True, disc_after_style=False, gp_split='f16',
+                 stream_offset=0)
         unknown = set(cfg.get('engine_opts', {}) or {}) - set(o)
         assert not unknown, f"unknown engine_opts {sorted(unknown)}"
         o.update(cfg.get('engine_opts', {}) or {})
@@ -967,6 +970,8 @@ class UpdateEngine:
         if not self.multi_stream:
             return None
         if self._side_streams is None:
+            self._pad_streams = [torch.cuda.Stream(device=self.dev, priority=p) for _ in range(int(self.engine_opts['stream_offset']))
+                                 for p in (0, -1)]
             self._side_streams = [torch.cuda.Stream(device=self.dev, priority=self._side_prio[k % 3]) for k in range(self._n_side)]
             if self.gp32 and not self._gp_side and self._gp_stream_obj is None:
                 # A gp_f32 engine takes its value-path stream from the pool even when it does not use it (gp_stream off): streams
