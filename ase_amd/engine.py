@@ -182,6 +182,8 @@ class UpdateEngine:
         #                   -1 = high; the main stream's priority is the caller's)
         #   gp_split        gp_f32 = 'x3': 'f16' = three f16 MFMAs per product on hi / lo splits of scaled operands (ASE_F32H3, ~2^-22),
         #                   'bf16' = round 4's bf16 split (ASE_F32X3, ~2^-17; penalty 1.08e-4 off in the driver's round-4 run)
+        #   gp_value_late   (gp_stream off) the penalty's value path behind the loss rows' forward and heads instead of in front of them.
+        #                   Measured SLOWER: 76.28 vs 75.61 ms (four interleaved repetitions, profiles/r06_schedule_options_ab.txt): off
         #   stream_offset   (measurement aid) throw-away streams taken from the pool in front of the branch streams: streams land on the
         #                   hardware queues in creation order, this shifts the engine's places
         #   gp_stream       gp_f32 modes: the penalty's value path (f32 / bf16x3 forward of the demo rows + chain: independent of
@@ -197,7 +199,7 @@ class UpdateEngine:
         o = dict(tn_grouped=True, tn_wg_side=64, tn_early=False, disc_early=True, short_prologue=True, style_early=False,
                  relu_bits=True, fused_apply=True, apply_wide=True, side_streams=2, gp_scale_split=True, xstep=True,
                  gp_stream='auto', style_side=0, style_wg=0, side_priority=None, prefetch=True, disc_after_style=False, gp_split='f16',
-                 stream_offset=0)
+                 stream_offset=0, gp_value_late=False)
         unknown = set(cfg.get('engine_opts', {}) or {}) - set(o)
         assert not unknown, f"unknown engine_opts {sorted(unknown)}"
         o.update(cfg.get('engine_opts', {}) or {})
@@ -1107,6 +1109,8 @@ class UpdateEngine:
                 with self._Branch(self, self._gp_stream(), gp_fork) as br:
                     self._gp_value(amp_streams, gp_coef)
                 self._gp_value_done = br
+            elif self.engine_opts['gp_value_late']:
+                self._gp_value_pending = (amp_streams, gp_coef)         # launched by _gp_f32, behind the loss rows' forward and heads
             else:
                 self._gp_value(amp_streams, gp_coef)
 
@@ -1686,6 +1690,9 @@ class UpdateEngine:
         if self._gp_value_done is not None:
             self._join_branch(self._gp_value_done)
             self._gp_value_done = None
+        if getattr(self, '_gp_value_pending', None) is not None:
+            self._gp_value(*self._gp_value_pending)
+            self._gp_value_pending = None
         be.sqnorm(g.G0, AMB, d0.k_pad, self.acc, L.ACC_GP, scale=1.0 / (cg * S * S), dyn=self._dI2)
         # [dZ_l ; s g_l] and [X ; S s g_0]: the exact chain, rounded once, in the storage type
         if g.cast is None:
