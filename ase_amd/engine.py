@@ -237,7 +237,9 @@ class UpdateEngine:
             # measured on MI355X, config 2, with the main stream high (agents: main_stream_priority): the policy's second stream
             # (critic) high and the discriminator's normal - 66.4 -> 62.9 ms (bf16); gp_f32 modes carry ~280 us more work per
             # step on the discriminator side and want that stream high instead - 73.4 -> 72.8 ms (f16gpx3)
-            sp = [0, -1, 0] if self.gp32 else [-1, 0, 0]
+            # (round 6: under the dynamic loss scale the ONE decision per step makes the discriminator branch the step's critical path:
+            #  its stream high there too - mixed_precision 65.64 -> 64.62 ms, three interleaved repetitions, profiles/r06_schedule_options_ab.txt)
+            sp = [0, -1, 0] if (self.gp32 or self.dyn_scale) else [-1, 0, 0]
         self._side_prio = [int(x) for x in sp] if isinstance(sp, (list, tuple)) else [int(sp)] * 3      # critic, disc, gp streams
         self._gp_stream_obj = None
         self._xs = False                 # this step runs the cross-step schedule (decided per step in step())

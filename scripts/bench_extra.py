@@ -137,7 +137,7 @@ def main():
         if name.startswith('amp-cfg1'):
             ag, cfg, spec = build(kind, envs, prec, overrides=cfg1, net_overrides={'mlp': [256, 128], 'disc': [256, 128]})
         else:
-            ag, cfg, spec = build(kind, envs, prec)
+            ag, cfg, spec = build(kind, envs, prec, overrides=({'engine_opts': json.loads(args.engine_opts)} if args.engine_opts else None))
         dt = time_updates(ag, args.updates if (prec in ('bf16', 'mixed') or prec.endswith('+dyn')) else 2)
         B = ag.batch_size
         steps = cfg['mini_epochs'] * (B // cfg['minibatch_size'])
