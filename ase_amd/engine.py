@@ -1807,7 +1807,8 @@ class UpdateEngine:
 
     def _exchange_bucket(self, group, lo, hi, with_acc=False):
         """SUM exchange of one gradient bucket (+ with_acc: the step's loss partial sums acc[1 : ACC_LOGIT_W2], f64, travelling as
-        (hi, lo) f32 pairs - their sums are exact to f64 rounding) as ONE collective.  f32 payload without the sums: in place, no copy.
+        (hi, lo) f32 pairs: every rank's value is carried to ~2^-48, the all-reduce ADDS in f32, so the exchanged sums are good to
+        ~2^-24 relative - they are reported scalars and the kl of the adaptive schedule, no gradient depends on them) as ONE collective.  f32 payload without the sums: in place, no copy.
         Otherwise through a persistent exchange buffer inside the host callback: pack (+ convert: dp_grad_dtype 'bf16' halves the
         bytes on the links) -> all-reduce -> unpack; two device copies of the bucket against an xGMI ring pass of it."""
         g = self.grads[lo:hi]
